@@ -1,0 +1,108 @@
+"""ctypes binding of the C-ABI library ``csrc/libimmunostruct_hip.so``.
+
+The library is the product: if it is missing, or a tensor is not a contiguous
+fp32/int32 ROCm tensor, the call raises -- there is NO CPU or eager-PyTorch
+fallback anywhere in ``immunostruct_amd`` (the CPU oracle lives in ``oracle/``
+and is test infrastructure only).
+
+Entry points are declared in ``include/immunostruct_hip.h``; every function
+returns 0 on success or a negative errno-style code, never throws, never
+allocates and never owns memory: the caller (PyTorch) owns every buffer and
+passes the HIP stream the kernels are enqueued on.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libimmunostruct_hip.so")
+
+_P, _I, _F, _LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+
+# symbol -> argtypes ; keep in sync with include/immunostruct_hip.h
+SIGNATURES = {
+    "is_version": [],
+    "is_mfma_selftest": [_P, _P, _P, _P],
+    "is_mfma_outer_selftest": [_P, _P, _P, _P],
+    "is_egnn_edge_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "is_egnn_edge_bwd_partials_floats": [_I],
+    "is_egnn_edge_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I,
+                         _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
+    "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
+    "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_loss_partials_floats": [],
+    "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P],
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found: build it with `make -C immunostruct_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "immunostruct_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.argtypes = argtypes
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (``None`` -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipExtensionError(
+                "immunostruct_amd kernels run on a ROCm device only (got a CPU tensor); "
+                "there is no CPU fallback -- move the model and the batch to 'cuda'.")
+
+
+def f32c(t):
+    """fp32, contiguous (copies only when needed)."""
+    if t.dtype != torch.float32:
+        raise ValueError(f"expected float32 tensor, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rows_ld(t):
+    """Return (tensor, leading dimension) for a 2-d fp32 tensor with unit column stride."""
+    if t.dtype != torch.float32:
+        raise ValueError(f"expected float32 tensor, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError("expected a 2-d tensor")
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t, int(t.stride(0))
+
+
+def check(code, what):
+    if code != 0:
+        raise HipExtensionError(f"{what} failed with code {code}")

@@ -1,0 +1,56 @@
+// Library identification + a tiny MFMA layout self-test used by the GPU test-suite.
+#include "common.h"
+
+namespace is {
+
+// out[32 x 64] = A[32 x 64] * W[64 x 64]^T through the same mm_rows path the kernels use.
+__global__ __launch_bounds__(64) void mfma_selftest_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                           float* __restrict__ out) {
+  __shared__ float a_lds[TE * LD];
+  __shared__ float w_lds[H * LD];
+  const int lane = threadIdx.x;
+  load_matrix_lds(a_lds, A, TE, lane, 64);
+  load_matrix_lds(w_lds, W, H, lane, 64);
+  __syncthreads();
+  f32x16 acc[2];
+  for (int nt = 0; nt < 2; ++nt)
+    for (int t = 0; t < 16; ++t) acc[nt][t] = 0.0f;
+  mm_rows<2, H>(acc, a_lds, w_lds, lane);
+  const int r = lane & 31, hf = lane >> 5;
+  for (int nt = 0; nt < 2; ++nt)
+    for (int t = 0; t < 16; ++t) out[tile_row(t, hf) * H + nt * 32 + r] = acc[nt][t];
+}
+
+// outer[64 x 64] = G[32 x 64]^T * M[32 x 64] through mm_outer.
+__global__ __launch_bounds__(64) void mfma_outer_selftest_kernel(const float* __restrict__ G, const float* __restrict__ M,
+                                                                 float* __restrict__ out) {
+  __shared__ float g_lds[TE * LD];
+  __shared__ float m_lds[TE * LD];
+  const int lane = threadIdx.x;
+  load_matrix_lds(g_lds, G, TE, lane, 64);
+  load_matrix_lds(m_lds, M, TE, lane, 64);
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.0f;
+  mm_outer<2, 2>(acc, g_lds, m_lds, lane);
+  const int r = lane & 31, hf = lane >> 5;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int t = 0; t < 16; ++t) out[(a * 32 + tile_row(t, hf)) * H + b * 32 + r] = acc[a][b][t];
+}
+
+}  // namespace is
+
+extern "C" int is_version(void) { return 100; }  // 0.1.0
+
+extern "C" int is_mfma_selftest(const float* A, const float* W, float* out, void* stream) {
+  hipLaunchKernelGGL(is::mfma_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), A, W, out);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* stream) {
+  hipLaunchKernelGGL(is::mfma_outer_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), G, M, out);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -1,0 +1,116 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wavefront = 64 lanes; workgroups are 256 threads = 4 waves unless stated.
+//   * hidden width H = 64 channels (reference: gat_hidden_channels = 64,
+//     models/hybrid_models.py:247) -- one wave lane per channel in the
+//     "lane = channel" phases, two 32-column MFMA tiles in the matrix phases.
+//   * matrix work uses v_mfma_f32_32x32x2_f32 (exact fp32, bit-equal to an fmaf
+//     chain).  Operand map (lane l, r = l & 31, hf = l >> 5):
+//         A[i = r][k-slot = hf]   B[k-slot = hf][j = r]
+//         D reg t  ->  row (t & 3) + 8 * (t >> 2) + 4 * hf ,  col r
+//     The two k-slots of one instruction may be ANY two distinct k as long as
+//     A and B agree, so half hf walks k in [hf*K/2, (hf+1)*K/2): each lane then
+//     reads CONTIGUOUS k from LDS and one ds_read_b128 feeds four MFMAs.
+//   * LDS tiles are row-major with row stride LD = 68 floats: 16-byte aligned
+//     rows for ds_read_b128 and conflict-free for both the row-per-lane b128
+//     reads ((4*row) mod 64 distinct per 16-lane group) and the
+//     lane-per-column b32 accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace is {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = 64;    // hidden channels
+constexpr int LD = 68;   // LDS row stride in floats
+constexpr int TE = 32;   // edges (rows) per wave tile
+constexpr int NV = 32;   // destination nodes owned by one workgroup pass
+constexpr int WAVES = 4;
+
+__device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v); }
+
+// SiLU and its derivative.  sigma = 1 / (1 + exp(-z)).
+__device__ __forceinline__ float silu_f(float z) {
+  const float s = rcp_f(1.0f + __expf(-z));
+  return z * s;
+}
+__device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
+  const float s = rcp_f(1.0f + __expf(-z));
+  y = z * s;
+  dy = s * (1.0f + z * (1.0f - s));
+}
+
+// D-register t of a 32x32 tile -> row inside the tile.
+__device__ __forceinline__ int tile_row(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
+
+// acc[nt] (32 x 32) += A[32 x K] * W[nt*32 .. nt*32+32) x K]^T
+//   a_lds: tile row 0 of A (row stride LD), w_lds: row 0 of W (row stride LD).
+template <int NT, int K>
+__device__ __forceinline__ void mm_rows(f32x16 (&acc)[NT], const float* a_lds, const float* w_lds, int lane) {
+  const int r = lane & 31, hf = lane >> 5;
+  const float* ap = a_lds + r * LD + hf * (K / 2);
+  const float* wp = w_lds + r * LD + hf * (K / 2);
+#pragma unroll
+  for (int s = 0; s < K / 2; s += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + s);
+    f32x4 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LD + s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+// acc[mt][nt] (32 x 32) += sum over the 32 tile rows e of G[e][mt*32 + i] * M[e][nt*32 + j]
+//   (outer-product accumulation: the tile ROW index is the contraction index).
+template <int MT, int NT>
+__device__ __forceinline__ void mm_outer(f32x16 (&acc)[MT][NT], const float* g_lds, const float* m_lds, int lane) {
+  const int r = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < TE / 2; ++s) {
+    const int e = hf * (TE / 2) + s;
+    float a[MT], b[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = g_lds[e * LD + mt * 32 + r];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = m_lds[e * LD + nt * 32 + r];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  }
+}
+
+// sum of v over the 32 lanes that share hf (lanes differ in r = lane & 31).
+__device__ __forceinline__ float sum_over_r(float v) {
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// copy a row-major [rows x 64] fp32 matrix from global into an LD-strided LDS tile.
+__device__ __forceinline__ void load_matrix_lds(float* dst_lds, const float* __restrict__ src, int rows, int tid, int nthreads) {
+  for (int idx = tid; idx < rows * (H / 4); idx += nthreads) {
+    const int row = idx / (H / 4), c4 = idx % (H / 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * H + c4 * 4);
+    *reinterpret_cast<f32x4*>(dst_lds + row * LD + c4 * 4) = v;
+  }
+}
+// same, but stores the transpose: dst[c][r] = src[r][c]  (src is [64 x 64]).
+__device__ __forceinline__ void load_matrix_lds_t(float* dst_lds, const float* __restrict__ src, int tid, int nthreads) {
+  for (int idx = tid; idx < H * H; idx += nthreads) {
+    const int row = idx / H, col = idx % H;
+    dst_lds[col * LD + row] = src[idx];
+  }
+}
+
+}  // namespace is

@@ -1,0 +1,132 @@
+// CSR segment reductions: the deterministic replacement for torch_scatter /
+// DGL SpMM scatter-adds on this path.
+//
+//   is_gather_segment_sum : out[v] = sum over p in [ptr[v], ptr[v+1]) of rows[pos[p]]
+//       -- the source-side "scatter-add" of the EGNN backward (dPs[src] += dz1,
+//       dx[src] += dD) expressed as a gather over the CSR-by-source index, one
+//       wave per node, one coalesced 256-byte row per edge.
+//   is_segment_pool_{fwd,bwd} : per-graph mean / max readout, the
+//       torch_geometric.nn.global_mean_pool / global_max_pool replacement
+//       (reference models/hybrid_models.py:331, models/ablation_models.py:296-297).
+//       mean = sum / max(count, 1); max of an empty segment = 0 (PyG semantics).
+//       Backward of max splits the gradient evenly among tied maxima (torch
+//       amax semantics; padded nodes produce identical rows, so ties are real).
+// Fixed summation order everywhere => bitwise reproducible.
+#include "common.h"
+
+namespace is {
+
+__global__ __launch_bounds__(256) void gather_segment_sum_kernel(
+    const float* __restrict__ rows, const float* __restrict__ vec3,
+    const int* __restrict__ ptr, const int* __restrict__ pos,
+    float* __restrict__ out_rows, int ld_out, float* __restrict__ out_vec3, int N) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= N) return;
+  const int lo = ptr[v], hi = ptr[v + 1];
+  float acc = 0.0f, acc3 = 0.0f;
+  int p = lo;
+  for (; p + 4 <= hi; p += 4) {
+    const int e0 = pos[p], e1 = pos[p + 1], e2 = pos[p + 2], e3 = pos[p + 3];
+    const float a0 = rows[(size_t)e0 * H + lane], a1 = rows[(size_t)e1 * H + lane];
+    const float a2 = rows[(size_t)e2 * H + lane], a3 = rows[(size_t)e3 * H + lane];
+    acc += a0; acc += a1; acc += a2; acc += a3;
+    if (vec3 != nullptr && lane < 3) {
+      acc3 += vec3[(size_t)e0 * 3 + lane]; acc3 += vec3[(size_t)e1 * 3 + lane];
+      acc3 += vec3[(size_t)e2 * 3 + lane]; acc3 += vec3[(size_t)e3 * 3 + lane];
+    }
+  }
+  for (; p < hi; ++p) {
+    const int e0 = pos[p];
+    acc += rows[(size_t)e0 * H + lane];
+    if (vec3 != nullptr && lane < 3) acc3 += vec3[(size_t)e0 * 3 + lane];
+  }
+  out_rows[(size_t)v * ld_out + lane] = acc;
+  if (vec3 != nullptr && lane < 3) out_vec3[v * 3 + lane] += acc3;
+}
+
+// one workgroup per (segment, 64-channel slab)
+__global__ __launch_bounds__(256) void segment_pool_fwd_kernel(
+    const float* __restrict__ x, int ld_x, const int* __restrict__ seg_ptr,
+    float* __restrict__ out_mean, float* __restrict__ out_max, int C) {
+  __shared__ float red_s[4][64];
+  __shared__ float red_m[4][64];
+  const int seg = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int lo = seg_ptr[seg], hi = seg_ptr[seg + 1];
+  float s = 0.0f, m = -INFINITY;
+  if (c < C) {
+    for (int row = lo + rg; row < hi; row += 4) {
+      const float v = x[(size_t)row * ld_x + c];
+      s += v;
+      m = fmaxf(m, v);
+    }
+  }
+  red_s[rg][threadIdx.x & 63] = s;
+  red_m[rg][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    const float st = ((red_s[0][l] + red_s[1][l]) + red_s[2][l]) + red_s[3][l];
+    const float mt = fmaxf(fmaxf(red_m[0][l], red_m[1][l]), fmaxf(red_m[2][l], red_m[3][l]));
+    const int cnt = hi - lo;
+    if (out_mean != nullptr) out_mean[(size_t)seg * C + c] = st / (float)max(cnt, 1);
+    if (out_max != nullptr) out_max[(size_t)seg * C + c] = cnt > 0 ? mt : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
+    const float* __restrict__ x, int ld_x, const int* __restrict__ seg_ptr,
+    const float* __restrict__ out_max, const float* __restrict__ g_mean, const float* __restrict__ g_max,
+    float* __restrict__ dx, int ld_dx, int C) {
+  __shared__ int ties[4][64];
+  const int seg = blockIdx.x, l = threadIdx.x & 63, c = blockIdx.y * 64 + l, rg = threadIdx.x >> 6;
+  const int lo = seg_ptr[seg], hi = seg_ptr[seg + 1];
+  const bool on = c < C;
+  const float gm = (on && g_mean != nullptr) ? g_mean[(size_t)seg * C + c] / (float)max(hi - lo, 1) : 0.0f;
+  float mx = 0.0f, gx = 0.0f;
+  int cnt = 0;
+  if (g_max != nullptr) {
+    if (on) {
+      mx = out_max[(size_t)seg * C + c];
+      gx = g_max[(size_t)seg * C + c];
+      for (int row = lo + rg; row < hi; row += 4) cnt += (x[(size_t)row * ld_x + c] == mx) ? 1 : 0;
+    }
+    ties[rg][l] = cnt;
+    __syncthreads();
+    cnt = ties[0][l] + ties[1][l] + ties[2][l] + ties[3][l];
+    gx = cnt > 0 ? gx / (float)cnt : 0.0f;
+  }
+  if (!on) return;
+  for (int row = lo + rg; row < hi; row += 4) {
+    float g = gm;
+    if (g_max != nullptr && x[(size_t)row * ld_x + c] == mx) g += gx;
+    dx[(size_t)row * ld_dx + c] = g;
+  }
+}
+
+}  // namespace is
+
+extern "C" int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
+                                     float* out_rows, int ld_out, float* out_vec3, int N, void* stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(is::gather_segment_sum_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     rows, vec3, ptr, pos, out_rows, ld_out, out_vec3, N);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_ptr, float* out_mean, float* out_max,
+                                   int num_segments, int C, void* stream) {
+  if (num_segments <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(is::segment_pool_fwd_kernel, dim3(num_segments, (C + 63) / 64), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ld_x, seg_ptr, out_mean, out_max, C);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const float* out_max,
+                                   const float* g_mean, const float* g_max, float* dx, int ld_dx, int num_segments,
+                                   int C, void* stream) {
+  if (num_segments <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(is::segment_pool_bwd_kernel, dim3(num_segments, (C + 63) / 64), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ld_x, seg_ptr, out_max, g_mean, g_max, dx, ld_dx, C);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

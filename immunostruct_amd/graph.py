@@ -1,0 +1,176 @@
+"""Batched residue-graph container with the DGLGraph surface the reference uses.
+
+The reference hands the models a batched ``DGLGraph`` (``dgl.batch`` in
+``data/utils.py:160-176``) and only touches ``ndata['x']``,
+``edata['edge_attr']``, ``batch_num_nodes()``, ``.device`` and ``.to()``
+(``models/hybrid_models.py:316-321``).  ``PackedGraphBatch`` offers exactly that
+surface plus what the HIP kernels need:
+
+* CSR by destination: ``rowptr_dst`` (N+1), ``src_sorted`` (E), ``eperm`` (E,
+  original edge id of each CSR slot; stable sort, so a node's in-edges keep
+  their original relative order and the segment sums have a fixed order);
+* CSR by source over the *CSR-by-destination slots*: ``rowptr_src`` (N+1),
+  ``pos_by_src`` (E) -- used by the backward gather that replaces the
+  scatter-add to source rows;
+* ``seg_ptr`` (B+1): node offsets of the graphs (block-diagonal batch).
+
+All indices are int32 (N, E < 2^31).  Index construction is plain torch
+(sort / bincount / cumsum) and runs on whichever device the graph lives on, so
+it can be done once per graph in DataLoader workers or on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class CSRIndex:
+    __slots__ = ("rowptr_dst", "src_sorted", "eperm", "rowptr_src", "pos_by_src", "num_nodes", "num_edges")
+
+    def __init__(self, src, dst, num_nodes):
+        src = src.long()
+        dst = dst.long()
+        n, e = int(num_nodes), int(src.numel())
+        order = torch.argsort(dst, stable=True)
+        src_sorted = src[order]
+        self.eperm = order
+        self.src_sorted = src_sorted.to(torch.int32)
+        self.rowptr_dst = _rowptr(dst, n)
+        order2 = torch.argsort(src_sorted, stable=True)
+        self.pos_by_src = order2.to(torch.int32)
+        self.rowptr_src = _rowptr(src, n)
+        self.num_nodes, self.num_edges = n, e
+
+    def to(self, device):
+        out = object.__new__(CSRIndex)
+        for k in ("rowptr_dst", "src_sorted", "eperm", "rowptr_src", "pos_by_src"):
+            setattr(out, k, getattr(self, k).to(device))
+        out.num_nodes, out.num_edges = self.num_nodes, self.num_edges
+        return out
+
+
+def _rowptr(index, n):
+    counts = torch.bincount(index, minlength=n)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=index.device)
+    ptr[1:] = torch.cumsum(counts, 0)
+    return ptr.to(torch.int32)
+
+
+class PackedGraphBatch:
+    """A (batched) directed graph in COO form with feature frames and cached CSR indices."""
+
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None):
+        self._src = torch.as_tensor(src).long()
+        self._dst = torch.as_tensor(dst).long()
+        self._num_nodes = int(num_nodes)
+        if batch_num_nodes is None:
+            batch_num_nodes = [self._num_nodes]
+        self._counts = [int(c) for c in (batch_num_nodes.tolist() if torch.is_tensor(batch_num_nodes)
+                                         else list(batch_num_nodes))]
+        if sum(self._counts) != self._num_nodes:
+            raise ValueError("batch_num_nodes does not sum to num_nodes")
+        self.ndata = {}
+        self.edata = {}
+        self._csr = None
+        self._seg_ptr = None
+        self._sorted_cache = {}
+
+    # ---- DGLGraph surface ------------------------------------------------
+    def edges(self):
+        return self._src, self._dst
+
+    def num_nodes(self):
+        return self._num_nodes
+
+    def num_edges(self):
+        return int(self._src.numel())
+
+    def batch_num_nodes(self):
+        return torch.tensor(self._counts, dtype=torch.int64, device=self.device)
+
+    @property
+    def batch_size(self):
+        return len(self._counts)
+
+    @property
+    def device(self):
+        return self._src.device
+
+    def to(self, device, non_blocking=False):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = PackedGraphBatch(self._src.to(device, non_blocking=non_blocking),
+                             self._dst.to(device, non_blocking=non_blocking), self._num_nodes, self._counts)
+        g.ndata = {k: v.to(device, non_blocking=non_blocking) for k, v in self.ndata.items()}
+        g.edata = {k: v.to(device, non_blocking=non_blocking) for k, v in self.edata.items()}
+        if self._csr is not None:
+            g._csr = self._csr.to(device)
+        return g
+
+    # ---- kernel-side indices ----------------------------------------------
+    def uniform_nodes_per_graph(self):
+        """n if every graph has the same (padded) node count, else None (F5 in SURVEY.md)."""
+        first = self._counts[0] if self._counts else 0
+        return first if all(c == first for c in self._counts) else None
+
+    def csr(self) -> CSRIndex:
+        if self._csr is None:
+            self._csr = CSRIndex(self._src, self._dst, self._num_nodes)
+        return self._csr
+
+    def seg_ptr(self):
+        if self._seg_ptr is None or self._seg_ptr.device != self.device:
+            ptr = [0]
+            for c in self._counts:
+                ptr.append(ptr[-1] + c)
+            self._seg_ptr = torch.tensor(ptr, dtype=torch.int32, device=self.device)
+        return self._seg_ptr
+
+    def edge_feat_csr(self, edge_feat):
+        """``edge_feat`` (E, Fe) permuted into CSR-by-destination slot order (cached per tensor)."""
+        key = (edge_feat.data_ptr(), tuple(edge_feat.shape), edge_feat._version)
+        hit = self._sorted_cache.get("ea")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = edge_feat.detach().to(torch.float32).index_select(0, self.csr().eperm).contiguous()
+        self._sorted_cache["ea"] = (key, out)
+        return out
+
+    @classmethod
+    def from_raw(cls, raw, device=None):
+        """Build from a ``synthetic.RawBatch`` (numpy arrays)."""
+        g = cls(torch.from_numpy(raw.src), torch.from_numpy(raw.dst), raw.num_nodes, raw.batch_num_nodes.tolist())
+        g.ndata["x"] = torch.from_numpy(raw.x)
+        g.edata["edge_attr"] = torch.from_numpy(raw.edge_attr)
+        g.csr()
+        return g.to(device) if device is not None else g
+
+
+def graph(edges, num_nodes=None):
+    """``dgl.graph((src, dst), num_nodes=n)`` (reference ``data/utils.py:64``)."""
+    src, dst = edges
+    src = torch.as_tensor(src).long()
+    dst = torch.as_tensor(dst).long()
+    if num_nodes is None:
+        num_nodes = int(max(int(src.max()), int(dst.max()))) + 1 if src.numel() else 0
+    return PackedGraphBatch(src, dst, num_nodes)
+
+
+def batch(graphs):
+    """``dgl.batch``: block-diagonal union of graphs (reference ``data/utils.py:163``)."""
+    srcs, dsts, counts = [], [], []
+    offset = 0
+    for g in graphs:
+        s, d = g.edges()
+        srcs.append(s + offset)
+        dsts.append(d + offset)
+        counts.extend(g._counts)
+        offset += g.num_nodes()
+    dev = graphs[0].device
+    empty = torch.zeros(0, dtype=torch.int64, device=dev)
+    out = PackedGraphBatch(torch.cat(srcs) if srcs else empty, torch.cat(dsts) if dsts else empty, offset, counts)
+    for key in graphs[0].ndata:
+        out.ndata[key] = torch.cat([g.ndata[key] for g in graphs], dim=0)
+    for key in graphs[0].edata:
+        out.edata[key] = torch.cat([g.edata[key] for g in graphs], dim=0)
+    return out

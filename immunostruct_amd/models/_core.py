@@ -1,0 +1,210 @@
+"""One parametrised implementation behind the 14 reference model classes.
+
+The reference spells every variant out as its own ``nn.Module`` with a copy of
+the same forward body (``models/hybrid_models.py``, ``comparative_models.py``,
+``ablation_models.py``).  Here a single ``MultimodalNet`` is configured by a
+small spec (which encoders exist, which node attention, whether the fused
+scalars go through the "combined attention", SSL heads, paired mode); the
+public classes in the sibling modules only pin the spec and the constructor
+signature.  Sub-module NAMES and shapes are the reference's, so
+``state_dict()`` is key-for-key compatible.
+
+Graph work runs on the HIP kernels (``immunostruct_amd.nn.EGNNConv`` and
+``functional.segment_pool``); there is no CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as HF
+from ..nn import EGNNConv
+from .layers import MultiHeadAttention, SelfAttention
+
+NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
+
+
+@dataclass(frozen=True)
+class Spec:
+    graph: bool = True          # EGNN + node attention + pooling branch
+    attn: str = "mha"           # "v1" (SelfAttention) | "mha" (heads from ctor) | "mha8"
+    vae: bool = True            # sequence VAE branch
+    prop: str = "emb"           # "emb" (property MLP) | "raw" (concat raw 2-d) | "none"
+    comb: int = 0               # feature width of the combined attention (0 = absent)
+    ssl: bool = False           # classifier_head + node_predictor_head
+    paired: bool = False        # cancer / wild-type comparative model
+    pool: str = "mean"          # "mean" | "meanmax"
+
+
+class MultimodalNet(nn.Module):
+    SPEC = Spec()
+
+    def __init__(self, vae_input_dim, device, gcn_layers=5, vae_hidden_dim=512, vae_latent_dim=32,
+                 gat_hidden_channels=64, self_attention_heads=1, property_embedding_dim=8,
+                 combined_attention_heads=8, use_wt_for_downstream=True, mlp_features=32):
+        super().__init__()
+        sp = self.SPEC
+        self.device = device
+        self.vae_input_dim = vae_input_dim
+        self.vae_hidden_dim = vae_hidden_dim
+        self.vae_latent_dim = vae_latent_dim
+        self.gat_hidden_channels = gat_hidden_channels
+        self.property_embedding_dim = property_embedding_dim
+        self.use_wt_for_downstream = use_wt_for_downstream
+        self.mlp_features = mlp_features
+        c = gat_hidden_channels
+
+        if sp.graph:
+            layers = [EGNNConv(NODE_ONEHOT, c, c, 1)]
+            layers += [EGNNConv(c, c, c, 1) for _ in range(gcn_layers)]
+            self.GCN_layers = nn.ModuleList(layers)
+            if sp.attn == "v1":
+                self.self_attention = SelfAttention(c)
+            else:
+                self.self_attention = MultiHeadAttention(c, 8 if sp.attn == "mha8" else self_attention_heads)
+        if sp.vae:
+            extra = {"emb": property_embedding_dim, "raw": 2, "none": 0}[sp.prop]
+            self.vae_fc1 = nn.Linear(vae_input_dim, vae_hidden_dim)
+            self.vae_fc21 = nn.Linear(vae_hidden_dim, vae_latent_dim)
+            self.vae_fc22 = nn.Linear(vae_hidden_dim, vae_latent_dim)
+            self.vae_fc3 = nn.Linear(vae_latent_dim + extra, vae_hidden_dim)
+            self.vae_fc4 = nn.Linear(vae_hidden_dim, vae_input_dim)
+        if sp.comb:
+            self.combined_attention = MultiHeadAttention(sp.comb, combined_attention_heads, input_dim=1)
+        self.classifier = self.get_classifier()
+        if sp.ssl:
+            self.classifier_head = nn.Linear(mlp_features, 1)
+            self.node_predictor_head = nn.Linear(mlp_features, NODE_ONEHOT)
+        if sp.prop == "emb":
+            self.property_embedding = nn.Sequential(
+                nn.Linear(2, 32), nn.ReLU(True), nn.Dropout(0.1),
+                nn.Linear(32, property_embedding_dim), nn.ReLU(True))
+
+    # ---- pieces with reference-visible names ------------------------------
+    def _fused_width(self):
+        sp = self.SPEC
+        w = 0
+        if sp.graph:
+            w += self.gat_hidden_channels * (2 if sp.pool == "meanmax" else 1)
+        if sp.vae:
+            w += self.vae_latent_dim + {"emb": self.property_embedding_dim, "raw": 2, "none": 0}[sp.prop]
+        if sp.paired and self.use_wt_for_downstream:
+            w *= 2
+        return w
+
+    def get_classifier(self):
+        mods = [nn.Flatten(1), nn.Linear(self._fused_width(), 32), nn.ReLU(True), nn.Dropout(0.1)]
+        if not self.SPEC.ssl:
+            mods.append(nn.Linear(32, 1))
+        return nn.Sequential(*mods)
+
+    def encode_vae(self, x):
+        h1 = F.relu(self.vae_fc1(x))
+        return self.vae_fc21(h1), self.vae_fc22(h1)
+
+    def reparameterize(self, mu, logvar):
+        # sampled on every call, also in eval mode (reference hybrid_models.py:301-304)
+        return mu + torch.randn_like(mu) * torch.exp(0.5 * logvar)
+
+    def decode_vae(self, z):
+        return self.vae_fc4(F.relu(self.vae_fc3(z)))
+
+    def load_trained(self, path, new_head=False, map_location=None):
+        self.load_state_dict(torch.load(path, map_location=map_location))
+        if new_head:
+            if self.SPEC.ssl:
+                self.classifier_head = nn.Linear(self.mlp_features, 1).to(self.device)
+            else:
+                self.classifier = self.get_classifier().to(self.device)
+
+    # ---- encoders ------------------------------------------------------------
+    def _encode_graph(self, g):
+        feats = g.ndata["x"]
+        h, x, a = feats[:, :NODE_ONEHOT], feats[:, NODE_ONEHOT:], g.edata["edge_attr"]
+        for layer in self.GCN_layers:
+            h, x = layer(g, h, x, a)
+        c = self.gat_hidden_channels
+        if g.uniform_nodes_per_graph() is None:
+            raise ValueError("all graphs of a batch must be padded to the same node count "
+                             "(reference data/preprocess.py:343-349)")
+        out, weights = self.self_attention(h.view(g.batch_size, -1, c))
+        pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)
+        return pooled, weights
+
+    def _encode(self, g, seq, prop):
+        sp = self.SPEC
+        o = {}
+        if sp.graph:
+            o["x_gat_node"], o["attention"] = self._encode_graph(g)
+        p = None
+        if sp.prop == "emb":
+            p = self.property_embedding(prop)
+        elif sp.prop == "raw":
+            p = prop
+        if sp.vae:
+            mu, logvar = self.encode_vae(seq.reshape(-1, self.vae_input_dim))
+            z = self.reparameterize(mu, logvar)
+            if p is not None:
+                z = torch.cat([z, p], dim=1)
+            o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=self.decode_vae(z))
+        return o
+
+    def _head(self, fused):
+        if self.SPEC.comb:
+            fused = self.combined_attention(fused.unsqueeze(2))[0].mean(dim=2)
+        hid = self.classifier(fused)
+        if self.SPEC.ssl:
+            return self.classifier_head(hid), self.node_predictor_head(hid)
+        return hid, None
+
+    def _pack(self, first, o, final, node_pred):
+        if self.SPEC.vae:
+            head = (first, o["mu"], o["logvar"], final)
+        else:
+            head = (0, 0, 0, final)
+        return head + ((node_pred,) if self.SPEC.ssl else ())
+
+    # ---- public forward passes --------------------------------------------
+    def forward(self, graph_data, sequence_data, peptide_property, return_embedding=False, return_attention=False):
+        sp = self.SPEC
+        o = self._encode(graph_data, sequence_data, peptide_property)
+        if sp.graph and sp.vae:
+            parts = [o["x_gat_node"], o["z_vae"]]
+            if sp.paired and self.use_wt_for_downstream:
+                parts = parts * 2   # single-sample pretraining of a paired model
+            fused = torch.cat(parts, dim=1)
+        else:
+            fused = o["x_gat_node"] if sp.graph else o["z_vae"]
+        final, node_pred = self._head(fused)
+        first = o.get("recon_x")
+        if sp.graph and sp.vae:
+            if return_embedding:
+                first = o["x_gat_node"]
+            elif return_attention:
+                first = o["attention"]
+        return self._pack(first, o, final, node_pred)
+
+    def forward_item(self, graph_data, sequence_data, peptide_property):
+        o = self._encode(graph_data, sequence_data, peptide_property)
+        return o["mu"], o["logvar"], o["x_gat_node"], o["z_vae"], o["attention"], o["recon_x"]
+
+    def forward_comparative(self, graph_data_pair, sequence_data_pair, peptide_property_pair,
+                            return_embedding=False, return_attention=False):
+        if not self.SPEC.paired:
+            raise AttributeError(f"{type(self).__name__} has no comparative forward")
+        oc = self._encode(graph_data_pair[0], sequence_data_pair[0], peptide_property_pair[0])
+        ow = self._encode(graph_data_pair[1], sequence_data_pair[1], peptide_property_pair[1])
+        emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)
+        emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)
+        fused = torch.cat([emb_c, emb_w], dim=1) if self.use_wt_for_downstream else emb_c
+        final, node_pred = self._head(fused)
+        tail = (node_pred,) if self.SPEC.ssl else ()
+        if return_embedding:
+            return (oc["x_gat_node"], oc["mu"], oc["logvar"], final) + tail
+        if return_attention:
+            return (oc["attention"], oc["mu"], oc["logvar"], final) + tail
+        return ([emb_c, emb_w], [oc["recon_x"], ow["recon_x"]], [oc["mu"], ow["mu"]],
+                [oc["logvar"], ow["logvar"]], final) + tail

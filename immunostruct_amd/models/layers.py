@@ -1,0 +1,59 @@
+"""Attention blocks with the reference's parameter names.
+
+* ``SelfAttention(feature_dim)`` -- parameters ``query/key/value``; single
+  head, no output projection, returns ``(out, weights)``
+  (reference ``models/layers.py:6-22``).
+* ``MultiHeadAttention(feature_dim, n_head, input_dim=None)`` -- parameters
+  ``w_q/w_k/w_v/w_concat``; returns ``(out, weights[b, head, n, n])``; no mask is
+  ever passed on this path (reference ``models/layers.py:51-106``).
+
+Both evaluate through one shared routine (:func:`attend`).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def attend(q, k, v, heads):
+    """softmax(q k^T / sqrt(d_head)) v for (b, n, d) inputs; returns (out (b,n,d), weights (b,heads,n,n))."""
+    b, n, d = q.shape
+    dh = d // heads
+    q, k, v = (t.reshape(b, n, heads, dh).transpose(1, 2) for t in (q, k, v))
+    w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
+    out = torch.matmul(w, v).transpose(1, 2).reshape(b, n, d)
+    return out, w
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.query = nn.Linear(feature_dim, feature_dim)
+        self.key = nn.Linear(feature_dim, feature_dim)
+        self.value = nn.Linear(feature_dim, feature_dim)
+
+    def forward(self, x):
+        out, w = attend(self.query(x), self.key(x), self.value(x), 1)
+        return out, w.squeeze(1)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, feature_dim, n_head, input_dim=None):
+        super().__init__()
+        if feature_dim % n_head != 0:
+            raise AssertionError("Embedding dimension must be 0 modulo number of heads.")
+        input_dim = input_dim or feature_dim
+        self.n_head = n_head
+        self.w_q = nn.Linear(input_dim, feature_dim)
+        self.w_k = nn.Linear(input_dim, feature_dim)
+        self.w_v = nn.Linear(input_dim, feature_dim)
+        self.w_concat = nn.Linear(feature_dim, feature_dim)
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("attention masks are never used on this path")
+        out, w = attend(self.w_q(x), self.w_k(x), self.w_v(x), self.n_head)
+        return self.w_concat(out), w

@@ -1,0 +1,94 @@
+"""Operator API the reference models call, backed by the HIP kernels.
+
+Drop-in replacements (same names, argument meaning and return values) for
+
+* ``dgl.nn.EGNNConv(in_size, hidden_size, out_size, edge_feat_size)`` and its
+  ``forward(graph, node_feat, coord_feat, edge_feat) -> (h, x)`` -- reference
+  call sites ``models/hybrid_models.py:29-31,89-90,261-263,323-324``;
+* ``torch_geometric.nn.global_mean_pool(x, batch)`` / ``global_max_pool`` --
+  reference ``models/hybrid_models.py:97,331``, ``ablation_models.py:296-297``.
+
+``EGNNConv`` keeps DGL's parameter layout (``edge_mlp.{0,2}``,
+``node_mlp.{0,2}``, ``coord_mlp.{0,2}``) so reference checkpoints load
+unchanged.  How the layer is evaluated differs from DGL by design:
+
+  edge_mlp.0 is split as W1 = [W1s | W1d | w_r | W_a]; the node-level
+  projections Ps = h W1s^T and Pd = h W1d^T + b1 are computed once per node
+  (dense GEMM) so the per-edge work is a 256-byte row gather + two 64x64 MFMA
+  layers; gather, messages, coordinate messages and the sum/mean reductions
+  run in ONE fused kernel (``csrc/egnn_edge_fwd.hip``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as HF
+from .graph import PackedGraphBatch
+
+
+class EGNNConv(nn.Module):
+    def __init__(self, in_size, hidden_size, out_size, edge_feat_size=0):
+        super().__init__()
+        if hidden_size != HF.HIDDEN:
+            raise NotImplementedError(
+                f"the HIP EGNN kernels are built for hidden_size={HF.HIDDEN} "
+                f"(reference gat_hidden_channels, models/hybrid_models.py:247); got {hidden_size}")
+        if edge_feat_size > 8:
+            raise NotImplementedError("edge_feat_size > 8 is not supported by the HIP EGNN kernels")
+        self.in_size, self.hidden_size = in_size, hidden_size
+        self.out_size, self.edge_feat_size = out_size, edge_feat_size
+        act = nn.SiLU()
+        self.edge_mlp = nn.Sequential(
+            nn.Linear(in_size * 2 + edge_feat_size + 1, hidden_size), act,
+            nn.Linear(hidden_size, hidden_size), act)
+        self.node_mlp = nn.Sequential(
+            nn.Linear(in_size + hidden_size, hidden_size), act,
+            nn.Linear(hidden_size, out_size))
+        self.coord_mlp = nn.Sequential(
+            nn.Linear(hidden_size, hidden_size), act,
+            nn.Linear(hidden_size, 1, bias=False))
+
+    def forward(self, graph, node_feat, coord_feat, edge_feat=None):
+        if not isinstance(graph, PackedGraphBatch):
+            raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
+        d, hid, fe = self.in_size, self.hidden_size, self.edge_feat_size
+        if fe > 0 and edge_feat is None:
+            raise ValueError("Edge features must be provided.")
+        if edge_feat is not None and edge_feat.requires_grad:
+            raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
+        csr = graph.csr()
+        w1 = self.edge_mlp[0].weight
+        b1 = self.edge_mlp[0].bias
+        # node-level pre-projection of the first edge-MLP layer: [Ps | Pd]
+        w_sd = torch.cat([w1[:, :d], w1[:, d:2 * d]], dim=0)
+        b_sd = torch.cat([torch.zeros_like(b1), b1], dim=0)
+        psd = F.linear(node_feat, w_sd, b_sd)
+        w_r = w1[:, 2 * d]
+        w_a = w1[:, 2 * d + 1:] if fe > 0 else None
+        ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
+        h_neigh, x_out = HF.egnn_edge(
+            psd, coord_feat, ea, w_r, w_a,
+            self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+            self.coord_mlp[0].weight, self.coord_mlp[0].bias,
+            self.coord_mlp[2].weight.reshape(-1), csr)
+        h = self.node_mlp(torch.cat([node_feat, h_neigh], dim=-1))
+        return h, x_out
+
+
+def _seg_ptr_from_batch(batch_index, size=None):
+    n = int(batch_index.max()) + 1 if size is None else int(size)
+    counts = torch.bincount(batch_index, minlength=n)
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=batch_index.device)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ptr
+
+
+def global_mean_pool(x, batch, size=None):
+    """PyG signature; ``batch`` must be sorted (block-diagonal batches always are)."""
+    return HF.segment_pool(x, _seg_ptr_from_batch(batch, size), "mean")
+
+
+def global_max_pool(x, batch, size=None):
+    return HF.segment_pool(x, _seg_ptr_from_batch(batch, size), "max")

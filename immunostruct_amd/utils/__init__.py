@@ -1,0 +1,3 @@
+from .contrastive import PairedContrastiveLoss  # noqa: F401
+from .loss import Losses  # noqa: F401
+from .seed import seed_everything  # noqa: F401

@@ -1,0 +1,64 @@
+"""``PairedContrastiveLoss`` with the reference's interface (``utils/contrastive.py:6-83``).
+
+Pulls the cancer / wild-type embedding pair together for non-immunogenic
+peptides, pushes it apart for immunogenic ones, decorrelates non-pairs and
+feature dimensions.  Same sub-module layout (``projector.{0,1,3}``), same
+early-out (python ``0`` unless the target holds exactly two distinct values),
+BatchNorm always on batch statistics (the reference never puts the module in
+eval mode, ``procedures/train.py:76``).
+
+Evaluated in closed form with diagonal/off-diagonal weights instead of the
+reference's boolean-mask in-place scaling:
+    loss = sum_ij w_ij (zc zw^T / D - diag(pos))_ij^2 + sum_kl w_kl (zc^T zw / B - I)_kl^2 + std hinge
+with w = 1 on the diagonal and ``lambda_off_diag`` elsewhere.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ["PairedContrastiveLoss"]
+
+
+def _weighted_sq(m, ideal_diag, off_weight):
+    """sum of squared deviation from diag(ideal_diag), off-diagonal entries weighted by ``off_weight``."""
+    sq = m.pow(2)
+    diag = torch.diagonal(m)
+    on = (diag - ideal_diag).pow(2).sum()
+    off = sq.sum() - diag.pow(2).sum()
+    return on + off_weight * off
+
+
+class PairedContrastiveLoss(nn.Module):
+    def __init__(self, embedding_dim: int = 104, z_dim: int = 128, lambda_off_diag: float = 1e-2,
+                 device: torch.device = torch.device("cpu")):
+        super().__init__()
+        self.z_dim = z_dim
+        self.lambda_off_diag = lambda_off_diag
+        self.projector = nn.Sequential(
+            nn.Linear(embedding_dim, z_dim, bias=False),
+            nn.BatchNorm1d(z_dim),
+            nn.ReLU(inplace=True),
+            nn.Linear(z_dim, z_dim, bias=False))
+        self.device = device
+        self.projector.to(device)
+
+    def forward(self, embedding_cancer, embedding_wt, is_immunogenic):
+        if is_immunogenic.unique().numel() != 2:
+            return 0  # nothing to contrast (continuous target, or a single-class batch)
+        pos = (is_immunogenic > is_immunogenic.mean()).to(embedding_cancer.dtype)
+        if embedding_cancer.shape != embedding_wt.shape:
+            raise AssertionError("cancer / wild-type embeddings must have equal shapes")
+        zc = self.projector(embedding_cancer)
+        zw = self.projector(embedding_wt)
+        b = zc.shape[0]
+        zc = zc - zc.mean(0)
+        zw = zw - zw.mean(0)
+        hinge = 0.5 * (F.relu(1 - torch.sqrt(zc.var(dim=0) + 1e-4)).mean()
+                       + F.relu(1 - torch.sqrt(zw.var(dim=0) + 1e-4)).mean())
+        pair = zc @ zw.T / self.z_dim
+        corr = zc.T @ zw / b
+        ones = torch.ones(self.z_dim, dtype=zc.dtype, device=zc.device)
+        return (_weighted_sq(pair, pos, self.lambda_off_diag)
+                + _weighted_sq(corr, ones, self.lambda_off_diag) + hinge)

@@ -1,0 +1,108 @@
+/* immunostruct_hip.h -- C ABI of libimmunostruct_hip.so (gfx950 / MI355X).
+ *
+ * The reference (KrishnaswamyLab/ImmunoStruct) has no FFI layer: its hot path
+ * reaches native code through the Python operator APIs of DGL / PyG / torch.
+ * Each entry point below replaces the native kernels reached by one of those
+ * call sites (paths relative to /root/reference/immunostruct):
+ *
+ *   is_egnn_edge_fwd / _bwd   dgl.nn.EGNNConv.forward + its autograd
+ *                             (models/hybrid_models.py:323-324; SDDMM u_sub_v,
+ *                             edges.src/dst gathers, edge/coord MLP, SpMM
+ *                             copy_e sum/mean -- SURVEY.md section 2, K1-K5, K7)
+ *   is_gather_segment_sum     the scatter-add to SOURCE rows in that backward,
+ *                             expressed as a CSR-by-source gather (K7)
+ *   is_segment_pool_fwd/_bwd  torch_geometric.nn.global_mean_pool /
+ *                             global_max_pool (models/hybrid_models.py:331,
+ *                             models/ablation_models.py:296-297; K9)
+ *   is_vae_loss               Losses.regression_loss / BCE_loss
+ *                             (utils/loss.py:13-31; K11)
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  All buffers are
+ * device memory owned by the caller, fp32 / int32, row-major, contiguous unless
+ * a leading dimension `ld_*` (in elements) is given.  Kernels are enqueued on
+ * `stream` (a hipStream_t passed as void*) and are asynchronous.  Every function
+ * returns 0 on success, -22 (EINVAL) on a bad argument, -5 (EIO) if the launch
+ * failed; it never throws, allocates or keeps pointers.  Hidden width is 64.
+ */
+#ifndef IMMUNOSTRUCT_HIP_H
+#define IMMUNOSTRUCT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library version: major*10000 + minor*100 + patch */
+int is_version(void);
+
+/* MFMA operand/accumulator layout self-tests (one wave).
+ *   is_mfma_selftest:       out[32x64] = A[32x64] * W[64x64]^T
+ *   is_mfma_outer_selftest: out[64x64] = G[32x64]^T * M[32x64]                */
+int is_mfma_selftest(const float* A, const float* W, float* out, void* stream);
+int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* stream);
+
+/* Fused EGNN edge pass, forward, for one EGNNConv layer.
+ *   ps, pd   [N, ld_p]  node pre-projections of edge_mlp.0:  Ps = h W1s^T,
+ *                       Pd = h W1d^T + b1  (64 columns each are read)
+ *   x        [N, 3]     coordinates            ea [E, Fe] edge features, CSR slot order
+ *   rowptr   [N+1], srcs [E]   CSR by destination (in-edges of node v are the
+ *                       slots rowptr[v] .. rowptr[v+1])
+ *   w_r [64], w_a [64, Fe]   the radial / edge-feature columns of edge_mlp.0.weight
+ *   W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
+ *   h_neigh  [N, ld_hn] out: sum of messages     x_out [N, 3] out: x + mean coord message
+ *   z2s, z3s [E, 64]    out (may be NULL): pre-activations saved for the backward
+ *   Fe in [0, 8].                                                              */
+int is_egnn_edge_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                     const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                     const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                     const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                     float* z3s, int N, int Fe, void* stream);
+
+/* number of floats of the `partials` scratch buffer is_egnn_edge_bwd needs for `grid` workgroups */
+int is_egnn_edge_bwd_partials_floats(int grid);
+
+/* Fused EGNN edge pass, backward.  Inputs as in the forward plus
+ *   g_hn [N, ld_ghn] = dL/dh_neigh, g_xout [N,3] = dL/dx_out.
+ * Outputs: dZ1 [E,64] and dD [E,3] (per-edge gradients of the first edge-MLP
+ * pre-activation and of x_src - x_dst, CSR slot order, consumed by
+ * is_gather_segment_sum), dPd [N, ld_dpd], dx [N,3] (destination-side part,
+ * incl. the identity path), and the weight gradients gW2 [64,64], gWc1 [64,64],
+ * gb2, gbc1, gwc2, gw_r [64], gw_a [64,Fe].  `grid` persistent workgroups
+ * (<= number of 32-node tiles); `partials` scratch per the function above.     */
+int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                     const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                     const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                     const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
+                     float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid,
+                     float* gW2, float* gWc1, float* gb2, float* gbc1, float* gwc2, float* gw_r,
+                     float* gw_a, int N, int Fe, void* stream);
+
+/* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
+ * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
+int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
+                          float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
+
+/* Per-segment mean and/or max over rows seg_ptr[s] .. seg_ptr[s+1] of x [rows, ld_x] (C channels).
+ * out_mean / out_max [num_segments, C] may each be NULL.  Empty segment: mean 0, max 0.            */
+int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_ptr, float* out_mean, float* out_max,
+                        int num_segments, int C, void* stream);
+/* dx[row, c] = g_mean[s,c]/count + (x[row,c]==out_max[s,c] ? g_max[s,c]/ties : 0); g_mean/g_max may be NULL. */
+int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const float* out_max,
+                        const float* g_mean, const float* g_max, float* dx, int ld_dx, int num_segments,
+                        int C, void* stream);
+
+/* floats of scratch is_vae_loss needs */
+int is_loss_partials_floats(void);
+/* mode 0: c_pred*MSE(logit,y), mode 1: c_pred*BCEWithLogits(logit,y,pos_weight);
+ * + c_mse*MSE(recon,x) + c_kld*(-0.5*mean(1+logvar-mu^2-exp(logvar))).
+ * recon/x/d_recon may be NULL with recon_total = 0, mu/logvar likewise with latent_total = 0.
+ * out[4] = {total, prediction term, recon MSE, KLD}; d_* receive d total / d input.           */
+int is_vae_loss(const float* recon, const float* x, float* d_recon, long long recon_total,
+                const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total,
+                const float* logit, const float* y, float* d_logit, int batch, int mode,
+                float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

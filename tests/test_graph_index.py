@@ -1,0 +1,56 @@
+"""Host-side logic: CSR index construction, batching, synthetic generator invariants."""
+import numpy as np
+import torch
+
+from immunostruct_amd import synthetic
+from immunostruct_amd.graph import PackedGraphBatch, batch
+
+
+def test_csr_by_destination_and_by_source():
+    raw = synthetic.make_batch(3, seed=9, n_pad=25, n_real_choices=(20, 23, 25))
+    g = PackedGraphBatch.from_raw(raw)
+    csr = g.csr()
+    src, dst = raw.src, raw.dst
+    rp = csr.rowptr_dst.numpy()
+    assert rp[0] == 0 and rp[-1] == raw.num_edges
+    for v in range(raw.num_nodes):
+        slots = np.arange(rp[v], rp[v + 1])
+        orig = csr.eperm.numpy()[slots]
+        assert (dst[orig] == v).all()
+        assert (np.diff(orig) > 0).all()           # stable: original relative order kept
+        assert (csr.src_sorted.numpy()[slots] == src[orig]).all()
+    rps, pos = csr.rowptr_src.numpy(), csr.pos_by_src.numpy()
+    seen = np.zeros(raw.num_edges, dtype=bool)
+    for u in range(raw.num_nodes):
+        for p in pos[rps[u]:rps[u + 1]]:
+            assert csr.src_sorted.numpy()[p] == u
+            seen[p] = True
+    assert seen.all()
+    assert g.seg_ptr().tolist() == [0, 25, 50, 75]
+    assert g.uniform_nodes_per_graph() == 25
+
+
+def test_batch_offsets_and_frames():
+    raws = [synthetic.make_batch(1, seed=s, n_pad=12, n_real_choices=(10, 11, 12)) for s in (1, 2)]
+    gs = [PackedGraphBatch.from_raw(r) for r in raws]
+    big = batch(gs)
+    assert big.num_nodes() == 24 and big.batch_size == 2
+    s, d = big.edges()
+    e0 = raws[0].num_edges
+    assert (s[e0:] >= 12).all() and (d[e0:] >= 12).all() and (s[:e0] < 12).all()
+    assert big.ndata["x"].shape == (24, 23) and big.edata["edge_attr"].shape[0] == s.numel()
+
+
+def test_synthetic_batch_invariants():
+    raw = synthetic.make_batch(8, seed=3)
+    assert raw.x.shape == (8 * 190, 23)
+    assert (raw.src != raw.dst).all()                       # no self loops (sqrt'(0) would be NaN)
+    onehot = raw.x[:, :20].sum(1)
+    real = onehot == 1
+    assert set(np.unique(onehot)) <= {0.0, 1.0}
+    assert real[raw.src].all() and real[raw.dst].all()      # padded nodes carry no edges
+    assert (raw.x[~real] == 0).all()
+    seq = raw.one_hot_sequence()
+    assert seq.shape == (8, 283, 21) and (seq.sum(-1) == 1).all()
+    again = synthetic.make_batch(8, seed=3)
+    assert np.array_equal(raw.x, again.x) and np.array_equal(raw.src, again.src)

@@ -1,0 +1,164 @@
+"""The oracle reproduces the golden vectors captured from the reference (runs anywhere, CPU)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from immunostruct_amd import synthetic
+from oracle import functional_ref as FR
+from oracle import graph_ref
+from tests import helpers as H
+
+torch.set_num_threads(1)
+BATCH = 16
+
+
+def _key(name, kw):
+    return name + ("" if not kw else f"/wt{int(kw['use_wt_for_downstream'])}")
+
+
+def _cases():
+    gold = H.golden("forward.npz")
+    names = sorted({k.split("/")[1] for k in gold.files if k.startswith("fwd/") and k.count("/") >= 2})
+    out = []
+    for n in names:
+        if "Comparative" in n:
+            out += [(n, dict(use_wt_for_downstream=True)), (n, dict(use_wt_for_downstream=False))]
+        else:
+            out.append((n, {}))
+    return out
+
+
+def test_inputs_regenerate_bit_identically():
+    raw = synthetic.make_batch(BATCH, seed=1)
+    h = hashlib.sha256()
+    for a in (raw.x, raw.src, raw.dst, raw.edge_attr, raw.seq_tokens, raw.prop):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert bytes(H.golden("forward.npz")["fwd/input_checksum"]).hex() == h.hexdigest()
+
+
+@pytest.mark.parametrize("name,kw", _cases())
+def test_forward_matches_reference_golden(name, kw):
+    gold = H.golden("forward.npz")
+    raw = synthetic.make_batch(BATCH, seed=1)
+    g = H.oracle_graph(raw)
+    seq, prop = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop)
+    sd = H.det_sd(H.model_shapes(name, **kw), seed=3)
+    it = FR.forward(name, sd, g, seq, prop, eps=H.make_eps(11, BATCH), **kw)
+    tag = f"fwd/{_key(name, kw)}"
+    np.testing.assert_array_equal(it["final_output"].numpy(), gold[f"{tag}/final_output"])
+    if f"{tag}/mu" in gold.files:
+        np.testing.assert_array_equal(it["mu"].numpy(), gold[f"{tag}/mu"])
+        np.testing.assert_array_equal(it["logvar"].numpy(), gold[f"{tag}/logvar"])
+        np.testing.assert_array_equal(it["recon_x"][:, H.RECON_COLS].numpy(), gold[f"{tag}/recon_x_cols"])
+    if f"{tag}/x_gat_node" in gold.files:
+        np.testing.assert_array_equal(it["x_gat_node"].numpy(), gold[f"{tag}/x_gat_node"])
+    if f"{tag}/attention_rows" in gold.files:
+        np.testing.assert_array_equal(it["attention_weights"][..., H.ATTN_ROWS, :].numpy(), gold[f"{tag}/attention_rows"])
+    if f"{tag}/node_prediction" in gold.files:
+        np.testing.assert_array_equal(it["node_prediction"].numpy(), gold[f"{tag}/node_prediction"])
+
+
+@pytest.mark.parametrize("name", ["HybridModelv2_Comparative", "HybridModel_Comparative"])
+@pytest.mark.parametrize("wt", [True, False])
+def test_comparative_step_matches_reference_golden(name, wt):
+    gold = H.golden("comparative.npz")
+    raw_c, raw_w = synthetic.make_batch(BATCH, seed=21), synthetic.make_batch(BATCH, seed=22)
+    gc, gw = H.oracle_graph(raw_c), H.oracle_graph(raw_w)
+    sc, sw = torch.from_numpy(raw_c.one_hot_sequence()), torch.from_numpy(raw_w.one_hot_sequence())
+    pc, pw = torch.from_numpy(raw_c.prop), torch.from_numpy(raw_w.prop)
+    y = torch.from_numpy(raw_c.y_bin)
+    sd = {k: v.requires_grad_(True) for k, v in H.det_sd(H.model_shapes(name, use_wt_for_downstream=wt), seed=5).items()}
+    psd = H.det_sd({"projector.0.weight": (128, 104), "projector.1.weight": (128,), "projector.1.bias": (128,),
+                    "projector.3.weight": (128, 128)}, seed=9)
+    o = FR.forward_comparative(name, sd, (gc, gw), (sc, sw), (pc, pw), (H.make_eps(31, BATCH), H.make_eps(32, BATCH)),
+                               use_wt_for_downstream=wt)
+    tag = f"cmp/{name}/wt{int(wt)}"
+    np.testing.assert_array_equal(o["final_output"].detach().numpy(), gold[f"{tag}/final_output"])
+    np.testing.assert_array_equal(o["embeddings"][0].detach().numpy(), gold[f"{tag}/emb_cancer"])
+    lc = FR.bce_loss(o["cancer"]["recon_x"], sc, o["cancer"]["mu"], o["cancer"]["logvar"], o["final_output"], y, H.VAE_IN, 81.0 / 19.0)
+    lw = FR.bce_loss(o["wt"]["recon_x"], sw, o["wt"]["mu"], o["wt"]["logvar"], o["final_output"], y, H.VAE_IN, 81.0 / 19.0)
+    lcon = FR.paired_contrastive_loss(psd, o["embeddings"][0], o["embeddings"][1], y)
+    loss = (lc + lw) / 2 + 0.01 * lcon
+    assert abs(float(lc) - float(gold[f"{tag}/bce_cancer"])) <= 1e-6 * abs(float(lc))
+    assert abs(float(lcon) - float(gold[f"{tag}/contrastive"])) <= 1e-5 * abs(float(lcon))
+    assert abs(float(loss) - float(gold[f"{tag}/loss"])) <= 1e-6 * abs(float(loss))
+    loss.backward()
+    for key in [k for k in gold.files if k.startswith(f"{tag}/grad/")]:
+        pname = key.split("/grad/")[1]
+        H.assert_close(sd[pname].grad, gold[key], 2e-5, f"grad {pname}")
+
+
+def test_contrastive_early_outs_match_reference():
+    gold = H.golden("comparative.npz")
+    assert float(gold["cmp/contrastive_all_equal"]) == 0.0 and float(gold["cmp/contrastive_continuous"]) == 0.0
+    psd = H.det_sd({"projector.0.weight": (128, 104), "projector.1.weight": (128,), "projector.1.bias": (128,),
+                    "projector.3.weight": (128, 128)}, seed=9)
+    e = torch.randn(8, 104)
+    assert FR.paired_contrastive_loss(psd, e, e, torch.ones(8)) == 0
+    assert FR.paired_contrastive_loss(psd, e, e, torch.linspace(-1, 1, 8)) == 0
+
+
+def _loss_inputs():
+    rng = np.random.RandomState(77)
+    b = BATCH
+    recon = torch.from_numpy(rng.normal(size=(b, H.VAE_IN)).astype(np.float32) * 0.3).requires_grad_(True)
+    x = torch.from_numpy(synthetic.make_batch(b, seed=4).one_hot_sequence())
+    mu = torch.from_numpy(rng.normal(size=(b, 32)).astype(np.float32)).requires_grad_(True)
+    lv = torch.from_numpy(rng.normal(size=(b, 32)).astype(np.float32) * 0.5).requires_grad_(True)
+    logit = torch.from_numpy(rng.normal(size=(b, 1)).astype(np.float32)).requires_grad_(True)
+    y_reg = torch.from_numpy(rng.uniform(-1, 1, size=(b,)).astype(np.float32))
+    y_bin = torch.from_numpy((rng.uniform(size=(b,)) < 0.3).astype(np.float32))
+    ec = torch.from_numpy(rng.normal(size=(b, 104)).astype(np.float32)).requires_grad_(True)
+    ew = torch.from_numpy(rng.normal(size=(b, 104)).astype(np.float32)).requires_grad_(True)
+    return recon, x, mu, lv, logit, y_reg, y_bin, ec, ew
+
+
+@pytest.mark.parametrize("seq_flag", [True, False])
+@pytest.mark.parametrize("kind", ["regression", "bce"])
+def test_losses_match_reference_golden(kind, seq_flag):
+    gold = H.golden("losses.npz")
+    recon, x, mu, lv, logit, y_reg, y_bin, _, _ = _loss_inputs()
+    if kind == "regression":
+        val = FR.regression_loss(recon, x, mu, lv, logit, y_reg, H.VAE_IN, sequence=seq_flag)
+    else:
+        val = FR.bce_loss(recon, x, mu, lv, logit, y_bin, H.VAE_IN, 81.0 / 19.0, sequence=seq_flag)
+    val.backward()
+    tag = f"loss/{kind}/seq{int(seq_flag)}"
+    assert abs(float(val) - float(gold[f"{tag}/value"])) <= 1e-6 * abs(float(val))
+    H.assert_close(logit.grad, gold[f"{tag}/grad_logit"], 1e-6, "grad logit")
+    if seq_flag:
+        H.assert_close(recon.grad[:, H.RECON_COLS], gold[f"{tag}/grad_recon_cols"], 1e-6, "grad recon")
+        H.assert_close(mu.grad, gold[f"{tag}/grad_mu"], 1e-6, "grad mu")
+        H.assert_close(lv.grad, gold[f"{tag}/grad_logvar"], 1e-6, "grad logvar")
+
+
+def test_contrastive_matches_reference_golden():
+    gold = H.golden("losses.npz")
+    *_, y_bin, ec, ew = _loss_inputs()
+    psd = H.det_sd({"projector.0.weight": (128, 104), "projector.1.weight": (128,), "projector.1.bias": (128,),
+                    "projector.3.weight": (128, 128)}, seed=9)
+    val = FR.paired_contrastive_loss(psd, ec, ew, y_bin)
+    val.backward()
+    assert abs(float(val) - float(gold["contrastive/value"])) <= 1e-5 * abs(float(val))
+    H.assert_close(ec.grad, gold["contrastive/grad_cancer"], 2e-5, "grad cancer emb")
+    H.assert_close(ew.grad, gold["contrastive/grad_wt"], 2e-5, "grad wt emb")
+
+
+@pytest.mark.parametrize("fe,seed", [(1, 1), (8, 41)])
+def test_egnn_trajectory_matches_golden(fe, seed):
+    gold = H.golden("egnn.npz")
+    raw = synthetic.make_batch(2, seed=seed, deg_extra=2 if fe == 1 else 7, edge_feats=fe)
+    src, dst = torch.from_numpy(raw.src), torch.from_numpy(raw.dst)
+    sd32 = H.det_sd(H.egnn_shapes([20, 64, 64], fe), seed=13)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        sd = {k: v.to(dt) for k, v in sd32.items()}
+        h = torch.from_numpy(raw.x[:, :20]).to(dt)
+        x = torch.from_numpy(raw.x[:, 20:]).to(dt)
+        a = torch.from_numpy(raw.edge_attr).to(dt)
+        for i in range(3):
+            h, x = graph_ref.egnn_conv(sd, f"GCN_layers.{i}.", src, dst, raw.num_nodes, h, x, a)
+            tol = 1e-5 if dt == torch.float32 else 1e-12
+            H.assert_close(h, gold[f"egnn/fe{fe}/{tag}/layer{i}/h"], tol, f"h layer {i} {tag}")
+            H.assert_close(x, gold[f"egnn/fe{fe}/{tag}/layer{i}/x"], tol, f"x layer {i} {tag}")
