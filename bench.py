@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Throughput of the ImmunoStruct train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic peptide-MHC residue graphs already
+resident in HBM: HybridModelv2 forward (6 EGNN layers -> node attention -> mean-pool, sequence VAE,
+property MLP, fusion head) + regression loss + backward + Adam, i.e. the inner loop of
+``procedures/train.py:18-29`` on BASELINE config 2 (B = 128 graphs of 190 padded nodes per GPU,
+``--full-sequence --sequence-loss``).  N > 1: one process per GPU (launched by torch.distributed.run),
+graphs sharded over ranks (weak scaling), one RCCL all-reduce of the flat gradient per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline"     -- the dominant HIP kernel (fused EGNN edge backward): algorithmic FLOP / launch divided
+                    by its mean launch duration measured with HIP events inside the timed region,
+                    against the fp32 MFMA peak; the HBM view of the same launches is included.
+  "cpu_baseline" -- the CPU oracle (a port of the reference's un-fused PyTorch path) timed on this
+                    box's host cores on a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from immunostruct_amd import distributed as D  # noqa: E402
+from immunostruct_amd import functional as HF  # noqa: E402
+from immunostruct_amd import synthetic  # noqa: E402
+from immunostruct_amd.graph import PackedGraphBatch  # noqa: E402
+from immunostruct_amd.models import model_map  # noqa: E402
+from immunostruct_amd.utils import Losses  # noqa: E402
+
+VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+H = 64
+
+
+def edge_pass_algorithmic(n_nodes, n_edges, din, fe):
+    """Algorithmic bytes / FLOP of one fused EGNN edge launch (DESIGN.md section "Roofline accounting").
+
+    bytes follow SURVEY.md section 8(d); FLOP count only the per-edge dense layers the fused kernel
+    actually needs after hoisting the first edge-MLP layer to node level (2 x 64x64 + 64 forward;
+    backward = 2 data-grad + 2 weight-grad 64x64 products).
+    """
+    bytes_fwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + (n_nodes + 1) * 4 + n_nodes * (din * 4 + 12) + n_nodes * (H * 4 + 12)
+    bytes_bwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + n_nodes * H * 4 + 2 * n_nodes * (din + 3) * 4
+    flop_fwd = 2.0 * n_edges * (H * H + H * H + H)
+    flop_bwd = 2.0 * n_edges * (4 * H * H + 2 * H)
+    return bytes_fwd, bytes_bwd, flop_fwd, flop_bwd
+
+
+def build_batches(n_batches, batch, deg_extra, device, seed0):
+    out = []
+    for i in range(n_batches):
+        raw = synthetic.make_batch(batch, seed=seed0 + i, deg_extra=deg_extra)
+        g = PackedGraphBatch.from_raw(raw, device=device)
+        out.append(dict(g=g, seq=torch.from_numpy(raw.one_hot_sequence()).to(device),
+                        prop=torch.from_numpy(raw.prop).to(device), y=torch.from_numpy(raw.y_reg).to(device),
+                        raw=raw))
+    return out
+
+
+def cpu_baseline(batch, deg_extra, budget_s=20.0):
+    """Oracle train step (forward + loss + backward + Adam) on the host cores; returns graphs/s."""
+    from oracle import functional_ref as FR
+    from oracle import graph_ref
+    threads = torch.get_num_threads()
+    raw = synthetic.make_batch(batch, seed=1, deg_extra=deg_extra)
+    shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    g = graph_ref.RefGraph(raw.src, raw.dst, raw.num_nodes, raw.batch_num_nodes)
+    g.ndata["x"], g.edata["edge_attr"] = torch.from_numpy(raw.x), torch.from_numpy(raw.edge_attr)
+    seq, prop, y = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop), torch.from_numpy(raw.y_reg)
+
+    def step():
+        opt.zero_grad()
+        it = FR.forward("HybridModelv2", sd, g, seq, prop)
+        loss = FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 40:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * n / dt, 2), unit="graphs/s", cores=threads, kind="port",
+                sample=f"{n} train steps of B={batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam, "
+                       f"{threads} torch threads, {dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="graphs per GPU per step")
+    ap.add_argument("--deg-extra", type=int, default=2, help="random contact edges per residue (E/N - 1)")
+    ap.add_argument("--model", default="HybridModelv2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    torch.manual_seed(1)
+    model = model_map[args.model](vae_input_dim=VAE_IN, device=dev).to(dev)
+    D.broadcast_parameters(model)
+    model.train()
+    reducer = D.FlatGradReducer(model.parameters(), world=world)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+    pool = build_batches(4, args.batch, args.deg_extra, dev, seed0=1000 * (rank + 1))
+
+    def step(i):
+        b = pool[i % len(pool)]
+        reducer.zero()
+        recon, mu, logvar, final = model(b["g"], b["seq"], b["prop"])
+        loss = losses.regression_loss(recon, b["seq"], mu, logvar, final, b["y"])
+        loss.backward()
+        reducer.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    HF.KernelTimer.reset()
+    HF.KernelTimer.enabled = not args.no_kernel_timers
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    HF.KernelTimer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(last.detach())
+
+    if rank == 0:
+        graphs = args.batch * world * args.steps
+        n_nodes = pool[0]["raw"].num_nodes
+        n_edges = float(np.mean([b["raw"].num_edges for b in pool]))
+        timers = HF.KernelTimer.summary()
+        roof = None
+        if "egnn_edge_bwd" in timers:
+            # 5 of the 6 launches per step have Din = 64 (layer 0: Din = 20); weight the algorithmic counts
+            per = [edge_pass_algorithmic(n_nodes, n_edges, din, 1) for din in (20, 64, 64, 64, 64, 64)]
+            b_fwd, b_bwd = np.mean([p[0] for p in per]), np.mean([p[1] for p in per])
+            f_fwd, f_bwd = np.mean([p[2] for p in per]), np.mean([p[3] for p in per])
+            n_b, ms_b = timers["egnn_edge_bwd"]
+            n_f, ms_f = timers["egnn_edge_fwd"]
+            tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
+            roof = dict(kernel="egnn_edge_bwd_kernel (+ partial reduce)", bound="mfma", achieved=round(tf_b, 2),
+                        peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4),
+                        traffic=None, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
+                        algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
+                        hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                      frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
+                        forward_kernel=dict(kernel="egnn_edge_fwd_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
+                                            tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
+                                            hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
+                                            frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
+            if "gather_segment_sum" in timers:
+                n_g, ms_g = timers["gather_segment_sum"]
+                gbytes = n_edges * (H * 4 + 12 + 4) + n_nodes * (H * 4 + 12 + 4)
+                roof["gather_kernel"] = dict(kernel="gather_segment_sum_kernel", bound="hbm", mean_launch_us=round(ms_g * 1e3, 2),
+                                             launches=n_g, achieved=round(gbytes / (ms_g * 1e-3) / 1e9, 1), unit="GB/s",
+                                             frac=round(gbytes / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.batch, args.deg_extra)
+        line = dict(metric="peptide-MHC graphs/sec (train step)", value=round(graphs / dt, 1), unit="graphs/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=f"IEDB pretrain step (BASELINE config 2): {args.model}, full-sequence + sequence-loss, "
+                                         f"regression loss, Adam; B={args.batch} graphs/GPU x 190 padded nodes, "
+                                         f"E~{int(n_edges)} edges/batch (deg_extra={args.deg_extra}), Fe=1",
+                                global_batch=args.batch * world, nodes_per_batch=n_nodes, edges_per_batch=int(n_edges),
+                                parallelism=f"dp{world}", final_loss=round(final_loss, 5)),
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,8 +16,47 @@ _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
 _NODES_PER_TILE = 32
 
 
-def _zeros_like_rows(n, c, ref):
-    return torch.zeros(n, c, dtype=torch.float32, device=ref.device)
+class KernelTimer:
+    """Optional HIP-event bracketing of individual kernel launches (used by bench.py for the roofline).
+
+    Events are recorded on the stream the kernel is launched on (torch's current stream).
+    """
+    enabled = False
+    records = {}
+
+    class _Span:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            if KernelTimer.enabled:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if KernelTimer.enabled:
+                self.e1.record()
+                KernelTimer.records.setdefault(self.name, []).append((self.e0, self.e1))
+            return False
+
+    @classmethod
+    def span(cls, name):
+        return cls._Span(name)
+
+    @classmethod
+    def reset(cls):
+        cls.records = {}
+
+    @classmethod
+    def summary(cls):
+        """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in cls.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
 
 
 class EGNNEdgeFn(torch.autograd.Function):
@@ -53,11 +92,12 @@ class EGNNEdgeFn(torch.autograd.Function):
         z2s = torch.empty(max(e, 1), HIDDEN, dtype=torch.float32, device=x.device) if need_grad else None
         z3s = torch.empty(max(e, 1), HIDDEN, dtype=torch.float32, device=x.device) if need_grad else None
         pd_view = psd[:, HIDDEN:]
-        code = lib.is_egnn_edge_fwd(
-            _lib.ptr(psd), _lib.ptr(pd_view), ld_p, _lib.ptr(x), _lib.ptr(ea),
-            _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
-            _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-            _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, _lib.stream_ptr())
+        with KernelTimer.span("egnn_edge_fwd"):
+            code = lib.is_egnn_edge_fwd(
+                _lib.ptr(psd), _lib.ptr(pd_view), ld_p, _lib.ptr(x), _lib.ptr(ea),
+                _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
+                _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+                _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, _lib.stream_ptr())
         _lib.check(code, "is_egnn_edge_fwd")
         ctx.csr, ctx.fe, ctx.ld_p = csr, fe, ld_p
         ctx.save_for_backward(psd, x, ea, w_r, w_a, W2, Wc1, wc2, z2s, z3s)
@@ -90,18 +130,20 @@ class EGNNEdgeFn(torch.autograd.Function):
         gw_r = torch.empty_like(gb2)
         gw_a = torch.zeros(HIDDEN, max(fe, 1), dtype=torch.float32, device=dev)
         st = _lib.stream_ptr()
-        code = lib.is_egnn_edge_bwd(
-            _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), ld_p, _lib.ptr(x), _lib.ptr(ea),
-            _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
-            _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(z2s), _lib.ptr(z3s),
-            _lib.ptr(g_hn), ld_ghn, _lib.ptr(g_xout), _lib.ptr(dZ1), _lib.ptr(dD),
-            _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(partials), grid,
-            _lib.ptr(gW2), _lib.ptr(gWc1), _lib.ptr(gb2), _lib.ptr(gbc1), _lib.ptr(gwc2), _lib.ptr(gw_r),
-            _lib.ptr(gw_a), n, fe, st)
+        with KernelTimer.span("egnn_edge_bwd"):
+            code = lib.is_egnn_edge_bwd(
+                _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), ld_p, _lib.ptr(x), _lib.ptr(ea),
+                _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
+                _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(z2s), _lib.ptr(z3s),
+                _lib.ptr(g_hn), ld_ghn, _lib.ptr(g_xout), _lib.ptr(dZ1), _lib.ptr(dD),
+                _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(partials), grid,
+                _lib.ptr(gW2), _lib.ptr(gWc1), _lib.ptr(gb2), _lib.ptr(gbc1), _lib.ptr(gwc2), _lib.ptr(gw_r),
+                _lib.ptr(gw_a), n, fe, st)
         _lib.check(code, "is_egnn_edge_bwd")
         # source-side scatter-add as a CSR-by-source gather: dPs[u] = sum dz1, dx[u] += sum dD
-        code = lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src),
-                                         _lib.ptr(csr.pos_by_src), _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st)
+        with KernelTimer.span("gather_segment_sum"):
+            code = lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src),
+                                             _lib.ptr(csr.pos_by_src), _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st)
         _lib.check(code, "is_gather_segment_sum")
         g_wa = gw_a if fe else None
         # inputs: psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr

@@ -1,0 +1,253 @@
+"""GPU parity tests of the individual HIP kernels against the CPU oracle (through the C ABI).
+
+Tolerances (scaled max error = max|hip - oracle| / max|oracle|, fp32 both sides):
+  forward values 2e-5, gradients 1e-4 -- the fp32 oracle itself is ~1e-6..1e-5 away from the
+  fp64 oracle on these quantities, and the kernels use a different (hoisted, MFMA k-split)
+  summation order.  Deterministic kernels: repeated runs must be bit-identical.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from immunostruct_amd import _lib, synthetic
+from immunostruct_amd import functional as HF
+from immunostruct_amd.graph import PackedGraphBatch
+from immunostruct_amd.nn import EGNNConv
+from oracle import functional_ref as FR
+from oracle import graph_ref
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 2e-5, 1e-4
+
+
+def test_mfma_layout_selftests(cuda_device):
+    """A . W^T and G^T . M through the kernels' own tile routines, ASYMMETRIC operands."""
+    lib = _lib.load()
+    rng = np.random.RandomState(0)
+    a = torch.from_numpy(rng.normal(size=(32, 64)).astype(np.float32))
+    w = torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32))
+    out = torch.zeros(32, 64, device=cuda_device)
+    a_d, w_d = a.to(cuda_device), w.to(cuda_device)
+    assert lib.is_mfma_selftest(_lib.ptr(a_d), _lib.ptr(w_d), _lib.ptr(out), _lib.stream_ptr()) == 0
+    H.assert_close(out, a.double() @ w.double().T, 1e-6, "mm_rows")
+    # identity check catches row/col swaps
+    eye = torch.eye(64)[:32].contiguous().to(cuda_device)
+    assert lib.is_mfma_selftest(_lib.ptr(eye), _lib.ptr(w_d), _lib.ptr(out), _lib.stream_ptr()) == 0
+    assert torch.equal(out.cpu(), w.T[:32].contiguous())
+    g = torch.from_numpy(rng.normal(size=(32, 64)).astype(np.float32))
+    m = torch.from_numpy(rng.normal(size=(32, 64)).astype(np.float32))
+    out2 = torch.zeros(64, 64, device=cuda_device)
+    g_d, m_d = g.to(cuda_device), m.to(cuda_device)
+    assert lib.is_mfma_outer_selftest(_lib.ptr(g_d), _lib.ptr(m_d), _lib.ptr(out2), _lib.stream_ptr()) == 0
+    H.assert_close(out2, g.double().T @ m.double(), 1e-6, "mm_outer")
+
+
+def _raw_cases():
+    return {
+        "padded190_deg3": synthetic.make_batch(3, seed=1),
+        "ragged_nodes": synthetic.make_batch(2, seed=2, n_pad=45, n_real_choices=(40, 43, 45)),   # N = 90, not a tile multiple
+        "dense_fe8": synthetic.make_batch(2, seed=3, n_pad=70, n_real_choices=(64, 66, 70), deg_extra=9, edge_feats=8),
+        "single_graph_small": synthetic.make_batch(1, seed=4, n_pad=9, n_real_choices=(7, 8, 9), deg_extra=1),
+    }
+
+
+def _hub_graph():
+    """one node with 300 in-edges (segment spans several 128-edge windows) + isolated nodes."""
+    rng = np.random.RandomState(5)
+    n = 400
+    x = np.zeros((n, 23), dtype=np.float32)
+    x[np.arange(n), rng.randint(0, 20, n)] = 1
+    x[:, 20:] = rng.normal(size=(n, 3)).astype(np.float32) * 5
+    src = np.concatenate([np.arange(1, 301), rng.randint(0, 350, 200)])
+    dst = np.concatenate([np.zeros(300, dtype=np.int64), rng.randint(301, 350, 200)])
+    keep = src != dst
+    src, dst = src[keep].astype(np.int64), dst[keep].astype(np.int64)
+    return synthetic.RawBatch(x=x, src=src, dst=dst, edge_attr=np.ones((src.size, 1), np.float32),
+                              batch_num_nodes=np.array([n]), seq_tokens=np.zeros((1, 283), np.uint8),
+                              prop=np.zeros((1, 2), np.float32), y_reg=np.zeros(1, np.float32), y_bin=np.zeros(1, np.float32))
+
+
+def _no_edge_graph():
+    rng = np.random.RandomState(6)
+    n = 37
+    x = rng.normal(size=(n, 23)).astype(np.float32)
+    return synthetic.RawBatch(x=x, src=np.zeros(0, np.int64), dst=np.zeros(0, np.int64),
+                              edge_attr=np.ones((0, 1), np.float32), batch_num_nodes=np.array([n]),
+                              seq_tokens=np.zeros((1, 283), np.uint8), prop=np.zeros((1, 2), np.float32),
+                              y_reg=np.zeros(1, np.float32), y_bin=np.zeros(1, np.float32))
+
+
+def _run_layer(raw, din, fe, device, seed=17):
+    """Returns dicts (hip, oracle) with outputs and gradients of one EGNN layer under the same upstream grads."""
+    rng = np.random.RandomState(seed)
+    n = raw.num_nodes
+    if din == 20:
+        h0 = raw.x[:, :20].copy()
+    else:
+        h0 = rng.normal(size=(n, din)).astype(np.float32)
+    x0 = raw.x[:, 20:].copy()
+    gh = rng.normal(size=(n, 64)).astype(np.float32)
+    gx = rng.normal(size=(n, 3)).astype(np.float32)
+    sd = H.det_sd(H.egnn_shapes([din], fe, prefix="L"), seed=seed)
+    # ---- oracle (CPU fp32) ----
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    h_o = torch.from_numpy(h0).requires_grad_(True)
+    x_o = torch.from_numpy(x0).requires_grad_(True)
+    a_o = torch.from_numpy(raw.edge_attr) if fe else None
+    ho, xo = graph_ref.egnn_conv(sd_o, "L0.", torch.from_numpy(raw.src), torch.from_numpy(raw.dst), n, h_o, x_o, a_o)
+    ((ho * torch.from_numpy(gh)).sum() + (xo * torch.from_numpy(gx)).sum()).backward()
+    oracle = {"h": ho.detach(), "x": xo.detach(), "dh": h_o.grad, "dx": x_o.grad}
+    oracle.update({"d" + k[3:]: v.grad for k, v in sd_o.items()})
+    # ---- HIP ----
+    layer = EGNNConv(din, 64, 64, fe).to(device)
+    layer.load_state_dict({k[3:]: v for k, v in sd.items()})
+    g = H.product_graph(raw, device)
+    h_d = torch.from_numpy(h0).to(device).requires_grad_(True)
+    x_d = torch.from_numpy(x0).to(device).requires_grad_(True)
+    a_d = g.edata["edge_attr"] if fe else None
+    hd, xd = layer(g, h_d, x_d, a_d)
+    ((hd * torch.from_numpy(gh).to(device)).sum() + (xd * torch.from_numpy(gx).to(device)).sum()).backward()
+    hip = {"h": hd.detach().cpu(), "x": xd.detach().cpu(), "dh": h_d.grad.cpu(), "dx": x_d.grad.cpu()}
+    hip.update({"d" + k: v.grad.cpu() for k, v in layer.named_parameters()})
+    return hip, oracle
+
+
+@pytest.mark.parametrize("case", ["padded190_deg3", "ragged_nodes", "dense_fe8", "single_graph_small", "hub", "no_edges"])
+@pytest.mark.parametrize("din", [20, 64])
+def test_egnn_layer_forward_backward(cuda_device, case, din):
+    raw = {"hub": _hub_graph, "no_edges": _no_edge_graph}[case]() if case in ("hub", "no_edges") else _raw_cases()[case]
+    fe = raw.edge_attr.shape[1]
+    hip, oracle = _run_layer(raw, din, fe, cuda_device)
+    report = {}
+    for key in ("h", "x"):
+        report[key] = H.assert_close(hip[key], oracle[key], FWD_TOL, f"{case} {key}")
+    for key in oracle:
+        if key.startswith("d"):
+            if raw.num_edges == 0 and float(oracle[key].abs().max()) == 0.0:
+                assert float(hip[key].abs().max()) == 0.0, f"{case} {key} should be exactly zero"
+                continue
+            report[key] = H.assert_close(hip[key], oracle[key], GRAD_TOL, f"{case} {key}")
+    print(case, din, {k: f"{v:.1e}" for k, v in report.items()})
+
+
+def test_egnn_layer_is_deterministic(cuda_device):
+    raw = synthetic.make_batch(4, seed=8)
+    a, _ = _run_layer(raw, 64, 1, cuda_device)
+    b, _ = _run_layer(raw, 64, 1, cuda_device)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k} differs between two identical runs"
+
+
+def test_egnn_vs_fp64_error_budget(cuda_device):
+    """HIP-vs-fp64 error must be of the same order as fp32-oracle-vs-fp64 error."""
+    raw = synthetic.make_batch(3, seed=12)
+    sd = H.det_sd(H.egnn_shapes([20, 64, 64, 64, 64, 64], 1), seed=21)
+    src, dst = torch.from_numpy(raw.src), torch.from_numpy(raw.dst)
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        h, x = torch.from_numpy(raw.x[:, :20]).to(dt), torch.from_numpy(raw.x[:, 20:]).to(dt)
+        a = torch.from_numpy(raw.edge_attr).to(dt)
+        for i in range(6):
+            h, x = graph_ref.egnn_conv({k: v.to(dt) for k, v in sd.items()}, f"GCN_layers.{i}.", src, dst, raw.num_nodes, h, x, a)
+        outs[dt] = (h, x)
+    g = H.product_graph(raw, cuda_device)
+    layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(cuda_device) for i in range(6)]
+    for i, layer in enumerate(layers):
+        layer.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"GCN_layers.{i}.")})
+    with torch.no_grad():
+        h, x = g.ndata["x"][:, :20], g.ndata["x"][:, 20:]
+        for layer in layers:
+            h, x = layer(g, h, x, g.edata["edge_attr"])
+    e_hip = H.rel_err(h.cpu(), outs[torch.float64][0])
+    e_f32 = H.rel_err(outs[torch.float32][0], outs[torch.float64][0])
+    print(f"6-layer h: hip-vs-f64 {e_hip:.2e}, f32oracle-vs-f64 {e_f32:.2e}")
+    assert e_hip <= max(8 * e_f32, 2e-5)
+    H.assert_close(h.cpu(), outs[torch.float32][0], 5e-5, "6-layer h vs fp32 oracle")
+    H.assert_close(x.cpu(), outs[torch.float32][1], 5e-5, "6-layer x vs fp32 oracle")
+
+
+def test_egnn_golden_trajectory(cuda_device):
+    gold = H.golden("egnn.npz")
+    for fe, seed in ((1, 1), (8, 41)):
+        raw = synthetic.make_batch(2, seed=seed, deg_extra=2 if fe == 1 else 7, edge_feats=fe)
+        sd = H.det_sd(H.egnn_shapes([20, 64, 64], fe), seed=13)
+        g = H.product_graph(raw, cuda_device)
+        h, x = g.ndata["x"][:, :20], g.ndata["x"][:, 20:]
+        with torch.no_grad():
+            for i in range(3):
+                layer = EGNNConv(20 if i == 0 else 64, 64, 64, fe).to(cuda_device)
+                layer.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"GCN_layers.{i}.")})
+                h, x = layer(g, h, x, g.edata["edge_attr"])
+                H.assert_close(h.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/h"], 3e-5, f"fe{fe} layer{i} h vs f64 golden")
+                H.assert_close(x.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/x"], 3e-5, f"fe{fe} layer{i} x vs f64 golden")
+
+
+@pytest.mark.parametrize("mode", ["mean", "max", "meanmax"])
+def test_segment_pool(cuda_device, mode):
+    rng = np.random.RandomState(3)
+    counts = [190, 0, 17, 190, 1]
+    n = sum(counts)
+    x = rng.normal(size=(n, 64)).astype(np.float32)
+    x[5] = x[9] = x[100] = 7.5          # exact ties for the max (identical padded rows in practice)
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
+    idx = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts))
+    xo = torch.from_numpy(x).requires_grad_(True)
+    parts = []
+    if mode in ("mean", "meanmax"):
+        parts.append(graph_ref.global_mean_pool(xo, idx, len(counts)))
+    if mode in ("max", "meanmax"):
+        parts.append(graph_ref.global_max_pool(xo, idx, len(counts)))
+    ref = torch.cat(parts, 1)
+    gup = torch.from_numpy(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    (ref * gup).sum().backward()
+    xd = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
+    out = HF.segment_pool(xd, ptr.to(cuda_device), mode)
+    (out * gup.to(cuda_device)).sum().backward()
+    H.assert_close(out.detach().cpu(), ref.detach(), 1e-6, f"pool {mode}")
+    H.assert_close(xd.grad.cpu(), xo.grad, 1e-6, f"pool {mode} grad")
+
+
+@pytest.mark.parametrize("seq_flag", [True, False])
+@pytest.mark.parametrize("kind", ["regression", "bce"])
+def test_fused_loss_matches_golden_and_oracle(cuda_device, kind, seq_flag):
+    from immunostruct_amd.utils import Losses
+    from tests.test_oracle_golden import _loss_inputs
+    gold = H.golden("losses.npz")
+    recon, x, mu, lv, logit, y_reg, y_bin, _, _ = _loss_inputs()
+    dev = cuda_device
+    t = [v.detach().to(dev).requires_grad_(True) for v in (recon, mu, lv, logit)]
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=seq_flag)
+    y = (y_reg if kind == "regression" else y_bin).to(dev)
+    fn = losses.regression_loss if kind == "regression" else losses.BCE_loss
+    val = fn(t[0], x.to(dev), t[1], t[2], t[3], y)
+    val.backward()
+    tag = f"loss/{kind}/seq{int(seq_flag)}"
+    assert abs(float(val) - float(gold[f"{tag}/value"])) <= 2e-6 * abs(float(gold[f"{tag}/value"]))
+    H.assert_close(t[3].grad.cpu(), gold[f"{tag}/grad_logit"], 2e-6, "grad logit")
+    if seq_flag:
+        H.assert_close(t[0].grad.cpu()[:, H.RECON_COLS], gold[f"{tag}/grad_recon_cols"], 2e-6, "grad recon")
+        H.assert_close(t[1].grad.cpu(), gold[f"{tag}/grad_mu"], 2e-6, "grad mu")
+        H.assert_close(t[2].grad.cpu(), gold[f"{tag}/grad_logvar"], 2e-6, "grad logvar")
+
+
+def test_contrastive_loss_matches_golden(cuda_device):
+    from immunostruct_amd.utils import PairedContrastiveLoss
+    from tests.test_oracle_golden import _loss_inputs
+    gold = H.golden("losses.npz")
+    *_, y_bin, ec, ew = _loss_inputs()
+    dev = cuda_device
+    pcl = PairedContrastiveLoss(embedding_dim=104, device=dev)
+    psd = H.det_sd({k: tuple(v.shape) for k, v in pcl.state_dict().items()}, seed=9)
+    pcl.load_state_dict(psd)
+    ecd, ewd = ec.detach().to(dev).requires_grad_(True), ew.detach().to(dev).requires_grad_(True)
+    val = pcl(ecd, ewd, y_bin.to(dev))
+    val.backward()
+    ref = float(gold["contrastive/value"])
+    assert abs(float(val) - ref) <= 1e-4 * abs(ref), (float(val), ref)   # north-star tolerance: 1e-4 rel
+    H.assert_close(ecd.grad.cpu(), gold["contrastive/grad_cancer"], 1e-4, "grad cancer emb")
+    H.assert_close(ewd.grad.cpu(), gold["contrastive/grad_wt"], 1e-4, "grad wt emb")
+    assert pcl(ecd, ewd, torch.ones(16, device=dev)) == 0
+    assert pcl(ecd, ewd, torch.linspace(-1, 1, 16, device=dev)) == 0
