@@ -27,10 +27,18 @@ SIGNATURES = {
     "is_version": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
     "is_mfma_outer_selftest": [_P, _P, _P, _P],
-    "is_egnn_edge_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "is_egnn_edge_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
     "is_egnn_edge_bwd_partials_floats": [_I],
-    "is_egnn_edge_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I,
-                         _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "is_egnn_edge_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I,
+                         _I, _I, _P],
+    "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _I, _P],
+    "is_egnn_node_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "is_node_proj_bwd_floats": [_I],
+    "is_node_proj_bwd": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P],
+    "is_egnn_node_bwd_floats": [_I],
+    "is_egnn_node_bwd": [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "is_reduce_partials_scratch_floats": [_I],
+    "is_reduce_partials": [_P, _I, _I, _P, _P, _P, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -48,18 +48,19 @@ __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
 __device__ __forceinline__ int tile_row(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
 
 // acc[nt] (32 x 32) += A[32 x K] * W[nt*32 .. nt*32+32) x K]^T
-//   a_lds: tile row 0 of A (row stride LD), w_lds: row 0 of W (row stride LD).
-template <int NT, int K>
+//   a_lds: tile row 0 of A (row stride LDA), w_lds: row 0 of W (row stride LDW).
+//   LDA/4 and LDW/4 must be odd (conflict-free b128 rows) and K a multiple of 8.
+template <int NT, int K, int LDA = LD, int LDW = LD>
 __device__ __forceinline__ void mm_rows(f32x16 (&acc)[NT], const float* a_lds, const float* w_lds, int lane) {
   const int r = lane & 31, hf = lane >> 5;
-  const float* ap = a_lds + r * LD + hf * (K / 2);
-  const float* wp = w_lds + r * LD + hf * (K / 2);
+  const float* ap = a_lds + r * LDA + hf * (K / 2);
+  const float* wp = w_lds + r * LDW + hf * (K / 2);
 #pragma unroll
   for (int s = 0; s < K / 2; s += 4) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(ap + s);
     f32x4 b[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LD + s);
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LDW + s);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -71,7 +72,7 @@ __device__ __forceinline__ void mm_rows(f32x16 (&acc)[NT], const float* a_lds, c
 
 // acc[mt][nt] (32 x 32) += sum over the 32 tile rows e of G[e][mt*32 + i] * M[e][nt*32 + j]
 //   (outer-product accumulation: the tile ROW index is the contraction index).
-template <int MT, int NT>
+template <int MT, int NT, int LDG = LD, int LDM = LD>
 __device__ __forceinline__ void mm_outer(f32x16 (&acc)[MT][NT], const float* g_lds, const float* m_lds, int lane) {
   const int r = lane & 31, hf = lane >> 5;
 #pragma unroll
@@ -79,15 +80,32 @@ __device__ __forceinline__ void mm_outer(f32x16 (&acc)[MT][NT], const float* g_l
     const int e = hf * (TE / 2) + s;
     float a[MT], b[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = g_lds[e * LD + mt * 32 + r];
+    for (int mt = 0; mt < MT; ++mt) a[mt] = g_lds[e * LDG + mt * 32 + r];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = m_lds[e * LD + nt * 32 + r];
+    for (int nt = 0; nt < NT; ++nt) b[nt] = m_lds[e * LDM + nt * 32 + r];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[i][t] = 0.0f;
+}
+template <int M, int N>
+__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[M][N]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
 }
 
 // sum of v over the 32 lanes that share hf (lanes differ in r = lane & 31).

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void egnn_edge_bwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs,
-    const float* __restrict__ w_r, const float* __restrict__ w_a,
+    const float* __restrict__ W1, int ldw, int din,
     const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ wc2,
     const float* __restrict__ z2s, const float* __restrict__ z3s,
     const float* __restrict__ g_hn, int ld_ghn, const float* __restrict__ g_xout,
@@ -75,15 +75,15 @@ __global__ __launch_bounds__(256, 1) void egnn_edge_bwd_kernel(
   load_matrix_lds_t(sm.w2t, W2, tid, 256);
   load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
 
-  const float wr_c = w_r[lane];
+  const float wr_c = W1[lane * ldw + 2 * din];
   float wa_c[FE_MAX];
 #pragma unroll
-  for (int f = 0; f < FE_MAX; ++f) wa_c[f] = (f < Fe) ? w_a[lane * Fe + f] : 0.0f;
+  for (int f = 0; f < FE_MAX; ++f) wa_c[f] = (f < Fe) ? W1[lane * ldw + 2 * din + 1 + f] : 0.0f;
   float wc2_c[2], wr_t[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     wc2_c[nt] = wc2[nt * 32 + r];
-    wr_t[nt] = w_r[nt * 32 + r];
+    wr_t[nt] = W1[(nt * 32 + r) * ldw + 2 * din];
   }
 
   // launch-persistent weight-gradient accumulators
@@ -407,52 +407,26 @@ __global__ __launch_bounds__(256, 1) void egnn_edge_bwd_kernel(
   }
 }
 
-// Sum the per-workgroup partial records (fixed order => deterministic) and scatter
-// them into the individual gradient buffers.
-__global__ void egnn_edge_bwd_reduce_kernel(const float* __restrict__ partials, int nparts,
-                                            float* __restrict__ gW2, float* __restrict__ gWc1,
-                                            float* __restrict__ gb2, float* __restrict__ gbc1,
-                                            float* __restrict__ gwc2, float* __restrict__ gw_r,
-                                            float* __restrict__ gw_a, int Fe) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= PART_STRIDE) return;
-  float v = 0.0f;
-  for (int p = 0; p < nparts; ++p) v += partials[(size_t)p * PART_STRIDE + idx];
-  if (idx < 4096) gW2[idx] = v;
-  else if (idx < 8192) gWc1[idx - 4096] = v;
-  else if (idx < 8256) gb2[idx - 8192] = v;
-  else if (idx < 8320) gbc1[idx - 8256] = v;
-  else if (idx < 8384) gwc2[idx - 8320] = v;
-  else if (idx < 8448) gw_r[idx - 8384] = v;
-  else {
-    const int k = idx - 8448, c = k / 8, f = k % 8;
-    if (f < Fe) gw_a[c * Fe + f] = v;
-  }
-}
-
 }  // namespace is
 
 extern "C" int is_egnn_edge_bwd_partials_floats(int grid) { return grid * is::PART_STRIDE; }
 
 extern "C" int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                                const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                                const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                                 const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                                 const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                                float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid,
-                                float* gW2, float* gWc1, float* gb2, float* gbc1, float* gwc2, float* gw_r,
-                                float* gw_a, int N, int Fe, void* stream) {
+                                float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
+                                int Fe, void* stream) {
   if (N <= 0) return 0;
   if (Fe < 0 || Fe > 8 || grid <= 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
   if (Fe <= 1) {
-    hipLaunchKernelGGL(is::egnn_edge_bwd_kernel<1>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, w_r,
-                       w_a, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
+    hipLaunchKernelGGL(is::egnn_edge_bwd_kernel<1>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
+                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
   } else {
-    hipLaunchKernelGGL(is::egnn_edge_bwd_kernel<8>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, w_r,
-                       w_a, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
+    hipLaunchKernelGGL(is::egnn_edge_bwd_kernel<8>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
+                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
   }
-  hipLaunchKernelGGL(is::egnn_edge_bwd_reduce_kernel, dim3((is::PART_STRIDE + 255) / 256), block, 0, st, partials,
-                     grid, gW2, gWc1, gb2, gbc1, gwc2, gw_r, gw_a, Fe);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

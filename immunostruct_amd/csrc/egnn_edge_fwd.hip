@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs,
-    const float* __restrict__ w_r, const float* __restrict__ w_a,
+    const float* __restrict__ W1, int ldw, int din,
     const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ Wc1, const float* __restrict__ bc1, const float* __restrict__ wc2,
     float* __restrict__ h_neigh, int ld_hn, float* __restrict__ x_out,
@@ -58,10 +58,11 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd_kernel(
   if (tid <= NV) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
 
   // lane = channel constants
-  const float wr_c = w_r[lane];
+  // radial / edge-feature columns of the native edge_mlp.0.weight [64, 2*din + 1 + Fe]
+  const float wr_c = W1[lane * ldw + 2 * din];
   float wa_c[FE_MAX];
 #pragma unroll
-  for (int f = 0; f < FE_MAX; ++f) wa_c[f] = (f < Fe) ? w_a[lane * Fe + f] : 0.0f;
+  for (int f = 0; f < FE_MAX; ++f) wa_c[f] = (f < Fe) ? W1[lane * ldw + 2 * din + 1 + f] : 0.0f;
   // lane = tile-column constants (col = nt*32 + r)
   float b2_c[2], bc1_c[2], wc2_c[2];
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd_kernel(
 }  // namespace is
 
 extern "C" int is_egnn_edge_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                                const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                                const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                                 const float* W2, const float* b2, const float* Wc1, const float* bc1,
                                 const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                                 float* z3s, int N, int Fe, void* stream) {
@@ -232,10 +233,10 @@ extern "C" int is_egnn_edge_fwd(const float* ps, const float* pd, int ld_p, cons
   const dim3 grid((N + is::NV - 1) / is::NV), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Fe <= 1) {
-    hipLaunchKernelGGL(is::egnn_edge_fwd_kernel<1>, grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, w_r, w_a,
+    hipLaunchKernelGGL(is::egnn_edge_fwd_kernel<1>, grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1, ldw, din,
                        W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, Fe);
   } else {
-    hipLaunchKernelGGL(is::egnn_edge_fwd_kernel<8>, grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, w_r, w_a,
+    hipLaunchKernelGGL(is::egnn_edge_fwd_kernel<8>, grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1, ldw, din,
                        W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, Fe);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;

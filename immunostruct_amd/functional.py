@@ -59,95 +59,244 @@ class KernelTimer:
         return out
 
 
-class EGNNEdgeFn(torch.autograd.Function):
-    """Fused edge pass of one EGNNConv layer (``csrc/egnn_edge_fwd.hip`` / ``_bwd.hip``).
+# ---------------------------------------------------------------------------
+# EGNN stack
+# ---------------------------------------------------------------------------
+PARAMS_PER_LAYER = 11
+# order of the per-layer parameter tensors handed to EGNNStackFn (the reference's native tensors):
+#   edge_mlp.0.weight [64, 2*Din+1+Fe], edge_mlp.0.bias, edge_mlp.2.weight, edge_mlp.2.bias,
+#   node_mlp.0.weight [64, Din+64], node_mlp.0.bias, node_mlp.2.weight, node_mlp.2.bias,
+#   coord_mlp.0.weight, coord_mlp.0.bias, coord_mlp.2.weight [1, 64]
+_EDGE_STRIDE = 8448 + 64 * 8
+_NODE_STRIDE = 64 * 128 + 64 * 64 + 128
+_PROJ_STRIDE = 128 * 64 + 64
+_plan_cache = {}
 
-    inputs : psd (N,128) = [h W1s^T | h W1d^T + b1], x (N,3), ea (E,Fe) in CSR slot
-             order, w_r (64,), w_a (64,Fe), W2 (64,64), b2, Wc1 (64,64), bc1, wc2 (64,)
-    outputs: h_neigh (N,64) = sum of messages, x_out (N,3) = x + mean coordinate message
+
+class _LayerPlan:
+    """Offsets of one layer's native gradient tensors in a flat buffer + the scatter maps that send the
+    kernels' partial-record layouts there (built once per (Din, Fe, device))."""
+
+    def __init__(self, din, fe, device):
+        import numpy as np
+        h = HIDDEN
+        self.din, self.fe = din, fe
+        self.ldw = 2 * din + 1 + fe
+        shapes = [(h, self.ldw), (h,), (h, h), (h,), (h, din + h), (h,), (h, h), (h,), (h, h), (h,), (1, h)]
+        self.shapes = shapes
+        offs, total = [], 0
+        for sh in shapes:
+            offs.append(total)
+            total += int(np.prod(sh))
+        self.offsets, self.total = offs, total
+        o_w1, o_b1, o_w2, o_b2, o_wn1, o_bn1, o_wn2, o_bn2, o_wc1, o_bc1, o_wc2 = offs
+        c = np.arange(h)
+        # edge record: dW2 | dWc1 | db2 | dbc1 | dwc2 | dw_r | dW_a[c][8]
+        edge = np.full(_EDGE_STRIDE, -1, dtype=np.int32)
+        edge[0:4096] = o_w2 + np.arange(4096)
+        edge[4096:8192] = o_wc1 + np.arange(4096)
+        edge[8192:8256] = o_b2 + c
+        edge[8256:8320] = o_bc1 + c
+        edge[8320:8384] = o_wc2 + c
+        edge[8384:8448] = o_w1 + c * self.ldw + 2 * din
+        for f in range(fe):
+            edge[8448 + c * 8 + f] = o_w1 + c * self.ldw + 2 * din + 1 + f
+        # node record: dWn1 [64][128] (h part padded to 64 | h_neigh part) | dWn2 | dbn1 | dbn2
+        node = np.full(_NODE_STRIDE, -1, dtype=np.int32)
+        oo, kk = np.meshgrid(c, np.arange(128), indexing="ij")
+        dst = np.where(kk < 64, np.where(kk < din, o_wn1 + oo * (din + h) + kk, -1), o_wn1 + oo * (din + h) + din + (kk - 64))
+        node[0:8192] = dst.reshape(-1)
+        node[8192:12288] = o_wn2 + np.arange(4096)
+        node[12288:12352] = o_bn1 + c
+        node[12352:12416] = o_bn2 + c
+        # proj record: dW1sd [128][64] | db1
+        proj = np.full(_PROJ_STRIDE, -1, dtype=np.int32)
+        cc, kk = np.meshgrid(np.arange(128), np.arange(64), indexing="ij")
+        dst = np.where(kk < din, np.where(cc < 64, o_w1 + cc * self.ldw + kk, o_w1 + (cc - 64) * self.ldw + din + kk), -1)
+        proj[0:8192] = dst.reshape(-1)
+        proj[8192:8256] = o_b1 + c
+        covered = np.zeros(total, dtype=bool)
+        for m in (edge, node, proj):
+            covered[m[m >= 0]] = True
+        assert covered.all(), "gradient scatter maps do not cover the layer's parameters"
+        self.edge_map = torch.from_numpy(edge).to(device)
+        self.node_map = torch.from_numpy(node).to(device)
+        self.proj_map = torch.from_numpy(proj).to(device)
+
+    def views(self, flat):
+        return [flat[o:o + int(torch.Size(sh).numel())].view(sh) for o, sh in zip(self.offsets, self.shapes)]
+
+
+def layer_plan(din, fe, device):
+    key = (din, fe, str(device))
+    if key not in _plan_cache:
+        _plan_cache[key] = _LayerPlan(din, fe, device)
+    return _plan_cache[key]
+
+
+def _grid_for(n_rows, rows_per_wg):
+    return max(1, min(_MAX_BWD_GRID, (n_rows + rows_per_wg - 1) // rows_per_wg))
+
+
+class EGNNStackFn(torch.autograd.Function):
+    """L chained EGNNConv layers as fused HIP kernels (2 launches per layer forward, 4 + reductions backward).
+
+    forward(h0 (N, Din0) [row stride may exceed Din0], x0 (N,3), ea_csr (E,Fe) | None, csr, n_layers, *params)
+      -> (h_L (N,64), x_L (N,3)).  Layer 0 has Din0 in {20, 64}; later layers 64.
     """
 
     @staticmethod
-    def forward(ctx, psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr):
+    def forward(ctx, h0, x0, ea, csr, n_layers, *params):
         lib = _lib.load()
-        _lib.require_device(psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr.rowptr_dst)
+        _lib.require_device(h0, x0, ea, csr.rowptr_dst, *params)
+        if len(params) != PARAMS_PER_LAYER * n_layers:
+            raise ValueError("expected 11 parameter tensors per layer")
         n, e = csr.num_nodes, csr.num_edges
-        if psd.shape != (n, 2 * HIDDEN):
-            raise ValueError(f"psd must be ({n}, {2 * HIDDEN}), got {tuple(psd.shape)}")
-        if x.shape != (n, 3):
-            raise ValueError(f"coordinates must be ({n}, 3), got {tuple(x.shape)}")
-        fe = int(ea.shape[1]) if ea is not None and ea.dim() == 2 else 0
+        dev = x0.device
+        din0 = int(h0.shape[1])
+        if din0 not in (20, HIDDEN):
+            raise ValueError(f"node feature width must be 20 or {HIDDEN}, got {din0}")
+        if h0.shape[0] != n or x0.shape != (n, 3):
+            raise ValueError("node feature / coordinate rows must equal the number of nodes")
+        fe = int(ea.shape[1]) if ea is not None else 0
         if fe > 8:
             raise ValueError("edge_feat_size > 8 is not supported by the HIP kernel")
-        if fe and ea.shape[0] != e:
-            raise ValueError("edge feature rows must equal the number of edges")
-        psd, ld_p = _lib.rows_ld(psd)
-        x = _lib.f32c(x)
+        h0, ld_h0 = _lib.rows_ld(h0)
+        x = _lib.f32c(x0)
         ea = _lib.f32c(ea) if fe else None
-        w_r, W2, b2, Wc1, bc1, wc2 = (_lib.f32c(t) for t in (w_r, W2, b2, Wc1, bc1, wc2))
-        w_a = _lib.f32c(w_a) if fe else None
+        params = [_lib.f32c(p) for p in params]
         need_grad = any(ctx.needs_input_grad)
-        h_neigh = torch.empty(n, HIDDEN, dtype=torch.float32, device=x.device)
-        x_out = torch.empty(n, 3, dtype=torch.float32, device=x.device)
-        z2s = torch.empty(max(e, 1), HIDDEN, dtype=torch.float32, device=x.device) if need_grad else None
-        z3s = torch.empty(max(e, 1), HIDDEN, dtype=torch.float32, device=x.device) if need_grad else None
-        pd_view = psd[:, HIDDEN:]
-        with KernelTimer.span("egnn_edge_fwd"):
-            code = lib.is_egnn_edge_fwd(
-                _lib.ptr(psd), _lib.ptr(pd_view), ld_p, _lib.ptr(x), _lib.ptr(ea),
-                _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
-                _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-                _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, _lib.stream_ptr())
-        _lib.check(code, "is_egnn_edge_fwd")
-        ctx.csr, ctx.fe, ctx.ld_p = csr, fe, ld_p
-        ctx.save_for_backward(psd, x, ea, w_r, w_a, W2, Wc1, wc2, z2s, z3s)
-        return h_neigh, x_out
+        st = _lib.stream_ptr()
+        f32 = dict(dtype=torch.float32, device=dev)
+        layers = []
+        P = PARAMS_PER_LAYER
+        w1_0, b1_0 = params[0], params[1]
+        psd = torch.empty(n, 2 * HIDDEN, **f32)
+        with KernelTimer.span("node_proj_fwd"):
+            _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), _lib.ptr(b1_0),
+                                            _lib.ptr(psd), n, st), "is_node_proj_fwd")
+        h_in, ld_h, din = h0, ld_h0, din0
+        for i in range(n_layers):
+            W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
+            ldw = int(W1.shape[1])
+            if ldw != 2 * din + 1 + fe:
+                raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
+            h_neigh = torch.empty(n, HIDDEN, **f32)
+            x_out = torch.empty(n, 3, **f32)
+            z2s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
+            z3s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
+            with KernelTimer.span("egnn_edge_fwd"):
+                _lib.check(lib.is_egnn_edge_fwd(
+                    _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
+                    _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
+                    _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+                    _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, st), "is_egnn_edge_fwd")
+            last = i == n_layers - 1
+            zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
+            h_out = torch.empty(n, HIDDEN, **f32)
+            psd_next = None if last else torch.empty(n, 2 * HIDDEN, **f32)
+            W1n = None if last else params[(i + 1) * P]
+            b1n = None if last else params[(i + 1) * P + 1]
+            with KernelTimer.span("egnn_node_fwd"):
+                _lib.check(lib.is_egnn_node_fwd(
+                    _lib.ptr(h_in), ld_h, din, _lib.ptr(h_neigh), HIDDEN, _lib.ptr(Wn1), _lib.ptr(bn1), _lib.ptr(Wn2),
+                    _lib.ptr(bn2), _lib.ptr(W1n), 0 if last else int(W1n.shape[1]), _lib.ptr(b1n), _lib.ptr(zn1),
+                    _lib.ptr(h_out), _lib.ptr(psd_next), n, st), "is_egnn_node_fwd")
+            layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
+                               h_out=h_out))
+            psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
+        ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers = layers, params, csr, ea, fe, n_layers
+        ctx.h0_needs_grad, ctx.x0_needs_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        return h_in, x
 
     @staticmethod
-    def backward(ctx, g_hn, g_xout):
+    def backward(ctx, g_h, g_x):
         lib = _lib.load()
-        psd, x, ea, w_r, w_a, W2, Wc1, wc2, z2s, z3s = ctx.saved_tensors
-        csr, fe, ld_p = ctx.csr, ctx.fe, ctx.ld_p
+        layers, params, csr, ea, fe, L = ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers
         n, e = csr.num_nodes, csr.num_edges
-        dev = x.device
-        if g_hn is None:
-            g_hn = torch.zeros(n, HIDDEN, dtype=torch.float32, device=dev)
-        if g_xout is None:
-            g_xout = torch.zeros(n, 3, dtype=torch.float32, device=dev)
-        g_hn, ld_ghn = _lib.rows_ld(g_hn)
-        g_xout = _lib.f32c(g_xout)
-        dZ1 = torch.empty(max(e, 1), HIDDEN, dtype=torch.float32, device=dev)
-        dD = torch.empty(max(e, 1), 3, dtype=torch.float32, device=dev)
-        dpsd = torch.empty(n, 2 * HIDDEN, dtype=torch.float32, device=dev)
-        dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        grid = max(1, min(_MAX_BWD_GRID, (n + _NODES_PER_TILE - 1) // _NODES_PER_TILE))
-        partials = torch.empty(lib.is_egnn_edge_bwd_partials_floats(grid), dtype=torch.float32, device=dev)
-        gW2 = torch.empty_like(W2)
-        gWc1 = torch.empty_like(Wc1)
-        gb2 = torch.empty(HIDDEN, dtype=torch.float32, device=dev)
-        gbc1 = torch.empty_like(gb2)
-        gwc2 = torch.empty_like(gb2)
-        gw_r = torch.empty_like(gb2)
-        gw_a = torch.zeros(HIDDEN, max(fe, 1), dtype=torch.float32, device=dev)
+        dev = params[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
         st = _lib.stream_ptr()
-        with KernelTimer.span("egnn_edge_bwd"):
-            code = lib.is_egnn_edge_bwd(
-                _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), ld_p, _lib.ptr(x), _lib.ptr(ea),
-                _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(w_r), _lib.ptr(w_a),
-                _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(z2s), _lib.ptr(z3s),
-                _lib.ptr(g_hn), ld_ghn, _lib.ptr(g_xout), _lib.ptr(dZ1), _lib.ptr(dD),
-                _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(partials), grid,
-                _lib.ptr(gW2), _lib.ptr(gWc1), _lib.ptr(gb2), _lib.ptr(gbc1), _lib.ptr(gwc2), _lib.ptr(gw_r),
-                _lib.ptr(gw_a), n, fe, st)
-        _lib.check(code, "is_egnn_edge_bwd")
-        # source-side scatter-add as a CSR-by-source gather: dPs[u] = sum dz1, dx[u] += sum dD
-        with KernelTimer.span("gather_segment_sum"):
-            code = lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src),
-                                             _lib.ptr(csr.pos_by_src), _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st)
-        _lib.check(code, "is_gather_segment_sum")
-        g_wa = gw_a if fe else None
-        # inputs: psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr
-        return dpsd, dx, None, gw_r, g_wa, gW2, gb2, gWc1, gbc1, gwc2, None
+        P = PARAMS_PER_LAYER
+        g_hd = _lib.f32c(g_h) if g_h is not None else torch.zeros(n, HIDDEN, **f32)
+        g_xc = _lib.f32c(g_x) if g_x is not None else torch.zeros(n, 3, **f32)
+        plans = [layer_plan(layers[i]["din"], fe, dev) for i in range(L)]
+        gflat = [torch.empty(pl.total, **f32) for pl in plans]
+        grid_e = _grid_for(n, _NODES_PER_TILE)
+        grid_n = _grid_for(n, 128)
+        part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)
+        part_n = torch.empty(grid_n * _NODE_STRIDE, **f32)
+        part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
+        scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_NODE_STRIDE), **f32)
+
+        def reduce(part, nparts, stride, mp, dst):
+            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, _lib.ptr(mp), _lib.ptr(dst), _lib.ptr(scratch), st),
+                       "is_reduce_partials")
+
+        g_psd_next = None
+        for i in reversed(range(L)):
+            lay = layers[i]
+            W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
+            ldw, din = int(W1.shape[1]), lay["din"]
+            # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
+            if g_psd_next is not None:
+                W1n = params[(i + 1) * P]
+                dh_total = torch.empty(n, HIDDEN, **f32)
+                with KernelTimer.span("node_proj_bwd"):
+                    _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), HIDDEN, HIDDEN,
+                                                    _lib.ptr(W1n), int(W1n.shape[1]), _lib.ptr(dh_total), _lib.ptr(part_p),
+                                                    grid_n, n, st), "is_node_proj_bwd")
+                reduce(part_p, grid_n, _PROJ_STRIDE, plans[i + 1].proj_map, gflat[i + 1])
+            else:
+                dh_total = g_hd
+            # (2) node MLP backward
+            need_dh = i > 0 or ctx.h0_needs_grad
+            d_h = torch.empty(n, HIDDEN, **f32) if need_dh else None
+            d_hn = torch.empty(n, HIDDEN, **f32)
+            with KernelTimer.span("egnn_node_bwd"):
+                _lib.check(lib.is_egnn_node_bwd(_lib.ptr(dh_total), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
+                                                HIDDEN, _lib.ptr(lay["zn1"]), _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(d_h),
+                                                _lib.ptr(d_hn), _lib.ptr(part_n), grid_n, n, st), "is_egnn_node_bwd")
+            reduce(part_n, grid_n, _NODE_STRIDE, plans[i].node_map, gflat[i])
+            # (3) fused edge backward + source-side gather
+            dZ1 = torch.empty(max(e, 1), HIDDEN, **f32)
+            dD = torch.empty(max(e, 1), 3, **f32)
+            dpsd = torch.empty(n, 2 * HIDDEN, **f32)
+            dx = torch.empty(n, 3, **f32)
+            psd = lay["psd"]
+            with KernelTimer.span("egnn_edge_bwd"):
+                _lib.check(lib.is_egnn_edge_bwd(
+                    _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
+                    _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
+                    _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
+                    _lib.ptr(d_hn), HIDDEN, _lib.ptr(g_xc), _lib.ptr(dZ1), _lib.ptr(dD),
+                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), grid_e, n, fe, st), "is_egnn_edge_bwd")
+            reduce(part_e, grid_e, _EDGE_STRIDE, plans[i].edge_map, gflat[i])
+            with KernelTimer.span("gather_segment_sum"):
+                _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
+                                                     _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st), "is_gather_segment_sum")
+            g_hd, g_psd_next, g_xc = d_h, dpsd, dx
+        # (4) layer-0 pre-projection: weight gradient (+ input-feature gradient when requested)
+        lay0 = layers[0]
+        W1_0 = params[0]
+        dh0 = torch.empty(n, HIDDEN, **f32) if ctx.h0_needs_grad else None
+        with KernelTimer.span("node_proj_bwd"):
+            _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
+                                            _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
+                       "is_node_proj_bwd")
+        reduce(part_p, grid_n, _PROJ_STRIDE, plans[0].proj_map, gflat[0])
+        grads = []
+        for i in range(L):
+            grads.extend(plans[i].views(gflat[i]))
+        g_h0 = dh0[:, :lay0["din"]] if dh0 is not None else None
+        g_x0 = g_xc if ctx.x0_needs_grad else None
+        return (g_h0, g_x0, None, None, None) + tuple(grads)
+
+
+def egnn_stack(h0, x0, ea_csr, csr, layer_params):
+    """layer_params: list (one entry per layer) of the 11 native parameter tensors."""
+    flat = [p for lp in layer_params for p in lp]
+    return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), *flat)
 
 
 class SegmentPoolFn(torch.autograd.Function):
@@ -201,10 +350,6 @@ class SegmentPoolFn(torch.autograd.Function):
                                        _lib.stream_ptr())
         _lib.check(code, "is_segment_pool_bwd")
         return dx, None, None
-
-
-def egnn_edge(psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr):
-    return EGNNEdgeFn.apply(psd, x, ea, w_r, w_a, W2, b2, Wc1, bc1, wc2, csr)
 
 
 def segment_pool(x, seg_ptr, mode="mean"):

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as HF
-from ..nn import EGNNConv
+from ..nn import EGNNConv, egnn_stack_forward
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
@@ -124,8 +124,7 @@ class MultimodalNet(nn.Module):
     def _encode_graph(self, g):
         feats = g.ndata["x"]
         h, x, a = feats[:, :NODE_ONEHOT], feats[:, NODE_ONEHOT:], g.edata["edge_attr"]
-        for layer in self.GCN_layers:
-            h, x = layer(g, h, x, a)
+        h, x = egnn_stack_forward(list(self.GCN_layers), g, h, x, a)   # all layers, fused HIP kernels
         c = self.gat_hidden_channels
         if g.uniform_nodes_per_graph() is None:
             raise ValueError("all graphs of a batch must be padded to the same node count "

@@ -13,16 +13,16 @@ Drop-in replacements (same names, argument meaning and return values) for
 unchanged.  How the layer is evaluated differs from DGL by design:
 
   edge_mlp.0 is split as W1 = [W1s | W1d | w_r | W_a]; the node-level
-  projections Ps = h W1s^T and Pd = h W1d^T + b1 are computed once per node
-  (dense GEMM) so the per-edge work is a 256-byte row gather + two 64x64 MFMA
-  layers; gather, messages, coordinate messages and the sum/mean reductions
-  run in ONE fused kernel (``csrc/egnn_edge_fwd.hip``).
+  projections Ps = h W1s^T and Pd = h W1d^T + b1 are computed once per node so
+  the per-edge work is a 256-byte row gather + two 64x64 MFMA layers; gather,
+  messages, coordinate messages and the sum/mean reductions run in ONE fused
+  kernel (``csrc/egnn_edge_fwd.hip``); the node MLP and the NEXT layer's
+  projections run in a second fused kernel (``csrc/egnn_node.hip``).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import functional as HF
 from .graph import PackedGraphBatch
@@ -50,31 +50,31 @@ class EGNNConv(nn.Module):
             nn.Linear(hidden_size, hidden_size), act,
             nn.Linear(hidden_size, 1, bias=False))
 
+    def native_parameters(self):
+        """The 11 parameter tensors in the order ``functional.EGNNStackFn`` expects."""
+        return [self.edge_mlp[0].weight, self.edge_mlp[0].bias, self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+                self.node_mlp[0].weight, self.node_mlp[0].bias, self.node_mlp[2].weight, self.node_mlp[2].bias,
+                self.coord_mlp[0].weight, self.coord_mlp[0].bias, self.coord_mlp[2].weight]
+
     def forward(self, graph, node_feat, coord_feat, edge_feat=None):
-        if not isinstance(graph, PackedGraphBatch):
-            raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
-        d, hid, fe = self.in_size, self.hidden_size, self.edge_feat_size
-        if fe > 0 and edge_feat is None:
-            raise ValueError("Edge features must be provided.")
-        if edge_feat is not None and edge_feat.requires_grad:
-            raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
-        csr = graph.csr()
-        w1 = self.edge_mlp[0].weight
-        b1 = self.edge_mlp[0].bias
-        # node-level pre-projection of the first edge-MLP layer: [Ps | Pd]
-        w_sd = torch.cat([w1[:, :d], w1[:, d:2 * d]], dim=0)
-        b_sd = torch.cat([torch.zeros_like(b1), b1], dim=0)
-        psd = F.linear(node_feat, w_sd, b_sd)
-        w_r = w1[:, 2 * d]
-        w_a = w1[:, 2 * d + 1:] if fe > 0 else None
-        ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
-        h_neigh, x_out = HF.egnn_edge(
-            psd, coord_feat, ea, w_r, w_a,
-            self.edge_mlp[2].weight, self.edge_mlp[2].bias,
-            self.coord_mlp[0].weight, self.coord_mlp[0].bias,
-            self.coord_mlp[2].weight.reshape(-1), csr)
-        h = self.node_mlp(torch.cat([node_feat, h_neigh], dim=-1))
-        return h, x_out
+        h, x = egnn_stack_forward([self], graph, node_feat, coord_feat, edge_feat)
+        return h, x
+
+
+def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None):
+    """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``)."""
+    if not isinstance(graph, PackedGraphBatch):
+        raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
+    fe = layers[0].edge_feat_size
+    for i, layer in enumerate(layers):
+        if layer.edge_feat_size != fe or layer.out_size != HF.HIDDEN or (i > 0 and layer.in_size != HF.HIDDEN):
+            raise NotImplementedError("fused EGNN stack needs out_size = 64 and a common edge_feat_size")
+    if fe > 0 and edge_feat is None:
+        raise ValueError("Edge features must be provided.")
+    if edge_feat is not None and edge_feat.requires_grad:
+        raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
+    ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
+    return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers])
 
 
 def _seg_ptr_from_batch(batch_index, size=None):

@@ -46,13 +46,15 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *   x        [N, 3]     coordinates            ea [E, Fe] edge features, CSR slot order
  *   rowptr   [N+1], srcs [E]   CSR by destination (in-edges of node v are the
  *                       slots rowptr[v] .. rowptr[v+1])
- *   w_r [64], w_a [64, Fe]   the radial / edge-feature columns of edge_mlp.0.weight
+ *   W1 [64, ldw]        the NATIVE edge_mlp.0.weight, ldw = 2*din + 1 + Fe, columns
+ *                       [h_src (din) | h_dst (din) | radial | edge feats]; only the radial
+ *                       and edge-feature columns are read here
  *   W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
  *   h_neigh  [N, ld_hn] out: sum of messages     x_out [N, 3] out: x + mean coord message
  *   z2s, z3s [E, 64]    out (may be NULL): pre-activations saved for the backward
  *   Fe in [0, 8].                                                              */
 int is_egnn_edge_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                     const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                     const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                      const float* W2, const float* b2, const float* Wc1, const float* bc1,
                      const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                      float* z3s, int N, int Fe, void* stream);
@@ -65,16 +67,47 @@ int is_egnn_edge_bwd_partials_floats(int grid);
  * Outputs: dZ1 [E,64] and dD [E,3] (per-edge gradients of the first edge-MLP
  * pre-activation and of x_src - x_dst, CSR slot order, consumed by
  * is_gather_segment_sum), dPd [N, ld_dpd], dx [N,3] (destination-side part,
- * incl. the identity path), and the weight gradients gW2 [64,64], gWc1 [64,64],
- * gb2, gbc1, gwc2, gw_r [64], gw_a [64,Fe].  `grid` persistent workgroups
- * (<= number of 32-node tiles); `partials` scratch per the function above.     */
+ * incl. the identity path), and ONE partial weight-gradient record per workgroup
+ * (`grid` persistent workgroups, <= number of 32-node tiles) laid out as
+ *   dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
+ * to be summed by is_reduce_partials.                                             */
 int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                     const int32_t* rowptr, const int32_t* srcs, const float* w_r, const float* w_a,
+                     const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                      const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                      const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                     float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid,
-                     float* gW2, float* gWc1, float* gb2, float* gbc1, float* gwc2, float* gw_r,
-                     float* gw_a, int N, int Fe, void* stream);
+                     float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
+                     int Fe, void* stream);
+
+/* Node-level kernels of an EGNNConv layer (replace the torch/hipBLASLt Linear, cat and SiLU
+ * launches around the edge pass; node_mlp of dgl.nn.EGNNConv).
+ *   is_node_proj_fwd : psd [N,128] = [h W1s^T | h W1d^T + b1], h [N, ld_h] with din in {20, 64}
+ *   is_egnn_node_fwd : zn1 [N,64] = [h | h_neigh] Wn1^T + bn1 (saved, may be NULL);
+ *                      h_out = SiLU(zn1) Wn2^T + bn2; if W1n != NULL also the NEXT layer's
+ *                      psd_next [N,128] from h_out (W1n [64, ldw_n] = next edge_mlp.0.weight, b1n its bias)
+ *   is_node_proj_bwd : dh_total [N,64] = g_h + g_psd W1sd (either may be NULL: g_h treated as 0,
+ *                      dh_total skipped); partial record dW1sd [128,64] | db1 [64]
+ *   is_egnn_node_bwd : d_h [N,64] (may be NULL) and d_hneigh [N,64] from g_hout; partial record
+ *                      dWn1 [64,128] (h part padded to 64 columns | h_neigh part) | dWn2 [64,64] | dbn1 | dbn2
+ * The *_floats functions give the size of the `partials` buffer for `grid` workgroups.          */
+int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b1,
+                     float* psd, int N, void* stream);
+int is_egnn_node_fwd(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
+                     const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
+                     const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream);
+int is_node_proj_bwd_floats(int grid);
+int is_node_proj_bwd(const float* g_h, const float* g_psd, const float* h, int ld_h, int din,
+                     const float* W1, int ldw, float* dh_total, float* partials, int grid, int N,
+                     void* stream);
+int is_egnn_node_bwd_floats(int grid);
+int is_egnn_node_bwd(const float* g_hout, const float* h, int ld_h, int din, const float* h_neigh, int ld_hn,
+                     const float* zn1, const float* Wn1, const float* Wn2, float* d_h, float* d_hneigh,
+                     float* partials, int grid, int N, void* stream);
+
+/* dst[map[i]] = sum_p partials[p*stride + i], fixed summation order (deterministic); map may be
+ * NULL (identity), entries < 0 are skipped.  scratch: is_reduce_partials_scratch_floats(stride). */
+int is_reduce_partials_scratch_floats(int stride);
+int is_reduce_partials(const float* partials, int nparts, int stride, const int32_t* map, float* dst,
+                       float* scratch, void* stream);
 
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
  * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
