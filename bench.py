@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--model", default="HybridModelv2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
     rank, local_rank, world = D.init_from_env()
@@ -128,24 +129,39 @@ def main():
     D.broadcast_parameters(model)
     model.train()
     reducer = D.FlatGradReducer(model.parameters(), world=world)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=not args.eager)
     losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
     pool = build_batches(4, args.batch, args.deg_extra, dev, seed0=1000 * (rank + 1))
 
-    def step(i):
+    def forward_loss(m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return losses.regression_loss(recon, seq, mu, logvar, final, y)
+
+    def eager_step(i):
         b = pool[i % len(pool)]
         reducer.zero()
-        recon, mu, logvar, final = model(b["g"], b["seq"], b["prop"])
-        loss = losses.regression_loss(recon, b["seq"], mu, logvar, final, b["y"])
+        loss = forward_loss(model, b["g"], b["seq"], b["prop"], b["y"])
         loss.backward()
         reducer.all_reduce_mean()
         opt.step()
-        return loss
+        return loss.detach()
+
+    if args.eager:
+        step = eager_step
+    else:
+        from immunostruct_amd.engine import CapturedTrainStep
+        b0 = pool[0]
+        captured = CapturedTrainStep(model, opt, reducer, forward_loss, (b0["g"], b0["seq"], b0["prop"], b0["y"]),
+                                     edge_capacity=max(b["raw"].num_edges for b in pool))
+
+        def step(i):
+            b = pool[i % len(pool)]
+            return captured(b["g"], b["seq"], b["prop"], b["y"])
 
     for i in range(args.warmup):
         step(i)
     HF.KernelTimer.reset()
-    HF.KernelTimer.enabled = not args.no_kernel_timers
+    HF.KernelTimer.enabled = args.eager and not args.no_kernel_timers
 
     def fence():
         if world > 1:
@@ -164,6 +180,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(last.detach())
+    timers_mode = "HIP events around each launch inside the timed region (eager launches)"
+    if not args.eager and not args.no_kernel_timers:
+        # the timed region replays a captured HIP graph (individual launches cannot be bracketed there):
+        # measure per-kernel durations with HIP events on an eager re-run of the same steps
+        HF.KernelTimer.reset()
+        HF.KernelTimer.enabled = True
+        for i in range(min(args.steps, 10)):
+            eager_step(args.warmup + i)
+        torch.cuda.synchronize()
+        HF.KernelTimer.enabled = False
+        timers_mode = "HIP events around each launch, eager re-run of the timed steps (the timed region replays a HIP graph)"
 
     if rank == 0:
         graphs = args.batch * world * args.steps
@@ -181,7 +208,7 @@ def main():
             tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
             roof = dict(kernel="egnn_edge_bwd_kernel (+ partial reduce)", bound="mfma", achieved=round(tf_b, 2),
                         peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4),
-                        traffic=None, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
+                        traffic=None, measured=timers_mode, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
                         algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
                         hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                       frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
@@ -205,8 +232,10 @@ def main():
                                          f"regression loss, Adam; B={args.batch} graphs/GPU x 190 padded nodes, "
                                          f"E~{int(n_edges)} edges/batch (deg_extra={args.deg_extra}), Fe=1",
                                 global_batch=args.batch * world, nodes_per_batch=n_nodes, edges_per_batch=int(n_edges),
-                                parallelism=f"dp{world}", final_loss=round(final_loss, 5)),
-                    roofline=roof, cpu_baseline=cpu)
+                                parallelism=f"dp{world}", final_loss=round(final_loss, 5),
+                                launch="eager" if args.eager else "hipGraph replay"),
+                    roofline=roof, cpu_baseline=cpu,
+                    kernel_timers_us={k: [v[0], round(v[1] * 1e3, 2)] for k, v in timers.items()})
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

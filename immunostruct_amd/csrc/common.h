@@ -108,6 +108,85 @@ __device__ __forceinline__ void zero_acc2(f32x16 (&acc)[M][N]) {
       for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
 }
 
+// ---------------------------------------------------------------------------
+// 16-row tiles on v_mfma_f32_16x16x4_f32 (32-cycle issue, 4 accumulator registers):
+//   A[i = l & 15][k-slot = l >> 4]   B[k-slot = l >> 4][j = l & 15]
+//   D reg t -> row 4 * (l >> 4) + t , col l & 15
+// Quarter q = l >> 4 walks k in [q*K/4, (q+1)*K/4) (contiguous => ds_read_b128).
+// Half the per-wave LDS footprint of the 32-row tiles => twice the waves per CU,
+// which is what hides the gather / epilogue latency on these small batches.
+constexpr int TE16 = 16;
+__device__ __forceinline__ int tile16_row(int t, int q) { return 4 * q + t; }
+
+template <int NT, int K, int LDA = LD, int LDW = LD>
+__device__ __forceinline__ void mm16_rows(f32x4 (&acc)[NT], const float* a_lds, const float* w_lds, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const float* ap = a_lds + r * LDA + q * (K / 4);
+  const float* wp = w_lds + r * LDW + q * (K / 4);
+#pragma unroll
+  for (int s = 0; s < K / 4; s += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + s);
+    f32x4 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 16 * LDW + s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+// acc[mt][nt] (16 x 16) += sum over the 16 tile rows e of G[e][mt*16 + i] * M[e][nt*16 + j]
+template <int MT, int NT, int LDG = LD, int LDM = LD>
+__device__ __forceinline__ void mm16_outer(f32x4 (&acc)[MT][NT], const float* g_lds, const float* m_lds, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int e = 4 * q + s;
+    float a[MT], b[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = g_lds[e * LDG + mt * 16 + r];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = m_lds[e * LDM + nt * 16 + r];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  }
+}
+
+// acc[nt] (16 x 16) += sum over the 16 rows e of one edge tile of G[e][mt*16 + i] * M[e][nt*16 + j]
+//   for ONE output row-tile mt (the calling wave's share of a 64 x 64 weight gradient).
+__device__ __forceinline__ void mm16_outer_rows(f32x4 (&acc)[4], const float* g_lds, const float* m_lds, int mt, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int e = 4 * q + s;
+    const float a = g_lds[e * LD + mt * 16 + r];
+    float b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = m_lds[e * LD + nt * 16 + r];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[nt], 0, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc4(f32x4 (&acc)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// sum of v over the 16 lanes that share q = lane >> 4.
+__device__ __forceinline__ float sum_over_r16(float v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
 // sum of v over the 32 lanes that share hf (lanes differ in r = lane & 31).
 __device__ __forceinline__ float sum_over_r(float v) {
 #pragma unroll
@@ -124,10 +203,40 @@ __device__ __forceinline__ void load_matrix_lds(float* dst_lds, const float* __r
   }
 }
 // same, but stores the transpose: dst[c][r] = src[r][c]  (src is [64 x 64]).
+// loads are issued as one batch (16 B per lane each) before any LDS store.
 __device__ __forceinline__ void load_matrix_lds_t(float* dst_lds, const float* __restrict__ src, int tid, int nthreads) {
-  for (int idx = tid; idx < H * H; idx += nthreads) {
-    const int row = idx / H, col = idx % H;
-    dst_lds[col * LD + row] = src[idx];
+  f32x4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + j * nthreads;
+    v[j] = (idx < H * H / 4) ? *reinterpret_cast<const f32x4*>(src + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + j * nthreads;
+    if (idx < H * H / 4) {
+      const int row = idx / (H / 4), c4 = (idx % (H / 4)) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst_lds[(c4 + k) * LD + row] = v[j][k];
+    }
+  }
+}
+
+// Generic staged copy: element i (0 <= i < COUNT) is fetched by `load(i)` and placed by `store(i, v)`;
+// each of the NT threads issues all of its loads before its first store (one memory round trip).
+template <int COUNT, int NT, typename LoadF, typename StoreF>
+__device__ __forceinline__ void staged_copy(int tid, LoadF load, StoreF store) {
+  constexpr int PER = (COUNT + NT - 1) / NT;
+  float v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + j * NT;
+    v[j] = (i < COUNT) ? load(i) : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + j * NT;
+    if (i < COUNT) store(i, v[j]);
   }
 }
 

@@ -82,19 +82,22 @@ __global__ __launch_bounds__(256, 1) void egnn_node_fwd_kernel(
   const int r = lane & 31, hf = lane >> 5;
   const bool has_next = W1n != nullptr;
 
-  for (int idx = tid; idx < 64 * D::K1; idx += 256) {
-    const int o = idx / D::K1, k = idx % D::K1;
-    float v = 0.0f;
-    if (k < DIN) v = Wn1[o * (DIN + 64) + k];
-    else if (k >= D::KH) v = Wn1[o * (DIN + 64) + DIN + (k - D::KH)];
-    sm.wn1[o * D::LD1 + k] = v;
-  }
+  staged_copy<64 * D::K1, 256>(tid,
+      [&](int idx) {
+        const int o = idx / D::K1, k = idx % D::K1;
+        if (k < DIN) return Wn1[o * (DIN + 64) + k];
+        if (k >= D::KH) return Wn1[o * (DIN + 64) + DIN + (k - D::KH)];
+        return 0.0f;
+      },
+      [&](int idx, float v) { sm.wn1[(idx / D::K1) * D::LD1 + idx % D::K1] = v; });
   load_matrix_lds(sm.wn2, Wn2, H, tid, 256);
   if (has_next) {
-    for (int idx = tid; idx < 128 * 64; idx += 256) {
-      const int c = idx / 64, k = idx % 64;
-      sm.wsd[c * LD + k] = (c < 64) ? W1n[c * ldw_n + k] : W1n[(c - 64) * ldw_n + 64 + k];
-    }
+    staged_copy<128 * 64, 256>(tid,
+        [&](int idx) {
+          const int c = idx / 64, k = idx % 64;
+          return (c < 64) ? W1n[c * ldw_n + k] : W1n[(c - 64) * ldw_n + 64 + k];
+        },
+        [&](int idx, float v) { sm.wsd[(idx / 64) * LD + idx % 64] = v; });
   }
   float bn1_c[2], bn2_c[2], b1n_c[2];
 #pragma unroll
@@ -181,12 +184,13 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
   __shared__ ProjBwdSmem sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hf = lane >> 5;
-  for (int idx = tid; idx < 128 * 64; idx += 256) {
-    const int c = idx / 64, i = idx % 64;
-    float v = 0.0f;
-    if (i < din) v = (c < 64) ? W1n[c * ldw_n + i] : W1n[(c - 64) * ldw_n + din + i];
-    sm.w1sdT[i * LDW2 + c] = v;
-  }
+  staged_copy<128 * 64, 256>(tid,
+      [&](int idx) {
+        const int c = idx / 64, i = idx % 64;
+        if (i >= din) return 0.0f;
+        return (c < 64) ? W1n[c * ldw_n + i] : W1n[(c - 64) * ldw_n + din + i];
+      },
+      [&](int idx, float v) { sm.w1sdT[(idx % 64) * LDW2 + idx / 64] = v; });
   __syncthreads();
   f32x16 dW[4][2];
   zero_acc2(dW);
@@ -270,13 +274,13 @@ __global__ __launch_bounds__(256, 1) void egnn_node_bwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hf = lane >> 5;
   load_matrix_lds_t(sm.wn2t, Wn2, tid, 256);
-  for (int idx = tid; idx < 64 * 128; idx += 256) {
-    const int o = idx / 128, k = idx % 128;
-    float v = 0.0f;
-    if (k < 64) { if (k < DIN) v = Wn1[o * (DIN + 64) + k]; }
-    else v = Wn1[o * (DIN + 64) + DIN + (k - 64)];
-    sm.wn1t[k * LD + o] = v;
-  }
+  staged_copy<64 * 128, 256>(tid,
+      [&](int idx) {
+        const int o = idx / 128, k = idx % 128;
+        if (k < 64) return (k < DIN) ? Wn1[o * (DIN + 64) + k] : 0.0f;
+        return Wn1[o * (DIN + 64) + DIN + (k - 64)];
+      },
+      [&](int idx, float v) { sm.wn1t[(idx % 128) * LD + idx / 128] = v; });
   __syncthreads();
 
   f32x16 dWn1h[2][2], dWn1n[2][2], dWn2[2][2];

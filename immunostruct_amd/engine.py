@@ -1,0 +1,134 @@
+"""hipGraph-captured train step + the static device-side batch it replays on.
+
+The per-step work of this model is a few hundred short kernels (N = 24k nodes, E ~ 72k edges at
+B = 128): launched eagerly the step is bound by host launch overhead, not by the GPU.  The engine
+captures ``zero-grad -> forward -> loss -> backward [-> optimizer]`` ONCE into a HIP graph (through
+``torch.cuda.CUDAGraph``; every HIP kernel of this package is enqueued on the capturing stream and
+allocates only through torch's graph-aware allocator) and replays it per step.
+
+Replay needs fixed addresses and launch geometry:
+
+* ``StaticGraphBatch`` is a ``PackedGraphBatch`` whose node / edge / CSR arrays live in
+  fixed-capacity device buffers.  All kernels take their edge ranges from the device-side
+  ``rowptr`` arrays and size their grids by the (fixed, padded) node count, so a batch with fewer
+  edges than the capacity replays correctly: slots past ``rowptr[N]`` are never touched.
+* ``load(batch)`` copies a device-resident batch into those buffers (async D2D on the same stream);
+  this is the on-GPU batcher's hand-over point.
+
+With data parallelism the gradient all-reduce (RCCL) stays outside the graphs: graph A = zero +
+forward + loss + backward, eager all-reduce of the flat bucket, graph B = optimizer step.
+"""
+from __future__ import annotations
+
+import torch
+
+from .graph import CSRIndex, PackedGraphBatch
+
+
+class StaticGraphBatch(PackedGraphBatch):
+    """Fixed-capacity device buffers with the PackedGraphBatch surface."""
+
+    def __init__(self, template: PackedGraphBatch, edge_capacity: int):
+        dev = template.device
+        n = template.num_nodes()
+        super().__init__(torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int64, device=dev),
+                         n, template._counts)
+        self._device = dev
+        self.edge_capacity = int(edge_capacity)
+        fe = template.edata["edge_attr"].shape[1]
+        self.ndata["x"] = torch.zeros_like(template.ndata["x"])
+        self.edata["edge_attr"] = torch.zeros(self.edge_capacity, fe, dtype=torch.float32, device=dev)
+        csr = object.__new__(CSRIndex)
+        csr.rowptr_dst = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        csr.rowptr_src = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        csr.src_sorted = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
+        csr.pos_by_src = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
+        csr.eperm = torch.zeros(0, dtype=torch.int64, device=dev)
+        csr.num_nodes, csr.num_edges = n, self.edge_capacity
+        self._csr = csr
+        self._ea_csr = torch.zeros(self.edge_capacity, fe, dtype=torch.float32, device=dev)
+        self._seg_ptr = template.seg_ptr().clone()
+
+    @property
+    def device(self):
+        return self._device
+
+    def num_edges(self):
+        return self.edge_capacity
+
+    def edge_feat_csr(self, edge_feat):
+        return self._ea_csr
+
+    def load(self, g: PackedGraphBatch):
+        """Copy a device-resident batch (same node layout, E <= capacity) into the static buffers."""
+        e = g.num_edges()
+        if e > self.edge_capacity:
+            raise ValueError(f"batch has {e} edges, static capacity is {self.edge_capacity}")
+        if g.num_nodes() != self._num_nodes or g._counts != self._counts:
+            raise ValueError("node layout differs from the captured batch")
+        src = g.csr()
+        self.ndata["x"].copy_(g.ndata["x"], non_blocking=True)
+        self._csr.rowptr_dst.copy_(src.rowptr_dst, non_blocking=True)
+        self._csr.rowptr_src.copy_(src.rowptr_src, non_blocking=True)
+        self._csr.src_sorted[:e].copy_(src.src_sorted, non_blocking=True)
+        self._csr.pos_by_src[:e].copy_(src.pos_by_src, non_blocking=True)
+        self._ea_csr[:e].copy_(g.edge_feat_csr(g.edata["edge_attr"]), non_blocking=True)
+
+
+class CapturedTrainStep:
+    """``step(graph, seq, prop, y) -> loss`` replaying captured HIP graphs.
+
+    ``forward_loss(model, graph, seq, prop, y) -> scalar loss`` defines the step body (so the same
+    engine serves the regression / BCE / comparative stages).
+    """
+
+    def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3):
+        g, seq, prop, y = template
+        self.model, self.optimizer, self.reducer, self.forward_loss = model, optimizer, reducer, forward_loss
+        self.sgraph = StaticGraphBatch(g, edge_capacity)
+        self.seq, self.prop, self.y = torch.zeros_like(seq), torch.zeros_like(prop), torch.zeros_like(y)
+        self._load(g, seq, prop, y)
+        self.fused_optimizer = reducer.world == 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body(eager=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+            if self.fused_optimizer:
+                self.optimizer.step()
+        self.graph_b = None
+        if not self.fused_optimizer:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b):
+                self.optimizer.step()
+
+    def _load(self, g, seq, prop, y):
+        self.sgraph.load(g)
+        self.seq.copy_(seq, non_blocking=True)
+        self.prop.copy_(prop, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+
+    def _fwd_bwd(self):
+        self.reducer.zero()
+        loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        loss.backward()
+        return loss.detach()
+
+    def _body(self, eager=False):
+        loss = self._fwd_bwd()
+        self.reducer.all_reduce_mean()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, g, seq, prop, y):
+        self._load(g, seq, prop, y)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self.reducer.all_reduce_mean()
+            self.graph_b.replay()
+        return self.loss

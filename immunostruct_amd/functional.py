@@ -11,9 +11,13 @@ import torch
 
 from . import _lib
 
+import os
+
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
 _NODES_PER_TILE = 32
+# edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
+EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
 
 
 class KernelTimer:
@@ -185,8 +189,9 @@ class EGNNStackFn(torch.autograd.Function):
             x_out = torch.empty(n, 3, **f32)
             z2s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
             z3s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
+            edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
             with KernelTimer.span("egnn_edge_fwd"):
-                _lib.check(lib.is_egnn_edge_fwd(
+                _lib.check(edge_fwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
@@ -222,7 +227,9 @@ class EGNNStackFn(torch.autograd.Function):
         g_xc = _lib.f32c(g_x) if g_x is not None else torch.zeros(n, 3, **f32)
         plans = [layer_plan(layers[i]["din"], fe, dev) for i in range(L)]
         gflat = [torch.empty(pl.total, **f32) for pl in plans]
-        grid_e = _grid_for(n, _NODES_PER_TILE)
+        use_v2 = EDGE_KERNELS == "v2" and fe <= 1   # (the Fe = 8 instantiation of the v2 backward spills)
+        edge_bwd = lib.is_egnn_edge_bwd_v2 if use_v2 else lib.is_egnn_edge_bwd
+        grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16)) if use_v2 else _grid_for(n, _NODES_PER_TILE)
         grid_n = _grid_for(n, 128)
         part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)
         part_n = torch.empty(grid_n * _NODE_STRIDE, **f32)
@@ -265,7 +272,7 @@ class EGNNStackFn(torch.autograd.Function):
             dx = torch.empty(n, 3, **f32)
             psd = lay["psd"]
             with KernelTimer.span("egnn_edge_bwd"):
-                _lib.check(lib.is_egnn_edge_bwd(
+                _lib.check(edge_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),

@@ -78,6 +78,21 @@ int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x,
                      float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
                      int Fe, void* stream);
 
+/* Second mapping of the same two edge passes (identical arguments, results and partial-record
+ * layout): 16-edge tiles on v_mfma_f32_16x16x4_f32, 2-4 waves per SIMD; the default for Fe <= 1.
+ * is_egnn_edge_bwd_v2 takes grid <= number of 16-node tiles.                                     */
+int is_egnn_edge_fwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                        const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
+                        const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                        const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                        float* z3s, int N, int Fe, void* stream);
+int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                        const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
+                        const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                        const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
+                        float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
+                        int Fe, void* stream);
+
 /* Node-level kernels of an EGNNConv layer (replace the torch/hipBLASLt Linear, cat and SiLU
  * launches around the edge pass; node_mlp of dgl.nn.EGNNConv).
  *   is_node_proj_fwd : psd [N,128] = [h W1s^T | h W1d^T + b1], h [N, ld_h] with din in {20, 64}
