@@ -55,18 +55,31 @@ __device__ __forceinline__ void mm_rows(f32x16 (&acc)[NT], const float* a_lds, c
   const int r = lane & 31, hf = lane >> 5;
   const float* ap = a_lds + r * LDA + hf * (K / 2);
   const float* wp = w_lds + r * LDW + hf * (K / 2);
+  // operands of step s+4 are fetched from LDS before the MFMAs of step s are issued
+  f32x4 a = *reinterpret_cast<const f32x4*>(ap);
+  f32x4 b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LDW);
 #pragma unroll
   for (int s = 0; s < K / 2; s += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + s);
-    f32x4 b[NT];
+    f32x4 an = a;
+    f32x4 bn[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LDW + s);
+    for (int nt = 0; nt < NT; ++nt) bn[nt] = b[nt];
+    if (s + 4 < K / 2) {
+      an = *reinterpret_cast<const f32x4*>(ap + s + 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bn[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 32 * LDW + s + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
     }
+    a = an;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
   }
 }
 
@@ -123,18 +136,30 @@ __device__ __forceinline__ void mm16_rows(f32x4 (&acc)[NT], const float* a_lds, 
   const int r = lane & 15, q = lane >> 4;
   const float* ap = a_lds + r * LDA + q * (K / 4);
   const float* wp = w_lds + r * LDW + q * (K / 4);
+  f32x4 a = *reinterpret_cast<const f32x4*>(ap);
+  f32x4 b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 16 * LDW);
 #pragma unroll
   for (int s = 0; s < K / 4; s += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + s);
-    f32x4 b[NT];
+    f32x4 an = a;
+    f32x4 bn[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 16 * LDW + s);
+    for (int nt = 0; nt < NT; ++nt) bn[nt] = b[nt];
+    if (s + 4 < K / 4) {
+      an = *reinterpret_cast<const f32x4*>(ap + s + 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bn[nt] = *reinterpret_cast<const f32x4*>(wp + nt * 16 * LDW + s + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt][j], acc[nt], 0, 0, 0);
     }
+    a = an;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
   }
 }
 
@@ -185,6 +210,28 @@ __device__ __forceinline__ float sum_over_r16(float v) {
 #pragma unroll
   for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+}
+
+// Sum a [64 x 64] accumulator (2 x 2 tiles of 32 x 32, one copy per wave) over the 4 waves of a
+// workgroup and store it to dst[o * ld_dst + i].  Every wave first dumps its copy into its own LDS
+// region (independent stores), then all 256 threads add the 4 regions in a fixed order -- no
+// serialized read-modify-write chain.  scratch: 4 * 4096 floats of LDS; contains two barriers.
+__device__ __forceinline__ void wg_sum_store_64x64(const f32x16 (&acc)[2][2], float* scratch, float* dst, int ld_dst,
+                                                   int tid, int wave, int lane) {
+  const int r = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        scratch[wave * 4096 + (mt * 32 + tile_row(t, hf)) * 64 + nt * 32 + r] = acc[mt][nt][t];
+  __syncthreads();
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const float v = ((scratch[idx] + scratch[4096 + idx]) + scratch[8192 + idx]) + scratch[12288 + idx];
+    dst[(idx >> 6) * ld_dst + (idx & 63)] = v;
+  }
+  __syncthreads();
 }
 
 // sum of v over the 32 lanes that share hf (lanes differ in r = lane & 31).

@@ -358,27 +358,9 @@ __global__ __launch_bounds__(256, 1) void egnn_edge_bwd_kernel(
   // ---- reduce the weight-gradient accumulators over the 4 waves, write one partial ----
   __syncthreads();
   float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
-  float* red = &sm.actA[0][0];  // 4 * 32 * 68 floats = 8704 >= 4096 + scratch
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    for (int w = 0; w < WAVES; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              const int o = mt * 32 + tile_row(t, hf), i = nt * 32 + r;
-              const float v = which == 0 ? dW2[mt][nt][t] : dWc1[mt][nt][t];
-              if (w == 0) red[o * H + i] = v; else red[o * H + i] += v;
-            }
-      }
-      __syncthreads();
-    }
-    for (int idx = tid; idx < H * H; idx += 256) part[which * H * H + idx] = red[idx];
-    __syncthreads();
-  }
+  float* scratch = &sm.actA[0][0];  // actA + actB are contiguous: 2 * 4 * 32 * 68 = 17408 floats >= 16384
+  wg_sum_store_64x64(dW2, scratch, part, 64, tid, wave, lane);
+  wg_sum_store_64x64(dWc1, scratch, part + H * H, 64, tid, wave, lane);
   // per-column vectors: tile-layout sums (db2, dbc1, dwc2) combine the two lane halves
   // (different rows), lane = channel sums (dw_r, dW_a) are already per channel; then 4 waves.
   {

@@ -228,25 +228,21 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
         }
     }
   }
-  // ---- workgroup partial: sum the 4 waves through LDS (reuse bufP) ----
+  // ---- workgroup partial: sum the 4 waves through LDS ----
   __syncthreads();
-  float* red = &sm.bufP[0][0];  // 4 * 32 * 132 = 16896 floats >= 8192
-  for (int w = 0; w < WAVES; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int c = mt * 32 + tile_row(t, hf), i = nt * 32 + r;
-            if (w == 0) red[c * H + i] = dW[mt][nt][t]; else red[c * H + i] += dW[mt][nt][t];
-          }
-    }
-    __syncthreads();
-  }
   float* part = partials + (size_t)blockIdx.x * PROJ_STRIDE;
-  for (int idx = tid; idx < 128 * 64; idx += 256) part[idx] = red[idx];
+  float* scratch = &sm.bufP[0][0];  // 4 * 32 * 132 = 16896 floats >= 16384
+  {
+    f32x16 blk[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) blk[mt][nt] = dW[half * 2 + mt][nt];
+      wg_sum_store_64x64(blk, scratch, part + half * 64 * 64, 64, tid, wave, lane);
+    }
+  }
   float* vec = &sm.bufH[0][0];
   vec[wave * H + lane] = db1_c;
   __syncthreads();
@@ -359,32 +355,10 @@ __global__ __launch_bounds__(256, 1) void egnn_node_bwd_kernel(
   // ---- workgroup partial record ----
   __syncthreads();
   float* part = partials + (size_t)blockIdx.x * NODE_STRIDE;
-  float* red = sm.wn1t;  // 128 * 68 = 8704 floats >= 8192
-  for (int which = 0; which < 2; ++which) {   // 0: dWn1 [64][128], 1: dWn2 [64][64]
-    for (int w = 0; w < WAVES; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              const int o = mt * 32 + tile_row(t, hf), i = nt * 32 + r;
-              if (which == 0) {
-                if (w == 0) { red[o * 128 + i] = dWn1h[mt][nt][t]; red[o * 128 + 64 + i] = dWn1n[mt][nt][t]; }
-                else { red[o * 128 + i] += dWn1h[mt][nt][t]; red[o * 128 + 64 + i] += dWn1n[mt][nt][t]; }
-              } else {
-                if (w == 0) red[o * H + i] = dWn2[mt][nt][t]; else red[o * H + i] += dWn2[mt][nt][t];
-              }
-            }
-      }
-      __syncthreads();
-    }
-    const int count = which == 0 ? 64 * 128 : 64 * 64;
-    const int base = which == 0 ? 0 : 64 * 128;
-    for (int idx = tid; idx < count; idx += 256) part[base + idx] = red[idx];
-    __syncthreads();
-  }
+  float* scratch = reinterpret_cast<float*>(&sm);   // 16384 floats of the (now idle) LDS image
+  wg_sum_store_64x64(dWn1h, scratch, part, 128, tid, wave, lane);
+  wg_sum_store_64x64(dWn1n, scratch, part + 64, 128, tid, wave, lane);
+  wg_sum_store_64x64(dWn2, scratch, part + 64 * 128, 64, tid, wave, lane);
   float* vec = &sm.bufA[0][0];  // [wave][2][64]
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {

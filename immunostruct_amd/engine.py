@@ -79,16 +79,26 @@ class CapturedTrainStep:
     """``step(graph, seq, prop, y) -> loss`` replaying captured HIP graphs.
 
     ``forward_loss(model, graph, seq, prop, y) -> scalar loss`` defines the step body (so the same
-    engine serves the regression / BCE / comparative stages).
+    engine serves the regression / BCE / comparative stages).  Construction runs ``warmup`` (>= 1) REAL
+    eager train steps on the template batch (they update the model like any other step), then captures.
     """
 
     def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3):
+        if warmup < 1:
+            raise ValueError("warmup must be >= 1: optimizer state and BLAS handles have to be created by an eager "
+                             "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
         g, seq, prop, y = template
         self.model, self.optimizer, self.reducer, self.forward_loss = model, optimizer, reducer, forward_loss
         self.sgraph = StaticGraphBatch(g, edge_capacity)
         self.seq, self.prop, self.y = torch.zeros_like(seq), torch.zeros_like(prop), torch.zeros_like(y)
         self._load(g, seq, prop, y)
         self.fused_optimizer = reducer.world == 1
+        # host->device uploads must not happen inside the capture: build the (cached) gradient scatter
+        # maps of both layer shapes now, even when no eager warm-up step is requested
+        from . import functional as HF
+        fe = int(g.edata["edge_attr"].shape[1])
+        for din in (20, HF.HIDDEN):
+            HF.layer_plan(din, fe, g.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
