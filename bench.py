@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--model", default="HybridModelv2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--force-pack", action="store_true", help="exercise the multi-rank gradient-bucket path on one GPU")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
@@ -128,7 +129,7 @@ def main():
     model = model_map[args.model](vae_input_dim=VAE_IN, device=dev).to(dev)
     D.broadcast_parameters(model)
     model.train()
-    reducer = D.FlatGradReducer(model.parameters(), world=world)
+    reducer = D.FlatGradReducer(model.parameters(), world=world, always_pack=args.force_pack)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=not args.eager)
     losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
     pool = build_batches(4, args.batch, args.deg_extra, dev, seed0=1000 * (rank + 1))

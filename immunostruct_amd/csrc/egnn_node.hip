@@ -29,8 +29,8 @@ constexpr int LDW2 = 132;  // row stride for 128-wide LDS tiles (132/4 odd => co
 template <int DIN>
 __global__ __launch_bounds__(256) void node_proj_fwd_kernel(const float* __restrict__ h, int ld_h,
                                                             const float* __restrict__ W1, int ldw,
-                                                            const float* __restrict__ b1, float* __restrict__ psd,
-                                                            int N) {
+                                                            const float* __restrict__ b0, const float* __restrict__ b1,
+                                                            float* __restrict__ psd, int N) {
   const int lane = threadIdx.x & 63;
   float ws[DIN], wd[DIN];
 #pragma unroll
@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void node_proj_fwd_kernel(const float* __restr
     wd[k] = W1[lane * ldw + DIN + k];
   }
   const float bias = b1[lane];
+  const float bias0 = b0 != nullptr ? b0[lane] : 0.0f;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   for (int n = wave_global; n < N; n += gridDim.x * 4) {
     const float hv = (lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
-    float as = 0.0f, ad = bias;
+    float as = bias0, ad = bias;
 #pragma unroll
     for (int k = 0; k < DIN; ++k) {
       const float hk = __shfl(hv, k, 64);
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(256, 1) void egnn_node_fwd_kernel(
 
 // ---------------------------------------------------------------------------
 // dh_total = g_h + g_psd W1sd ; dW1sd += g_psd^T h_out ; db1 += colsum(g_psd[:, 64:])
-// record: [dW1sd 128 x 64][db1 64]
-constexpr int PROJ_STRIDE = 128 * 64 + 64;
+// record: [dW1sd 128 x 64][db1 64][db0 64]   (db0 = column sums of g_psd[:, :64], used by callers with a bias on the first half)
+constexpr int PROJ_STRIDE = 128 * 64 + 128;
 
 struct ProjBwdSmem {
   float w1sdT[64 * LDW2];  // w1sdT[i][c] = W1sd[c][i]
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
   __syncthreads();
   f32x16 dW[4][2];
   zero_acc2(dW);
-  float db1_c = 0.0f;  // lane = channel
+  float db1_c = 0.0f, db0_c = 0.0f;  // lane = channel
   float* bufP = sm.bufP[wave];
   float* bufH = sm.bufH[wave];
   const int num_tiles = (N + 31) / 32;
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
       bufP[i * LDW2 + lane] = p0;
       bufP[i * LDW2 + 64 + lane] = p1;
       db1_c += p1;
+      db0_c += p0;
       bufH[i * LD + lane] = (valid && lane < din) ? h_out[(size_t)row * ld_h + lane] : 0.0f;
     }
     mm_outer<4, 2, LDW2, LD>(dW, bufP, bufH, lane);
@@ -245,8 +247,13 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
   }
   float* vec = &sm.bufH[0][0];
   vec[wave * H + lane] = db1_c;
+  vec[(WAVES + wave) * H + lane] = db0_c;
   __syncthreads();
-  if (tid < H) part[128 * 64 + tid] = ((vec[tid] + vec[H + tid]) + vec[2 * H + tid]) + vec[3 * H + tid];
+  if (tid < 2 * H) {
+    const int s = tid / H, c = tid % H;
+    const float* v = vec + s * WAVES * H;
+    part[128 * 64 + tid] = ((v[c] + v[H + c]) + v[2 * H + c]) + v[3 * H + c];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -407,12 +414,12 @@ __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __res
 #define IS_STREAM(s) static_cast<hipStream_t>(s)
 #define IS_RET() return hipGetLastError() == hipSuccess ? 0 : -5
 
-extern "C" int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b1,
-                                float* psd, int N, void* stream) {
+extern "C" int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b0,
+                                const float* b1, float* psd, int N, void* stream) {
   if (N <= 0) return 0;
   const dim3 grid(std::min((N + 3) / 4, 2048)), block(256);
-  if (din == 20) hipLaunchKernelGGL(is::node_proj_fwd_kernel<20>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b1, psd, N);
-  else if (din == 64) hipLaunchKernelGGL(is::node_proj_fwd_kernel<64>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b1, psd, N);
+  if (din == 20) hipLaunchKernelGGL(is::node_proj_fwd_kernel<20>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b0, b1, psd, N);
+  else if (din == 64) hipLaunchKernelGGL(is::node_proj_fwd_kernel<64>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b0, b1, psd, N);
   else return -22;
   IS_RET();
 }

@@ -33,35 +33,53 @@ def init_from_env(backend=None):
 
 
 class FlatGradReducer:
-    """Keeps every parameter's ``.grad`` as a view into one flat fp32 buffer and all-reduces it."""
+    """One flat fp32 gradient bucket per step, all-reduced with a single collective.
 
-    def __init__(self, parameters, world=None):
+    ``zero()`` drops the gradients (autograd then *assigns* fresh ones: no per-parameter add kernels);
+    ``all_reduce_mean()`` packs them into the persistent flat bucket with ONE concatenation kernel,
+    all-reduces it (RCCL over xGMI: the whole 25 MB model as a single collective) and re-points every
+    ``.grad`` at its slice of the bucket, which is what the optimizer then reads.  With one rank and
+    ``always_pack=False`` both calls are no-ops apart from dropping the gradients.
+    """
+
+    def __init__(self, parameters, world=None, always_pack=False):
         self.params = [p for p in parameters if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.always_pack = always_pack
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev) if (self.world > 1 or always_pack) else None
+        self.sources = None   # gradient tensors to pack (defaults to the parameters' current .grad)
+
+    @property
+    def packing(self):
+        return self.flat is not None
+
+    def zero(self):
+        for p in self.params:
+            p.grad = None
+
+    def bind_sources(self):
+        """Remember the CURRENT .grad tensors as the pack sources (used with captured graphs, where the
+        backward always writes the same buffers while ``.grad`` is re-pointed at the bucket)."""
+        self.sources = [p.grad for p in self.params]
+
+    def all_reduce_mean(self, async_op=False):
+        if not self.packing:
+            return None
+        src = self.sources if self.sources is not None else [p.grad for p in self.params]
+        pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(src, self.params)]
+        torch.cat(pieces, out=self.flat)
+        work = None
+        if self.world > 1:
+            self.flat.div_(self.world)
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-
-    def zero(self):
-        self.flat.zero_()
-
-    def check_views(self):
-        """Autograd must have accumulated in place (``zero_grad(set_to_none=True)`` would break the views)."""
-        base = self.flat.data_ptr()
-        for p in self.params:
-            if p.grad is None or not (base <= p.grad.data_ptr() < base + self.flat.numel() * 4):
-                raise RuntimeError("a .grad no longer aliases the flat bucket; use reducer.zero(), not zero_grad()")
-
-    def all_reduce_mean(self, async_op=False):
-        if self.world == 1:
-            return None
-        self.flat.div_(self.world)
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        return work
 
 
 def broadcast_parameters(module, src=0):

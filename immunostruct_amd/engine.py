@@ -92,7 +92,7 @@ class CapturedTrainStep:
         self.sgraph = StaticGraphBatch(g, edge_capacity)
         self.seq, self.prop, self.y = torch.zeros_like(seq), torch.zeros_like(prop), torch.zeros_like(y)
         self._load(g, seq, prop, y)
-        self.fused_optimizer = reducer.world == 1
+        self.fused_optimizer = not reducer.packing   # single rank: optimizer inside the same graph
         # host->device uploads must not happen inside the capture: build the (cached) gradient scatter
         # maps of both layer shapes now, even when no eager warm-up step is requested
         from . import functional as HF
@@ -113,6 +113,9 @@ class CapturedTrainStep:
                 self.optimizer.step()
         self.graph_b = None
         if not self.fused_optimizer:
+            # graph A always writes the gradient buffers it allocated while capturing: pack from those
+            self.reducer.bind_sources()
+            self.reducer.all_reduce_mean()        # .grad now aliases the persistent flat bucket
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self.optimizer.step()

@@ -73,7 +73,7 @@ PARAMS_PER_LAYER = 11
 #   coord_mlp.0.weight, coord_mlp.0.bias, coord_mlp.2.weight [1, 64]
 _EDGE_STRIDE = 8448 + 64 * 8
 _NODE_STRIDE = 64 * 128 + 64 * 64 + 128
-_PROJ_STRIDE = 128 * 64 + 64
+_PROJ_STRIDE = 128 * 64 + 128
 _plan_cache = {}
 
 
@@ -177,7 +177,7 @@ class EGNNStackFn(torch.autograd.Function):
         w1_0, b1_0 = params[0], params[1]
         psd = torch.empty(n, 2 * HIDDEN, **f32)
         with KernelTimer.span("node_proj_fwd"):
-            _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), _lib.ptr(b1_0),
+            _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0),
                                             _lib.ptr(psd), n, st), "is_node_proj_fwd")
         h_in, ld_h, din = h0, ld_h0, din0
         for i in range(n_layers):
@@ -298,6 +298,56 @@ class EGNNStackFn(torch.autograd.Function):
         g_h0 = dh0[:, :lay0["din"]] if dh0 is not None else None
         g_x0 = g_xc if ctx.x0_needs_grad else None
         return (g_h0, g_x0, None, None, None) + tuple(grads)
+
+
+class PairLinearFn(torch.autograd.Function):
+    """out (N,128) = [h Wa^T + ba | h Wb^T + bb] for h (N,64) -- the fused query/key projection of the
+    node attention, on the node pre-projection kernels (``csrc/egnn_node.hip``)."""
+
+    @staticmethod
+    def forward(ctx, h, wa, ba, wb, bb):
+        lib = _lib.load()
+        _lib.require_device(h, wa, ba, wb, bb)
+        if h.dim() != 2 or h.shape[1] != HIDDEN or wa.shape != (HIDDEN, HIDDEN) or wb.shape != (HIDDEN, HIDDEN):
+            raise ValueError("PairLinearFn expects h (N,64) and two (64,64) weights")
+        h, ld_h = _lib.rows_ld(h)
+        wpack = torch.cat([wa, wb], dim=1).contiguous()      # [64][128]: columns [Wa | Wb], the W1-style layout
+        ba, bb = _lib.f32c(ba), _lib.f32c(bb)
+        n = int(h.shape[0])
+        out = torch.empty(n, 2 * HIDDEN, dtype=torch.float32, device=h.device)
+        with KernelTimer.span("attn_qk_proj_fwd"):
+            _lib.check(lib.is_node_proj_fwd(_lib.ptr(h), ld_h, HIDDEN, _lib.ptr(wpack), 2 * HIDDEN, _lib.ptr(ba), _lib.ptr(bb),
+                                            _lib.ptr(out), n, _lib.stream_ptr()), "is_node_proj_fwd")
+        ctx.ld_h = ld_h
+        ctx.save_for_backward(h, wpack)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        h, wpack = ctx.saved_tensors
+        n = int(h.shape[0])
+        dev = h.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = _lib.f32c(g)
+        st = _lib.stream_ptr()
+        grid = _grid_for(n, 128)
+        part = torch.empty(grid * _PROJ_STRIDE, **f32)
+        dh = torch.empty(n, HIDDEN, **f32)
+        with KernelTimer.span("attn_qk_proj_bwd"):
+            _lib.check(lib.is_node_proj_bwd(None, _lib.ptr(g), _lib.ptr(h), ctx.ld_h, HIDDEN, _lib.ptr(wpack), 2 * HIDDEN,
+                                            _lib.ptr(dh), _lib.ptr(part), grid, n, st), "is_node_proj_bwd")
+        flat = torch.empty(_PROJ_STRIDE, **f32)
+        scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_PROJ_STRIDE), **f32)
+        _lib.check(lib.is_reduce_partials(_lib.ptr(part), grid, _PROJ_STRIDE, None, _lib.ptr(flat), _lib.ptr(scratch), st),
+                   "is_reduce_partials")
+        hh = HIDDEN * HIDDEN
+        return (dh, flat[0:hh].view(HIDDEN, HIDDEN), flat[2 * hh + HIDDEN:2 * hh + 2 * HIDDEN],
+                flat[hh:2 * hh].view(HIDDEN, HIDDEN), flat[2 * hh:2 * hh + HIDDEN])
+
+
+def pair_linear(h, wa, ba, wb, bb):
+    return PairLinearFn.apply(h, wa, ba, wb, bb)
 
 
 def egnn_stack(h0, x0, ea_csr, csr, layer_params):

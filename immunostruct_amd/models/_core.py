@@ -129,8 +129,14 @@ class MultimodalNet(nn.Module):
         if g.uniform_nodes_per_graph() is None:
             raise ValueError("all graphs of a batch must be padded to the same node count "
                              "(reference data/preprocess.py:343-349)")
-        out, weights = self.self_attention(h.view(g.batch_size, -1, c))
-        pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)
+        hb = h.view(g.batch_size, -1, c)
+        if self.SPEC.pool == "mean":
+            # all graphs are padded to the same node count (checked above), so global_mean_pool over the
+            # attention output is a plain mean over the n rows -- taken inside the attention block
+            pooled, weights = self.self_attention.pooled_mean(hb)
+        else:
+            out, weights = self.self_attention(hb)
+            pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)
         return pooled, weights
 
     def _encode(self, g, seq, prop):

@@ -95,17 +95,19 @@ int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float*
 
 /* Node-level kernels of an EGNNConv layer (replace the torch/hipBLASLt Linear, cat and SiLU
  * launches around the edge pass; node_mlp of dgl.nn.EGNNConv).
- *   is_node_proj_fwd : psd [N,128] = [h W1s^T | h W1d^T + b1], h [N, ld_h] with din in {20, 64}
+ *   is_node_proj_fwd : psd [N,128] = [h W1s^T + b0 | h W1d^T + b1], h [N, ld_h] with din in {20, 64};
+ *                      b0 may be NULL (EGNN); with W1 = [Wq | Wk] it is also the fused query/key
+ *                      projection of the node attention (models/layers.py:13-16,68)
  *   is_egnn_node_fwd : zn1 [N,64] = [h | h_neigh] Wn1^T + bn1 (saved, may be NULL);
  *                      h_out = SiLU(zn1) Wn2^T + bn2; if W1n != NULL also the NEXT layer's
  *                      psd_next [N,128] from h_out (W1n [64, ldw_n] = next edge_mlp.0.weight, b1n its bias)
  *   is_node_proj_bwd : dh_total [N,64] = g_h + g_psd W1sd (either may be NULL: g_h treated as 0,
- *                      dh_total skipped); partial record dW1sd [128,64] | db1 [64]
+ *                      dh_total skipped); partial record dW1sd [128,64] | db1 [64] | db0 [64]
  *   is_egnn_node_bwd : d_h [N,64] (may be NULL) and d_hneigh [N,64] from g_hout; partial record
  *                      dWn1 [64,128] (h part padded to 64 columns | h_neigh part) | dWn2 [64,64] | dbn1 | dbn2
  * The *_floats functions give the size of the `partials` buffer for `grid` workgroups.          */
-int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b1,
-                     float* psd, int N, void* stream);
+int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b0,
+                     const float* b1, float* psd, int N, void* stream);
 int is_egnn_node_fwd(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                      const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
                      const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream);

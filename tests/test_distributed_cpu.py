@@ -35,8 +35,9 @@ def _worker(rank, world, port, out):
     red.zero()
     loss = ((net(data[idx]).squeeze(1) - y[idx]) ** 2).mean()
     loss.backward()
-    red.check_views()
     red.all_reduce_mean()
+    for p in net.parameters():   # the optimizer must see the reduced bucket
+        assert p.grad.data_ptr() >= red.flat.data_ptr()
     if rank == 0:
         torch.save({"flat": red.flat.clone(), "idx": idx}, out)
     dist.destroy_process_group()

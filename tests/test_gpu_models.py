@@ -148,7 +148,8 @@ def test_full_train_step_gradients_vs_oracle(cuda_device):
     print("worst parameter-gradient error", worst)
 
 
-def test_captured_hip_graph_step_matches_eager(cuda_device):
+@pytest.mark.parametrize("always_pack", [False, True])
+def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack):
     """engine.CapturedTrainStep (HIP-graph replay on static, fixed-capacity buffers) reproduces eager training.
 
     Batches with MORE and with FEWER edges than the captured one are replayed.  (Tolerance, not bit
@@ -171,7 +172,7 @@ def test_captured_hip_graph_step_matches_eager(cuda_device):
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
         model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=6))
         model.eval()
-        red = FlatGradReducer(model.parameters(), world=1)
+        red = FlatGradReducer(model.parameters(), world=1, always_pack=always_pack)   # True: the multi-rank two-graph path
         opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True, capturable=True)
         out = []
         if captured:
@@ -184,6 +185,7 @@ def test_captured_hip_graph_step_matches_eager(cuda_device):
                 red.zero()
                 loss = forward_loss(model, *b)
                 loss.backward()
+                red.all_reduce_mean()
                 opt.step()
                 out.append(float(loss.detach()))
         return out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
