@@ -388,15 +388,23 @@ __global__ __launch_bounds__(256, 1) void egnn_node_bwd_kernel(
 // ---------------------------------------------------------------------------
 // dst[map[idx]] = sum_p partials[p * stride + idx]   (map may be NULL => dst[idx]; map < 0 => skipped)
 // two stages so that small records still fill the chip; order of summation is fixed.
-constexpr int RED_SPLIT = 8;
+constexpr int RED_SPLIT = 16;
 
 __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __restrict__ partials, int nparts,
                                                               int stride, float* __restrict__ scratch) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= stride) return;
-  float v = 0.0f;
-  for (int p = blockIdx.y; p < nparts; p += RED_SPLIT) v += partials[(size_t)p * stride + idx];
-  scratch[(size_t)blockIdx.y * stride + idx] = v;
+  // 4 independent chains keep several loads in flight; the summation order is fixed (deterministic)
+  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+  int p = blockIdx.y;
+  for (; p + 3 * RED_SPLIT < nparts; p += 4 * RED_SPLIT) {
+    v0 += partials[(size_t)p * stride + idx];
+    v1 += partials[(size_t)(p + RED_SPLIT) * stride + idx];
+    v2 += partials[(size_t)(p + 2 * RED_SPLIT) * stride + idx];
+    v3 += partials[(size_t)(p + 3 * RED_SPLIT) * stride + idx];
+  }
+  for (; p < nparts; p += RED_SPLIT) v0 += partials[(size_t)p * stride + idx];
+  scratch[(size_t)blockIdx.y * stride + idx] = (v0 + v1) + (v2 + v3);
 }
 __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __restrict__ scratch, int stride,
                                                               const int* __restrict__ map, float* __restrict__ dst) {
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __res
   if (idx >= stride) return;
   float v = 0.0f;
 #pragma unroll
-  for (int s = 0; s < RED_SPLIT; ++s) v += scratch[(size_t)s * stride + idx];
+  for (int s = 0; s < RED_SPLIT; ++s) v += scratch[(size_t)s * stride + idx];  // loads are independent: issued together
   const int d = map != nullptr ? map[idx] : idx;
   if (d >= 0) dst[d] = v;
 }

@@ -350,6 +350,59 @@ def pair_linear(h, wa, ba, wb, bb):
     return PairLinearFn.apply(h, wa, ba, wb, bb)
 
 
+class CombinedAttentionMeanFn(torch.autograd.Function):
+    """z (B,T) = mean over features of MultiHeadAttention(F, 8, input_dim=1) applied to the scalar tokens x (B,T)
+    (``csrc/combined_attention.hip``, closed form)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wc, bc):
+        lib = _lib.load()
+        _lib.require_device(x, wq, bq, wk, bk, wv, bv, wc, bc)
+        if x.dim() != 2:
+            raise ValueError("expected (batch, tokens)")
+        b, t = int(x.shape[0]), int(x.shape[1])
+        f = int(wc.shape[0])
+        if f not in (16, 32) or t > 256:
+            raise NotImplementedError("combined attention kernel supports feature_dim 16/32 and <= 256 tokens")
+        x = _lib.f32c(x)
+        wq, bq, wk, wv, bv, wc, bc = (_lib.f32c(v) for v in (wq, bq, wk, wv, bv, wc, bc))
+        dev = x.device
+        z = torch.empty(b, t, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        stats = torch.empty(lib.is_comb_attn_stats_floats(b, t), dtype=torch.float32, device=dev) if need else None
+        with KernelTimer.span("comb_attn_fwd"):
+            _lib.check(lib.is_comb_attn_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(bv),
+                                            _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), _lib.ptr(stats), b, t, f, _lib.stream_ptr()),
+                       "is_comb_attn_fwd")
+        ctx.dims = (b, t, f)
+        ctx.save_for_backward(x, stats, wq, bq, wk, wv, bv, wc, bc)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, stats, wq, bq, wk, wv, bv, wc, bc = ctx.saved_tensors
+        b, t, f = ctx.dims
+        dev = x.device
+        dz = _lib.f32c(dz)
+        dx = torch.empty(b, t, dtype=torch.float32, device=dev)
+        part = torch.empty(lib.is_comb_attn_partials_floats(b), dtype=torch.float32, device=dev)
+        g = torch.empty(lib.is_comb_attn_grad_floats(f), dtype=torch.float32, device=dev)
+        with KernelTimer.span("comb_attn_bwd"):
+            _lib.check(lib.is_comb_attn_bwd(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(dz), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk),
+                                            _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(dx), _lib.ptr(part),
+                                            _lib.ptr(g), b, t, f, _lib.stream_ptr()), "is_comb_attn_bwd")
+        col = lambda i: g[i * f:(i + 1) * f]
+        return (dx, col(0).view(f, 1), col(1), col(2).view(f, 1), col(3), col(4).view(f, 1), col(5),
+                g[6 * f:6 * f + f * f].view(f, f), g[6 * f + f * f:7 * f + f * f])
+
+
+def combined_attention_mean(x, mha):
+    """``mha``: a models.layers.MultiHeadAttention built with input_dim=1 and 8 heads."""
+    return CombinedAttentionMeanFn.apply(x, mha.w_q.weight, mha.w_q.bias, mha.w_k.weight, mha.w_k.bias,
+                                         mha.w_v.weight, mha.w_v.bias, mha.w_concat.weight, mha.w_concat.bias)
+
+
 def egnn_stack(h0, x0, ea_csr, csr, layer_params):
     """layer_params: list (one entry per layer) of the 11 native parameter tensors."""
     flat = [p for lp in layer_params for p in lp]

@@ -159,7 +159,11 @@ class MultimodalNet(nn.Module):
 
     def _head(self, fused):
         if self.SPEC.comb:
-            fused = self.combined_attention(fused.unsqueeze(2))[0].mean(dim=2)
+            ca = self.combined_attention
+            if ca.n_head == 8 and ca.w_q.in_features == 1 and fused.shape[1] <= 256:
+                fused = HF.combined_attention_mean(fused, ca)     # closed-form HIP kernel
+            else:
+                fused = ca(fused.unsqueeze(2))[0].mean(dim=2)
         hid = self.classifier(fused)
         if self.SPEC.ssl:
             return self.classifier_head(hid), self.node_predictor_head(hid)

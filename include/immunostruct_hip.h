@@ -140,6 +140,23 @@ int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const 
                         const float* g_mean, const float* g_max, float* dx, int ld_dx, int num_segments,
                         int C, void* stream);
 
+/* "Combined attention" of the fusion head in closed form (models/hybrid_models.py:344-347 with
+ * MultiHeadAttention(F, 8 heads, input_dim = 1), models/layers.py:51-106): x [B,T] scalar tokens ->
+ * z [B,T] = mean over the F features of the attention block's output.  F in {16, 32}, T <= 256.
+ * wq,bq,wk,wv,bv [F] (Linear(1,F) weights / biases; the key bias does not influence the result),
+ * Wc [F,F], bc [F] = w_concat.  stats (is_comb_attn_stats_floats) is written by the forward for the
+ * backward (may be NULL).  The backward returns dx [B,T] and the parameter gradients packed as
+ * dwq|dbq|dwk|dbk|dwv|dbv [F each] | dWc [F*F] | dbc [F]  (is_comb_attn_grad_floats).              */
+int is_comb_attn_stats_floats(int B, int T);
+int is_comb_attn_partials_floats(int B);
+int is_comb_attn_grad_floats(int F);
+int is_comb_attn_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* wv,
+                     const float* bv, const float* Wc, const float* bc, float* z, float* stats, int B,
+                     int T, int F, void* stream);
+int is_comb_attn_bwd(const float* x, const float* stats, const float* dz, const float* wq, const float* bq,
+                     const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
+                     float* dx, float* partials, float* grads, int B, int T, int F, void* stream);
+
 /* floats of scratch is_vae_loss needs */
 int is_loss_partials_floats(void);
 /* mode 0: c_pred*MSE(logit,y), mode 1: c_pred*BCEWithLogits(logit,y,pos_weight);

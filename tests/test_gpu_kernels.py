@@ -251,3 +251,34 @@ def test_contrastive_loss_matches_golden(cuda_device):
     H.assert_close(ewd.grad.cpu(), gold["contrastive/grad_wt"], 1e-4, "grad wt emb")
     assert pcl(ecd, ewd, torch.ones(16, device=dev)) == 0
     assert pcl(ecd, ewd, torch.linspace(-1, 1, 16, device=dev)) == 0
+
+
+@pytest.mark.parametrize("feat,tokens", [(16, 104), (32, 104), (32, 208)])
+def test_combined_attention_closed_form(cuda_device, feat, tokens):
+    """closed-form HIP kernel == the reference's MultiHeadAttention(F, 8, input_dim=1) + mean over features (oracle, fp64)."""
+    rng = np.random.RandomState(feat + tokens)
+    b = 5
+    shapes = {"c.w_q.weight": (feat, 1), "c.w_q.bias": (feat,), "c.w_k.weight": (feat, 1), "c.w_k.bias": (feat,),
+              "c.w_v.weight": (feat, 1), "c.w_v.bias": (feat,), "c.w_concat.weight": (feat, feat), "c.w_concat.bias": (feat,)}
+    sd = H.det_sd(shapes, seed=31)
+    x = rng.normal(size=(b, tokens)).astype(np.float32) * 2.0
+    gup = rng.normal(size=(b, tokens)).astype(np.float32)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    ref, _ = FR.multi_head_attention(sd64, "c.", x64.unsqueeze(2), 8)
+    ref = ref.mean(dim=2)
+    (ref * torch.from_numpy(gup).double()).sum().backward()
+    from immunostruct_amd.models.layers import MultiHeadAttention
+    mha = MultiHeadAttention(feat, 8, input_dim=1).to(cuda_device)
+    mha.load_state_dict({k[2:]: v for k, v in sd.items()})
+    xd = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
+    z = HF.combined_attention_mean(xd, mha)
+    (z * torch.from_numpy(gup).to(cuda_device)).sum().backward()
+    H.assert_close(z.detach().cpu(), ref.detach(), 2e-6, "combined attention z")
+    H.assert_close(xd.grad.cpu(), x64.grad, 2e-5, "combined attention dx")
+    for name, p in mha.named_parameters():
+        refg = sd64["c." + name].grad
+        if float(refg.abs().max()) < 1e-12:
+            assert float(p.grad.abs().max()) == 0.0, name      # key bias: exactly no influence
+        else:
+            H.assert_close(p.grad.cpu(), refg, 2e-5, f"combined attention d{name}")
