@@ -1,0 +1,101 @@
+"""Training loops with the reference's signatures (``procedures/train.py:10-67`` and ``:70-185``).
+
+``train_model(config, device, model, train_loader, val_loader, optimizer, loss_function, scheduler=None,
+stage="pretrain")`` and ``train_model_comparative(...)``: epoch loop, forward, loss, backward, optimizer
+step, validation pass, best-validation checkpoint (``config.model_save_path_{pretrain,finetune}``),
+optional wandb logging.  Differences that do not change results: the running loss is accumulated on
+the device and read back once per epoch (the reference calls ``loss.item()`` every step, a host sync
+per step), and ``wandb`` is optional.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from ..utils import PairedContrastiveLoss
+
+try:  # optional, exactly as inert as a disabled wandb run when missing
+    import wandb
+except Exception:  # pragma: no cover
+    wandb = None
+
+__all__ = ["train_model", "train_model_comparative"]
+
+
+def _to(device, obj):
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_to(device, o) for o in obj)
+    return obj.to(device)
+
+
+def _save_best(config, model, stage):
+    path = config.model_save_path_pretrain if stage == "pretrain" else config.model_save_path_finetune
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save(model.state_dict(), path)
+
+
+def _single_loss(model, loss_function, batch, device, extra=None):
+    graph, seq, target, prop = _to(device, batch)
+    recon, mu, logvar, final = model(graph, seq, prop)
+    return loss_function(recon, seq, mu, logvar, final, target)
+
+
+def _paired_loss(model, loss_function, batch, device, contrastive, coeff):
+    graphs, seqs, target, props = _to(device, batch)
+    emb, recon, mu, logvar, final = model.forward_comparative(graphs, seqs, props)
+    # the prediction term is shared, the reconstruction terms are averaged (reference :107-114)
+    loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
+                  + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
+    if coeff > 0:
+        loss = loss + coeff * contrastive(emb[0], emb[1], target)
+    return loss
+
+
+def _fit(config, model, train_loader, val_loader, optimizer, scheduler, stage, step_loss):
+    train_losses, val_losses = [], []
+    best = float("inf")
+    for epoch in range(config.num_epochs):
+        model.train()
+        running = None
+        for batch in train_loader:
+            optimizer.zero_grad(set_to_none=True)
+            loss = step_loss(batch)
+            loss.backward()
+            optimizer.step()
+            running = loss.detach() if running is None else running + loss.detach()
+        train_loss = float(running) / max(len(train_loader), 1)
+        train_losses.append(train_loss)
+        if scheduler is not None:
+            scheduler.step()
+        model.eval()
+        running = None
+        with torch.no_grad():
+            for batch in val_loader:
+                loss = step_loss(batch)
+                running = loss.detach() if running is None else running + loss.detach()
+        val_total = float(running) if running is not None else 0.0
+        if val_total < best:
+            _save_best(config, model, stage)
+            best = val_total
+        val_loss = val_total / max(len(val_loader), 1)
+        val_losses.append(val_loss)
+        if wandb is not None and getattr(wandb, "run", None) is not None:
+            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
+        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
+    return train_losses, val_losses
+
+
+def train_model(config, device, model, train_loader, val_loader, optimizer, loss_function, scheduler=None, stage="pretrain"):
+    return _fit(config, model, train_loader, val_loader, optimizer, scheduler, stage,
+                lambda batch: _single_loss(model, loss_function, batch, device))
+
+
+def train_model_comparative(config, device, model, train_loader, val_loader, optimizer, loss_function, scheduler=None,
+                            stage="pretrain"):
+    coeff = float(getattr(config, "coeff_contrastive", 0) or 0)
+    # as in the reference (:74-78) the projector is created here, is NOT handed to the optimizer and stays in
+    # train mode (batch statistics) -- gradients still flow through it into the embeddings
+    contrastive = PairedContrastiveLoss(device=device, embedding_dim=104) if coeff > 0 else None
+    return _fit(config, model, train_loader, val_loader, optimizer, scheduler, stage,
+                lambda batch: _paired_loss(model, loss_function, batch, device, contrastive, coeff))

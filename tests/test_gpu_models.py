@@ -197,3 +197,13 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack):
         assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
     for k in sd_e:
         H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 3 captured steps")
+
+
+def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
+    """both entry points: pretrain -> new head -> finetune -> inference on a small synthetic set (1 epoch)."""
+    from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "48",
+              "--model-save-dir", str(tmp_path)]
+    train_IEDB_wFT.main(["--model", "HybridModelv2"] + common)
+    train_Cancer_wFT.main(["--use-wt-for-downstream", "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common)
+    assert len(list(tmp_path.glob("*_finetune.pt"))) == 2
