@@ -41,7 +41,12 @@ SIGNATURES = {
     "is_egnn_node_bwd_floats": [_I],
     "is_egnn_node_bwd": [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_reduce_partials_scratch_floats": [_I],
-    "is_reduce_partials": [_P, _I, _I, _P, _P, _P, _P],
+    "is_reduce_partials": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "is_egnn_node_fwd_v2": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "is_egnn_node_bwd_data": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "is_egnn_node_wgrad_stride": [],
+    "is_egnn_node_wgrad_proj_floats": [],
+    "is_egnn_node_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -391,9 +391,9 @@ __global__ __launch_bounds__(256, 1) void egnn_node_bwd_kernel(
 constexpr int RED_SPLIT = 16;
 
 __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __restrict__ partials, int nparts,
-                                                              int stride, float* __restrict__ scratch) {
+                                                              int stride, int count, float* __restrict__ scratch) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= stride) return;
+  if (idx >= count) return;
   // 4 independent chains keep several loads in flight; the summation order is fixed (deterministic)
   float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
   int p = blockIdx.y;
@@ -404,15 +404,15 @@ __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __res
     v3 += partials[(size_t)(p + 3 * RED_SPLIT) * stride + idx];
   }
   for (; p < nparts; p += RED_SPLIT) v0 += partials[(size_t)p * stride + idx];
-  scratch[(size_t)blockIdx.y * stride + idx] = (v0 + v1) + (v2 + v3);
+  scratch[(size_t)blockIdx.y * count + idx] = (v0 + v1) + (v2 + v3);
 }
-__global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __restrict__ scratch, int stride,
+__global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __restrict__ scratch, int count,
                                                               const int* __restrict__ map, float* __restrict__ dst) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= stride) return;
+  if (idx >= count) return;
   float v = 0.0f;
 #pragma unroll
-  for (int s = 0; s < RED_SPLIT; ++s) v += scratch[(size_t)s * stride + idx];  // loads are independent: issued together
+  for (int s = 0; s < RED_SPLIT; ++s) v += scratch[(size_t)s * count + idx];  // loads are independent: issued together
   const int d = map != nullptr ? map[idx] : idx;
   if (d >= 0) dst[d] = v;
 }
@@ -467,11 +467,12 @@ extern "C" int is_egnn_node_bwd(const float* g_hout, const float* h, int ld_h, i
 
 extern "C" int is_reduce_partials_scratch_floats(int stride) { return is::RED_SPLIT * stride; }
 
-extern "C" int is_reduce_partials(const float* partials, int nparts, int stride, const int32_t* map, float* dst,
-                                  float* scratch, void* stream) {
-  if (nparts <= 0 || stride <= 0) return -22;
+// record p starts at partials + p*stride; its first `count` floats are reduced
+extern "C" int is_reduce_partials(const float* partials, int nparts, int stride, int count, const int32_t* map,
+                                  float* dst, float* scratch, void* stream) {
+  if (nparts <= 0 || stride <= 0 || count <= 0 || count > stride) return -22;
   const dim3 block(256);
-  hipLaunchKernelGGL(is::reduce_partials_stage1, dim3((stride + 255) / 256, is::RED_SPLIT), block, 0, IS_STREAM(stream), partials, nparts, stride, scratch);
-  hipLaunchKernelGGL(is::reduce_partials_stage2, dim3((stride + 255) / 256), block, 0, IS_STREAM(stream), scratch, stride, map, dst);
+  hipLaunchKernelGGL(is::reduce_partials_stage1, dim3((count + 255) / 256, is::RED_SPLIT), block, 0, IS_STREAM(stream), partials, nparts, stride, count, scratch);
+  hipLaunchKernelGGL(is::reduce_partials_stage2, dim3((count + 255) / 256), block, 0, IS_STREAM(stream), scratch, count, map, dst);
   IS_RET();
 }

@@ -1,0 +1,449 @@
+// Node-level kernels, second mapping (v2): one workgroup per 32-row tile, weights straight from L2.
+//
+// The first mapping (egnn_node.hip) stages ~86 KB of weights into LDS per workgroup to process 128
+// rows: at N = 24k rows that staging and the single wave per SIMD dominate the run time.  Here
+//   * a workgroup (4 waves) owns ONE 32-row tile; wave w produces output columns [16w, 16w+16)
+//     (16x16x4 MFMA, two row tiles), so the 64 x 64 layers of a tile run 4-wide;
+//   * the B operands (weights) are fetched by each lane directly from the NATIVE row-major parameter
+//     tensors in global memory (L2-resident, 16 B per lane per 4 k) at kernel start -- they do not
+//     depend on the tile's data, so their latency overlaps the staging of the activations;
+//   * LDS holds only the tile's activations (~34 KB) => 4 workgroups = 16 waves per CU;
+//   * the backward data path (is_egnn_node_bwd_data) carries no weight-gradient accumulators; the
+//     weight gradients of a layer are produced by ONE streaming outer-product kernel
+//     (is_egnn_node_wgrad) from the tensors the data path leaves in HBM.
+#include "common.h"
+
+namespace is {
+
+__device__ __forceinline__ f32x4 ldg4(const float* p, int align) {
+  if (align >= 4) return *reinterpret_cast<const f32x4*>(p);
+  if (align == 2) {
+    const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+    return f32x4{a.x, a.y, b.x, b.y};
+  }
+  return f32x4{p[0], p[1], p[2], p[3]};
+}
+__device__ __forceinline__ int align_of(const float* base, int ld) {
+  const bool a16 = ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && ((ld & 3) == 0);
+  const bool a8 = ((reinterpret_cast<uintptr_t>(base) & 7) == 0) && ((ld & 1) == 0);
+  return a16 ? 4 : (a8 ? 2 : 1);
+}
+
+// acc[mt] (16 x 16) += A[mt*16 + i][k] * B[k][j]: A rows from LDS (stride LDA), B from registers
+// (b[g] holds the 4 consecutive k of group g of this lane's quarter).
+template <int MT, int KQ, int LDA>
+__device__ __forceinline__ void mm16_regB(f32x4 (&acc)[MT], const float* a_lds, const f32x4 (&b)[KQ / 4], int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < KQ / 4; ++g) {
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_lds + (mt * 16 + r) * LDA + q * KQ + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[g][j], acc[mt], 0, 0, 0);
+  }
+}
+
+template <int DIN>
+struct Node16Dims {
+  static constexpr int KV = DIN + 64;                       // valid k of the node-MLP input
+  static constexpr int KP = (KV + 15) / 16 * 16;            // padded: 96 (Din 20) or 128 (Din 64)
+  static constexpr int LD1 = KP + 4;                        // 100 / 132 (LD/4 odd)
+  static constexpr int KQ1 = KP / 4;                        // k per quarter: 24 / 32
+};
+
+template <int DIN>
+__global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
+    const float* __restrict__ h, int ld_h, const float* __restrict__ h_neigh, int ld_hn,
+    const float* __restrict__ Wn1, const float* __restrict__ bn1, const float* __restrict__ Wn2,
+    const float* __restrict__ bn2, const float* __restrict__ W1n, int ldw_n, const float* __restrict__ b1n,
+    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N) {
+  using D = Node16Dims<DIN>;
+  __shared__ float xs[32 * D::LD1];
+  __shared__ float a1s[32 * LD];
+  __shared__ float hps[32 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * 32;
+  const bool has_next = W1n != nullptr;
+
+  // ---- B operands of all three layers for this wave's output columns (independent of the tile data) ----
+  const int col = wave * 16 + r;                       // output column of MM_a / MM_b
+  f32x4 b1[D::KQ1 / 4], b2[4], b3[2][4];
+  {
+    const float* wrow = Wn1 + (size_t)col * D::KV;
+    const int al = align_of(Wn1, D::KV);
+#pragma unroll
+    for (int g = 0; g < D::KQ1 / 4; ++g) {
+      const int k = q * D::KQ1 + 4 * g;
+      b1[g] = (k < D::KV) ? ldg4(wrow + k, al) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* w2row = Wn2 + (size_t)col * H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(w2row + q * 16 + 4 * g);
+    if (has_next) {
+      const int al3 = align_of(W1n, ldw_n);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c = wave * 32 + nt * 16 + r;          // psd column: [0,64) = Ps, [64,128) = Pd
+        const float* w3row = (c < 64) ? W1n + (size_t)c * ldw_n : W1n + (size_t)(c - 64) * ldw_n + 64;
+        const int al3c = (c < 64) ? al3 : ((al3 == 4 || al3 == 2) ? al3 : 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b3[nt][g] = ldg4(w3row + q * 16 + 4 * g, al3c);
+      }
+    }
+  }
+  const float bn1_c = bn1[col], bn2_c = bn2[col];
+  float b1n_c[2] = {0.f, 0.f};
+  if (has_next) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c = wave * 32 + nt * 16 + r;
+      b1n_c[nt] = c >= 64 ? b1n[c - 64] : 0.0f;
+    }
+  }
+
+  // ---- X = [h | h_neigh | 0] rows of the tile -> LDS (wave w stages rows 8w .. 8w+7) ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, row = row0 + lr;
+    const bool valid = row < N;
+    if (lane < DIN) xs[lr * D::LD1 + lane] = valid ? h[(size_t)row * ld_h + lane] : 0.0f;
+    xs[lr * D::LD1 + DIN + lane] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+    if (lane < D::KP - D::KV) xs[lr * D::LD1 + D::KV + lane] = 0.0f;
+  }
+  __syncthreads();
+
+  // ---- zn1 = X Wn1^T + bn1 ; a1 = SiLU(zn1) ----
+  {
+    f32x4 acc[2];
+    zero_acc4(acc);
+    mm16_regB<2, D::KQ1, D::LD1>(acc, xs, b1, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int lr = mt * 16 + tile16_row(t, q);
+        const float z = acc[mt][t] + bn1_c;
+        if (zn1 != nullptr && row0 + lr < N) zn1[(size_t)(row0 + lr) * H + col] = z;
+        a1s[lr * LD + col] = silu_f(z);
+      }
+  }
+  __syncthreads();
+  // ---- h' = a1 Wn2^T + bn2 ----
+  {
+    f32x4 acc[2];
+    zero_acc4(acc);
+    mm16_regB<2, 16, LD>(acc, a1s, b2, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int lr = mt * 16 + tile16_row(t, q);
+        const float v = acc[mt][t] + bn2_c;
+        if (row0 + lr < N) h_out[(size_t)(row0 + lr) * H + col] = v;
+        hps[lr * LD + col] = v;
+      }
+  }
+  if (!has_next) return;
+  __syncthreads();
+  // ---- next layer's node pre-projection: wave w produces psd columns [32w, 32w + 32) ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    f32x4 acc[2];
+    zero_acc4(acc);
+    mm16_regB<2, 16, LD>(acc, hps, b3[nt], lane);
+    const int c = wave * 32 + nt * 16 + r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int lr = mt * 16 + tile16_row(t, q);
+        if (row0 + lr < N) psd_next[(size_t)(row0 + lr) * 128 + c] = acc[mt][t] + b1n_c[nt];
+      }
+  }
+}
+
+
+// acc[mt] += A[mt*16 + i][k] * Bt[k][j] with Bt given per k (scalar registers: transposed weights).
+template <int MT, int KQ, int LDA>
+__device__ __forceinline__ void mm16_regBt(f32x4 (&acc)[MT], const float* a_lds, const float (&bt)[KQ], int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < KQ / 4; ++g) {
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(a_lds + (mt * 16 + r) * LDA + q * KQ + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], bt[4 * g + j], acc[mt], 0, 0, 0);
+  }
+}
+
+// Backward data path of one layer's node block for one 32-row tile:
+//   dh   = g_h + g_psd W1sd          (only when g_psd != NULL; W1sd = next layer's [W1s ; W1d])
+//   dzn1 = (dh Wn2) * SiLU'(zn1)
+//   dX   = dzn1 Wn1   ->  d_h (first DIN columns, optional) , d_hneigh (last 64 columns)
+// dh (when computed) and dzn1 are written to HBM for the weight-gradient kernel.
+template <int DIN>
+__global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
+    const float* __restrict__ g_h, const float* __restrict__ g_psd, const float* __restrict__ W1n, int ldw_n,
+    const float* __restrict__ zn1, const float* __restrict__ Wn1, const float* __restrict__ Wn2,
+    float* __restrict__ dh_total, float* __restrict__ dzn1, float* __restrict__ d_h, float* __restrict__ d_hneigh,
+    int N) {
+  using D = Node16Dims<DIN>;
+  constexpr int LDP = 132;
+  __shared__ float ps_[32 * LDP];
+  __shared__ float gs[32 * LD];
+  __shared__ float zs[32 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * 32;
+  const bool has_psd = g_psd != nullptr;
+  const int col = wave * 16 + r;
+
+  // ---- transposed-weight operands (independent of the tile data) ----
+  float bp[32], ba[16], bx[2][16];
+  if (has_psd) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int c = q * 32 + s;   // psd column; quarters 0,1 -> Ps rows, 2,3 -> Pd rows
+      bp[s] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1n[(size_t)(c - 64) * ldw_n + 64 + col];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) ba[s] = Wn2[(size_t)(q * 16 + s) * H + col];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int xc = (wave * 2 + nt) * 16 + r;      // column of dX = [d_h | d_hneigh]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bx[nt][s] = (xc < D::KV) ? Wn1[(size_t)(q * 16 + s) * D::KV + xc] : 0.0f;
+  }
+
+  // ---- stage g_psd (or g_h) rows: wave w stages rows 8w .. 8w+7 ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, row = row0 + lr;
+    const bool valid = row < N;
+    if (has_psd) {
+      ps_[lr * LDP + lane] = valid ? g_psd[(size_t)row * 128 + lane] : 0.0f;
+      ps_[lr * LDP + 64 + lane] = valid ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
+    } else {
+      gs[lr * LD + lane] = valid ? g_h[(size_t)row * H + lane] : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (has_psd) {
+    f32x4 acc[2];
+    zero_acc4(acc);
+    mm16_regBt<2, 32, LDP>(acc, ps_, bp, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int lr = mt * 16 + tile16_row(t, q), row = row0 + lr;
+        float v = 0.0f;
+        if (row < N) {
+          v = acc[mt][t] + (g_h != nullptr ? g_h[(size_t)row * H + col] : 0.0f);
+          dh_total[(size_t)row * H + col] = v;
+        }
+        gs[lr * LD + col] = v;
+      }
+    __syncthreads();
+  }
+  // ---- da1 = dh Wn2 ; dzn1 = da1 * SiLU'(zn1) ----
+  {
+    f32x4 acc[2];
+    zero_acc4(acc);
+    mm16_regBt<2, 16, LD>(acc, gs, ba, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int lr = mt * 16 + tile16_row(t, q), row = row0 + lr;
+        float dz = 0.0f;
+        if (row < N) {
+          float y, dy;
+          silu_fg(zn1[(size_t)row * H + col], y, dy);
+          dz = acc[mt][t] * dy;
+          dzn1[(size_t)row * H + col] = dz;
+        }
+        zs[lr * LD + col] = dz;
+      }
+  }
+  __syncthreads();
+  // ---- dX = dzn1 Wn1 ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int xc = (wave * 2 + nt) * 16 + r;
+    if ((wave * 2 + nt) * 16 < D::KV) {          // wave-uniform: column tile exists
+      f32x4 acc[2];
+      zero_acc4(acc);
+      mm16_regBt<2, 16, LD>(acc, zs, bx[nt], lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = row0 + mt * 16 + tile16_row(t, q);
+          if (row < N && xc < D::KV) {
+            if (xc < DIN) { if (d_h != nullptr) d_h[(size_t)row * H + xc] = acc[mt][t]; }
+            else d_hneigh[(size_t)row * H + (xc - DIN)] = acc[mt][t];
+          }
+        }
+    }
+  }
+}
+
+// Streaming weight-gradient kernel of one layer's node block (outer products over the N rows):
+//   dW1sd[c][i] = sum_n g_psd[n][c] h_out[n][i]   (128 x 64, next layer's edge_mlp.0 node part; optional)
+//   dWn2[o][i]  = sum_n dh[n][o] SiLU(zn1[n][i])  (64 x 64)
+//   dWn1[o][k]  = sum_n dzn1[n][o] [h | h_neigh][n][k]   (64 x 128, h part padded to 64 columns)
+//   + the column sums db0/db1 (g_psd), dbn2 (dh), dbn1 (dzn1).
+// Workgroup g owns a contiguous slice of rows; wave w owns output row tiles (no cross-wave reduction of
+// the matrices).  Partial record = [PROJ part | NODE part] with the layouts of the v1 kernels.
+constexpr int WG_PROJ = 128 * 64 + 128;
+constexpr int WG_NODE = 64 * 128 + 64 * 64 + 128;
+constexpr int WG_STRIDE = WG_PROJ + WG_NODE;
+
+template <int DIN>
+__global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
+    const float* __restrict__ g_psd, const float* __restrict__ h_out, const float* __restrict__ dh,
+    const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
+    const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
+  constexpr int LDP = 132;
+  __shared__ float Ps[16 * LDP], Xs[16 * LDP];
+  __shared__ float Hs[16 * LD], Gs[16 * LD], As[16 * LD], Zs[16 * LD];
+  __shared__ float vec[4][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const bool has_psd = g_psd != nullptr;
+  const int r_begin = blockIdx.x * rows_per_wg, r_end = min(N, r_begin + rows_per_wg);
+
+  f32x4 dW1[2][4], dW2[4], dWn[8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) zero_acc4(dW1[a]);
+  zero_acc4(dW2);
+  zero_acc4(dWn);
+  float s_p0 = 0.f, s_p1 = 0.f, s_g = 0.f, s_z = 0.f;   // lane = column partial sums
+
+  for (int c0 = r_begin; c0 < r_end; c0 += 16) {
+    __syncthreads();
+    // ---- stage 16 rows: wave w stages rows 4w .. 4w+3 (lane = column) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = wave * 4 + i, row = c0 + lr;
+      const bool valid = row < r_end;
+      if (has_psd) {
+        const float p0 = valid ? g_psd[(size_t)row * 128 + lane] : 0.0f;
+        const float p1 = valid ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
+        Ps[lr * LDP + lane] = p0; Ps[lr * LDP + 64 + lane] = p1;
+        s_p0 += p0; s_p1 += p1;
+        Hs[lr * LD + lane] = valid ? h_out[(size_t)row * H + lane] : 0.0f;
+      }
+      const float g = valid ? dh[(size_t)row * H + lane] : 0.0f;
+      const float z = valid ? dzn1[(size_t)row * H + lane] : 0.0f;
+      Gs[lr * LD + lane] = g; Zs[lr * LD + lane] = z;
+      s_g += g; s_z += z;
+      As[lr * LD + lane] = valid ? silu_f(zn1[(size_t)row * H + lane]) : 0.0f;
+      Xs[lr * LDP + lane] = (valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
+      Xs[lr * LDP + 64 + lane] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+    }
+    __syncthreads();
+    // ---- outer products: contraction over the 16 staged rows ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = 4 * q + s;
+      const float ag = Gs[e * LD + wave * 16 + r], az = Zs[e * LD + wave * 16 + r];
+      float bh[4], ba1[4], bxv[8];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) ba1[nt] = As[e * LD + nt * 16 + r];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) bxv[nt] = Xs[e * LDP + nt * 16 + r];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dW2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, ba1[nt], dW2[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
+      if (has_psd) {
+        const float ap0 = Ps[e * LDP + (2 * wave) * 16 + r], ap1 = Ps[e * LDP + (2 * wave + 1) * 16 + r];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bh[nt] = Hs[e * LD + nt * 16 + r];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          dW1[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap0, bh[nt], dW1[0][nt], 0, 0, 0);
+          dW1[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, bh[nt], dW1[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial record ----
+  float* part = partials + (size_t)blockIdx.x * WG_STRIDE;
+  float* pn = part + WG_PROJ;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int lr = tile16_row(t, q);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      part[((2 * wave) * 16 + lr) * H + nt * 16 + r] = dW1[0][nt][t];
+      part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
+      pn[64 * 128 + (wave * 16 + lr) * H + nt * 16 + r] = dW2[nt][t];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
+  }
+  vec[wave][0][lane] = s_p1; vec[wave][1][lane] = s_p0; vec[wave][2][lane] = s_z; vec[wave][3][lane] = s_g;
+  __syncthreads();
+  {
+    const int which = tid >> 6;   // 0: db1, 1: db0, 2: dbn1, 3: dbn2
+    const float v = ((vec[0][which][lane] + vec[1][which][lane]) + vec[2][which][lane]) + vec[3][which][lane];
+    if (which < 2) part[128 * 64 + which * 64 + lane] = v;
+    else pn[64 * 128 + 64 * 64 + (which - 2) * 64 + lane] = v;
+  }
+}
+
+}  // namespace is
+
+extern "C" int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
+                                   const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
+                                   const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream) {
+  if (N <= 0) return 0;
+  const dim3 grid((N + 31) / 32), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<20>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<64>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
+  else return -22;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
+                                     int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
+                                     float* d_h, float* d_hneigh, int N, void* stream) {
+  if (N <= 0) return 0;
+  if (g_psd == nullptr && g_h == nullptr) return -22;
+  const dim3 grid((N + 31) / 32), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<20>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<64>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N);
+  else return -22;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_egnn_node_wgrad_stride(void) { return is::WG_STRIDE; }
+extern "C" int is_egnn_node_wgrad_proj_floats(void) { return is::WG_PROJ; }
+
+// grid workgroups, each owning ceil(N / grid) rows rounded up to 16; partials: grid * is_egnn_node_wgrad_stride() floats
+extern "C" int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, const float* zn1,
+                                  const float* dzn1, const float* h, int ld_h, int din, const float* h_neigh,
+                                  int ld_hn, float* partials, int grid, int N, void* stream) {
+  if (N <= 0 || grid <= 0) return -22;
+  const int rows = (((N + grid - 1) / grid) + 15) / 16 * 16;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_wgrad16_kernel<20>, dim3(grid), dim3(256), 0, st, g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_wgrad16_kernel<64>, dim3(grid), dim3(256), 0, st, g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows);
+  else return -22;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

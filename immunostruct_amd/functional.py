@@ -18,6 +18,8 @@ _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
 _NODES_PER_TILE = 32
 # edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
+# node-kernel mapping: "v2" = one workgroup per 32-row tile, weights from L2, separate weight-gradient kernel
+NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
 
 
 class KernelTimer:
@@ -202,8 +204,9 @@ class EGNNStackFn(torch.autograd.Function):
             psd_next = None if last else torch.empty(n, 2 * HIDDEN, **f32)
             W1n = None if last else params[(i + 1) * P]
             b1n = None if last else params[(i + 1) * P + 1]
+            node_fwd = lib.is_egnn_node_fwd_v2 if NODE_KERNELS == "v2" else lib.is_egnn_node_fwd
             with KernelTimer.span("egnn_node_fwd"):
-                _lib.check(lib.is_egnn_node_fwd(
+                _lib.check(node_fwd(
                     _lib.ptr(h_in), ld_h, din, _lib.ptr(h_neigh), HIDDEN, _lib.ptr(Wn1), _lib.ptr(bn1), _lib.ptr(Wn2),
                     _lib.ptr(bn2), _lib.ptr(W1n), 0 if last else int(W1n.shape[1]), _lib.ptr(b1n), _lib.ptr(zn1),
                     _lib.ptr(h_out), _lib.ptr(psd_next), n, st), "is_egnn_node_fwd")
@@ -236,35 +239,60 @@ class EGNNStackFn(torch.autograd.Function):
         part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
         scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_NODE_STRIDE), **f32)
 
-        def reduce(part, nparts, stride, mp, dst):
-            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, _lib.ptr(mp), _lib.ptr(dst), _lib.ptr(scratch), st),
-                       "is_reduce_partials")
+        def reduce(part, nparts, stride, mp, dst, count=None):
+            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, stride if count is None else count, _lib.ptr(mp),
+                                              _lib.ptr(dst), _lib.ptr(scratch), st), "is_reduce_partials")
+
+        node_v2 = NODE_KERNELS == "v2"
+        if node_v2:
+            wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
+            grid_w = _grid_for(n, 96)
+            part_w = torch.empty(grid_w * wg_stride, **f32)
 
         g_psd_next = None
         for i in reversed(range(L)):
             lay = layers[i]
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
             ldw, din = int(W1.shape[1]), lay["din"]
-            # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
-            if g_psd_next is not None:
-                W1n = params[(i + 1) * P]
-                dh_total = torch.empty(n, HIDDEN, **f32)
-                with KernelTimer.span("node_proj_bwd"):
-                    _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), HIDDEN, HIDDEN,
-                                                    _lib.ptr(W1n), int(W1n.shape[1]), _lib.ptr(dh_total), _lib.ptr(part_p),
-                                                    grid_n, n, st), "is_node_proj_bwd")
-                reduce(part_p, grid_n, _PROJ_STRIDE, plans[i + 1].proj_map, gflat[i + 1])
-            else:
-                dh_total = g_hd
-            # (2) node MLP backward
             need_dh = i > 0 or ctx.h0_needs_grad
             d_h = torch.empty(n, HIDDEN, **f32) if need_dh else None
             d_hn = torch.empty(n, HIDDEN, **f32)
-            with KernelTimer.span("egnn_node_bwd"):
-                _lib.check(lib.is_egnn_node_bwd(_lib.ptr(dh_total), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
-                                                HIDDEN, _lib.ptr(lay["zn1"]), _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(d_h),
-                                                _lib.ptr(d_hn), _lib.ptr(part_n), grid_n, n, st), "is_egnn_node_bwd")
-            reduce(part_n, grid_n, _NODE_STRIDE, plans[i].node_map, gflat[i])
+            if node_v2:
+                # (1+2) data path: dh = g_h + g_psd W1sd(next), node-MLP backward; then the streaming weight gradients
+                has_psd = g_psd_next is not None
+                W1n = params[(i + 1) * P] if has_psd else None
+                dh_total = torch.empty(n, HIDDEN, **f32) if has_psd else g_hd
+                dzn1 = torch.empty(n, HIDDEN, **f32)
+                with KernelTimer.span("egnn_node_bwd"):
+                    _lib.check(lib.is_egnn_node_bwd_data(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(W1n),
+                                                         int(W1n.shape[1]) if has_psd else 0, _lib.ptr(lay["zn1"]), din,
+                                                         _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(dh_total) if has_psd else None,
+                                                         _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n, st), "is_egnn_node_bwd_data")
+                with KernelTimer.span("egnn_node_wgrad"):
+                    _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
+                                                      _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
+                                                      HIDDEN, _lib.ptr(part_w), grid_w, n, st), "is_egnn_node_wgrad")
+                if has_psd:
+                    reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
+                reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
+            else:
+                # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
+                if g_psd_next is not None:
+                    W1n = params[(i + 1) * P]
+                    dh_total = torch.empty(n, HIDDEN, **f32)
+                    with KernelTimer.span("node_proj_bwd"):
+                        _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), HIDDEN, HIDDEN,
+                                                        _lib.ptr(W1n), int(W1n.shape[1]), _lib.ptr(dh_total), _lib.ptr(part_p),
+                                                        grid_n, n, st), "is_node_proj_bwd")
+                    reduce(part_p, grid_n, _PROJ_STRIDE, plans[i + 1].proj_map, gflat[i + 1])
+                else:
+                    dh_total = g_hd
+                # (2) node MLP backward
+                with KernelTimer.span("egnn_node_bwd"):
+                    _lib.check(lib.is_egnn_node_bwd(_lib.ptr(dh_total), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
+                                                    HIDDEN, _lib.ptr(lay["zn1"]), _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(d_h),
+                                                    _lib.ptr(d_hn), _lib.ptr(part_n), grid_n, n, st), "is_egnn_node_bwd")
+                reduce(part_n, grid_n, _NODE_STRIDE, plans[i].node_map, gflat[i])
             # (3) fused edge backward + source-side gather
             dZ1 = torch.empty(max(e, 1), HIDDEN, **f32)
             dD = torch.empty(max(e, 1), 3, **f32)
@@ -339,7 +367,7 @@ class PairLinearFn(torch.autograd.Function):
                                             _lib.ptr(dh), _lib.ptr(part), grid, n, st), "is_node_proj_bwd")
         flat = torch.empty(_PROJ_STRIDE, **f32)
         scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_PROJ_STRIDE), **f32)
-        _lib.check(lib.is_reduce_partials(_lib.ptr(part), grid, _PROJ_STRIDE, None, _lib.ptr(flat), _lib.ptr(scratch), st),
+        _lib.check(lib.is_reduce_partials(_lib.ptr(part), grid, _PROJ_STRIDE, _PROJ_STRIDE, None, _lib.ptr(flat), _lib.ptr(scratch), st),
                    "is_reduce_partials")
         hh = HIDDEN * HIDDEN
         return (dh, flat[0:hh].view(HIDDEN, HIDDEN), flat[2 * hh + HIDDEN:2 * hh + 2 * HIDDEN],

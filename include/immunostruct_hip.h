@@ -120,11 +120,33 @@ int is_egnn_node_bwd(const float* g_hout, const float* h, int ld_h, int din, con
                      const float* zn1, const float* Wn1, const float* Wn2, float* d_h, float* d_hneigh,
                      float* partials, int grid, int N, void* stream);
 
-/* dst[map[i]] = sum_p partials[p*stride + i], fixed summation order (deterministic); map may be
- * NULL (identity), entries < 0 are skipped.  scratch: is_reduce_partials_scratch_floats(stride). */
+/* dst[map[i]] = sum_p partials[p*stride + i] for i < count, fixed summation order (deterministic);
+ * map may be NULL (identity), entries < 0 are skipped.  scratch: is_reduce_partials_scratch_floats(count). */
 int is_reduce_partials_scratch_floats(int stride);
-int is_reduce_partials(const float* partials, int nparts, int stride, const int32_t* map, float* dst,
-                       float* scratch, void* stream);
+int is_reduce_partials(const float* partials, int nparts, int stride, int count, const int32_t* map,
+                       float* dst, float* scratch, void* stream);
+
+/* Second mapping of the node block (default): one workgroup per 32-row tile, weights fetched by the
+ * lanes straight from the native parameter tensors (L2), no LDS weight staging.
+ *   is_egnn_node_fwd_v2   : same arguments / results as is_egnn_node_fwd
+ *   is_egnn_node_bwd_data : dh_total = g_h + g_psd W1sd (when g_psd != NULL; else dh := g_h and dh_total
+ *                           is not written), dzn1 [N,64] = (dh Wn2) * SiLU'(zn1), d_h [N,64] (first
+ *                           din columns valid; may be NULL), d_hneigh [N,64].  No weight gradients.
+ *   is_egnn_node_wgrad    : the layer's weight gradients as streaming outer products over the rows:
+ *                           partial record per workgroup = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out,
+ *                           present when g_psd != NULL; is_egnn_node_wgrad_proj_floats floats) followed by
+ *                           [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride is_egnn_node_wgrad_stride. */
+int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
+                        const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
+                        const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream);
+int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
+                          int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
+                          float* d_h, float* d_hneigh, int N, void* stream);
+int is_egnn_node_wgrad_stride(void);
+int is_egnn_node_wgrad_proj_floats(void);
+int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, const float* zn1,
+                       const float* dzn1, const float* h, int ld_h, int din, const float* h_neigh,
+                       int ld_hn, float* partials, int grid, int N, void* stream);
 
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
  * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
