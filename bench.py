@@ -122,6 +122,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    if os.environ.get("IMMUNOSTRUCT_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU (gloo)
+        local_rank = int(os.environ["IMMUNOSTRUCT_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
