@@ -331,29 +331,45 @@ __global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
   zero_acc4(dWn);
   float s_p0 = 0.f, s_p1 = 0.f, s_g = 0.f, s_z = 0.f;   // lane = column partial sums
 
+  // rows are fetched one chunk ahead into registers so that the loads of chunk c+1 are in flight
+  // while the MFMAs of chunk c run
+  float rp0[4], rp1[4], rho[4], rg[4], rz[4], rzn[4], rxh[4], rxn[4];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c0 + wave * 4 + i;
+      const bool valid = row < r_end;
+      rp0[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + lane] : 0.0f;
+      rp1[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
+      rho[i] = (has_psd && valid) ? h_out[(size_t)row * H + lane] : 0.0f;
+      rg[i] = valid ? dh[(size_t)row * H + lane] : 0.0f;
+      rz[i] = valid ? dzn1[(size_t)row * H + lane] : 0.0f;
+      rzn[i] = valid ? zn1[(size_t)row * H + lane] : 0.0f;
+      rxh[i] = (valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
+      rxn[i] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
   for (int c0 = r_begin; c0 < r_end; c0 += 16) {
     __syncthreads();
     // ---- stage 16 rows: wave w stages rows 4w .. 4w+3 (lane = column) ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int lr = wave * 4 + i, row = c0 + lr;
-      const bool valid = row < r_end;
+      const int lr = wave * 4 + i;
+      const bool valid = c0 + lr < r_end;
       if (has_psd) {
-        const float p0 = valid ? g_psd[(size_t)row * 128 + lane] : 0.0f;
-        const float p1 = valid ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
-        Ps[lr * LDP + lane] = p0; Ps[lr * LDP + 64 + lane] = p1;
-        s_p0 += p0; s_p1 += p1;
-        Hs[lr * LD + lane] = valid ? h_out[(size_t)row * H + lane] : 0.0f;
+        Ps[lr * LDP + lane] = rp0[i]; Ps[lr * LDP + 64 + lane] = rp1[i];
+        s_p0 += rp0[i]; s_p1 += rp1[i];
+        Hs[lr * LD + lane] = rho[i];
       }
-      const float g = valid ? dh[(size_t)row * H + lane] : 0.0f;
-      const float z = valid ? dzn1[(size_t)row * H + lane] : 0.0f;
-      Gs[lr * LD + lane] = g; Zs[lr * LD + lane] = z;
-      s_g += g; s_z += z;
-      As[lr * LD + lane] = valid ? silu_f(zn1[(size_t)row * H + lane]) : 0.0f;
-      Xs[lr * LDP + lane] = (valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
-      Xs[lr * LDP + 64 + lane] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+      Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
+      s_g += rg[i]; s_z += rz[i];
+      As[lr * LD + lane] = valid ? silu_f(rzn[i]) : 0.0f;
+      Xs[lr * LDP + lane] = rxh[i];
+      Xs[lr * LDP + 64 + lane] = rxn[i];
     }
     __syncthreads();
+    if (c0 + 16 < r_end) fetch(c0 + 16);
     // ---- outer products: contraction over the 16 staged rows ----
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
