@@ -209,9 +209,14 @@ def main():
             n_b, ms_b = timers["egnn_edge_bwd"]
             n_f, ms_f = timers["egnn_edge_fwd"]
             tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
-            roof = dict(kernel="egnn_edge_bwd_kernel (+ partial reduce)", bound="mfma", achieved=round(tf_b, 2),
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.isfile(tpath) and args.batch == 128 and args.deg_extra == 2:
+                # PMC-measured HBM bytes per launch of this kernel on this workload (profiles/README.md)
+                traffic = json.load(open(tpath)).get("egnn_edge_bwd16_kernel", {}).get("bytes")
+            roof = dict(kernel="egnn_edge_bwd16_kernel", bound="mfma", achieved=round(tf_b, 2),
                         peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4),
-                        traffic=None, measured=timers_mode, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
+                        traffic=traffic, measured=timers_mode, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
                         algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
                         hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                       frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),

@@ -100,6 +100,19 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
       const int cb = win + wave * TE16;
       const int nvalid = max(0, min(TE16, e_end - cb));
       float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
+      // the saved pre-activation tiles only depend on the window position: issue their loads first so that
+      // they are in flight during S0's dependent (src index -> coordinates) chain
+      float z3v[4][4], z2v[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int row = tile16_row(t, q);
+          const bool rv = row < nvalid;
+          const size_t off = (size_t)(cb + row) * H + nt * 16 + r;
+          z3v[t][nt] = rv ? z3s[off] : 0.0f;
+          z2v[t][nt] = rv ? z2s[off] : 0.0f;
+        }
       if (nvalid > 0) {
         // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
         if (lane < TE16) {
@@ -144,17 +157,6 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
         {
-          float z3v[4][4], z2v[4][4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              const int row = tile16_row(t, q);
-              const bool rv = row < nvalid;
-              const size_t off = (size_t)(cb + row) * H + nt * 16 + r;
-              z3v[t][nt] = rv ? z3s[off] : 0.0f;
-              z2v[t][nt] = rv ? z2s[off] : 0.0f;
-            }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int row = tile16_row(t, q);
