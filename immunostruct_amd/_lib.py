@@ -50,6 +50,8 @@ SIGNATURES = {
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_attn_colmean_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_attn_colmean_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_comb_attn_stats_floats": [_I, _I],
     "is_comb_attn_partials_floats": [_I],
     "is_comb_attn_grad_floats": [_I],

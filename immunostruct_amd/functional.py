@@ -378,6 +378,49 @@ def pair_linear(h, wa, ba, wb, bb):
     return PairLinearFn.apply(h, wa, ba, wb, bb)
 
 
+class AttnColMeanFn(torch.autograd.Function):
+    """ctx (B, heads, 64) = sum_j abar_h[j] x_j, abar = column mean of the per-graph attention matrix
+    (``csrc/node_attention.hip``).  qk (B*n, 128) = [Q | K], x (B*n, 64)."""
+
+    @staticmethod
+    def forward(ctx_, qk, x, b, n, heads):
+        lib = _lib.load()
+        _lib.require_device(qk, x)
+        if qk.shape != (b * n, 2 * HIDDEN) or x.shape != (b * n, HIDDEN):
+            raise ValueError("expected qk (B*n,128) and x (B*n,64)")
+        if heads not in (1, 8) or n > 256:
+            raise NotImplementedError("attention kernel supports 1 or 8 heads and <= 256 nodes per graph")
+        qk, x = _lib.f32c(qk), _lib.f32c(x)
+        dev = x.device
+        out = torch.empty(b, heads, HIDDEN, dtype=torch.float32, device=dev)
+        need = any(ctx_.needs_input_grad)
+        abar = torch.empty(b, heads, n, dtype=torch.float32, device=dev) if need else None
+        rowstat = torch.empty(b, heads, n, 2, dtype=torch.float32, device=dev) if need else None
+        with KernelTimer.span("attn_colmean_fwd"):
+            _lib.check(lib.is_attn_colmean_fwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(out), _lib.ptr(abar), _lib.ptr(rowstat),
+                                               b, n, heads, _lib.stream_ptr()), "is_attn_colmean_fwd")
+        ctx_.dims = (b, n, heads)
+        ctx_.save_for_backward(qk, x, abar, rowstat)
+        return out
+
+    @staticmethod
+    def backward(ctx_, g):
+        lib = _lib.load()
+        qk, x, abar, rowstat = ctx_.saved_tensors
+        b, n, heads = ctx_.dims
+        g = _lib.f32c(g)
+        dqk = torch.empty_like(qk)
+        dx = torch.empty_like(x)
+        with KernelTimer.span("attn_colmean_bwd"):
+            _lib.check(lib.is_attn_colmean_bwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(rowstat), _lib.ptr(g),
+                                               _lib.ptr(dqk), _lib.ptr(dx), b, n, heads, _lib.stream_ptr()), "is_attn_colmean_bwd")
+        return dqk, dx, None, None, None
+
+
+def attn_colmean(qk, x, b, n, heads):
+    return AttnColMeanFn.apply(qk, x, b, n, heads)
+
+
 class CombinedAttentionMeanFn(torch.autograd.Function):
     """z (B,T) = mean over features of MultiHeadAttention(F, 8, input_dim=1) applied to the scalar tokens x (B,T)
     (``csrc/combined_attention.hip``, closed form)."""

@@ -121,7 +121,7 @@ class MultimodalNet(nn.Module):
                 self.classifier = self.get_classifier().to(self.device)
 
     # ---- encoders ------------------------------------------------------------
-    def _encode_graph(self, g):
+    def _encode_graph(self, g, need_attention=False):
         feats = g.ndata["x"]
         h, x, a = feats[:, :NODE_ONEHOT], feats[:, NODE_ONEHOT:], g.edata["edge_attr"]
         h, x = egnn_stack_forward(list(self.GCN_layers), g, h, x, a)   # all layers, fused HIP kernels
@@ -133,17 +133,17 @@ class MultimodalNet(nn.Module):
         if self.SPEC.pool == "mean":
             # all graphs are padded to the same node count (checked above), so global_mean_pool over the
             # attention output is a plain mean over the n rows -- taken inside the attention block
-            pooled, weights = self.self_attention.pooled_mean(hb)
+            pooled, weights = self.self_attention.pooled_mean(hb, need_weights=need_attention)
         else:
             out, weights = self.self_attention(hb)
             pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)
         return pooled, weights
 
-    def _encode(self, g, seq, prop):
+    def _encode(self, g, seq, prop, need_attention=False):
         sp = self.SPEC
         o = {}
         if sp.graph:
-            o["x_gat_node"], o["attention"] = self._encode_graph(g)
+            o["x_gat_node"], o["attention"] = self._encode_graph(g, need_attention)
         p = None
         if sp.prop == "emb":
             p = self.property_embedding(prop)
@@ -179,7 +179,7 @@ class MultimodalNet(nn.Module):
     # ---- public forward passes --------------------------------------------
     def forward(self, graph_data, sequence_data, peptide_property, return_embedding=False, return_attention=False):
         sp = self.SPEC
-        o = self._encode(graph_data, sequence_data, peptide_property)
+        o = self._encode(graph_data, sequence_data, peptide_property, need_attention=return_attention)
         if sp.graph and sp.vae:
             parts = [o["x_gat_node"], o["z_vae"]]
             if sp.paired and self.use_wt_for_downstream:
@@ -197,14 +197,14 @@ class MultimodalNet(nn.Module):
         return self._pack(first, o, final, node_pred)
 
     def forward_item(self, graph_data, sequence_data, peptide_property):
-        o = self._encode(graph_data, sequence_data, peptide_property)
+        o = self._encode(graph_data, sequence_data, peptide_property, need_attention=True)
         return o["mu"], o["logvar"], o["x_gat_node"], o["z_vae"], o["attention"], o["recon_x"]
 
     def forward_comparative(self, graph_data_pair, sequence_data_pair, peptide_property_pair,
                             return_embedding=False, return_attention=False):
         if not self.SPEC.paired:
             raise AttributeError(f"{type(self).__name__} has no comparative forward")
-        oc = self._encode(graph_data_pair[0], sequence_data_pair[0], peptide_property_pair[0])
+        oc = self._encode(graph_data_pair[0], sequence_data_pair[0], peptide_property_pair[0], need_attention=return_attention)
         ow = self._encode(graph_data_pair[1], sequence_data_pair[1], peptide_property_pair[1])
         emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)
         emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)

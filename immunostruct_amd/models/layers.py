@@ -28,22 +28,33 @@ def attend(q, k, v, heads):
     return out, w
 
 
-def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads):
+def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False):
     """mean over the n rows of softmax(q k^T / sqrt(d)) v  WITHOUT materialising v or the (n, d) output.
 
     mean_i sum_j A_ij v_j = sum_j abar_j v_j with abar = column mean of A, and
     sum_j abar_j (W_v x_j + b_v) = W_v (sum_j abar_j x_j) + b_v because sum_j abar_j = 1.
-    Only the fused query/key projection runs at node level (HIP kernel); the value projection acts on
-    one 64-vector per (graph, head).  Returns (pooled (b, d_model), weights (b, heads, n, n)).
+    HIP kernels: fused query/key projection (``PairLinearFn``) and scores -> softmax -> column mean ->
+    ctx = abar^T x (``AttnColMeanFn``); the value projection acts on one 64-vector per (graph, head).
+    Returns (pooled (b, d_model), weights (b, heads, n, n) or None).
     """
     from .. import functional as HF
     b, n, dm = x.shape
     dh = dm // heads
-    qk = HF.pair_linear(x.reshape(b * n, dm), wq, bq, wk, bk).view(b, n, 2, heads, dh)
-    q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)          # (b, heads, n, dh)
-    w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
-    abar = w.mean(dim=2)                                                       # (b, heads, n)
-    ctx = torch.matmul(abar, x)                                                # (b, heads, dm)
+    x2 = x.reshape(b * n, dm)
+    qk = HF.pair_linear(x2, wq, bq, wk, bk)
+    if heads in (1, 8) and n <= 256:
+        ctx = HF.attn_colmean(qk, x2, b, n, heads)                             # (b, heads, dm)
+        w = None
+        if need_weights:
+            with torch.no_grad():
+                q5 = qk.view(b, n, 2, heads, dh)
+                w = torch.softmax(torch.matmul(q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2).transpose(-1, -2))
+                                  * (1.0 / math.sqrt(dh)), dim=-1)
+    else:
+        q5 = qk.view(b, n, 2, heads, dh)
+        q, k = q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2)
+        w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
+        ctx = torch.matmul(w.mean(dim=2), x)
     u = torch.einsum("bhk,hdk->bhd", ctx, wv.view(heads, dh, dm)).reshape(b, dm) + bv
     return u, w
 
@@ -59,11 +70,11 @@ class SelfAttention(nn.Module):
         out, w = attend(self.query(x), self.key(x), self.value(x), 1)
         return out, w.squeeze(1)
 
-    def pooled_mean(self, x):
+    def pooled_mean(self, x, need_weights=False):
         """(mean over rows of the attention output, weights) -- what the models feed to global_mean_pool."""
         u, w = attend_pooled_mean(x, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
-                                  self.value.weight, self.value.bias, 1)
-        return u, w.squeeze(1)
+                                  self.value.weight, self.value.bias, 1, need_weights)
+        return u, (w.squeeze(1) if w is not None else None)
 
 
 class MultiHeadAttention(nn.Module):
@@ -84,11 +95,11 @@ class MultiHeadAttention(nn.Module):
         out, w = attend(self.w_q(x), self.w_k(x), self.w_v(x), self.n_head)
         return self.w_concat(out), w
 
-    def pooled_mean(self, x):
+    def pooled_mean(self, x, need_weights=False):
         """mean over rows of ``forward(x)[0]`` (the output projection commutes with the mean)."""
         if self.w_q.in_features != self.w_q.out_features or self.w_q.out_features != 64:
             out, w = self.forward(x)
             return out.mean(dim=1), w
         u, w = attend_pooled_mean(x, self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias,
-                                  self.w_v.weight, self.w_v.bias, self.n_head)
+                                  self.w_v.weight, self.w_v.bias, self.n_head, need_weights)
         return self.w_concat(u), w

@@ -162,6 +162,18 @@ int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const 
                         const float* g_mean, const float* g_max, float* dx, int ld_dx, int num_segments,
                         int C, void* stream);
 
+/* Node self-attention reduced to what the mean-pooled readout needs (models/layers.py:13-22,67-78 followed by
+ * global_mean_pool, models/hybrid_models.py:326-331): qk [B*n,128] = [Q | K] (from is_node_proj_fwd with
+ * W1 = [Wq | Wk]), x [B*n,64]; heads in {1, 8}; n <= 256 padded nodes per graph.
+ *   ctx [B, heads, 64] = sum_j abar_h[j] x_j with abar_h = column mean of softmax(Q_h K_h^T / sqrt(d));
+ *   the pooled attention output is then W_v,h ctx_h + b_v,h (and w_concat) on B x 64 vectors.
+ * abar [B,heads,n] and rowstat [B,heads,n,2] (row max, 1/row sum) are saved for the backward (may be NULL).
+ * Backward: dqk [B*n,128] (fully written) and dx [B*n,64] (direct term through ctx).                       */
+int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* rowstat, int B, int n,
+                        int heads, void* stream);
+int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* rowstat,
+                        const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream);
+
 /* "Combined attention" of the fusion head in closed form (models/hybrid_models.py:344-347 with
  * MultiHeadAttention(F, 8 heads, input_dim = 1), models/layers.py:51-106): x [B,T] scalar tokens ->
  * z [B,T] = mean over the F features of the attention block's output.  F in {16, 32}, T <= 256.

@@ -282,3 +282,35 @@ def test_combined_attention_closed_form(cuda_device, feat, tokens):
             assert float(p.grad.abs().max()) == 0.0, name      # key bias: exactly no influence
         else:
             H.assert_close(p.grad.cpu(), refg, 2e-5, f"combined attention d{name}")
+
+
+@pytest.mark.parametrize("heads,n", [(1, 190), (8, 190), (1, 45), (8, 9), (1, 256), (8, 70)])
+def test_node_attention_pooled_mean(cuda_device, heads, n):
+    """fused Q/K projection + scores/softmax/column-mean kernel == mean over nodes of the reference attention block."""
+    from immunostruct_amd.models.layers import MultiHeadAttention
+    rng = np.random.RandomState(heads * 1000 + n)
+    b = 3
+    shapes = {f"a.{k}.{p}": ((64, 64) if p == "weight" else (64,)) for k in ("w_q", "w_k", "w_v", "w_concat") for p in ("weight", "bias")}
+    sd = H.det_sd(shapes, seed=77)
+    x = rng.normal(size=(b, n, 64)).astype(np.float32)
+    gup = rng.normal(size=(b, 64)).astype(np.float32)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    out, w_ref = FR.multi_head_attention(sd64, "a.", x64, heads)
+    ref = out.mean(dim=1)
+    (ref * torch.from_numpy(gup).double()).sum().backward()
+    mha = MultiHeadAttention(64, heads).to(cuda_device)
+    mha.load_state_dict({k[2:]: v for k, v in sd.items()})
+    xd = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
+    pooled, w = mha.pooled_mean(xd, need_weights=True)
+    (pooled * torch.from_numpy(gup).to(cuda_device)).sum().backward()
+    H.assert_close(pooled.detach().cpu(), ref.detach(), 5e-6, "pooled attention")
+    H.assert_close(w.cpu(), w_ref.detach(), 5e-6, "attention weights")
+    H.assert_close(xd.grad.cpu(), x64.grad, 5e-5, "d pooled / d x")
+    gmax = max(float(v.grad.abs().max()) for v in sd64.values())
+    for name, p in mha.named_parameters():
+        refg = sd64["a." + name].grad
+        if float(refg.abs().max()) < 1e-9 * gmax:      # key bias: softmax is shift invariant
+            assert float(p.grad.abs().max()) < 1e-5 * gmax, name
+        else:
+            H.assert_close(p.grad.cpu(), refg, 5e-5, f"d pooled / d {name}")
