@@ -14,6 +14,13 @@
 
 namespace is {
 
+#ifdef IS_STAGE_STAMPS
+__device__ long long g_stamps_b[24];
+#define STAMPB(k) do { if (blockIdx.x == 300 && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMPB(k) do { } while (0)
+#endif
+
 constexpr int WB16 = 4;
 constexpr int NV16 = 16;
 
@@ -23,6 +30,7 @@ struct Bwd16Smem {
   float wc1t[H * LD];
   float bufA[WB16][TE16 * LD];
   float bufB[WB16][TE16 * LD];
+  float pdt[NV16 * H];   // Pd rows of this tile's destination nodes
   int rp[NV16 + 1];
   int e_src[WB16][TE16];
   int e_dl[WB16][TE16];
@@ -86,10 +94,16 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
   constexpr int NPW = NV16 / WB16;
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    STAMPB(0);
     const int v0 = tile * NV16;
     const int nv = min(NV16, N - v0);
     __syncthreads();
     if (tid <= NV16) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
+#pragma unroll
+    for (int i = 0; i < NV16 / WB16; ++i) {
+      const int nl = wave * (NV16 / WB16) + i;
+      sm.pdt[nl * H + lane] = (nl < nv) ? pd[(size_t)(v0 + nl) * ld_p + lane] : 0.0f;
+    }
     __syncthreads();
     const int e_begin = sm.rp[0], e_end = sm.rp[nv];
     float acc_h[NPW], acc_x[NPW];
@@ -99,7 +113,10 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
     for (int win = e_begin; win < e_end; win += WB16 * TE16) {
       const int cb = win + wave * TE16;
       const int nvalid = max(0, min(TE16, e_end - cb));
+      STAMPB(1);
       float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
+      float up[4][4];   // dL/dh_neigh[dst] for this tile (prefetched)
+      float gth[TE16];  // Ps[src] gathers for the z1 recompute (prefetched; Pd[dst] comes from the LDS tile)
       // the saved pre-activation tiles only depend on the window position: issue their loads first so that
       // they are in flight during S0's dependent (src index -> coordinates) chain
       float z3v[4][4], z2v[4][4];
@@ -154,6 +171,15 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
             sm.e_a[wave][f][lane] = (valid && f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
+        STAMPB(2);
+        // prefetch dL/dh_neigh rows of this tile's destinations: consumed after WG1 + MM3
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+          const int v = v0 + sm.e_dl[wave][row];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) up[t][nt] = (row < nvalid) ? g_hn[(size_t)v * ld_ghn + nt * 16 + r] : 0.0f;
+        }
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
         {
@@ -183,8 +209,16 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
             }
           }
         }
+        // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
+#pragma unroll
+        for (int i = 0; i < TE16; ++i) {
+          const int s = sm.e_src[wave][i];
+          gth[i] = ps[(size_t)s * ld_p + lane];      // raw: not consumed before SA
+        }
       }
+      STAMPB(3);
       __syncthreads();   // every wave's dz3 / mh tiles are staged
+      STAMPB(4);
 
       // ---- WG1: dWc1[16w.., :] += sum over the window's edge tiles of dz3^T mh ----
 #pragma unroll
@@ -200,17 +234,17 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
           const bool rv = row < nvalid;
-          const int v = v0 + sm.e_dl[wave][row];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const float up = rv ? g_hn[(size_t)v * ld_ghn + nt * 16 + r] : 0.0f;
-            const float dz2 = rv ? (acc[nt][t] + up) * dy[t][nt] : 0.0f;
+            const float dz2 = rv ? (acc[nt][t] + up[t][nt]) * dy[t][nt] : 0.0f;
             db2_a[nt] += dz2;
             dy[t][nt] = dz2;   // parked in registers until every wave has finished reading bufA / bufB
           }
         }
       }
+      STAMPB(5);
       __syncthreads();   // WG1 + MM3 reads of bufA / bufB are complete in all waves
+      STAMPB(6);
 
       if (nvalid > 0) {
 #pragma unroll
@@ -220,16 +254,9 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
 
         // ---- SA: recompute z1 (lane = channel) -> bufB ----
         {
-          float g[TE16];
 #pragma unroll
           for (int i = 0; i < TE16; ++i) {
-            const int s = sm.e_src[wave][i];
-            const int v = v0 + sm.e_dl[wave][i];
-            g[i] = ps[(size_t)s * ld_p + lane] + pd[(size_t)v * ld_p + lane];
-          }
-#pragma unroll
-          for (int i = 0; i < TE16; ++i) {
-            float z1 = g[i] + sm.e_rad[wave][i] * wr_c;
+            float z1 = gth[i] + sm.pdt[sm.e_dl[wave][i] * H + lane] + sm.e_rad[wave][i] * wr_c;
 #pragma unroll
             for (int f = 0; f < FE_MAX; ++f) z1 += sm.e_a[wave][f][i] * wa_c[f];
             bufB[i * LD + lane] = (i < nvalid) ? z1 : 0.0f;
@@ -250,7 +277,9 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           }
         }
       }
+      STAMPB(7);
       __syncthreads();   // every wave's dz2 / m1 tiles are staged
+      STAMPB(8);
 
       // ---- WG2: dW2[16w.., :] += sum over edge tiles of dz2^T m1 ----
 #pragma unroll
@@ -278,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           if (r == 0) sm.e_drad[wave][row] = part;
         }
       }
+      STAMPB(9);
       __syncthreads();   // WG2 + MM4 reads complete in all waves
+      STAMPB(10);
 
       if (nvalid > 0) {
 #pragma unroll
@@ -319,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
       }
       __syncthreads();
 
+      STAMPB(11);
       // ---- SEG: destination-side segment sums (deterministic, CSR order) ----
       {
         const int win_hi = min(win + WB16 * TE16, e_end);
@@ -341,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
       __syncthreads();
     }
 
+    STAMPB(12);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int nl = wave + WB16 * i;
@@ -392,6 +425,12 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
 }
 
 }  // namespace is
+
+#ifdef IS_STAGE_STAMPS
+extern "C" int is_debug_stamps_bwd(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b), sizeof(long long) * 24) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                    const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,

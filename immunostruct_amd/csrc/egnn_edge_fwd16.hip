@@ -10,6 +10,14 @@
 
 namespace is {
 
+// Optional per-stage timestamps (debug builds only: -DIS_STAGE_STAMPS): workgroup 300, wave 0.
+#ifdef IS_STAGE_STAMPS
+__device__ long long g_stamps[16];
+#define STAMP(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 constexpr int W16 = 8;  // waves per workgroup
 
 template <int FE_MAX>
@@ -27,7 +35,7 @@ struct Fwd16Smem {
 };
 
 template <int FE_MAX>
-__global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
+__global__ __launch_bounds__(512, 4) void egnn_edge_fwd16_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs,
@@ -37,13 +45,22 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
     float* __restrict__ h_neigh, int ld_hn, float* __restrict__ x_out,
     float* __restrict__ z2s, float* __restrict__ z3s, int N, int Fe) {
   __shared__ Fwd16Smem<FE_MAX> sm;
+  STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int v0 = blockIdx.x * NV;
   const int nv = min(NV, N - v0);
 
-  load_matrix_lds(sm.w2, W2, H, tid, 512);
-  load_matrix_lds(sm.wc1, Wc1, H, tid, 512);
+  // weight tiles: issue the global loads now, park them in registers and write them to LDS only before the
+  // first MFMA stage -- their latency overlaps the rowptr load and the S0 / SA stages of the first window
+  f32x4 wreg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + (j & 1) * 512;                      // 1024 float4 per matrix, 512 threads
+    const float* src = (j < 2) ? W2 : Wc1;
+    wreg[j] = *reinterpret_cast<const f32x4*>(src + idx * 4);
+  }
+  bool weights_staged = false;
   if (tid <= NV) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
 
   const float wr_c = W1[lane * ldw + 2 * din];
@@ -59,6 +76,7 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
   }
   __syncthreads();
 
+  STAMP(1);
   const int e_begin = sm.rp[0], e_end = sm.rp[nv];
   constexpr int NPW = NV / W16;  // nodes per wave in the segment phase
   float acc_h[NPW], acc_x[NPW];
@@ -70,12 +88,11 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
     const int cb = win + wave * TE16;
     const int nvalid = max(0, min(TE16, e_end - cb));
     if (nvalid > 0) {   // wave-uniform: everything in here touches wave-private LDS only
-      // ---- S0: per-edge scalars, lanes 0..15 = edges ----
+      // ---- S0a: source / destination ids of the tile (lanes 0..15 = edges) ----
       if (lane < TE16) {
         const bool valid = lane < nvalid;
         const int e = cb + lane;
         int s = v0, dl = 0;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f, rad = 0.f;
         if (valid) {
           s = srcs[e];
           int lo = 0, hi = nv;
@@ -84,7 +101,28 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
             if (sm.rp[mid] <= e) lo = mid; else hi = mid;
           }
           dl = lo;
-          const int v = v0 + dl;
+        }
+        sm.e_src[wave][lane] = s;
+        sm.e_dl[wave][lane] = dl;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- gathers (lane = channel) are issued as soon as the ids are known; the coordinate loads and the
+      //      geometry of S0b run while they are in flight ----
+      float g[TE16];
+#pragma unroll
+      for (int i = 0; i < TE16; ++i) {
+        const int s = sm.e_src[wave][i];
+        const int v = v0 + sm.e_dl[wave][i];
+        g[i] = ps[(size_t)s * ld_p + lane] + pd[(size_t)v * ld_p + lane];
+      }
+      // ---- S0b: geometry + edge features ----
+      if (lane < TE16) {
+        const bool valid = lane < nvalid;
+        const int e = cb + lane;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, rad = 0.f;
+        if (valid) {
+          const int s = sm.e_src[wave][lane];
+          const int v = v0 + sm.e_dl[wave][lane];
           d0 = x[s * 3 + 0] - x[v * 3 + 0];
           d1 = x[s * 3 + 1] - x[v * 3 + 1];
           d2 = x[s * 3 + 2] - x[v * 3 + 2];
@@ -92,8 +130,6 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
           const float inv = 1.0f / (sqrtf(rad) + 1e-30f);
           d0 *= inv; d1 *= inv; d2 *= inv;
         }
-        sm.e_src[wave][lane] = s;
-        sm.e_dl[wave][lane] = dl;
         sm.e_rad[wave][lane] = rad;
         sm.e_xd[wave][0][lane] = d0;
         sm.e_xd[wave][1][lane] = d1;
@@ -103,26 +139,31 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
           sm.e_a[wave][f][lane] = (valid && f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;
       }
       __builtin_amdgcn_wave_barrier();
+      STAMP(2);
 
-      // ---- SA: gather + first edge-MLP layer, lane = channel ----
-      {
-        float g[TE16];
+      // ---- SA: first edge-MLP layer, lane = channel ----
 #pragma unroll
-        for (int i = 0; i < TE16; ++i) {
-          const int s = sm.e_src[wave][i];
-          const int v = v0 + sm.e_dl[wave][i];
-          g[i] = ps[(size_t)s * ld_p + lane] + pd[(size_t)v * ld_p + lane];
-        }
+      for (int i = 0; i < TE16; ++i) {
+        float z1 = g[i] + sm.e_rad[wave][i] * wr_c;
 #pragma unroll
-        for (int i = 0; i < TE16; ++i) {
-          float z1 = g[i] + sm.e_rad[wave][i] * wr_c;
-#pragma unroll
-          for (int f = 0; f < FE_MAX; ++f) z1 += sm.e_a[wave][f][i] * wa_c[f];
-          act[i * LD + lane] = (i < nvalid) ? silu_f(z1) : 0.0f;
-        }
+        for (int f = 0; f < FE_MAX; ++f) z1 += sm.e_a[wave][f][i] * wa_c[f];
+        act[i * LD + lane] = (i < nvalid) ? silu_f(z1) : 0.0f;
       }
       __builtin_amdgcn_wave_barrier();
-
+    }
+    STAMP(3);
+    if (!weights_staged) {     // workgroup-uniform: first window only
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + (j & 1) * 512;
+        float* dst = (j < 2) ? sm.w2 : sm.wc1;
+        *reinterpret_cast<f32x4*>(dst + (idx / (H / 4)) * LD + (idx % (H / 4)) * 4) = wreg[j];
+      }
+      weights_staged = true;
+      __syncthreads();
+    }
+    STAMP(4);
+    if (nvalid > 0) {
       // ---- MM1: z2 = m1 W2^T + b2 ; mh = SiLU(z2) ----
       {
         f32x4 acc[4];
@@ -139,6 +180,7 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
           }
       }
       __builtin_amdgcn_wave_barrier();
+      STAMP(5);
 
       // ---- MM2: z3 = mh Wc1^T + bc1 ; s = SiLU(z3) . wc2 ----
       {
@@ -160,7 +202,9 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
         }
       }
     }
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
 
     // ---- SEG: deterministic segment reduction over this window ----
     {
@@ -184,6 +228,7 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
     __syncthreads();
   }
 
+  STAMP(8);
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int nl = wave + W16 * i;
@@ -200,6 +245,12 @@ __global__ __launch_bounds__(512) void egnn_edge_fwd16_kernel(
 }
 
 }  // namespace is
+
+#ifdef IS_STAGE_STAMPS
+extern "C" int is_debug_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" int is_egnn_edge_fwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                    const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,

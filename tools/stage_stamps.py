@@ -1,0 +1,39 @@
+"""Per-stage timeline of one edge-forward workgroup (debug build with -DIS_STAGE_STAMPS)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from immunostruct_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_dbg", "libimmunostruct_hip_dbg.so")
+from immunostruct_amd import synthetic
+from immunostruct_amd.graph import PackedGraphBatch
+from immunostruct_amd.nn import EGNNConv, egnn_stack_forward
+dev = torch.device("cuda:0")
+raw = synthetic.make_batch(128, seed=1)
+g = PackedGraphBatch.from_raw(raw, device=dev)
+layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(dev) for i in range(2)]
+lib = _lib.load()
+lib.is_debug_stamps.argtypes = [ctypes.c_void_p]; lib.is_debug_stamps.restype = ctypes.c_int
+names = ["entry", "consts+rp+barrier", "S0 done", "SA done", "weights staged", "MM1 done", "MM2 done", "barrier", "SEG done(+barrier)"]
+for rep in range(3):
+    with torch.no_grad():
+        egnn_stack_forward(layers, g, g.ndata["x"][:, :20], g.ndata["x"][:, 20:], g.edata["edge_attr"])
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 16)()
+    assert lib.is_debug_stamps(ctypes.cast(buf, ctypes.c_void_p)) == 0
+    t = list(buf)[:9]
+    print("rep", rep, " ".join(f"{names[i]}:+{t[i]-t[i-1]}" for i in range(1, 9)), " total", t[8] - t[0], "(shader-clock cycles)")
+
+# ---- backward timeline (first tile of workgroup 300) ----
+lib.is_debug_stamps_bwd.argtypes = [ctypes.c_void_p]; lib.is_debug_stamps_bwd.restype = ctypes.c_int
+bn = ["tile start", "rp+barriers+z loads issued", "S0", "E3", "barrier1", "WG1+MM3", "barrier2", "dz2,SA,E1", "barrier3", "WG2+MM4", "barrier4", "SB+GEO(+barrier5)", "SEG(+barrier6)"]
+for rep in range(3):
+    for l in layers:
+        l.zero_grad()
+    h0 = g.ndata["x"][:, :20]; x0 = g.ndata["x"][:, 20:]
+    hh, xx = egnn_stack_forward(layers, g, h0, x0, g.edata["edge_attr"])
+    (hh.sum() + xx.sum()).backward()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 24)()
+    assert lib.is_debug_stamps_bwd(ctypes.cast(buf, ctypes.c_void_p)) == 0
+    t = list(buf)[:13]
+    print("bwd rep", rep, " ".join(f"{bn[i]}:+{t[i]-t[i-1]}" for i in range(1, 13)), " total", t[12] - t[0])
