@@ -70,11 +70,14 @@ def build_batches(n_batches, batch, deg_extra, device, seed0):
     return out
 
 
-def cpu_baseline(batch, deg_extra, budget_s=20.0):
-    """Oracle train step (forward + loss + backward + Adam) on the host cores; returns graphs/s."""
+def cpu_baseline(batch, deg_extra, budget_s=24.0):
+    """Oracle train step (forward + loss + backward + Adam) on the host cores; returns graphs/s.
+
+    Two bounded samples (all hardware threads, and 16 threads: these small un-fused ops do not scale to
+    hundreds of threads) -- the faster one is reported together with the thread count it used.
+    """
     from oracle import functional_ref as FR
     from oracle import graph_ref
-    threads = torch.get_num_threads()
     raw = synthetic.make_batch(batch, seed=1, deg_extra=deg_extra)
     shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
@@ -90,17 +93,26 @@ def cpu_baseline(batch, deg_extra, budget_s=20.0):
         loss.backward()
         opt.step()
 
-    step()  # warm-up
-    t0, n = time.perf_counter(), 0
-    while True:
-        step()
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 40:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * n / dt, 2), unit="graphs/s", cores=threads, kind="port",
+    all_threads = torch.get_num_threads()
+    best = None
+    for threads in sorted({all_threads, min(16, all_threads)}, reverse=True):
+        torch.set_num_threads(threads)
+        step()  # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            step()
+            n += 1
+            if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
+                break
+        dt = time.perf_counter() - t0
+        rate = batch * n / dt
+        if best is None or rate > best[0]:
+            best = (rate, threads, n, dt)
+    torch.set_num_threads(all_threads)
+    rate, threads, n, dt = best
+    return dict(value=round(rate, 2), unit="graphs/s", cores=threads, kind="port",
                 sample=f"{n} train steps of B={batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam, "
-                       f"{threads} torch threads, {dt:.1f} s)")
+                       f"{threads} torch threads of {all_threads} available, {dt:.1f} s; best of the all-threads and 16-thread samples)")
 
 
 def main():

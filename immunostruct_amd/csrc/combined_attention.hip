@@ -173,32 +173,58 @@ __global__ __launch_bounds__(256) void comb_attn_bwd_kernel(
     partials[(size_t)b * CA_PART + 3 * CA_HEADS] = s;
   }
   // ---- phase 2: per key token j: dc_j = sum_{i,h} dm p_{ih}(j) (1 + gamma (c_j - m)) + direct ----
-  for (int j = tid; j < T; j += 256) {
-    const float cj = c[j];
+  // the (i,h) items are split over SPLIT thread groups so that all 256 threads work; the group partial
+  // sums are combined in a fixed order through LDS (deterministic)
+  __syncthreads();   // acc[][] has been consumed by the per-head sums above
+  {
+    const int split = (T <= 64) ? 4 : (T <= 128 ? 2 : 1);      // T * split <= 256
+    const int grp = tid / T, j = tid - grp * T;
     float a = 0.f;
-    for (int w = 0; w < items; ++w) {
-      const float gam = s_gamma[w];
-      const float p = __expf(gam * cj - s_mx[w]) * s_inv[w];
-      a += s_dm[w] * p * (1.0f + gam * (cj - s_m[w]));
+    if (grp < split) {
+      const float cj = c[j];
+      const int chunk = (items + split - 1) / split;
+      const int w_lo = grp * chunk, w_hi = min(items, w_lo + chunk);
+      for (int w = w_lo; w < w_hi; ++w) {
+        const float gam = s_gamma[w];
+        const float p = __expf(gam * cj - s_mx[w]) * s_inv[w];
+        a += s_dm[w] * p * (1.0f + gam * (cj - s_m[w]));
+      }
+      acc[grp][j] = a;
     }
-    dx[(size_t)b * T + j] = a + dxi[j];
+    __syncthreads();
+    if (tid < T) {
+      float v = dxi[tid];
+      for (int k = 0; k < split; ++k) v += acc[k][tid];
+      dx[(size_t)b * T + tid] = v;
+    }
   }
 }
 
 // sums the per-graph partials and applies the parameter chain rule; one workgroup.
 // out layout (floats): dwq[F] dbq[F] dwk[F] dbk[F] dwv[F] dbv[F] dWc[F*F] dbc[F]
 template <int F>
-__global__ __launch_bounds__(64) void comb_attn_finish_kernel(
+__global__ __launch_bounds__(256) void comb_attn_finish_kernel(
     const float* __restrict__ partials, int B, const float* __restrict__ wq, const float* __restrict__ bq,
     const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ bv,
     const float* __restrict__ Wc, float* __restrict__ out) {
   constexpr int D = F / CA_HEADS;
   __shared__ float tot[CA_PART];
   __shared__ float dwbar[F];
+  __shared__ float slice[8][32];
   const int tid = threadIdx.x;
+  {
+    // 8 slices of the batch are summed concurrently (independent loads), then combined in a fixed order
+    const int k = tid & 31, sl = tid >> 5;
+    float s = 0.f;
+    if (k < CA_PART)
+      for (int b = sl; b < B; b += 8) s += partials[(size_t)b * CA_PART + k];
+    slice[sl][k] = s;
+  }
+  __syncthreads();
   if (tid < CA_PART) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += partials[(size_t)b * CA_PART + tid];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) s += slice[sl][tid];
     tot[tid] = s;
   }
   __syncthreads();
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(64) void comb_attn_finish_kernel(
     out[6 * F + F * F + f] = dBeta / (float)F;          // dbc
   }
   __syncthreads();
-  for (int idx = tid; idx < F * F; idx += 64) out[6 * F + idx] = dwbar[idx % F];   // dWc[f'][f] = dwbar[f]
+  for (int idx = tid; idx < F * F; idx += 256) out[6 * F + idx] = dwbar[idx % F];   // dWc[f'][f] = dwbar[f]
 }
 
 }  // namespace is
@@ -246,10 +272,10 @@ extern "C" int is_comb_attn_bwd(const float* x, const float* stats, const float*
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (F == 16) {
     hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(256), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
-    hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(64), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
+    hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   } else {
     hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(256), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
-    hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(64), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
+    hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
