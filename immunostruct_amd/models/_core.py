@@ -14,6 +14,7 @@ Graph work runs on the HIP kernels (``immunostruct_amd.nn.EGNNConv`` and
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -25,6 +26,15 @@ from ..nn import EGNNConv, egnn_stack_forward
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
+OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 @dataclass(frozen=True)
@@ -139,11 +149,10 @@ class MultimodalNet(nn.Module):
             pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)
         return pooled, weights
 
-    def _encode(self, g, seq, prop, need_attention=False):
+    def _encode_sequence(self, seq, prop):
+        """property MLP + sequence VAE (everything that does not depend on the graph)."""
         sp = self.SPEC
         o = {}
-        if sp.graph:
-            o["x_gat_node"], o["attention"] = self._encode_graph(g, need_attention)
         p = None
         if sp.prop == "emb":
             p = self.property_embedding(prop)
@@ -155,6 +164,30 @@ class MultimodalNet(nn.Module):
             if p is not None:
                 z = torch.cat([z, p], dim=1)
             o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=self.decode_vae(z))
+        return o
+
+    def _encode(self, g, seq, prop, need_attention=False):
+        """Graph branch and sequence branch are independent until the fusion head: the sequence branch is
+        enqueued on a side HIP stream so that its (library) GEMMs overlap the latency-bound graph kernels --
+        also inside a captured HIP graph (fork/join) and, through autograd's stream bookkeeping, in backward."""
+        sp = self.SPEC
+        o = {}
+        overlap = sp.graph and sp.vae and seq.is_cuda and OVERLAP_BRANCHES
+        if overlap:
+            main = torch.cuda.current_stream()
+            side = _side_stream(seq.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                o.update(self._encode_sequence(seq, prop))
+        if sp.graph:
+            o["x_gat_node"], o["attention"] = self._encode_graph(g, need_attention)
+        if overlap:
+            main.wait_stream(side)
+            for t in o.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        else:
+            o.update(self._encode_sequence(seq, prop))
         return o
 
     def _head(self, fused):
