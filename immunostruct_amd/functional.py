@@ -77,6 +77,19 @@ _EDGE_STRIDE = 8448 + 64 * 8
 _NODE_STRIDE = 64 * 128 + 64 * 64 + 128
 _PROJ_STRIDE = 128 * 64 + 128
 _plan_cache = {}
+# weight-gradient work (streaming outer products + partial reductions) does not feed the backward data path and CAN
+# be enqueued on a side stream that joins at the end of the stack's backward.  Measured on MI355X (B = 128) this is
+# a loss (2.23 vs 2.05 ms/step: the side kernels take CUs/LDS away from the latency-critical edge kernels), so it
+# is off by default; IMMUNOSTRUCT_OVERLAP_WGRAD=1 turns it on.
+OVERLAP_WGRAD = os.environ.get("IMMUNOSTRUCT_OVERLAP_WGRAD", "0") == "1"
+_wgrad_streams = {}
+
+
+def _wgrad_stream(device):
+    key = (device.type, device.index)
+    if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(device=device)
+    return _wgrad_streams[key]
 
 
 class _LayerPlan:
@@ -234,14 +247,22 @@ class EGNNStackFn(torch.autograd.Function):
         edge_bwd = lib.is_egnn_edge_bwd_v2 if use_v2 else lib.is_egnn_edge_bwd
         grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16)) if use_v2 else _grid_for(n, _NODES_PER_TILE)
         grid_n = _grid_for(n, 128)
-        part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)
         part_n = torch.empty(grid_n * _NODE_STRIDE, **f32)
         part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
         scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_NODE_STRIDE), **f32)
+        main = torch.cuda.current_stream()
+        side = _wgrad_stream(dev) if (OVERLAP_WGRAD and NODE_KERNELS == "v2") else main
+        keep = []          # tensors the side stream still reads: released only after the final join
+
+        def on_side():
+            side.wait_stream(main)
+            return torch.cuda.stream(side)
 
         def reduce(part, nparts, stride, mp, dst, count=None):
-            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, stride if count is None else count, _lib.ptr(mp),
-                                              _lib.ptr(dst), _lib.ptr(scratch), st), "is_reduce_partials")
+            # every reduction runs on the side stream (single user of `scratch`)
+            with on_side():
+                _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, stride if count is None else count, _lib.ptr(mp),
+                                                  _lib.ptr(dst), _lib.ptr(scratch), _lib.stream_ptr()), "is_reduce_partials")
 
         node_v2 = NODE_KERNELS == "v2"
         if node_v2:
@@ -268,13 +289,15 @@ class EGNNStackFn(torch.autograd.Function):
                                                          int(W1n.shape[1]) if has_psd else 0, _lib.ptr(lay["zn1"]), din,
                                                          _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(dh_total) if has_psd else None,
                                                          _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n, st), "is_egnn_node_bwd_data")
-                with KernelTimer.span("egnn_node_wgrad"):
-                    _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
-                                                      _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
-                                                      HIDDEN, _lib.ptr(part_w), grid_w, n, st), "is_egnn_node_wgrad")
-                if has_psd:
-                    reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
-                reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
+                keep.extend([dh_total, dzn1, g_psd_next, g_hd])
+                with on_side():
+                    with KernelTimer.span("egnn_node_wgrad"):
+                        _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
+                                                          _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
+                                                          HIDDEN, _lib.ptr(part_w), grid_w, n, _lib.stream_ptr()), "is_egnn_node_wgrad")
+                    if has_psd:
+                        reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
+                    reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
             else:
                 # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
                 if g_psd_next is not None:
@@ -294,6 +317,7 @@ class EGNNStackFn(torch.autograd.Function):
                                                     _lib.ptr(d_hn), _lib.ptr(part_n), grid_n, n, st), "is_egnn_node_bwd")
                 reduce(part_n, grid_n, _NODE_STRIDE, plans[i].node_map, gflat[i])
             # (3) fused edge backward + source-side gather
+            part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)   # per layer: its reduction runs on the side stream
             dZ1 = torch.empty(max(e, 1), HIDDEN, **f32)
             dD = torch.empty(max(e, 1), 3, **f32)
             dpsd = torch.empty(n, 2 * HIDDEN, **f32)
@@ -306,6 +330,7 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
                     _lib.ptr(d_hn), HIDDEN, _lib.ptr(g_xc), _lib.ptr(dZ1), _lib.ptr(dD),
                     _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), grid_e, n, fe, st), "is_egnn_edge_bwd")
+            keep.append(part_e)
             reduce(part_e, grid_e, _EDGE_STRIDE, plans[i].edge_map, gflat[i])
             with KernelTimer.span("gather_segment_sum"):
                 _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
@@ -315,11 +340,15 @@ class EGNNStackFn(torch.autograd.Function):
         lay0 = layers[0]
         W1_0 = params[0]
         dh0 = torch.empty(n, HIDDEN, **f32) if ctx.h0_needs_grad else None
+        keep.extend([g_hd, g_psd_next])
         with KernelTimer.span("node_proj_bwd"):
             _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
                                             _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
                        "is_node_proj_bwd")
         reduce(part_p, grid_n, _PROJ_STRIDE, plans[0].proj_map, gflat[0])
+        if side is not main:
+            main.wait_stream(side)     # every weight gradient is complete before autograd hands them on
+        keep.clear()
         grads = []
         for i in range(L):
             grads.extend(plans[i].views(gflat[i]))
