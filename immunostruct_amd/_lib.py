@@ -47,6 +47,8 @@ SIGNATURES = {
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],
     "is_egnn_node_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
+    "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
+    "is_reduce_partials_batched": [_P, _I, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -60,6 +62,20 @@ SIGNATURES = {
     "is_loss_partials_floats": [],
     "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P],
 }
+
+
+
+class WgradLayer(ctypes.Structure):
+    """one layer of is_egnn_node_wgrad_batched (mirrors `WgradLayer` in csrc/egnn_node16.hip)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("g_psd", "h_out", "dh", "zn1", "dzn1", "h", "h_neigh", "partials")] + \
+               [(n, ctypes.c_int) for n in ("ld_h", "din", "ld_hn", "pad")]
+
+
+class ReduceJob(ctypes.Structure):
+    """one job of is_reduce_partials_batched (mirrors `ReduceJob` in csrc/egnn_node.hip)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("partials", "map", "dst", "scratch")] + \
+               [(n, ctypes.c_int) for n in ("nparts", "stride", "count", "pad")]
+
 
 _lib = None
 

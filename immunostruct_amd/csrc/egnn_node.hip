@@ -417,6 +417,44 @@ __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __res
   if (d >= 0) dst[d] = v;
 }
 
+
+// Batched form: up to RED_MAX_JOBS independent reductions (one per kernel's partial records) in two launches.
+struct ReduceJob {
+  const float* partials;
+  const int* map;
+  float* dst;
+  float* scratch;     // RED_SPLIT * count floats
+  int nparts, stride, count, pad;
+};
+constexpr int RED_MAX_JOBS = 24;
+struct ReduceBatch { ReduceJob job[RED_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void reduce_partials_batched_stage1(ReduceBatch batch) {
+  const ReduceJob& J = batch.job[blockIdx.z];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= J.count) return;
+  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+  int p = blockIdx.y;
+  for (; p + 3 * RED_SPLIT < J.nparts; p += 4 * RED_SPLIT) {
+    v0 += J.partials[(size_t)p * J.stride + idx];
+    v1 += J.partials[(size_t)(p + RED_SPLIT) * J.stride + idx];
+    v2 += J.partials[(size_t)(p + 2 * RED_SPLIT) * J.stride + idx];
+    v3 += J.partials[(size_t)(p + 3 * RED_SPLIT) * J.stride + idx];
+  }
+  for (; p < J.nparts; p += RED_SPLIT) v0 += J.partials[(size_t)p * J.stride + idx];
+  J.scratch[(size_t)blockIdx.y * J.count + idx] = (v0 + v1) + (v2 + v3);
+}
+__global__ __launch_bounds__(256) void reduce_partials_batched_stage2(ReduceBatch batch) {
+  const ReduceJob& J = batch.job[blockIdx.z];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= J.count) return;
+  float v = 0.0f;
+#pragma unroll
+  for (int s = 0; s < RED_SPLIT; ++s) v += J.scratch[(size_t)s * J.count + idx];
+  const int d = J.map != nullptr ? J.map[idx] : idx;
+  if (d >= 0) J.dst[d] = v;
+}
+
 }  // namespace is
 
 #define IS_STREAM(s) static_cast<hipStream_t>(s)
@@ -474,5 +512,22 @@ extern "C" int is_reduce_partials(const float* partials, int nparts, int stride,
   const dim3 block(256);
   hipLaunchKernelGGL(is::reduce_partials_stage1, dim3((count + 255) / 256, is::RED_SPLIT), block, 0, IS_STREAM(stream), partials, nparts, stride, count, scratch);
   hipLaunchKernelGGL(is::reduce_partials_stage2, dim3((count + 255) / 256), block, 0, IS_STREAM(stream), scratch, count, map, dst);
+  IS_RET();
+}
+
+// jobs: host array of `njobs` (<= 24) records {partials, map, dst, scratch, nparts, stride, count, pad}
+extern "C" int is_reduce_partials_batched(const void* jobs, int njobs, void* stream) {
+  if (njobs <= 0 || njobs > is::RED_MAX_JOBS) return -22;
+  is::ReduceBatch batch;
+  const is::ReduceJob* src = static_cast<const is::ReduceJob*>(jobs);
+  int maxcount = 0;
+  for (int i = 0; i < njobs; ++i) {
+    batch.job[i] = src[i];
+    if (src[i].count <= 0 || src[i].count > src[i].stride || src[i].nparts <= 0) return -22;
+    maxcount = src[i].count > maxcount ? src[i].count : maxcount;
+  }
+  const dim3 block(256);
+  hipLaunchKernelGGL(is::reduce_partials_batched_stage1, dim3((maxcount + 255) / 256, is::RED_SPLIT, njobs), block, 0, IS_STREAM(stream), batch);
+  hipLaunchKernelGGL(is::reduce_partials_batched_stage2, dim3((maxcount + 255) / 256, 1, njobs), block, 0, IS_STREAM(stream), batch);
   IS_RET();
 }

@@ -311,7 +311,7 @@ constexpr int WG_NODE = 64 * 128 + 64 * 64 + 128;
 constexpr int WG_STRIDE = WG_PROJ + WG_NODE;
 
 template <int DIN>
-__global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
+__device__ __forceinline__ void egnn_node_wgrad16_body(
     const float* __restrict__ g_psd, const float* __restrict__ h_out, const float* __restrict__ dh,
     const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
     const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
@@ -421,6 +421,33 @@ __global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
   }
 }
 
+
+template <int DIN>
+__global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
+    const float* __restrict__ g_psd, const float* __restrict__ h_out, const float* __restrict__ dh,
+    const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
+    const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
+  egnn_node_wgrad16_body<DIN>(g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows_per_wg);
+}
+
+// All layers of a stack in ONE launch (blockIdx.y = layer): 6 x 254 workgroups instead of six launches of 254
+// single-wave-per-SIMD workgroups -- the co-resident workgroups of different layers hide each other's latency.
+struct WgradLayer {
+  const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh;
+  float* partials;
+  int ld_h, din, ld_hn, pad;
+};
+constexpr int WGRAD_MAX_LAYERS = 8;
+struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256, 2) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
+  const WgradLayer& L = batch.layer[blockIdx.y];
+  if (L.din == 20)
+    egnn_node_wgrad16_body<20>(L.g_psd, L.h_out, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+  else
+    egnn_node_wgrad16_body<64>(L.g_psd, L.h_out, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+}
+
 }  // namespace is
 
 extern "C" int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
@@ -461,5 +488,20 @@ extern "C" int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const 
   if (din == 20) hipLaunchKernelGGL(is::egnn_node_wgrad16_kernel<20>, dim3(grid), dim3(256), 0, st, g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows);
   else if (din == 64) hipLaunchKernelGGL(is::egnn_node_wgrad16_kernel<64>, dim3(grid), dim3(256), 0, st, g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows);
   else return -22;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// layers: host array of `nlayers` (<= 8) records {g_psd, h_out, dh, zn1, dzn1, h, h_neigh, partials, ld_h, din, ld_hn, pad}
+// (pointers first, then four ints); every layer uses `grid` workgroups and the record layout of is_egnn_node_wgrad.
+extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream) {
+  if (N <= 0 || grid <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
+  is::WgradBatch batch;
+  const is::WgradLayer* src = static_cast<const is::WgradLayer*>(layers);
+  for (int i = 0; i < nlayers; ++i) {
+    batch.layer[i] = src[i];
+    if (src[i].din != 20 && src[i].din != 64) return -22;
+  }
+  const int rows = (((N + grid - 1) / grid) + 15) / 16 * 16;
+  hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(grid, nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), batch, N, rows);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

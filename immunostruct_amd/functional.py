@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 
+import ctypes
 import os
 
 HIDDEN = 64
@@ -20,6 +21,8 @@ _NODES_PER_TILE = 32
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
 # node-kernel mapping: "v2" = one workgroup per 32-row tile, weights from L2, separate weight-gradient kernel
 NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
+# weight gradients of all layers in one launch + all partial reductions in one launch pair, after the data path
+BATCH_WGRAD = os.environ.get("IMMUNOSTRUCT_BATCH_WGRAD", "1") != "0"
 
 
 class KernelTimer:
@@ -265,10 +268,12 @@ class EGNNStackFn(torch.autograd.Function):
                                                   _lib.ptr(dst), _lib.ptr(scratch), _lib.stream_ptr()), "is_reduce_partials")
 
         node_v2 = NODE_KERNELS == "v2"
+        batched = node_v2 and BATCH_WGRAD and L <= 7
+        wjobs, rjobs = [], []     # deferred weight-gradient layers / reduction jobs (batched mode)
         if node_v2:
             wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
             grid_w = _grid_for(n, 96)
-            part_w = torch.empty(grid_w * wg_stride, **f32)
+            part_w = None if batched else torch.empty(grid_w * wg_stride, **f32)
 
         g_psd_next = None
         for i in reversed(range(L)):
@@ -290,14 +295,24 @@ class EGNNStackFn(torch.autograd.Function):
                                                          _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(dh_total) if has_psd else None,
                                                          _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n, st), "is_egnn_node_bwd_data")
                 keep.extend([dh_total, dzn1, g_psd_next, g_hd])
-                with on_side():
-                    with KernelTimer.span("egnn_node_wgrad"):
-                        _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
-                                                          _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
-                                                          HIDDEN, _lib.ptr(part_w), grid_w, n, _lib.stream_ptr()), "is_egnn_node_wgrad")
+                if batched:
+                    pw = torch.empty(grid_w * wg_stride, **f32)
+                    keep.append(pw)
+                    wjobs.append(_lib.WgradLayer(_lib.ptr(g_psd_next).value if has_psd else None, lay["h_out"].data_ptr(),
+                                                 dh_total.data_ptr(), lay["zn1"].data_ptr(), dzn1.data_ptr(), lay["h_in"].data_ptr(),
+                                                 lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, 0))
                     if has_psd:
-                        reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
-                    reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
+                        rjobs.append((pw, grid_w, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
+                    rjobs.append((pw[wg_proj:], grid_w, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
+                else:
+                    with on_side():
+                        with KernelTimer.span("egnn_node_wgrad"):
+                            _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
+                                                              _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
+                                                              HIDDEN, _lib.ptr(part_w), grid_w, n, _lib.stream_ptr()), "is_egnn_node_wgrad")
+                        if has_psd:
+                            reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
+                        reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
             else:
                 # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
                 if g_psd_next is not None:
@@ -331,7 +346,10 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.ptr(d_hn), HIDDEN, _lib.ptr(g_xc), _lib.ptr(dZ1), _lib.ptr(dD),
                     _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), grid_e, n, fe, st), "is_egnn_edge_bwd")
             keep.append(part_e)
-            reduce(part_e, grid_e, _EDGE_STRIDE, plans[i].edge_map, gflat[i])
+            if batched:
+                rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
+            else:
+                reduce(part_e, grid_e, _EDGE_STRIDE, plans[i].edge_map, gflat[i])
             with KernelTimer.span("gather_segment_sum"):
                 _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
                                                      _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st), "is_gather_segment_sum")
@@ -345,7 +363,23 @@ class EGNNStackFn(torch.autograd.Function):
             _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
                                             _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
                        "is_node_proj_bwd")
-        reduce(part_p, grid_n, _PROJ_STRIDE, plans[0].proj_map, gflat[0])
+        if batched:
+            rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
+            arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
+            with KernelTimer.span("egnn_node_wgrad_batched"):
+                _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
+                           "is_egnn_node_wgrad_batched")
+            split = lib.is_reduce_partials_scratch_floats(1)
+            big = torch.empty(sum(split * c for (_, _, _, c, _, _) in rjobs), **f32)
+            jobs, off = [], 0
+            for (pt, nparts, stride, count, mp, dst) in rjobs:
+                jobs.append(_lib.ReduceJob(pt.data_ptr(), mp.data_ptr(), dst.data_ptr(), big[off:].data_ptr(), nparts, stride, count, 0))
+                off += split * count
+            jarr = (_lib.ReduceJob * len(jobs))(*jobs)
+            with KernelTimer.span("reduce_partials_batched"):
+                _lib.check(lib.is_reduce_partials_batched(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_reduce_partials_batched")
+        else:
+            reduce(part_p, grid_n, _PROJ_STRIDE, plans[0].proj_map, gflat[0])
         if side is not main:
             main.wait_stream(side)     # every weight gradient is complete before autograd hands them on
         keep.clear()

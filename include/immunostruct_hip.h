@@ -148,6 +148,16 @@ int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, 
                        const float* dzn1, const float* h, int ld_h, int din, const float* h_neigh,
                        int ld_hn, float* partials, int grid, int N, void* stream);
 
+/* Batched forms (one launch for all layers of a stack / for all pending reductions).
+ *   is_egnn_node_wgrad_batched: `layers` = host array of nlayers (<= 8) records
+ *       { const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh; float* partials; int ld_h, din, ld_hn, pad; }
+ *     each processed exactly like is_egnn_node_wgrad with `grid` workgroups.
+ *   is_reduce_partials_batched: `jobs` = host array of njobs (<= 24) records
+ *       { const float* partials; const int32_t* map; float* dst; float* scratch; int nparts, stride, count, pad; }
+ *     each processed exactly like is_reduce_partials (scratch: is_reduce_partials_scratch_floats(count) floats). */
+int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream);
+int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
+
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
  * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
