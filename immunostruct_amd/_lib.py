@@ -49,6 +49,7 @@ SIGNATURES = {
     "is_egnn_node_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
+    "is_multi_copy": [_P, _I, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -75,6 +76,11 @@ class ReduceJob(ctypes.Structure):
     """one job of is_reduce_partials_batched (mirrors `ReduceJob` in csrc/egnn_node.hip)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("partials", "map", "dst", "scratch")] + \
                [(n, ctypes.c_int) for n in ("nparts", "stride", "count", "pad")]
+
+
+class CopyJob(ctypes.Structure):
+    """one job of is_multi_copy"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
 
 
 _lib = None

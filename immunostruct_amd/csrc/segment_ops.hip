@@ -130,3 +130,48 @@ extern "C" int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_
                      static_cast<hipStream_t>(stream), x, ld_x, seg_ptr, out_max, g_mean, g_max, dx, ld_dx, C);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batched device-to-device copy: the per-step hand-over of a device-resident batch into the static
+// buffers a captured HIP graph replays on (node features, CSR arrays, edge features, sequence, property,
+// target) as ONE launch instead of ten hipMemcpyAsync calls.
+namespace is {
+struct CopyJob { const void* src; void* dst; long long bytes; };
+constexpr int COPY_MAX_JOBS = 16;
+struct CopyBatch { CopyJob job[COPY_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(CopyBatch batch) {
+  const CopyJob& J = batch.job[blockIdx.y];
+  const long long words = J.bytes >> 2;              // sizes are multiples of 4 bytes
+  const int* s = static_cast<const int*>(J.src);
+  int* d = static_cast<int*>(J.dst);
+  const bool vec = (((uintptr_t)s | (uintptr_t)d) & 15) == 0;
+  const long long stride = (long long)gridDim.x * 256;
+  if (vec) {
+    const long long quads = words >> 2;
+    const int4* s4 = reinterpret_cast<const int4*>(s);
+    int4* d4 = reinterpret_cast<int4*>(d);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += stride) d4[i] = s4[i];
+    for (long long i = (quads << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) d[i] = s[i];
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) d[i] = s[i];
+  }
+}
+}  // namespace is
+
+// jobs: host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; }, bytes % 4 == 0
+extern "C" int is_multi_copy(const void* jobs, int njobs, void* stream) {
+  if (njobs <= 0 || njobs > is::COPY_MAX_JOBS) return -22;
+  is::CopyBatch batch;
+  const is::CopyJob* src = static_cast<const is::CopyJob*>(jobs);
+  long long maxb = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (src[i].bytes < 0 || (src[i].bytes & 3)) return -22;
+    batch.job[i] = src[i];
+    maxb = src[i].bytes > maxb ? src[i].bytes : maxb;
+  }
+  int blocks = (int)((maxb / 16 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  hipLaunchKernelGGL(is::multi_copy_kernel, dim3(blocks, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

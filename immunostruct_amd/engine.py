@@ -59,20 +59,46 @@ class StaticGraphBatch(PackedGraphBatch):
     def edge_feat_csr(self, edge_feat):
         return self._ea_csr
 
-    def load(self, g: PackedGraphBatch):
-        """Copy a device-resident batch (same node layout, E <= capacity) into the static buffers."""
+    def copy_pairs(self, g: PackedGraphBatch):
+        """(source, destination) tensor pairs that hand a device-resident batch (same node layout,
+        E <= capacity) over to the static buffers."""
         e = g.num_edges()
         if e > self.edge_capacity:
             raise ValueError(f"batch has {e} edges, static capacity is {self.edge_capacity}")
         if g.num_nodes() != self._num_nodes or g._counts != self._counts:
             raise ValueError("node layout differs from the captured batch")
         src = g.csr()
-        self.ndata["x"].copy_(g.ndata["x"], non_blocking=True)
-        self._csr.rowptr_dst.copy_(src.rowptr_dst, non_blocking=True)
-        self._csr.rowptr_src.copy_(src.rowptr_src, non_blocking=True)
-        self._csr.src_sorted[:e].copy_(src.src_sorted, non_blocking=True)
-        self._csr.pos_by_src[:e].copy_(src.pos_by_src, non_blocking=True)
-        self._ea_csr[:e].copy_(g.edge_feat_csr(g.edata["edge_attr"]), non_blocking=True)
+        return [(g.ndata["x"], self.ndata["x"]), (src.rowptr_dst, self._csr.rowptr_dst),
+                (src.rowptr_src, self._csr.rowptr_src), (src.src_sorted, self._csr.src_sorted[:e]),
+                (src.pos_by_src, self._csr.pos_by_src[:e]),
+                (g.edge_feat_csr(g.edata["edge_attr"]), self._ea_csr[:e])]
+
+    def load(self, g: PackedGraphBatch):
+        multi_copy(self.copy_pairs(g))
+
+
+def multi_copy(pairs):
+    """All (source, destination) copies of one batch hand-over as ONE kernel launch
+    (csrc/segment_ops.hip ``is_multi_copy``) instead of one hipMemcpyAsync per array."""
+    import ctypes
+
+    from . import _lib
+    jobs = []
+    for s_, d_ in pairs:
+        if (s_.dtype != d_.dtype or s_.numel() != d_.numel() or not s_.is_contiguous() or not d_.is_contiguous()
+                or s_.device != d_.device):
+            raise ValueError("batch tensors must be contiguous, on the step's device, and match the captured "
+                             f"dtype / shape (got {tuple(s_.shape)} {s_.dtype} for {tuple(d_.shape)} {d_.dtype})")
+        nbytes = s_.numel() * s_.element_size()
+        if nbytes % 4:
+            raise ValueError("is_multi_copy moves 4-byte words")
+        if nbytes:
+            jobs.append(_lib.CopyJob(s_.data_ptr(), d_.data_ptr(), nbytes))
+    lib = _lib.load()
+    for at in range(0, len(jobs), 16):
+        chunk = jobs[at:at + 16]
+        arr = (_lib.CopyJob * len(chunk))(*chunk)
+        _lib.check(lib.is_multi_copy(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _lib.stream_ptr()), "is_multi_copy")
 
 
 class CapturedTrainStep:
@@ -121,10 +147,7 @@ class CapturedTrainStep:
                 self.optimizer.step()
 
     def _load(self, g, seq, prop, y):
-        self.sgraph.load(g)
-        self.seq.copy_(seq, non_blocking=True)
-        self.prop.copy_(prop, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
+        multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
 
     def _fwd_bwd(self):
         self.reducer.zero()

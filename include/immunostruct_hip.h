@@ -163,6 +163,11 @@ int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
                           float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
 
+/* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
+ * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
+ * bytes a multiple of 4.                                                                                   */
+int is_multi_copy(const void* jobs, int njobs, void* stream);
+
 /* Per-segment mean and/or max over rows seg_ptr[s] .. seg_ptr[s+1] of x [rows, ld_x] (C channels).
  * out_mean / out_max [num_segments, C] may each be NULL.  Empty segment: mean 0, max 0.            */
 int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_ptr, float* out_mean, float* out_max,

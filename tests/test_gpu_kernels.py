@@ -314,3 +314,22 @@ def test_node_attention_pooled_mean(cuda_device, heads, n):
             assert float(p.grad.abs().max()) < 1e-5 * gmax, name
         else:
             H.assert_close(p.grad.cpu(), refg, 5e-5, f"d pooled / d {name}")
+
+
+@pytest.mark.gpu
+def test_multi_copy_matches_copy(cuda_device):
+    """is_multi_copy: aligned, unaligned and ragged-size jobs, int and float payloads -- bit-exact."""
+    from immunostruct_amd.engine import multi_copy
+    g = torch.Generator().manual_seed(5)
+    pairs = []
+    for n, dt in [(1, torch.float32), (7, torch.int32), (4096, torch.float32), (100003, torch.float32), (64, torch.int64)]:
+        src = torch.randint(-2 ** 30, 2 ** 30, (n + 3,), generator=g).to(dt).to(cuda_device)
+        dst = torch.zeros(n + 3, dtype=dt, device=cuda_device)
+        pairs.append((src[1:n + 1], dst[2:n + 2]))           # deliberately 4/8-byte (not 16-byte) aligned views
+        pairs.append((src.clone(), torch.zeros_like(dst)))
+    multi_copy(pairs)
+    torch.cuda.synchronize()
+    for s_, d_ in pairs:
+        assert torch.equal(s_, d_)
+    with pytest.raises(ValueError):
+        multi_copy([(torch.zeros(4, device=cuda_device), torch.zeros(5, device=cuda_device))])
