@@ -44,6 +44,12 @@ __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
   dy = s * (1.0f + z * (1.0f - s));
 }
 
+// |d|^2 with a FIXED contraction (the compiler otherwise picks fma chains or packed multiplies per call site,
+// and the forward / backward / v2 / v3 kernels would disagree in the last bit).
+__device__ __forceinline__ float radial3(float d0, float d1, float d2) {
+  return __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0));
+}
+
 // D-register t of a 32x32 tile -> row inside the tile.
 __device__ __forceinline__ int tile_row(int t, int hf) { return (t & 3) + 8 * (t >> 2) + 4 * hf; }
 
@@ -205,11 +211,35 @@ __device__ __forceinline__ void zero_acc4(f32x4 (&acc)[N]) {
   for (int i = 0; i < N; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// sum of v over the 16 lanes that share q = lane >> 4.
+// sum of v over the 16 lanes that share q = lane >> 4 (one DPP row): four v_add_f32_dpp, no LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float sum_over_r16(float v) {
-#pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror
+  v += dpp_move<0x140>(v);   // row_mirror
   return v;
+}
+
+// ---------------------------------------------------------------------------
+// Raw buffer access: scalar (SGPR) row offset + per-lane (VGPR) offset, both in BYTES and 32-bit.
+// A gathered row costs one v_readlane + one s_mul + one buffer_load -- no 64-bit vector address math.
+// The compiler tracks these like ordinary loads (s_waitcnt vmcnt(N) with exact counts).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ int buf_load_i(rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t rs, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
 }
 
 // Sum a [64 x 64] accumulator (2 x 2 tiles of 32 x 32, one copy per wave) over the 4 waves of a

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void egnn_edge_bwd_kernel(
           d0 = x[s * 3 + 0] - x[v * 3 + 0];
           d1 = x[s * 3 + 1] - x[v * 3 + 1];
           d2 = x[s * 3 + 2] - x[v * 3 + 2];
-          rad = d0 * d0 + d1 * d1 + d2 * d2;
+          rad = radial3(d0, d1, d2);
           rr = sqrtf(rad);
           inv = 1.0f / (rr + 1e-30f);
           const float invdeg = 1.0f / (float)(sm.rp[dl + 1] - sm.rp[dl]);

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 4) void egnn_edge_fwd16_kernel(
           d0 = x[s * 3 + 0] - x[v * 3 + 0];
           d1 = x[s * 3 + 1] - x[v * 3 + 1];
           d2 = x[s * 3 + 2] - x[v * 3 + 2];
-          rad = d0 * d0 + d1 * d1 + d2 * d2;
+          rad = radial3(d0, d1, d2);
           const float inv = 1.0f / (sqrtf(rad) + 1e-30f);
           d0 *= inv; d1 *= inv; d2 *= inv;
         }

@@ -19,6 +19,15 @@ _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
 _NODES_PER_TILE = 32
 # edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
+EDGE_FWD = os.environ.get("IMMUNOSTRUCT_EDGE_FWD", "v3")          # v3: wave-autonomous pipelined forward
+FWD_CHUNKS_MAX = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNKS", "2048"))
+FWD_CHUNK_EDGES = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNK_EDGES", "32"))
+
+
+def fwd_chunk_count(num_edges):
+    """number of wave-chunks of the v3 forward: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves"""
+    k = max(4, min(FWD_CHUNKS_MAX, (num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES))
+    return (k + 3) // 4 * 4
 # node-kernel mapping: "v2" = one workgroup per 32-row tile, weights from L2, separate weight-gradient kernel
 NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
 # weight gradients of all layers in one launch + all partial reductions in one launch pair, after the data path
@@ -205,10 +214,21 @@ class EGNNStackFn(torch.autograd.Function):
                 raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
             h_neigh = torch.empty(n, HIDDEN, **f32)
             x_out = torch.empty(n, 3, **f32)
-            z2s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
-            z3s = torch.empty(max(e, 1), HIDDEN, **f32) if need_grad else None
+            z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # v3 stores full 16-row tiles
+            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None
             edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
-            with KernelTimer.span("egnn_edge_fwd"):
+            if EDGE_FWD == "v3" and EDGE_KERNELS == "v2":
+                kf = fwd_chunk_count(e)
+                with KernelTimer.span("egnn_edge_fwd"):
+                    _lib.check(lib.is_egnn_edge_fwd_v3(
+                        _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
+                        _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted),
+                        _lib.ptr(csr.chunks(kf)), kf, _lib.ptr(W1), ldw, din,
+                        _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+                        _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe, st),
+                        "is_egnn_edge_fwd_v3")
+            else:
+              with KernelTimer.span("egnn_edge_fwd"):
                 _lib.check(edge_fwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,

@@ -24,7 +24,8 @@ import torch
 
 
 class CSRIndex:
-    __slots__ = ("rowptr_dst", "src_sorted", "eperm", "rowptr_src", "pos_by_src", "num_nodes", "num_edges")
+    __slots__ = ("rowptr_dst", "src_sorted", "dst_sorted", "eperm", "rowptr_src", "pos_by_src", "num_nodes", "num_edges",
+                 "_chunks")
 
     def __init__(self, src, dst, num_nodes):
         src = src.long()
@@ -34,18 +35,43 @@ class CSRIndex:
         src_sorted = src[order]
         self.eperm = order
         self.src_sorted = src_sorted.to(torch.int32)
+        self.dst_sorted = dst[order].to(torch.int32)
         self.rowptr_dst = _rowptr(dst, n)
         order2 = torch.argsort(src_sorted, stable=True)
         self.pos_by_src = order2.to(torch.int32)
         self.rowptr_src = _rowptr(src, n)
         self.num_nodes, self.num_edges = n, e
+        self._chunks = {}
 
     def to(self, device):
         out = object.__new__(CSRIndex)
-        for k in ("rowptr_dst", "src_sorted", "eperm", "rowptr_src", "pos_by_src"):
+        for k in ("rowptr_dst", "src_sorted", "dst_sorted", "eperm", "rowptr_src", "pos_by_src"):
             setattr(out, k, getattr(self, k).to(device))
         out.num_nodes, out.num_edges = self.num_nodes, self.num_edges
+        out._chunks = {k: v.to(device) for k, v in self._chunks.items()}
         return out
+
+    def chunks(self, k):
+        """``chunk_ptr`` (k+1,) int32: the destination nodes cut into k contiguous ranges with (nearly) equal
+        in-edge counts -- the unit of work of one wave of the v3 edge kernels."""
+        k = int(k)
+        if k not in self._chunks:
+            self._chunks[k] = balanced_node_chunks(self.rowptr_dst, k)
+        return self._chunks[k]
+
+
+def balanced_node_chunks(rowptr, k):
+    """Boundaries b_0 = 0 <= b_1 <= ... <= b_k = N with b_j = first node whose first in-edge index is
+    >= j*E/k: node-aligned chunks of about E/k edges (a node of very high degree leaves its neighbours'
+    chunks short or empty; nodes without in-edges ride along with the following node)."""
+    n = rowptr.numel() - 1
+    rp = rowptr.long()
+    e = rp[-1:]                                                   # stays on the device: no sync
+    targets = (torch.arange(k + 1, device=rowptr.device, dtype=torch.int64) * e) // k
+    b = torch.searchsorted(rp, targets, right=False)
+    b[0] = 0
+    b[-1] = n
+    return torch.clamp(b, max=n).to(torch.int32)
 
 
 def _rowptr(index, n):

@@ -93,6 +93,19 @@ int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float*
                         float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
                         int Fe, void* stream);
 
+/* Third mapping of the forward edge pass (results bit-identical to v2): wave-autonomous and software-
+ * pipelined.  `dsts` [E] = destination of every CSR slot; `chunk_ptr` [nchunks+1] = node-aligned,
+ * edge-balanced cut of the destination nodes (b_0 = 0, b_nchunks = N, non-decreasing): one wave walks
+ * one chunk in full 16-edge tiles, prefetching the next tile's rows while the current one is on the
+ * matrix cores.  E = number of CSR slots (rowptr[N] <= E); z2s / z3s (when not NULL) need at least
+ * max(E, 16) rows: tiles are always stored at full width.                                           */
+int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                        const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                        const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                        const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                        const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                        float* z3s, int N, int E, int Fe, void* stream);
+
 /* Node-level kernels of an EGNNConv layer (replace the torch/hipBLASLt Linear, cat and SiLU
  * launches around the edge pass; node_mlp of dgl.nn.EGNNConv).
  *   is_node_proj_fwd : psd [N,128] = [h W1s^T + b0 | h W1d^T + b1], h [N, ld_h] with din in {20, 64};

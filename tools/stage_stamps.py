@@ -23,6 +23,19 @@ for rep in range(3):
     t = list(buf)[:9]
     print("rep", rep, " ".join(f"{names[i]}:+{t[i]-t[i-1]}" for i in range(1, 9)), " total", t[8] - t[0], "(shader-clock cycles)")
 
+if hasattr(lib, "is_debug_stamps3"):
+    lib.is_debug_stamps3.argtypes = [ctypes.c_void_p]; lib.is_debug_stamps3.restype = ctypes.c_int
+    for rep in range(3):
+        with torch.no_grad():
+            egnn_stack_forward(layers, g, g.ndata["x"][:, :20], g.ndata["x"][:, 20:], g.edata["edge_attr"])
+        torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * 64)()
+        assert lib.is_debug_stamps3(ctypes.cast(buf, ctypes.c_void_p)) == 0
+        t = list(buf)
+        n = max(i for i in range(64) if t[i] > 0) + 1
+        lab = ["S0", "SA", "MM1", "MM2", "SEG"]
+        print("fwd3 rep", rep, f"prologue:+{t[1]-t[0]}", " ".join(f"{lab[(i-2)%5]}:+{t[i]-t[i-1]}" for i in range(2, n)), " total", t[n-1]-t[0])
+
 # ---- backward timeline (first tile of workgroup 300) ----
 lib.is_debug_stamps_bwd.argtypes = [ctypes.c_void_p]; lib.is_debug_stamps_bwd.restype = ctypes.c_int
 bn = ["tile start", "rp+barriers+z loads issued", "S0", "E3", "barrier1", "WG1+MM3", "barrier2", "dz2,SA,E1", "barrier3", "WG2+MM4", "barrier4", "SB+GEO(+barrier5)", "SEG(+barrier6)"]
