@@ -34,8 +34,8 @@ SIGNATURES = {
     "is_egnn_edge_fwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
     "is_egnn_edge_fwd_v3": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                             _I, _P],
-    "is_egnn_edge_bwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I,
-                            _I, _I, _P],
+    "is_egnn_edge_bwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P,
+                            _I, _I, _I, _P],
     "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     "is_egnn_node_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "is_node_proj_bwd_floats": [_I],

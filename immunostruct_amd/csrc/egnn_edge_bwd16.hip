@@ -9,7 +9,10 @@
 //     tile: wave w owns rows [16w, 16w+16) of dW2 / dWc1 and contracts over all four edge
 //     tiles of the 64-edge window, so a wave carries 2 x 16 accumulator registers instead of
 //     2 x 64 and no cross-wave reduction is needed at the end;
-//   * a workgroup owns NV16 = 16 destination nodes per tile (~48 edges = one window).
+//   * a workgroup owns one node tile per pass: either NV16 = 16 consecutive destination nodes (~48 edges on
+//     degree-3 graphs: the fourth wave of the 64-edge window idles in the row phases), or -- when the caller
+//     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= NVB = 24 nodes per tile) -- a
+//     node range that fills the window (63 of 64 rows on the same graphs, 24 % fewer passes).
 #include "common.h"
 
 namespace is {
@@ -22,7 +25,8 @@ __device__ long long g_stamps_b[24];
 #endif
 
 constexpr int WB16 = 4;
-constexpr int NV16 = 16;
+constexpr int NV16 = 16;   // nodes per tile without a tile list
+constexpr int NVB = 24;    // most nodes a listed tile may hold
 
 template <int FE_MAX>
 struct Bwd16Smem {
@@ -30,8 +34,8 @@ struct Bwd16Smem {
   float wc1t[H * LD];
   float bufA[WB16][TE16 * LD];
   float bufB[WB16][TE16 * LD];
-  float pdt[NV16 * H];   // Pd rows of this tile's destination nodes
-  int rp[NV16 + 1];
+  float pdt[NVB * H];   // Pd rows of this tile's destination nodes
+  int rp[NVB + 1];
   int e_src[WB16][TE16];
   int e_dl[WB16][TE16];
   float e_rad[WB16][TE16];
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
     const float* __restrict__ g_hn, int ld_ghn, const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, int ld_dpd, float* __restrict__ dx,
-    float* __restrict__ partials, int N, int Fe) {
+    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe) {
   __shared__ Bwd16Smem<FE_MAX> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -90,18 +94,18 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
 
   float* bufA = sm.bufA[wave];
   float* bufB = sm.bufB[wave];
-  const int num_tiles = (N + NV16 - 1) / NV16;
-  constexpr int NPW = NV16 / WB16;
+  const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
+  constexpr int NPW = NVB / WB16;
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     STAMPB(0);
-    const int v0 = tile * NV16;
-    const int nv = min(NV16, N - v0);
+    const int v0 = (tiles != nullptr) ? tiles[1 + tile] : tile * NV16;
+    const int nv = (tiles != nullptr) ? min(NVB, tiles[2 + tile] - v0) : min(NV16, N - v0);
     __syncthreads();
-    if (tid <= NV16) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
+    if (tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
 #pragma unroll
-    for (int i = 0; i < NV16 / WB16; ++i) {
-      const int nl = wave * (NV16 / WB16) + i;
+    for (int i = 0; i < NVB / WB16; ++i) {
+      const int nl = wave * (NVB / WB16) + i;
       sm.pdt[nl * H + lane] = (nl < nv) ? pd[(size_t)(v0 + nl) * ld_p + lane] : 0.0f;
     }
     __syncthreads();
@@ -436,18 +440,18 @@ extern "C" int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, c
                                    const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                                    const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                                    const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                                   float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
-                                   int Fe, void* stream) {
+                                   float* dD, float* dPd, int ld_dpd, float* dx, float* partials,
+                                   const int32_t* tiles, int grid, int N, int Fe, void* stream) {
   if (N <= 0) return 0;
   if (Fe < 0 || Fe > 8 || grid <= 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
   if (Fe <= 1) {
     hipLaunchKernelGGL(is::egnn_edge_bwd16_kernel<1>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
-                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
+                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe);
   } else {
     hipLaunchKernelGGL(is::egnn_edge_bwd16_kernel<8>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
-                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, N, Fe);
+                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -44,6 +44,7 @@ class StaticGraphBatch(PackedGraphBatch):
         csr.src_sorted = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr.dst_sorted = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr._chunks = {}     # filled on first use from the loaded rowptr, refreshed by every load()
+        csr._tiles = {}      # same; sized for the edge capacity
         csr.pos_by_src = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr.eperm = torch.zeros(0, dtype=torch.int64, device=dev)
         csr.num_nodes, csr.num_edges = n, self.edge_capacity
@@ -74,7 +75,8 @@ class StaticGraphBatch(PackedGraphBatch):
                 (src.rowptr_src, self._csr.rowptr_src), (src.src_sorted, self._csr.src_sorted[:e]),
                 (src.dst_sorted, self._csr.dst_sorted[:e]), (src.pos_by_src, self._csr.pos_by_src[:e]),
                 (g.edge_feat_csr(g.edata["edge_attr"]), self._ea_csr[:e])] + \
-               [(src.chunks(k), dst) for k, dst in self._csr._chunks.items()]
+               [(src.chunks(k), dst) for k, dst in self._csr._chunks.items()] + \
+               [(t, dst[:t.numel()]) for t, dst in ((src.tiles(*k), d) for k, d in self._csr._tiles.items())]
 
     def load(self, g: PackedGraphBatch):
         multi_copy(self.copy_pairs(g))

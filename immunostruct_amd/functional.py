@@ -20,6 +20,17 @@ _NODES_PER_TILE = 32
 # edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
 EDGE_FWD = os.environ.get("IMMUNOSTRUCT_EDGE_FWD", "v3")          # v3: wave-autonomous pipelined forward
+BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "auto")   # greedy 64-edge node tiles for the v2 backward: 1 | 0 | auto
+
+
+def use_bwd_tiles(num_nodes, num_edges, slots):
+    """The backward edge kernel runs ceil(tiles / slots) rounds of persistent workgroups.  Greedy tiles (~62 edges)
+    fill the 64-edge windows but only pay when they save a whole round; on the B = 128 benchmark batch both cuts need
+    3 rounds and the fuller windows are slower per round (measured 82 vs 78 us), at B = 512 they save 2 of 12."""
+    if BWD_TILES in ("0", "1"):
+        return BWD_TILES == "1"
+    rounds = lambda tiles: (tiles + slots - 1) // slots
+    return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 FWD_CHUNKS_MAX = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNKS", "2048"))
 FWD_CHUNK_EDGES = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNK_EDGES", "32"))
 
@@ -268,7 +279,12 @@ class EGNNStackFn(torch.autograd.Function):
         gflat = [torch.empty(pl.total, **f32) for pl in plans]
         use_v2 = EDGE_KERNELS == "v2" and fe <= 1   # (the Fe = 8 instantiation of the v2 backward spills)
         edge_bwd = lib.is_egnn_edge_bwd_v2 if use_v2 else lib.is_egnn_edge_bwd
-        grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16)) if use_v2 else _grid_for(n, _NODES_PER_TILE)
+        # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
+        tiles = csr.tiles(64, 24) if (use_v2 and use_bwd_tiles(n, e, 2 * _MAX_BWD_GRID)) else None
+        if tiles is not None:
+            grid_e = max(1, min(2 * _MAX_BWD_GRID, tiles.numel() - 2))
+        else:
+            grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16)) if use_v2 else _grid_for(n, _NODES_PER_TILE)
         grid_n = _grid_for(n, 128)
         part_n = torch.empty(grid_n * _NODE_STRIDE, **f32)
         part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
@@ -358,13 +374,15 @@ class EGNNStackFn(torch.autograd.Function):
             dpsd = torch.empty(n, 2 * HIDDEN, **f32)
             dx = torch.empty(n, 3, **f32)
             psd = lay["psd"]
+            extra = (_lib.ptr(tiles),) if use_v2 else ()
             with KernelTimer.span("egnn_edge_bwd"):
                 _lib.check(edge_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
                     _lib.ptr(d_hn), HIDDEN, _lib.ptr(g_xc), _lib.ptr(dZ1), _lib.ptr(dD),
-                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), grid_e, n, fe, st), "is_egnn_edge_bwd")
+                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), *extra, grid_e, n, fe, st),
+                    "is_egnn_edge_bwd")
             keep.append(part_e)
             if batched:
                 rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))

@@ -80,7 +80,9 @@ int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x,
 
 /* Second mapping of the same two edge passes (identical arguments, results and partial-record
  * layout): 16-edge tiles on v_mfma_f32_16x16x4_f32, 2-4 waves per SIMD; the default for Fe <= 1.
- * is_egnn_edge_bwd_v2 takes grid <= number of 16-node tiles.                                     */
+ * is_egnn_edge_bwd_v2 takes grid <= number of tiles; `tiles` is NULL (tiles of 16 consecutive
+ * nodes) or the greedy tile list [count, b_0, ..., b_count, ...] (int32, <= 64 in-edges and <= 24
+ * nodes per tile, immunostruct_amd/graph.py greedy_node_tiles) that fills the 64-edge windows.    */
 int is_egnn_edge_fwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                         const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                         const float* W2, const float* b2, const float* Wc1, const float* bc1,
@@ -90,7 +92,8 @@ int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float*
                         const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                         const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                         const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                        float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
+                        float* dD, float* dPd, int ld_dpd, float* dx, float* partials,
+                        const int32_t* tiles, int grid, int N,
                         int Fe, void* stream);
 
 /* Third mapping of the forward edge pass (results bit-identical to v2): wave-autonomous and software-
