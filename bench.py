@@ -190,6 +190,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     HF.KernelTimer.enabled = False
+    if os.environ.get("IMMUNOSTRUCT_HOST_TIMES"):     # debugging aid: host-side cost of one isolated step vs its GPU time
+        for i in range(5):
+            fence()
+            h0 = time.perf_counter()
+            step(args.warmup + args.steps + i)
+            h1 = time.perf_counter()
+            fence()
+            h2 = time.perf_counter()
+            print(f"[host times] step call returned after {1e6 * (h1 - h0):.0f} us, GPU done after {1e6 * (h2 - h0):.0f} us", file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -59,8 +59,8 @@ template <int DIN>
 __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
     const float* __restrict__ h, int ld_h, const float* __restrict__ h_neigh, int ld_hn,
     const float* __restrict__ Wn1, const float* __restrict__ bn1, const float* __restrict__ Wn2,
-    const float* __restrict__ bn2, const float* __restrict__ W1n, int ldw_n, const float* __restrict__ b1n,
-    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N) {
+    const float* __restrict__ bn2, const float* __restrict__ W1n, int ldw_n, const float* __restrict__ b0n,
+    const float* __restrict__ b1n, float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N) {
   using D = Node16Dims<DIN>;
   __shared__ float xs[32 * D::LD1];
   __shared__ float a1s[32 * LD];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int c = wave * 32 + nt * 16 + r;
-      b1n_c[nt] = c >= 64 ? b1n[c - 64] : 0.0f;
+      b1n_c[nt] = c >= 64 ? b1n[c - 64] : (b0n != nullptr ? b0n[c] : 0.0f);
     }
   }
 
@@ -312,7 +312,7 @@ constexpr int WG_STRIDE = WG_PROJ + WG_NODE;
 
 template <int DIN>
 __device__ __forceinline__ void egnn_node_wgrad16_body(
-    const float* __restrict__ g_psd, const float* __restrict__ h_out, const float* __restrict__ dh,
+    const float* __restrict__ g_psd, const float* __restrict__ h_out, int ld_ho, int dho, const float* __restrict__ dh,
     const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
     const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
   constexpr int LDP = 132;
@@ -322,6 +322,7 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const bool has_psd = g_psd != nullptr;
+  const bool has_node = dzn1 != nullptr;     // false: a projection-only job (layer-0 pre-projection): NODE part left untouched
   const int r_begin = blockIdx.x * rows_per_wg, r_end = min(N, r_begin + rows_per_wg);
 
   f32x4 dW1[2][4], dW2[4], dWn[8];
@@ -341,12 +342,12 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
       const bool valid = row < r_end;
       rp0[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + lane] : 0.0f;
       rp1[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
-      rho[i] = (has_psd && valid) ? h_out[(size_t)row * H + lane] : 0.0f;
-      rg[i] = valid ? dh[(size_t)row * H + lane] : 0.0f;
-      rz[i] = valid ? dzn1[(size_t)row * H + lane] : 0.0f;
-      rzn[i] = valid ? zn1[(size_t)row * H + lane] : 0.0f;
-      rxh[i] = (valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
-      rxn[i] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+      rho[i] = (has_psd && valid && lane < dho) ? h_out[(size_t)row * ld_ho + lane] : 0.0f;
+      rg[i] = (has_node && valid) ? dh[(size_t)row * H + lane] : 0.0f;
+      rz[i] = (has_node && valid) ? dzn1[(size_t)row * H + lane] : 0.0f;
+      rzn[i] = (has_node && valid) ? zn1[(size_t)row * H + lane] : 0.0f;
+      rxh[i] = (has_node && valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
+      rxn[i] = (has_node && valid) ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
     }
   };
   if (r_begin < r_end) fetch(r_begin);
@@ -362,11 +363,13 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
         s_p0 += rp0[i]; s_p1 += rp1[i];
         Hs[lr * LD + lane] = rho[i];
       }
-      Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
-      s_g += rg[i]; s_z += rz[i];
-      As[lr * LD + lane] = valid ? silu_f(rzn[i]) : 0.0f;
-      Xs[lr * LDP + lane] = rxh[i];
-      Xs[lr * LDP + 64 + lane] = rxn[i];
+      if (has_node) {
+        Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
+        s_g += rg[i]; s_z += rz[i];
+        As[lr * LD + lane] = valid ? silu_f(rzn[i]) : 0.0f;
+        Xs[lr * LDP + lane] = rxh[i];
+        Xs[lr * LDP + 64 + lane] = rxn[i];
+      }
     }
     __syncthreads();
     if (c0 + 16 < r_end) fetch(c0 + 16);
@@ -374,16 +377,19 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int e = 4 * q + s;
-      const float ag = Gs[e * LD + wave * 16 + r], az = Zs[e * LD + wave * 16 + r];
-      float bh[4], ba1[4], bxv[8];
+      float bh[4];
+      if (has_node) {
+        const float ag = Gs[e * LD + wave * 16 + r], az = Zs[e * LD + wave * 16 + r];
+        float ba1[4], bxv[8];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) ba1[nt] = As[e * LD + nt * 16 + r];
+        for (int nt = 0; nt < 4; ++nt) ba1[nt] = As[e * LD + nt * 16 + r];
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) bxv[nt] = Xs[e * LDP + nt * 16 + r];
+        for (int nt = 0; nt < 8; ++nt) bxv[nt] = Xs[e * LDP + nt * 16 + r];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) dW2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, ba1[nt], dW2[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) dW2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, ba1[nt], dW2[nt], 0, 0, 0);
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
+        for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
+      }
       if (has_psd) {
         const float ap0 = Ps[e * LDP + (2 * wave) * 16 + r], ap1 = Ps[e * LDP + (2 * wave + 1) * 16 + r];
 #pragma unroll
@@ -404,20 +410,24 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
     const int lr = tile16_row(t, q);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      part[((2 * wave) * 16 + lr) * H + nt * 16 + r] = dW1[0][nt][t];
-      part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
-      pn[64 * 128 + (wave * 16 + lr) * H + nt * 16 + r] = dW2[nt][t];
+      if (has_psd) {
+        part[((2 * wave) * 16 + lr) * H + nt * 16 + r] = dW1[0][nt][t];
+        part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
+      }
+      if (has_node) pn[64 * 128 + (wave * 16 + lr) * H + nt * 16 + r] = dW2[nt][t];
     }
+    if (has_node) {
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
+      for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
+    }
   }
   vec[wave][0][lane] = s_p1; vec[wave][1][lane] = s_p0; vec[wave][2][lane] = s_z; vec[wave][3][lane] = s_g;
   __syncthreads();
   {
     const int which = tid >> 6;   // 0: db1, 1: db0, 2: dbn1, 3: dbn2
     const float v = ((vec[0][which][lane] + vec[1][which][lane]) + vec[2][which][lane]) + vec[3][which][lane];
-    if (which < 2) part[128 * 64 + which * 64 + lane] = v;
-    else pn[64 * 128 + 64 * 64 + (which - 2) * 64 + lane] = v;
+    if (which < 2) { if (has_psd) part[128 * 64 + which * 64 + lane] = v; }
+    else if (has_node) pn[64 * 128 + 64 * 64 + (which - 2) * 64 + lane] = v;
   }
 }
 
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
     const float* __restrict__ g_psd, const float* __restrict__ h_out, const float* __restrict__ dh,
     const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
     const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
-  egnn_node_wgrad16_body<DIN>(g_psd, h_out, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows_per_wg);
+  egnn_node_wgrad16_body<DIN>(g_psd, h_out, H, H, dh, zn1, dzn1, h, ld_h, h_neigh, ld_hn, partials, N, rows_per_wg);
 }
 
 // All layers of a stack in ONE launch (blockIdx.y = layer): 6 x 254 workgroups instead of six launches of 254
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(256) void egnn_node_wgrad16_kernel(
 struct WgradLayer {
   const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh;
   float* partials;
-  int ld_h, din, ld_hn, pad;
+  int ld_h, din, ld_hn, ld_ho, dho, pad;     // h_out: row stride and number of valid columns (64 / 64 for EGNN layers)
 };
 constexpr int WGRAD_MAX_LAYERS = 8;
 struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
@@ -443,21 +453,22 @@ struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
 __global__ __launch_bounds__(256, 2) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
   const WgradLayer& L = batch.layer[blockIdx.y];
   if (L.din == 20)
-    egnn_node_wgrad16_body<20>(L.g_psd, L.h_out, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+    egnn_node_wgrad16_body<20>(L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
   else
-    egnn_node_wgrad16_body<64>(L.g_psd, L.h_out, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+    egnn_node_wgrad16_body<64>(L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
 }
 
 }  // namespace is
 
 extern "C" int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                                    const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
-                                   const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream) {
+                                   const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
+                                   void* stream) {
   if (N <= 0) return 0;
   const dim3 grid((N + 31) / 32), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<20>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
-  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<64>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<20>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<64>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N);
   else return -22;
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -491,15 +502,18 @@ extern "C" int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const 
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// layers: host array of `nlayers` (<= 8) records {g_psd, h_out, dh, zn1, dzn1, h, h_neigh, partials, ld_h, din, ld_hn, pad}
-// (pointers first, then four ints); every layer uses `grid` workgroups and the record layout of is_egnn_node_wgrad.
+// layers: host array of `nlayers` (<= 8) records {g_psd, h_out, dh, zn1, dzn1, h, h_neigh, partials, ld_h, din, ld_hn, ld_ho,
+// dho, pad} (pointers first, then six ints); every layer uses `grid` workgroups and the record layout of
+// is_egnn_node_wgrad.  A record with dzn1 == NULL is a projection-only job (PROJ part from g_psd and the first dho
+// columns of h_out, row stride ld_ho); a record with g_psd == NULL leaves the PROJ part untouched.
 extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream) {
   if (N <= 0 || grid <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
   is::WgradBatch batch;
   const is::WgradLayer* src = static_cast<const is::WgradLayer*>(layers);
   for (int i = 0; i < nlayers; ++i) {
     batch.layer[i] = src[i];
-    if (src[i].din != 20 && src[i].din != 64) return -22;
+    if ((src[i].din != 20 && src[i].din != 64) || src[i].dho < 0 || src[i].dho > 64) return -22;
+    if (src[i].g_psd == nullptr && src[i].dzn1 == nullptr) return -22;
   }
   const int rows = (((N + grid - 1) / grid) + 15) / 16 * 16;
   hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(grid, nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), batch, N, rows);

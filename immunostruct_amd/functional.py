@@ -189,10 +189,15 @@ class EGNNStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, x0, ea, csr, n_layers, *params):
+        """params = 11 tensors per layer [+ (Wa, ba, Wb, bb) of an optional 128-wide projection head of the final h:
+        the node attention's query / key projection, emitted by the last layer's node kernel]"""
         lib = _lib.load()
         _lib.require_device(h0, x0, ea, csr.rowptr_dst, *params)
-        if len(params) != PARAMS_PER_LAYER * n_layers:
-            raise ValueError("expected 11 parameter tensors per layer")
+        has_head = len(params) == PARAMS_PER_LAYER * n_layers + 4
+        if not has_head and len(params) != PARAMS_PER_LAYER * n_layers:
+            raise ValueError("expected 11 parameter tensors per layer (+ 4 for the projection head)")
+        if has_head and not (NODE_KERNELS == "v2" and BATCH_WGRAD and n_layers <= 6):
+            raise ValueError("the fused projection head needs the v2 node kernels with batched weight gradients")
         n, e = csr.num_nodes, csr.num_edges
         dev = x0.device
         din0 = int(h0.shape[1])
@@ -207,6 +212,13 @@ class EGNNStackFn(torch.autograd.Function):
         x = _lib.f32c(x0)
         ea = _lib.f32c(ea) if fe else None
         params = [_lib.f32c(p) for p in params]
+        head = None
+        if has_head:
+            wa, ba, wb, bb = params[-4:]
+            params = params[:-4]
+            if wa.shape != (HIDDEN, HIDDEN) or wb.shape != (HIDDEN, HIDDEN):
+                raise ValueError("projection head weights must be (64, 64)")
+            head = (torch.cat([wa, wb], dim=1), ba, bb)      # [64][128]: column blocks [Wa | Wb], the edge_mlp.0 layout
         need_grad = any(ctx.needs_input_grad)
         st = _lib.stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -248,24 +260,30 @@ class EGNNStackFn(torch.autograd.Function):
             last = i == n_layers - 1
             zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
             h_out = torch.empty(n, HIDDEN, **f32)
-            psd_next = None if last else torch.empty(n, 2 * HIDDEN, **f32)
-            W1n = None if last else params[(i + 1) * P]
-            b1n = None if last else params[(i + 1) * P + 1]
+            emit = (not last) or head is not None
+            psd_next = torch.empty(n, 2 * HIDDEN, **f32) if emit else None
+            if last:
+                W1n, b0n, b1n = head if head is not None else (None, None, None)
+            else:
+                W1n, b0n, b1n = params[(i + 1) * P], None, params[(i + 1) * P + 1]
             node_fwd = lib.is_egnn_node_fwd_v2 if NODE_KERNELS == "v2" else lib.is_egnn_node_fwd
             with KernelTimer.span("egnn_node_fwd"):
                 _lib.check(node_fwd(
                     _lib.ptr(h_in), ld_h, din, _lib.ptr(h_neigh), HIDDEN, _lib.ptr(Wn1), _lib.ptr(bn1), _lib.ptr(Wn2),
-                    _lib.ptr(bn2), _lib.ptr(W1n), 0 if last else int(W1n.shape[1]), _lib.ptr(b1n), _lib.ptr(zn1),
-                    _lib.ptr(h_out), _lib.ptr(psd_next), n, st), "is_egnn_node_fwd")
+                    _lib.ptr(bn2), _lib.ptr(W1n), int(W1n.shape[1]) if emit else 0, *((_lib.ptr(b0n),) if NODE_KERNELS == "v2" else ()),
+                    _lib.ptr(b1n), _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), n, st), "is_egnn_node_fwd")
             layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
                                h_out=h_out))
             psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
         ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers = layers, params, csr, ea, fe, n_layers
         ctx.h0_needs_grad, ctx.x0_needs_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ctx.head = head
+        if head is not None:
+            return h_in, x, psd
         return h_in, x
 
     @staticmethod
-    def backward(ctx, g_h, g_x):
+    def backward(ctx, g_h, g_x, g_head=None):
         lib = _lib.load()
         layers, params, csr, ea, fe, L = ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers
         n, e = csr.num_nodes, csr.num_edges
@@ -311,7 +329,13 @@ class EGNNStackFn(torch.autograd.Function):
             grid_w = _grid_for(n, 96)
             part_w = None if batched else torch.empty(grid_w * wg_stride, **f32)
 
+        head = ctx.head
         g_psd_next = None
+        head_flat = None
+        if head is not None:
+            # the head's projection is "the next layer's pre-projection" of the last layer
+            g_psd_next = _lib.f32c(g_head) if g_head is not None else torch.zeros(n, 2 * HIDDEN, **f32)
+            head_flat = torch.empty(_PROJ_STRIDE, **f32)       # [dWa ; dWb] (128 x 64) | db_b | db_a
         for i in reversed(range(L)):
             lay = layers[i]
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
@@ -322,7 +346,8 @@ class EGNNStackFn(torch.autograd.Function):
             if node_v2:
                 # (1+2) data path: dh = g_h + g_psd W1sd(next), node-MLP backward; then the streaming weight gradients
                 has_psd = g_psd_next is not None
-                W1n = params[(i + 1) * P] if has_psd else None
+                is_head = has_psd and i == L - 1
+                W1n = (head[0] if is_head else params[(i + 1) * P]) if has_psd else None
                 dh_total = torch.empty(n, HIDDEN, **f32) if has_psd else g_hd
                 dzn1 = torch.empty(n, HIDDEN, **f32)
                 with KernelTimer.span("egnn_node_bwd"):
@@ -336,8 +361,10 @@ class EGNNStackFn(torch.autograd.Function):
                     keep.append(pw)
                     wjobs.append(_lib.WgradLayer(_lib.ptr(g_psd_next).value if has_psd else None, lay["h_out"].data_ptr(),
                                                  dh_total.data_ptr(), lay["zn1"].data_ptr(), dzn1.data_ptr(), lay["h_in"].data_ptr(),
-                                                 lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, 0))
-                    if has_psd:
+                                                 lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, HIDDEN, HIDDEN, 0))
+                    if is_head:
+                        rjobs.append((pw, grid_w, wg_stride, wg_proj, None, head_flat))
+                    elif has_psd:
                         rjobs.append((pw, grid_w, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
                     rjobs.append((pw[wg_proj:], grid_w, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
                 else:
@@ -397,12 +424,22 @@ class EGNNStackFn(torch.autograd.Function):
         W1_0 = params[0]
         dh0 = torch.empty(n, HIDDEN, **f32) if ctx.h0_needs_grad else None
         keep.extend([g_hd, g_psd_next])
-        with KernelTimer.span("node_proj_bwd"):
-            _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
-                                            _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
-                       "is_node_proj_bwd")
+        proj0_in_batch = batched and not ctx.h0_needs_grad and len(wjobs) < 8
+        if proj0_in_batch:
+            # weight gradient of the layer-0 pre-projection as one more (projection-only) job of the batched launch
+            pw0 = torch.empty(grid_w * wg_stride, **f32)
+            keep.append(pw0)
+            wjobs.append(_lib.WgradLayer(g_psd_next.data_ptr(), lay0["h_in"].data_ptr(), None, None, None, None, None,
+                                         pw0.data_ptr(), HIDDEN, HIDDEN, HIDDEN, lay0["ld_h"], lay0["din"], 0))
+            rjobs.append((pw0, grid_w, wg_stride, wg_proj, plans[0].proj_map, gflat[0]))
+        else:
+            with KernelTimer.span("node_proj_bwd"):
+                _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
+                                                _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
+                           "is_node_proj_bwd")
         if batched:
-            rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
+            if not proj0_in_batch:
+                rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
             arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
             with KernelTimer.span("egnn_node_wgrad_batched"):
                 _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
@@ -411,7 +448,8 @@ class EGNNStackFn(torch.autograd.Function):
             big = torch.empty(sum(split * c for (_, _, _, c, _, _) in rjobs), **f32)
             jobs, off = [], 0
             for (pt, nparts, stride, count, mp, dst) in rjobs:
-                jobs.append(_lib.ReduceJob(pt.data_ptr(), mp.data_ptr(), dst.data_ptr(), big[off:].data_ptr(), nparts, stride, count, 0))
+                jobs.append(_lib.ReduceJob(pt.data_ptr(), mp.data_ptr() if mp is not None else None, dst.data_ptr(),
+                                           big[off:].data_ptr(), nparts, stride, count, 0))
                 off += split * count
             jarr = (_lib.ReduceJob * len(jobs))(*jobs)
             with KernelTimer.span("reduce_partials_batched"):
@@ -426,6 +464,10 @@ class EGNNStackFn(torch.autograd.Function):
             grads.extend(plans[i].views(gflat[i]))
         g_h0 = dh0[:, :lay0["din"]] if dh0 is not None else None
         g_x0 = g_xc if ctx.x0_needs_grad else None
+        if head_flat is not None:
+            hh = HIDDEN * HIDDEN
+            grads.extend([head_flat[0:hh].view(HIDDEN, HIDDEN), head_flat[2 * hh + HIDDEN:2 * hh + 2 * HIDDEN],
+                          head_flat[hh:2 * hh].view(HIDDEN, HIDDEN), head_flat[2 * hh:2 * hh + HIDDEN]])
         return (g_h0, g_x0, None, None, None) + tuple(grads)
 
 
@@ -575,9 +617,17 @@ def combined_attention_mean(x, mha):
                                          mha.w_v.weight, mha.w_v.bias, mha.w_concat.weight, mha.w_concat.bias)
 
 
-def egnn_stack(h0, x0, ea_csr, csr, layer_params):
-    """layer_params: list (one entry per layer) of the 11 native parameter tensors."""
+def fused_head_available(n_layers):
+    """the (Wa, ba, Wb, bb) projection head of the final h can ride on the last layer's node kernels"""
+    return NODE_KERNELS == "v2" and BATCH_WGRAD and n_layers <= 6
+
+
+def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None):
+    """layer_params: list (one entry per layer) of the 11 native parameter tensors; ``head`` = optional
+    (Wa, ba, Wb, bb), 64x64 each: the call then also returns [h Wa^T + ba | h Wb^T + bb] (N, 128) of the final h."""
     flat = [p for lp in layer_params for p in lp]
+    if head is not None:
+        flat = flat + list(head)
     return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), *flat)
 
 

@@ -134,7 +134,14 @@ class MultimodalNet(nn.Module):
     def _encode_graph(self, g, need_attention=False):
         feats = g.ndata["x"]
         h, x, a = feats[:, :NODE_ONEHOT], feats[:, NODE_ONEHOT:], g.edata["edge_attr"]
-        h, x = egnn_stack_forward(list(self.GCN_layers), g, h, x, a)   # all layers, fused HIP kernels
+        layers = list(self.GCN_layers)
+        qk = None
+        head = self.self_attention.qk_head() if (self.SPEC.pool == "mean" and HF.fused_head_available(len(layers))) else None
+        if head is not None:
+            # the node attention's query / key projection rides on the last EGNN layer's node kernel
+            h, x, qk = egnn_stack_forward(layers, g, h, x, a, head=head)
+        else:
+            h, x = egnn_stack_forward(layers, g, h, x, a)   # all layers, fused HIP kernels
         c = self.gat_hidden_channels
         if g.uniform_nodes_per_graph() is None:
             raise ValueError("all graphs of a batch must be padded to the same node count "
@@ -143,7 +150,7 @@ class MultimodalNet(nn.Module):
         if self.SPEC.pool == "mean":
             # all graphs are padded to the same node count (checked above), so global_mean_pool over the
             # attention output is a plain mean over the n rows -- taken inside the attention block
-            pooled, weights = self.self_attention.pooled_mean(hb, need_weights=need_attention)
+            pooled, weights = self.self_attention.pooled_mean(hb, need_weights=need_attention, qk=qk)
         else:
             out, weights = self.self_attention(hb)
             pooled = HF.segment_pool(out.reshape(-1, c), g.seg_ptr(), self.SPEC.pool)

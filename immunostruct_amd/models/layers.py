@@ -28,7 +28,7 @@ def attend(q, k, v, heads):
     return out, w
 
 
-def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False):
+def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=None):
     """mean over the n rows of softmax(q k^T / sqrt(d)) v  WITHOUT materialising v or the (n, d) output.
 
     mean_i sum_j A_ij v_j = sum_j abar_j v_j with abar = column mean of A, and
@@ -41,7 +41,8 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False):
     b, n, dm = x.shape
     dh = dm // heads
     x2 = x.reshape(b * n, dm)
-    qk = HF.pair_linear(x2, wq, bq, wk, bk)
+    if qk is None:     # else: already produced by the EGNN stack's last node kernel (functional.egnn_stack head)
+        qk = HF.pair_linear(x2, wq, bq, wk, bk)
     if heads in (1, 8) and n <= 256:
         ctx = HF.attn_colmean(qk, x2, b, n, heads)                             # (b, heads, dm)
         w = None
@@ -70,10 +71,16 @@ class SelfAttention(nn.Module):
         out, w = attend(self.query(x), self.key(x), self.value(x), 1)
         return out, w.squeeze(1)
 
-    def pooled_mean(self, x, need_weights=False):
+    def qk_head(self):
+        """(Wq, bq, Wk, bk) when the query / key projection can ride on the EGNN stack's last node kernel"""
+        if self.query.in_features != 64 or self.query.out_features != 64:
+            return None
+        return self.query.weight, self.query.bias, self.key.weight, self.key.bias
+
+    def pooled_mean(self, x, need_weights=False, qk=None):
         """(mean over rows of the attention output, weights) -- what the models feed to global_mean_pool."""
         u, w = attend_pooled_mean(x, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
-                                  self.value.weight, self.value.bias, 1, need_weights)
+                                  self.value.weight, self.value.bias, 1, need_weights, qk=qk)
         return u, (w.squeeze(1) if w is not None else None)
 
 
@@ -95,11 +102,17 @@ class MultiHeadAttention(nn.Module):
         out, w = attend(self.w_q(x), self.w_k(x), self.w_v(x), self.n_head)
         return self.w_concat(out), w
 
-    def pooled_mean(self, x, need_weights=False):
+    def qk_head(self):
+        """(Wq, bq, Wk, bk) when the query / key projection can ride on the EGNN stack's last node kernel"""
+        if self.w_q.in_features != 64 or self.w_q.out_features != 64:
+            return None
+        return self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias
+
+    def pooled_mean(self, x, need_weights=False, qk=None):
         """mean over rows of ``forward(x)[0]`` (the output projection commutes with the mean)."""
         if self.w_q.in_features != self.w_q.out_features or self.w_q.out_features != 64:
             out, w = self.forward(x)
             return out.mean(dim=1), w
         u, w = attend_pooled_mean(x, self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias,
-                                  self.w_v.weight, self.w_v.bias, self.n_head, need_weights)
+                                  self.w_v.weight, self.w_v.bias, self.n_head, need_weights, qk=qk)
         return self.w_concat(u), w

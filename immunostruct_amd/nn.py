@@ -61,8 +61,11 @@ class EGNNConv(nn.Module):
         return h, x
 
 
-def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None):
-    """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``)."""
+def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None):
+    """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``).
+
+    ``head`` = optional (Wa, ba, Wb, bb): also return the 128-wide projection [h Wa^T + ba | h Wb^T + bb] of the
+    final node features (the node attention's query / key projection), computed by the last layer's node kernel."""
     if not isinstance(graph, PackedGraphBatch):
         raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
     fe = layers[0].edge_feat_size
@@ -74,7 +77,7 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None):
     if edge_feat is not None and edge_feat.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
     ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
-    return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers])
+    return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head)
 
 
 def _seg_ptr_from_batch(batch_index, size=None):

@@ -144,7 +144,10 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
 
 /* Second mapping of the node block (default): one workgroup per 32-row tile, weights fetched by the
  * lanes straight from the native parameter tensors (L2), no LDS weight staging.
- *   is_egnn_node_fwd_v2   : same arguments / results as is_egnn_node_fwd
+ *   is_egnn_node_fwd_v2   : arguments / results of is_egnn_node_fwd plus b0n (NULL or [64]): bias of the FIRST
+ *                           half of the pre-projection -- the last layer of a stack can so emit another
+ *                           128-wide projection of h' (the fused query / key projection of the node
+ *                           attention: W1n = [Wq | Wk] column blocks, ldw_n = 128, b0n = bq, b1n = bk)
  *   is_egnn_node_bwd_data : dh_total = g_h + g_psd W1sd (when g_psd != NULL; else dh := g_h and dh_total
  *                           is not written), dzn1 [N,64] = (dh Wn2) * SiLU'(zn1), d_h [N,64] (first
  *                           din columns valid; may be NULL), d_hneigh [N,64].  No weight gradients.
@@ -154,7 +157,8 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
  *                           [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride is_egnn_node_wgrad_stride. */
 int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                         const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
-                        const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream);
+                        const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
+                        void* stream);
 int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
                           int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
                           float* d_h, float* d_hneigh, int N, void* stream);
@@ -166,8 +170,11 @@ int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, 
 
 /* Batched forms (one launch for all layers of a stack / for all pending reductions).
  *   is_egnn_node_wgrad_batched: `layers` = host array of nlayers (<= 8) records
- *       { const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh; float* partials; int ld_h, din, ld_hn, pad; }
- *     each processed exactly like is_egnn_node_wgrad with `grid` workgroups.
+ *       { const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh; float* partials;
+ *         int ld_h, din, ld_hn, ld_ho, dho, pad; }
+ *     each processed like is_egnn_node_wgrad with `grid` workgroups; h_out has row stride ld_ho and dho (<= 64)
+ *     valid columns; dzn1 == NULL marks a projection-only job (only the dW1sd part, e.g. the layer-0
+ *     pre-projection of the raw node features), g_psd == NULL a job without projection part.
  *   is_reduce_partials_batched: `jobs` = host array of njobs (<= 24) records
  *       { const float* partials; const int32_t* map; float* dst; float* scratch; int nparts, stride, count, pad; }
  *     each processed exactly like is_reduce_partials (scratch: is_reduce_partials_scratch_floats(count) floats). */
