@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 from immunostruct_amd import distributed as D  # noqa: E402
 from immunostruct_amd import functional as HF  # noqa: E402
+from immunostruct_amd import optim  # noqa: E402
 from immunostruct_amd import synthetic  # noqa: E402
 from immunostruct_amd.graph import PackedGraphBatch  # noqa: E402
 from immunostruct_amd.models import model_map  # noqa: E402
@@ -144,7 +145,10 @@ def main():
     D.broadcast_parameters(model)
     model.train()
     reducer = D.FlatGradReducer(model.parameters(), world=world, always_pack=args.force_pack)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=not args.eager)
+    if os.environ.get("IMMUNOSTRUCT_TORCH_ADAM", "0") == "1":
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=not args.eager)
+    else:
+        opt = optim.Adam(model.parameters(), lr=1e-3)      # csrc/optimizer.hip
     losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
     pool = build_batches(4, args.batch, args.deg_extra, dev, seed0=1000 * (rank + 1))
 
@@ -199,6 +203,10 @@ def main():
             fence()
             h2 = time.perf_counter()
             print(f"[host times] step call returned after {1e6 * (h1 - h0):.0f} us, GPU done after {1e6 * (h2 - h0):.0f} us", file=sys.stderr)
+    if HF.Stamps.enabled and HF.Stamps.buf is not None:
+        fence()
+        for t_us, name in HF.Stamps.report():
+            print(f"[stamps] {t_us:9.1f} us  {name}", file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

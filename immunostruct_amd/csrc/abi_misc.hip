@@ -54,3 +54,14 @@ extern "C" int is_mfma_outer_selftest(const float* G, const float* M, float* out
   hipLaunchKernelGGL(is::mfma_outer_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), G, M, out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+
+// Debug aid: write the device wall clock (constant-rate counter) to *slot -- one tiny launch that can be captured in
+// a HIP graph to time-stamp points of a replayed step without a profiler attached.
+namespace is {
+__global__ void timestamp_kernel(long long* slot) { *slot = (long long)wall_clock64(); }
+}
+extern "C" int is_debug_timestamp(long long* slot, void* stream) {
+  hipLaunchKernelGGL(is::timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -142,6 +142,8 @@ class CapturedTrainStep:
             self.loss = self._fwd_bwd()
             if self.fused_optimizer:
                 self.optimizer.step()
+                from .functional import Stamps
+                Stamps.mark("optimizer done")
         self.graph_b = None
         if not self.fused_optimizer:
             # graph A always writes the gradient buffers it allocated while capturing: pack from those
@@ -155,9 +157,13 @@ class CapturedTrainStep:
         multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
 
     def _fwd_bwd(self):
+        from .functional import Stamps
+        Stamps.mark("step start")
         self.reducer.zero()
         loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        Stamps.mark("loss done")
         loss.backward()
+        Stamps.mark("backward done (main stream)")
         return loss.detach()
 
     def _body(self, eager=False):
@@ -167,6 +173,8 @@ class CapturedTrainStep:
         return loss
 
     def __call__(self, g, seq, prop, y):
+        if hasattr(self.optimizer, "refresh"):
+            self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
         self._load(g, seq, prop, y)
         self.graph_a.replay()
         if self.graph_b is not None:

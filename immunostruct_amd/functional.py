@@ -20,6 +20,8 @@ _NODES_PER_TILE = 32
 # edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
 EDGE_FWD = os.environ.get("IMMUNOSTRUCT_EDGE_FWD", "v3")          # v3: wave-autonomous pipelined forward
+WGRAD_ROWS = int(os.environ.get("IMMUNOSTRUCT_WGRAD_ROWS", "96"))     # rows per workgroup of a single-layer weight-gradient launch
+WGRAD_GRID = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID", "64"))     # workgroups per layer of the batched launch (x up to 8 layers)
 BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "auto")   # greedy 64-edge node tiles for the v2 backward: 1 | 0 | auto
 
 
@@ -43,6 +45,41 @@ def fwd_chunk_count(num_edges):
 NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
 # weight gradients of all layers in one launch + all partial reductions in one launch pair, after the data path
 BATCH_WGRAD = os.environ.get("IMMUNOSTRUCT_BATCH_WGRAD", "1") != "0"
+
+
+class Stamps:
+    """Debug aid (IMMUNOSTRUCT_STAMPS=1): device wall-clock stamps at named points of a step, also inside a captured
+    HIP graph -- the only way to see the schedule of a replayed graph without a profiler's perturbation."""
+    enabled = os.environ.get("IMMUNOSTRUCT_STAMPS", "0") == "1"
+    names = []
+    buf = None
+
+    @classmethod
+    def mark(cls, name):
+        if not cls.enabled:
+            return
+        if cls.buf is None:
+            cls.buf = torch.zeros(256, dtype=torch.int64, device="cuda")
+        if name not in cls.names:
+            cls.names.append(name)
+        slot = cls.buf[cls.names.index(name):]
+        _lib.check(_lib.load().is_debug_timestamp(_lib.ptr(slot), _lib.stream_ptr()), "is_debug_timestamp")
+
+    @classmethod
+    def hook(cls, tensor, name):
+        """stamp when the gradient of ``tensor`` is produced in backward"""
+        if cls.enabled and tensor.requires_grad:
+            def _h(g):
+                cls.mark(name)
+                return g
+            tensor.register_hook(_h)
+        return tensor
+
+    @classmethod
+    def report(cls):
+        vals = cls.buf[:len(cls.names)].tolist()
+        t0 = min(v for v in vals if v > 0)
+        return sorted(((v - t0) / 100.0, n) for v, n in zip(vals, cls.names))     # microseconds (100 MHz clock)
 
 
 class KernelTimer:
@@ -326,7 +363,7 @@ class EGNNStackFn(torch.autograd.Function):
         wjobs, rjobs = [], []     # deferred weight-gradient layers / reduction jobs (batched mode)
         if node_v2:
             wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
-            grid_w = _grid_for(n, 96)
+            grid_w = _grid_for(n, WGRAD_ROWS) if not batched else max(1, min(WGRAD_GRID, (n + 15) // 16))
             part_w = None if batched else torch.empty(grid_w * wg_stride, **f32)
 
         head = ctx.head

@@ -1,0 +1,119 @@
+"""``Adam`` / ``AdamW`` with the ``torch.optim`` interface on one streaming HIP kernel (``csrc/optimizer.hip``).
+
+The reference trains with ``torch.optim.Adam`` (``train_IEDB_wFT.py:69-74``) and ``torch.optim.AdamW``
+(``train_Cancer_wFT.py:76-92``).  These classes keep the constructor arguments, ``param_groups`` (so the reference's
+learning-rate schedulers work unchanged), ``zero_grad`` and ``state_dict`` layout of a torch optimizer; ``step()`` is
+one launch over a device-resident chunk table per parameter group instead of torch's multi-tensor loop.  Step count
+and learning rate live in device memory: the step can be captured in a HIP graph; call :meth:`refresh` (the engine
+does) after a scheduler changed ``lr`` so that the device copy follows.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["Adam", "AdamW"]
+
+CHUNK = 16384
+
+
+class Adam(torch.optim.Optimizer):
+    decoupled_weight_decay = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not used by the reference and not implemented")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._groups = {}       # id(group) -> dict(table, key, state, hyper, hyper_host)
+
+    # ---- helpers -------------------------------------------------------------
+    def _hyper_host(self, group):
+        return (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                float(group["weight_decay"]), 1.0 if self.decoupled_weight_decay else 0.0)
+
+    def _group_state(self, group, params):
+        dev = params[0].device
+        gs = self._groups.get(id(group))
+        if gs is None:
+            gs = dict(key=None, table=None, hyper_host=None,
+                      state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(6, dtype=torch.float32, device=dev))
+            self._groups[id(group)] = gs
+        return gs
+
+    def refresh(self):
+        """copy changed hyper-parameters (learning-rate schedulers) to their device copies; not capturable"""
+        for group in self.param_groups:
+            gs = self._groups.get(id(group))
+            if gs is not None:
+                self.refresh_group(group, gs)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        capturing = torch.cuda.is_current_stream_capturing()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            _lib.require_device(*params)
+            for p in params:
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise ValueError("Adam (HIP) needs contiguous fp32 parameters and gradients")
+                st = self.state[p]
+                if not st:
+                    if capturing:
+                        raise RuntimeError("optimizer state must exist before a HIP-graph capture: run one eager step first")
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            gs = self._group_state(group, params)
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+            if gs["key"] != key:
+                rows = []
+                for p in params:
+                    st = self.state[p]
+                    for off in range(0, p.numel(), CHUNK):
+                        cnt = min(CHUNK, p.numel() - off)
+                        rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
+                                     st["exp_avg_sq"].data_ptr() + 4 * off, cnt))
+                host = torch.from_numpy(np.asarray(rows, dtype=np.int64))
+                if capturing:
+                    # gradients produced inside a capture live at fixed addresses of the graph's memory pool: the table
+                    # upload becomes a memcpy node of the graph (pinned staging buffer allocated by the eager step --
+                    # no allocation is legal here -- and kept alive, unchanged, with the optimizer)
+                    if gs["table"] is None or gs["table"].shape != host.shape or gs.get("pinned") is None:
+                        raise RuntimeError("the chunk table must have been allocated by an eager step before a capture")
+                    gs["pinned"].copy_(host)
+                    gs["table"].copy_(gs["pinned"], non_blocking=True)
+                else:
+                    gs["table"] = host.to(params[0].device)
+                    if gs.get("pinned") is None or gs["pinned"].shape != host.shape:
+                        gs["pinned"] = torch.empty_like(host).pin_memory()
+                gs["key"] = key
+            if not capturing:
+                self.refresh_group(group, gs)
+            _lib.check(lib.is_adam_step(_lib.ptr(gs["table"]), int(gs["table"].shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+                                        _lib.stream_ptr()), "is_adam_step")
+        return loss
+
+    def refresh_group(self, group, gs):
+        hh = self._hyper_host(group)
+        if gs["hyper_host"] != hh:
+            gs["hyper_host"] = hh
+            gs["hyper"].copy_(torch.tensor(hh, dtype=torch.float32))
+
+
+class AdamW(Adam):
+    decoupled_weight_decay = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)

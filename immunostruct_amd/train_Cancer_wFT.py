@@ -12,6 +12,7 @@ import os
 import torch
 from torch.utils.data import DataLoader, random_split
 
+from . import optim
 from .data import SyntheticImmunoDataset, SyntheticPairedDataset, collate
 from .models.mapping import model_map
 from .procedures import binary_metrics, predict_proba, train_model, train_model_comparative
@@ -73,14 +74,14 @@ def main(argv=None):
     ds1 = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=False)
     tr, va, _ = random_split(ds1, [0.8, 0.1, 0.1], gen)
     losses = Losses(input_dim, ds1.class_weights, sequence=config.sequence_loss)
-    opt = torch.optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
+    opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
     train_model(config, device, model, mk(tr, True), mk(va, False), opt, losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
     # stage 2: comparative pretraining on (cancer, wild-type) pairs, continuous target
     ds2 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=False)
     tr2, va2, te2 = random_split(ds2, [0.8, 0.1, 0.1], gen)
-    opt = torch.optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
+    opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
     train_model_comparative(config, device, model, mk(tr2, True), mk(va2, False), opt, losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
@@ -89,7 +90,7 @@ def main(argv=None):
     tr3, va3, te3 = random_split(ds3, [0.8, 0.1, 0.1], gen)
     want = config.min_finetuning_batches * config.batch_size
     tr3 = _Extended(tr3, want) if len(tr3) < want else tr3
-    opt = torch.optim.AdamW(model.parameters(), lr=config.learning_rate_finetune, weight_decay=1e-6)
+    opt = optim.AdamW(model.parameters(), lr=config.learning_rate_finetune, weight_decay=1e-6)
     sched = torch.optim.lr_scheduler.SequentialLR(opt, [
         torch.optim.lr_scheduler.LinearLR(opt, 0.01, 1.0, total_iters=max(config.num_epochs // 4, 1)),
         torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(config.num_epochs - config.num_epochs // 4, 1))],

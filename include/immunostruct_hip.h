@@ -186,6 +186,17 @@ int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
                           float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
 
+/* Multi-tensor Adam / AdamW step with torch.optim semantics (reference: torch.optim.Adam in train_IEDB_wFT.py:69-74,
+ * torch.optim.AdamW in train_Cancer_wFT.py:76-92).  `chunks` = DEVICE array of nchunks records
+ * { float* p; const float* g; float* m; float* v; long long n; } (one workgroup each), `state` = device float[3]
+ * {step count, derived step size, derived sqrt(1 - beta2^t)} updated by the call, `hyper` = device float[6]
+ * {lr, beta1, beta2, eps, weight_decay, decoupled (AdamW) flag}.  Capturable in a HIP graph.                   */
+int is_adam_step(const void* chunks, int nchunks, float* state, const float* hyper, void* stream);
+
+/* Debug aid: one single-thread launch that writes the device wall clock (100 MHz) to *slot; can be captured in a
+ * HIP graph to time-stamp points of a replayed step without a profiler attached.                             */
+int is_debug_timestamp(long long* slot, void* stream);
+
 /* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
  * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
  * bytes a multiple of 4.                                                                                   */

@@ -148,8 +148,9 @@ def test_full_train_step_gradients_vs_oracle(cuda_device):
     print("worst parameter-gradient error", worst)
 
 
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
 @pytest.mark.parametrize("always_pack", [False, True])
-def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack):
+def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimizer):
     """engine.CapturedTrainStep (HIP-graph replay on static, fixed-capacity buffers) reproduces eager training.
 
     Batches with MORE and with FEWER edges than the captured one are replayed.  (Tolerance, not bit
@@ -173,7 +174,11 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack):
         model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=6))
         model.eval()
         red = FlatGradReducer(model.parameters(), world=1, always_pack=always_pack)   # True: the multi-rank two-graph path
-        opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True, capturable=True)
+        if optimizer == "torch":
+            opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True, capturable=True)
+        else:
+            from immunostruct_amd import optim
+            opt = optim.Adam(model.parameters(), lr=1e-5)      # csrc/optimizer.hip, capturable by construction
         out = []
         if captured:
             # construction performs one eager step on batches[0] (optimizer state must exist before capture)
