@@ -249,7 +249,7 @@ def main():
                         algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
                         hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                       frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
-                        forward_kernel=dict(kernel="egnn_edge_fwd_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
+                        forward_kernel=dict(kernel="egnn_edge_fwd3_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
                                             tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
                                             hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
                                             frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
