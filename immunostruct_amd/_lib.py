@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libimmunostruct_hip.so")
 _P, _I, _F, _LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 # symbol -> argtypes ; keep in sync with include/immunostruct_hip.h
+_RETURNS_LONGLONG = {"is_attn_colmean_probs_floats"}
 SIGNATURES = {
     "is_version": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_attn_colmean_probs_floats": [_I, _I, _I],
     "is_comb_attn_stats_floats": [_I, _I],
     "is_comb_attn_partials_floats": [_I],
     "is_comb_attn_grad_floats": [_I],
@@ -108,7 +110,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = _I
+        fn.restype = ctypes.c_longlong if name in _RETURNS_LONGLONG else _I
     _lib = lib
     return lib
 

@@ -12,10 +12,17 @@
 // One workgroup per graph, NT = ceil(n/32) waves; wave w owns query rows [32w, 32w+32).
 //   forward : S tile (32 x n_pad) on v_mfma_f32_32x32x2_f32 from LDS-resident Q,K; row softmax in
 //             registers; column sums -> abar; ctx = abar^T X.   Saves abar and the row statistics.
+//             Also saves the normalised probabilities P tile by tile in the MFMA accumulator layout
+//             (probs[b][head][query block][key block][register t][lane]: every store / load is one coalesced
+//             256-byte row) -- 148 KB per graph and head for n = 190.
 //   backward: dabar_j = g_ctx . x_j ; dS_ij = P_ij (dabar_j - t_i)/n , t_i = sum_k P_ik dabar_k ;
-//             dQ = scale dS K , dK = scale dS^T Q.  The score tile is recomputed twice, once with queries
-//             on the lanes (S^T tile: its accumulator registers ARE the MFMA A operand of dQ = dS K, no
-//             LDS round trip) and once with keys on the lanes (likewise for dK = dS^T Q).
+//             dQ = scale dS K , dK = scale dS^T Q.  P is READ BACK instead of recomputed (the first version
+//             recomputed the score tiles three times: 60 k MFMA cycles per wave, now 25 k):
+//               * wave w loads the six tiles of its query block once (keys on the lanes), gets t_i by a
+//                 lane reduction, then transposes each tile through a wave-private LDS tile so that the
+//                 queries sit on the lanes: the dS registers ARE the MFMA A operand of dQ = dS K;
+//               * then loads the six tiles of its KEY block (same layout): the dS registers are directly the
+//                 A operand of dK = dS^T Q.
 //             dx_j += sum_h abar_h[j] g_ctx_h (direct term).
 #include "common.h"
 
@@ -35,26 +42,63 @@ struct AttnSmem {
 };
 
 template <int NT, int D>
+struct AttnBwdSmem {
+  static constexpr int LDQ = D + 4;
+  float kq[NT * 32 * LDQ];    // K rows during pass A, then Q rows during pass B
+  float abar[NT * 32];
+  float dab[NT * 32];         // d abar_j
+  float tvec[NT * 32];        // t_i
+  float tr[NT][32 * 33];      // wave-private transposition tile
+};
+
+// stage one half of qk (which = 0: Q, 1: K) of head hd into an LDQ-strided LDS tile
+template <int NT, int D>
+__device__ __forceinline__ void attn_stage_half(float* dst, const float* __restrict__ qk, int which, int b, int n, int hd,
+                                                int tid, int nthreads) {
+  constexpr int LDQ = D + 4;
+  for (int idx0 = tid; idx0 < NT * 32 * D; idx0 += 8 * nthreads) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * nthreads, lr = idx / D, c = idx % D;
+      const bool ok = idx < NT * 32 * D && lr < n;
+      v[u] = ok ? qk[(size_t)(b * n + (ok ? lr : 0)) * 128 + which * 64 + hd * D + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * nthreads, lr = idx / D, c = idx % D;
+      if (idx < NT * 32 * D) dst[lr * LDQ + c] = v[u];
+    }
+  }
+}
+
+template <int NT, int D>
 __device__ __forceinline__ void attn_stage_qk(AttnSmem<NT, D>& sm, const float* __restrict__ qk, int b, int n, int hd,
                                               int tid, int nthreads) {
   constexpr int LDQ = AttnSmem<NT, D>::LDQ;
-  for (int idx = tid; idx < NT * 32 * D; idx += nthreads) {
-    const int lr = idx / D, c = idx % D;
-    float q = 0.f, k = 0.f;
-    if (lr < n) {
-      const size_t base = (size_t)(b * n + lr) * 128 + hd * D + c;
-      q = qk[base];
-      k = qk[base + 64];
+  // every thread issues 8 row-segment loads of Q and K before the first LDS store (one memory round trip per batch)
+  for (int idx0 = tid; idx0 < NT * 32 * D; idx0 += 8 * nthreads) {
+    float q[8], k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * nthreads, lr = idx / D, c = idx % D;
+      const bool ok = idx < NT * 32 * D && lr < n;
+      const size_t base = (size_t)(b * n + (ok ? lr : 0)) * 128 + hd * D + c;
+      q[u] = ok ? qk[base] : 0.f;
+      k[u] = ok ? qk[base + 64] : 0.f;
     }
-    sm.qs[lr * LDQ + c] = q;
-    sm.ks[lr * LDQ + c] = k;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * nthreads, lr = idx / D, c = idx % D;
+      if (idx < NT * 32 * D) { sm.qs[lr * LDQ + c] = q[u]; sm.ks[lr * LDQ + c] = k[u]; }
+    }
   }
 }
 
 template <int NT, int D>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, float* __restrict__ ctx, float* __restrict__ abar_out,
-    float* __restrict__ rowstat, int n, int heads) {
+    float* __restrict__ probs, int n, int heads) {
   constexpr int LDQ = AttnSmem<NT, D>::LDQ;
   __shared__ AttnSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -65,6 +109,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
     attn_stage_qk<NT, D>(sm, qk, b, n, hd, tid, 64 * NT);
     __syncthreads();
     {
+      float* ptile = probs != nullptr ? probs + ((size_t)(b * heads + hd) * NT + wave) * NT * 1024 : nullptr;
       f32x16 acc[NT];
       zero_acc(acc);
       mm_rows<NT, D, LDQ, LDQ>(acc, sm.qs + wave * 32 * LDQ, sm.ks, lane);
@@ -92,13 +137,11 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
         }
         l = sum_over_r(l);
         const float inv = 1.0f / l;
-        if (i < n) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) colsum[nt] += acc[nt][t] * inv;
-          if (r == 0 && rowstat != nullptr) {
-            float* rs = rowstat + ((size_t)(b * heads + hd) * n + i) * 2;
-            rs[0] = m; rs[1] = inv;
-          }
+        for (int nt = 0; nt < NT; ++nt) {
+          const float p = (i < n) ? acc[nt][t] * inv : 0.0f;      // rows of padded queries are stored as zeros
+          colsum[nt] += p;
+          if (ptile != nullptr) ptile[(nt * 16 + t) * 64 + lane] = p;
         }
       }
 #pragma unroll
@@ -119,7 +162,19 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
     __syncthreads();
     {
       float a = 0.f;
-      for (int j = wave; j < n; j += NT) a += sm.abar[j] * x[(size_t)(b * n + j) * 64 + lane];
+      for (int j0 = wave; j0 < n; j0 += 8 * NT) {     // same summation order as a plain loop, 8 row loads in flight
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * NT;
+          xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * NT;
+          if (j < n) a += sm.abar[j] * xv[u];
+        }
+      }
       sm.cpart[wave][lane] = a;
     }
     __syncthreads();
@@ -135,117 +190,133 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
 template <int NT, int D>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
-    const float* __restrict__ rowstat, const float* __restrict__ g_ctx, float* __restrict__ dqk,
+    const float* __restrict__ probs, const float* __restrict__ g_ctx, float* __restrict__ dqk,
     float* __restrict__ dx, int n, int heads) {
-  constexpr int LDQ = AttnSmem<NT, D>::LDQ;
-  __shared__ AttnSmem<NT, D> sm;
+  constexpr int LDQ = AttnBwdSmem<NT, D>::LDQ;
+  constexpr int CT = (D + 31) / 32;
+  __shared__ AttnBwdSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   const int r = lane & 31, hf = lane >> 5;
   const float scale = rsqrtf((float)D);
-  const float invn = 1.0f / (float)n;
+  const float coef = scale / (float)n;
   // direct term dx_j[c] = sum_h abar_h[j] g_ctx_h[c]: thread (wave, lane = c) owns rows j = wave, wave+NT, ...
   // and accumulates over the heads in global memory (same thread, same address: no race)
 
   for (int hd = 0; hd < heads; ++hd) {
     __syncthreads();
-    attn_stage_qk<NT, D>(sm, qk, b, n, hd, tid, 64 * NT);
+    attn_stage_half<NT, D>(sm.kq, qk, 1, b, n, hd, tid, 64 * NT);       // K rows
     const float* gc = g_ctx + (size_t)(b * heads + hd) * 64;
-    for (int j = tid; j < NT * 32; j += 64 * NT) {
-      float d = 0.f, ab = 0.f, m = 0.f, iv = 0.f;
-      if (j < n) {
-        const float* xr = x + (size_t)(b * n + j) * 64;
-        for (int c = 0; c < 64; ++c) d += gc[c] * xr[c];
-        ab = abar_in[(size_t)(b * heads + hd) * n + j];
-        const float* rs = rowstat + ((size_t)(b * heads + hd) * n + j) * 2;
-        m = rs[0]; iv = rs[1];
-      }
-      sm.dab[j] = d; sm.abar[j] = ab; sm.rmax[j] = m; sm.rinv[j] = iv;
-    }
-    __syncthreads();
-    // direct term
+    const float* pbase = probs + (size_t)(b * heads + hd) * NT * NT * 1024;
+    // this wave's query-block tiles (keys on the lanes): issued first, consumed after the staging barrier
+    float pq[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
+    // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NT, ... with
+    // lane = channel (one coalesced 256-byte row per load, 8 rows in flight)
     {
       const float g = gc[lane];
-      for (int j = wave; j < n; j += NT) {
-        float* dst = dx + (size_t)(b * n + j) * 64 + lane;
-        *dst = (hd == 0 ? 0.0f : *dst) + sm.abar[j] * g;
-      }
-    }
-    // ---- pass A: queries of this wave on the LANES (S^T tiles, one 32-key tile at a time): t_i, then dQ ----
-    {
-      const int i = wave * 32 + r;
-      const float mi = sm.rmax[i], li = sm.rinv[i];
-      // sweep 1: t_i = sum_j P_ij dabar_j
-      float ti = 0.f;
-#pragma unroll 1
-      for (int mt = 0; mt < NT; ++mt) {
-        f32x16 one[1];
-        zero_acc(one);
-        mm_rows<1, D, LDQ, LDQ>(one, sm.ks + mt * 32 * LDQ, sm.qs + wave * 32 * LDQ, lane);
+      for (int j0 = wave; j0 < NT * 32; j0 += 8 * NT) {
+        float xv[8], ab[8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int j = mt * 32 + tile_row(t, hf);   // key on the registers, query i = wave*32 + r on the lanes
-          const float p = (j < n && i < n) ? __expf(one[0][t] * scale - mi) * li : 0.f;
-          ti += p * sm.dab[j];
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * NT;
+          xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
+          ab[u] = (j < n) ? abar_in[(size_t)(b * heads + hd) * n + j] : 0.f;
         }
-      }
-      ti += __shfl_xor(ti, 32, 64);
-      if (hf == 0) sm.tvec[i] = ti;
-      // sweep 2: dS^T tile by tile; dQ[i][c] = scale * sum_j dS[i][j] K[j][c] (A operand = the score registers)
-      f32x16 dq[(D + 31) / 32];
-      zero_acc(dq);
-#pragma unroll 1
-      for (int mt = 0; mt < NT; ++mt) {
-        f32x16 one[1];
-        zero_acc(one);
-        mm_rows<1, D, LDQ, LDQ>(one, sm.ks + mt * 32 * LDQ, sm.qs + wave * 32 * LDQ, lane);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int j = mt * 32 + tile_row(t, hf);
-          const float p = (j < n && i < n) ? __expf(one[0][t] * scale - mi) * li : 0.f;
-          const float ds = p * (sm.dab[j] - ti) * invn * scale;
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * NT;
+          float d = xv[u] * g;
 #pragma unroll
-          for (int ct = 0; ct < (D + 31) / 32; ++ct) {
-            const int c = ct * 32 + r;
-            const float kv = (c < D) ? sm.ks[j * LDQ + c] : 0.f;
-            dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kv, dq[ct], 0, 0, 0);
+          for (int mk = 32; mk >= 1; mk >>= 1) d += __shfl_xor(d, mk, 64);
+          if (j < NT * 32 && lane == 0) sm.dab[j] = d;
+          if (j < n) {
+            float* dst = dx + (size_t)(b * n + j) * 64 + lane;
+            *dst = (hd == 0 ? 0.0f : *dst) + ab[u] * g;
           }
         }
       }
+    }
+    __syncthreads();
+    // ---- pass A: query block `wave`.  t_i = sum_j P_ij dabar_j (keys on the lanes -> lane reduction) ----
+    {
+      float tpart[16];
 #pragma unroll
-      for (int ct = 0; ct < (D + 31) / 32; ++ct)
+      for (int t = 0; t < 16; ++t) tpart[t] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float dj = sm.dab[nt * 32 + r];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tpart[t] += pq[nt][t] * dj;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float ti = sum_over_r(tpart[t]);
+        if (r == 0) sm.tvec[wave * 32 + tile_row(t, hf)] = ti;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float ti = sm.tvec[wave * 32 + r];       // query i = wave*32 + r on the lanes from here on
+      // dQ[i][c] = sum_j dS[i][j] K[j][c]: transpose each P tile (wave-private LDS) so that the queries sit on the
+      // lanes; the dS registers are then the MFMA A operand
+      f32x16 dq[CT];
+      zero_acc(dq);
+      float* tr = sm.tr[wave];
+#pragma unroll 1
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pq[nt][t];      // [query row][key col]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int jl = tile_row(t, hf), j = nt * 32 + jl;
+          const float p = tr[r * 33 + jl];                                          // P[i = lane][j]
+          const float ds = p * (sm.dab[j] - ti) * coef;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 32 + r;
+            const float kv = (c < D) ? sm.kq[j * LDQ + c] : 0.f;
+            dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kv, dq[ct], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int ii = wave * 32 + tile_row(t, hf), c = ct * 32 + r;
           if (ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
         }
     }
-    __syncthreads();   // t_i of every query block is in LDS
-    // ---- pass B: keys of this wave on the LANES (S tile, all queries on the registers): dK ----
+    __syncthreads();   // t_i of every query block is in LDS; every wave is done with the K rows
+    attn_stage_half<NT, D>(sm.kq, qk, 0, b, n, hd, tid, 64 * NT);       // Q rows
+    __syncthreads();
+    // ---- pass B: key block `wave` (keys on the lanes, queries on the registers): dK[j][c] = sum_i dS[i][j] Q[i][c] ----
     {
-      f32x16 dk[(D + 31) / 32];
+      f32x16 dk[CT];
       zero_acc(dk);
-      const int j = wave * 32 + r;
-      const float dabj = sm.dab[j];
+      const float dabj = sm.dab[wave * 32 + r];
 #pragma unroll 1
       for (int mt = 0; mt < NT; ++mt) {
-        f32x16 one[1];
-        zero_acc(one);
-        mm_rows<1, D, LDQ, LDQ>(one, sm.qs + mt * 32 * LDQ, sm.ks + wave * 32 * LDQ, lane);
+        float pk[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pk[t] = pbase[((mt * NT + wave) * 16 + t) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int i = mt * 32 + tile_row(t, hf);
-          const float p = (i < n && j < n) ? __expf(one[0][t] * scale - sm.rmax[i]) * sm.rinv[i] : 0.f;
-          const float ds = p * (dabj - sm.tvec[i]) * invn * scale;
+          const float ds = pk[t] * (dabj - sm.tvec[i]) * coef;
 #pragma unroll
-          for (int ct = 0; ct < (D + 31) / 32; ++ct) {
+          for (int ct = 0; ct < CT; ++ct) {
             const int c = ct * 32 + r;
-            const float qv = (c < D) ? sm.qs[i * LDQ + c] : 0.f;
+            const float qv = (c < D) ? sm.kq[i * LDQ + c] : 0.f;
             dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qv, dk[ct], 0, 0, 0);
           }
         }
       }
 #pragma unroll
-      for (int ct = 0; ct < (D + 31) / 32; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int jj = wave * 32 + tile_row(t, hf), c = ct * 32 + r;
@@ -275,20 +346,26 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
   } while (0)
 
 // qk [B*n, 128] = [Q | K], x [B*n, 64]; heads in {1, 8}; n <= 256 nodes per graph (all graphs equal, padded).
-// ctx [B, heads, 64]; abar [B, heads, n] and rowstat [B, heads, n, 2] are saved for the backward (may be NULL).
-extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* rowstat, int B, int n,
+// ctx [B, heads, 64]; abar [B, heads, n] and probs [is_attn_colmean_probs_floats(B, n, heads)] (the attention
+// probabilities in accumulator-tile order) are saved for the backward (both may be NULL).
+extern "C" long long is_attn_colmean_probs_floats(int B, int n, int heads) {
+  const long long nt = ((n + 31) / 32 <= 2) ? 2 : ((n + 31) / 32 <= 4) ? 4 : ((n + 31) / 32 <= 6) ? 6 : 8;
+  return (long long)B * heads * nt * nt * 1024;
+}
+
+extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,
                                    int heads, void* stream) {
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
-  ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, rowstat, n, heads);
+  ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 // dqk [B*n, 128] (every entry written), dx [B*n, 64] (direct term through ctx = abar^T x).
-extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* rowstat,
+extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* probs,
                                    const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream) {
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
-  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, rowstat, g_ctx, dqk, dx, n, heads);
+  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -575,24 +575,26 @@ class AttnColMeanFn(torch.autograd.Function):
         out = torch.empty(b, heads, HIDDEN, dtype=torch.float32, device=dev)
         need = any(ctx_.needs_input_grad)
         abar = torch.empty(b, heads, n, dtype=torch.float32, device=dev) if need else None
-        rowstat = torch.empty(b, heads, n, 2, dtype=torch.float32, device=dev) if need else None
+        # the attention probabilities in accumulator-tile order (148 KB per graph and head at n = 190): read back by
+        # the backward instead of recomputing the scores three times
+        probs = torch.empty(lib.is_attn_colmean_probs_floats(b, n, heads), dtype=torch.float32, device=dev) if need else None
         with KernelTimer.span("attn_colmean_fwd"):
-            _lib.check(lib.is_attn_colmean_fwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(out), _lib.ptr(abar), _lib.ptr(rowstat),
+            _lib.check(lib.is_attn_colmean_fwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(out), _lib.ptr(abar), _lib.ptr(probs),
                                                b, n, heads, _lib.stream_ptr()), "is_attn_colmean_fwd")
         ctx_.dims = (b, n, heads)
-        ctx_.save_for_backward(qk, x, abar, rowstat)
+        ctx_.save_for_backward(qk, x, abar, probs)
         return out
 
     @staticmethod
     def backward(ctx_, g):
         lib = _lib.load()
-        qk, x, abar, rowstat = ctx_.saved_tensors
+        qk, x, abar, probs = ctx_.saved_tensors
         b, n, heads = ctx_.dims
         g = _lib.f32c(g)
         dqk = torch.empty_like(qk)
         dx = torch.empty_like(x)
         with KernelTimer.span("attn_colmean_bwd"):
-            _lib.check(lib.is_attn_colmean_bwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(rowstat), _lib.ptr(g),
+            _lib.check(lib.is_attn_colmean_bwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(probs), _lib.ptr(g),
                                                _lib.ptr(dqk), _lib.ptr(dx), b, n, heads, _lib.stream_ptr()), "is_attn_colmean_bwd")
         return dqk, dx, None, None, None
 

@@ -216,11 +216,14 @@ int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const 
  * W1 = [Wq | Wk]), x [B*n,64]; heads in {1, 8}; n <= 256 padded nodes per graph.
  *   ctx [B, heads, 64] = sum_j abar_h[j] x_j with abar_h = column mean of softmax(Q_h K_h^T / sqrt(d));
  *   the pooled attention output is then W_v,h ctx_h + b_v,h (and w_concat) on B x 64 vectors.
- * abar [B,heads,n] and rowstat [B,heads,n,2] (row max, 1/row sum) are saved for the backward (may be NULL).
+ * abar [B,heads,n] and probs [is_attn_colmean_probs_floats(B, n, heads) floats: the attention probabilities in
+ * MFMA accumulator-tile order] are saved for the backward (both may be NULL), which reads the probabilities back
+ * instead of recomputing the scores.
  * Backward: dqk [B*n,128] (fully written) and dx [B*n,64] (direct term through ctx).                       */
-int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* rowstat, int B, int n,
+long long is_attn_colmean_probs_floats(int B, int n, int heads);
+int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,
                         int heads, void* stream);
-int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* rowstat,
+int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* probs,
                         const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream);
 
 /* "Combined attention" of the fusion head in closed form (models/hybrid_models.py:344-347 with
