@@ -28,6 +28,13 @@
 
 namespace is {
 
+#ifdef IS_STAGE_STAMPS
+__device__ long long g_stamps_attn[16];
+#define STAMPA(k) do { if (blockIdx.x == 50 && threadIdx.x == 0) g_stamps_attn[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMPA(k) do { } while (0)
+#endif
+
 template <int NT, int D>
 struct AttnSmem {
   static constexpr int LDQ = D + 4;
@@ -202,17 +209,13 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
   // direct term dx_j[c] = sum_h abar_h[j] g_ctx_h[c]: thread (wave, lane = c) owns rows j = wave, wave+NT, ...
   // and accumulates over the heads in global memory (same thread, same address: no race)
 
+  STAMPA(0);
   for (int hd = 0; hd < heads; ++hd) {
     __syncthreads();
     attn_stage_half<NT, D>(sm.kq, qk, 1, b, n, hd, tid, 64 * NT);       // K rows
+    STAMPA(1);
     const float* gc = g_ctx + (size_t)(b * heads + hd) * 64;
     const float* pbase = probs + (size_t)(b * heads + hd) * NT * NT * 1024;
-    // this wave's query-block tiles (keys on the lanes): issued first, consumed after the staging barrier
-    float pq[NT][16];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
     // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NT, ... with
     // lane = channel (one coalesced 256-byte row per load, 8 rows in flight)
     {
@@ -228,9 +231,9 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = j0 + u * NT;
-          float d = xv[u] * g;
-#pragma unroll
-          for (int mk = 32; mk >= 1; mk >>= 1) d += __shfl_xor(d, mk, 64);
+          float d = sum_over_r16(xv[u] * g);          // 16-lane rows by DPP, then the four rows
+          d += __shfl_xor(d, 16, 64);
+          d += __shfl_xor(d, 32, 64);
           if (j < NT * 32 && lane == 0) sm.dab[j] = d;
           if (j < n) {
             float* dst = dx + (size_t)(b * n + j) * 64 + lane;
@@ -239,7 +242,16 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
         }
       }
     }
+    // this wave's query-block tiles (keys on the lanes); issued AFTER the x rows: vector loads return in order, the
+    // reduction above must not wait behind these 24 KB
+    float pq[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
+    STAMPA(2);
     __syncthreads();
+    STAMPA(3);
     // ---- pass A: query block `wave`.  t_i = sum_j P_ij dabar_j (keys on the lanes -> lane reduction) ----
     {
       float tpart[16];
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
       }
       __builtin_amdgcn_wave_barrier();
       const float ti = sm.tvec[wave * 32 + r];       // query i = wave*32 + r on the lanes from here on
+      STAMPA(4);
       // dQ[i][c] = sum_j dS[i][j] K[j][c]: transpose each P tile (wave-private LDS) so that the queries sit on the
       // lanes; the dS registers are then the MFMA A operand
       f32x16 dq[CT];
@@ -268,18 +281,25 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pq[nt][t];      // [query row][key col]
         __builtin_amdgcn_wave_barrier();
+        // all LDS operands of the tile first, then the MFMAs back to back (an LDS read in front of every MFMA
+        // exposes its latency 16 times per tile when one wave has the SIMD to itself)
+        float ds[16], kv[16][CT];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int jl = tile_row(t, hf), j = nt * 32 + jl;
-          const float p = tr[r * 33 + jl];                                          // P[i = lane][j]
-          const float ds = p * (sm.dab[j] - ti) * coef;
+          ds[t] = tr[r * 33 + jl] * (sm.dab[j] - ti) * coef;                          // P[i = lane][j] -> dS
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const int c = ct * 32 + r;
-            const float kv = (c < D) ? sm.kq[j * LDQ + c] : 0.f;
-            dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kv, dq[ct], 0, 0, 0);
+            kv[t][ct] = (c < D) ? sm.kq[j * LDQ + c] : 0.f;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads above, the MFMAs below (the scheduler re-interleaves them)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[t], kv[t][ct], dq[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
@@ -290,30 +310,44 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
           if (ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
         }
     }
+    STAMPA(5);
     __syncthreads();   // t_i of every query block is in LDS; every wave is done with the K rows
+    STAMPA(6);
     attn_stage_half<NT, D>(sm.kq, qk, 0, b, n, hd, tid, 64 * NT);       // Q rows
     __syncthreads();
+    STAMPA(7);
     // ---- pass B: key block `wave` (keys on the lanes, queries on the registers): dK[j][c] = sum_i dS[i][j] Q[i][c] ----
     {
       f32x16 dk[CT];
       zero_acc(dk);
       const float dabj = sm.dab[wave * 32 + r];
+      float pk[16], pn[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pk[t] = pbase[((0 * NT + wave) * 16 + t) * 64 + lane];
 #pragma unroll 1
       for (int mt = 0; mt < NT; ++mt) {
-        float pk[16];
+        const int mn = min(mt + 1, NT - 1);                    // next tile in flight during this tile's MFMAs
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pk[t] = pbase[((mt * NT + wave) * 16 + t) * 64 + lane];
+        for (int t = 0; t < 16; ++t) pn[t] = pbase[((mn * NT + wave) * 16 + t) * 64 + lane];
+        float ds[16], qv[16][CT];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int i = mt * 32 + tile_row(t, hf);
-          const float ds = pk[t] * (dabj - sm.tvec[i]) * coef;
+          ds[t] = pk[t] * (dabj - sm.tvec[i]) * coef;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const int c = ct * 32 + r;
-            const float qv = (c < D) ? sm.kq[i * LDQ + c] : 0.f;
-            dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qv, dk[ct], 0, 0, 0);
+            qv[t][ct] = (c < D) ? sm.kq[i * LDQ + c] : 0.f;
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[t], qv[t][ct], dk[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pk[t] = pn[t];
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
@@ -323,10 +357,17 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
           if (jj < n && c < D) dqk[(size_t)(b * n + jj) * 128 + 64 + hd * D + c] = dk[ct][t];
         }
     }
+    STAMPA(8);
   }
 }
 
 }  // namespace is
+
+#ifdef IS_STAGE_STAMPS
+extern "C" int is_debug_stamps_attn(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_attn), sizeof(long long) * 16) == hipSuccess ? 0 : -5;
+}
+#endif
 
 #define ATTN_DISPATCH(KERNEL, ...)                                                                                   \
   do {                                                                                                               \
