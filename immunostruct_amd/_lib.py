@@ -54,6 +54,10 @@ SIGNATURES = {
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
+    "is_mlp2_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "is_mlp2_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "is_mlp2_bwd_records": [_I],
+    "is_mlp2_bwd_record_floats": [_I, _I, _I],
     "is_debug_timestamp": [_P, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],

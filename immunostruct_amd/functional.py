@@ -670,6 +670,92 @@ def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None):
     return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), *flat)
 
 
+class Mlp2Fn(torch.autograd.Function):
+    """y = act2(W2 (mask * act1(W1 X + b1)) + b2) per sample (``csrc/mlp_head.hip``): the classifier, the property
+    embedding and the pooled attention's W_v / w_concat tail as one launch forward, one (+ reduction) backward.
+
+    x (B, xrow); ``hgroup`` > 0: every group of hgroup hidden units reads its own ``in``-wide slice of the row."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, mask, act1, act2, hgroup):
+        lib = _lib.load()
+        _lib.require_device(x, w1, b1, w2, b2, mask)
+        if x.dim() != 2:
+            raise ValueError("expected x (batch, features)")
+        x, ld_x = _lib.rows_ld(x)
+        w1, b1, w2, b2 = (_lib.f32c(t) for t in (w1, b1, w2, b2))
+        mask = _lib.f32c(mask) if mask is not None else None
+        b = int(x.shape[0])
+        hid, inn = int(w1.shape[0]), int(w1.shape[1])
+        out = int(w2.shape[0])
+        heads = hid // hgroup if hgroup > 0 else 1
+        if int(x.shape[1]) != heads * inn or int(w2.shape[1]) != hid or (mask is not None and tuple(mask.shape) != (b, hid)):
+            raise ValueError("Mlp2Fn: inconsistent shapes")
+        dev = x.device
+        y = torch.empty(b, out, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        a1 = torch.empty(b, hid, dtype=torch.float32, device=dev) if need else None
+        with KernelTimer.span("mlp2_fwd"):
+            _lib.check(lib.is_mlp2_fwd(_lib.ptr(x), ld_x, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(mask),
+                                       _lib.ptr(a1), _lib.ptr(y), b, inn, hid, out, hgroup, act1, act2, _lib.stream_ptr()), "is_mlp2_fwd")
+        ctx.cfg = (ld_x, b, inn, hid, out, hgroup, act1, act2, heads)
+        ctx.save_for_backward(x, w1, w2, mask, a1, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w1, w2, mask, a1, y = ctx.saved_tensors
+        ld_x, b, inn, hid, out, hgroup, act1, act2, heads = ctx.cfg
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gy = _lib.f32c(gy)
+        st = _lib.stream_ptr()
+        nrec, rec = lib.is_mlp2_bwd_records(b), lib.is_mlp2_bwd_record_floats(inn, hid, out)
+        part = torch.empty(nrec * rec, **f32)
+        gx = torch.empty(b, heads * inn, **f32) if ctx.needs_input_grad[0] else None
+        with KernelTimer.span("mlp2_bwd"):
+            _lib.check(lib.is_mlp2_bwd(_lib.ptr(x), ld_x, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(mask), _lib.ptr(a1), _lib.ptr(y),
+                                       _lib.ptr(gy), _lib.ptr(gx), _lib.ptr(part), b, inn, hid, out, hgroup, act1, act2, st), "is_mlp2_bwd")
+            flat = torch.empty(rec, **f32)
+            scratch = torch.empty(lib.is_reduce_partials_scratch_floats(rec), **f32)
+            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nrec, rec, rec, None, _lib.ptr(flat), _lib.ptr(scratch), st), "is_reduce_partials")
+        o1, o2, o3 = hid * inn, hid * inn + hid, hid * inn + hid + out * hid
+        return (gx, flat[:o1].view(hid, inn), flat[o1:o2], flat[o2:o3].view(out, hid), flat[o3:], None, None, None, None)
+
+
+def mlp2(x, w1, b1, w2, b2, mask=None, act1=0, act2=0, hgroup=0):
+    return Mlp2Fn.apply(x, w1, b1, w2, b2, mask, int(act1), int(act2), int(hgroup))
+
+
+MLP_HEADS = os.environ.get("IMMUNOSTRUCT_MLP_HEADS", "1") != "0"
+_ones_cache = {}
+
+
+def dropout_mask(rows, cols, p, device):
+    """scaled keep-mask of nn.Dropout(p) in training mode (torch's generator: capturable), as an explicit tensor"""
+    key = (rows, cols, str(device))
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(rows, cols, dtype=torch.float32, device=device)
+    return torch.nn.functional.dropout(_ones_cache[key], p=p, training=True)
+
+
+def sequential_mlp2(seq, x):
+    """Run an ``nn.Sequential`` of the form [Flatten,] Linear, ReLU, Dropout, Linear [, ReLU] (the reference's classifier
+    and property embedding) through :func:`mlp2`; returns None when the module does not have that form or the sizes
+    exceed the kernel's limits (the caller then uses the module itself)."""
+    mods = [m for m in seq if not isinstance(m, torch.nn.Flatten)]
+    if not MLP_HEADS or len(mods) not in (4, 5) or not x.is_cuda or x.dim() != 2:
+        return None
+    l1, r1, dr, l2 = mods[:4]
+    ok = (isinstance(l1, torch.nn.Linear) and isinstance(r1, torch.nn.ReLU) and isinstance(dr, torch.nn.Dropout)
+          and isinstance(l2, torch.nn.Linear) and (len(mods) == 4 or isinstance(mods[4], torch.nn.ReLU)))
+    if not ok or l1.in_features > 256 or l1.out_features > 64 or l2.out_features > 64 or l1.bias is None or l2.bias is None:
+        return None
+    mask = dropout_mask(x.shape[0], l1.out_features, dr.p, x.device) if (seq.training and dr.p > 0) else None
+    return mlp2(x, l1.weight, l1.bias, l2.weight, l2.bias, mask=mask, act1=1, act2=1 if len(mods) == 5 else 0)
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """Per-segment mean and/or max over rows (``csrc/segment_ops.hip``).
 

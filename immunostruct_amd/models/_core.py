@@ -162,7 +162,9 @@ class MultimodalNet(nn.Module):
         o = {}
         p = None
         if sp.prop == "emb":
-            p = self.property_embedding(prop)
+            p = HF.sequential_mlp2(self.property_embedding, prop)      # one HIP launch (csrc/mlp_head.hip)
+            if p is None:
+                p = self.property_embedding(prop)
         elif sp.prop == "raw":
             p = prop
         if sp.vae:
@@ -213,7 +215,9 @@ class MultimodalNet(nn.Module):
                 fused = HF.combined_attention_mean(fused, ca)     # closed-form HIP kernel
             else:
                 fused = ca(fused.unsqueeze(2))[0].mean(dim=2)
-        hid = self.classifier(fused)
+        hid = HF.sequential_mlp2(self.classifier, fused.flatten(1)) if not self.SPEC.ssl else None
+        if hid is None:
+            hid = self.classifier(fused)
         if self.SPEC.ssl:
             return self.classifier_head(hid), self.node_predictor_head(hid)
         return hid, None

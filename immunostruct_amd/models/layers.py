@@ -28,7 +28,7 @@ def attend(q, k, v, heads):
     return out, w
 
 
-def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=None):
+def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=None, out_proj=None):
     """mean over the n rows of softmax(q k^T / sqrt(d)) v  WITHOUT materialising v or the (n, d) output.
 
     mean_i sum_j A_ij v_j = sum_j abar_j v_j with abar = column mean of A, and
@@ -56,7 +56,13 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=
         q, k = q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2)
         w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
         ctx = torch.matmul(w.mean(dim=2), x)
+    if out_proj is not None and HF.MLP_HEADS and x.is_cuda and dm == 64 and ctx.is_contiguous():
+        # per-head value projection and the output projection (w_concat) of the pooled vector in one HIP launch
+        u = HF.mlp2(ctx.reshape(b, heads * dm), wv, bv, out_proj.weight, out_proj.bias, hgroup=dh)
+        return u, w
     u = torch.einsum("bhk,hdk->bhd", ctx, wv.view(heads, dh, dm)).reshape(b, dm) + bv
+    if out_proj is not None:
+        u = out_proj(u)
     return u, w
 
 
@@ -113,6 +119,5 @@ class MultiHeadAttention(nn.Module):
         if self.w_q.in_features != self.w_q.out_features or self.w_q.out_features != 64:
             out, w = self.forward(x)
             return out.mean(dim=1), w
-        u, w = attend_pooled_mean(x, self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias,
-                                  self.w_v.weight, self.w_v.bias, self.n_head, need_weights, qk=qk)
-        return self.w_concat(u), w
+        return attend_pooled_mean(x, self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias,
+                                  self.w_v.weight, self.w_v.bias, self.n_head, need_weights, qk=qk, out_proj=self.w_concat)

@@ -186,6 +186,25 @@ int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
                           float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
 
+/* Two-layer per-sample MLP for the small dense heads (classifier Linear(F,32)-ReLU-Dropout-Linear(32,1),
+ * models/hybrid_models.py:288-295; property embedding :280-286; the pooled attention's W_v / w_concat tail,
+ * models/layers.py:74-77):
+ *   a1 = act1(W1 X + b1), hid = a1 * mask (mask [B,hid] = scaled dropout keep-mask or NULL), y = act2(W2 hid + b2)
+ * x [B, ld_x]; with hgroup > 0 every group of hgroup hidden units reads its own `in`-wide slice of the row
+ * (x holds (hid / hgroup) * in valid columns: per-head value projection).  in <= 256, hid, out <= 64.
+ * act: 0 identity, 1 ReLU.  a1_out [B,hid] (may be NULL) and y are what the backward needs.
+ * Backward: gx [B, ld_x] (may be NULL) and is_mlp2_bwd_records(B) partial records of
+ * is_mlp2_bwd_record_floats(in, hid, out) floats [dW1 (hid x in) | db1 | dW2 (out x hid) | db2], to be summed
+ * with is_reduce_partials.                                                                                   */
+int is_mlp2_fwd(const float* x, int ld_x, const float* W1, const float* b1, const float* W2, const float* b2,
+                const float* mask, float* a1_out, float* y, int B, int in, int hid, int out, int hgroup,
+                int act1, int act2, void* stream);
+int is_mlp2_bwd_records(int B);
+int is_mlp2_bwd_record_floats(int in, int hid, int out);
+int is_mlp2_bwd(const float* x, int ld_x, const float* W1, const float* W2, const float* mask, const float* a1,
+                const float* y, const float* gy, float* gx, float* partials, int B, int in, int hid, int out,
+                int hgroup, int act1, int act2, void* stream);
+
 /* Multi-tensor Adam / AdamW step with torch.optim semantics (reference: torch.optim.Adam in train_IEDB_wFT.py:69-74,
  * torch.optim.AdamW in train_Cancer_wFT.py:76-92).  `chunks` = DEVICE array of nchunks records
  * { float* p; const float* g; float* m; float* v; long long n; } (one workgroup each), `state` = device float[3]

@@ -382,3 +382,45 @@ def test_hip_adam_matches_torch_optim(cuda_device, kind, wd):
         hip.step()
     for a, b in zip(ref_p, hip_p):
         H.assert_close(b.detach().cpu(), a.detach().cpu(), 2e-6, f"{kind} param {tuple(a.shape)}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(b=128, inn=104, hid=32, out=1, act1=1, act2=0, drop=True, hgroup=0),     # classifier
+    dict(b=37, inn=208, hid=32, out=1, act1=1, act2=0, drop=False, hgroup=0),     # paired classifier, ragged batch
+    dict(b=16, inn=2, hid=32, out=8, act1=1, act2=1, drop=True, hgroup=0),        # property embedding
+    dict(b=5, inn=64, hid=64, out=64, act1=0, act2=0, drop=False, hgroup=8),      # pooled attention tail, 8 heads
+    dict(b=128, inn=64, hid=64, out=64, act1=0, act2=0, drop=False, hgroup=64),   # pooled attention tail, 1 head
+])
+def test_mlp2_matches_torch(cuda_device, cfg):
+    """csrc/mlp_head.hip vs the same two layers written with torch ops in fp64 (values + all gradients)."""
+    g = torch.Generator().manual_seed(21)
+    b, inn, hid, out, hg = cfg["b"], cfg["inn"], cfg["hid"], cfg["out"], cfg["hgroup"]
+    heads = hid // hg if hg else 1
+    x = torch.randn(b, heads * inn, generator=g)
+    w1, b1 = torch.randn(hid, inn, generator=g) * 0.2, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(out, hid, generator=g) * 0.2, torch.randn(out, generator=g) * 0.1
+    mask = ((torch.rand(b, hid, generator=g) > 0.1).float() / 0.9) if cfg["drop"] else None
+    gup = torch.randn(b, out, generator=g)
+
+    def ref(xx, ww1, bb1, ww2, bb2):
+        if hg:
+            xin = xx.view(b, heads, inn)
+            pre = torch.einsum("bhk,hdk->bhd", xin, ww1.view(heads, hg, inn)).reshape(b, hid) + bb1
+        else:
+            pre = xx @ ww1.T + bb1
+        a = torch.relu(pre) if cfg["act1"] else pre
+        if mask is not None:
+            a = a * mask.double()
+        yy = a @ ww2.T + bb2
+        return torch.relu(yy) if cfg["act2"] else yy
+
+    leaves_r = [t.double().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yr = ref(*leaves_r)
+    (yr * gup.double()).sum().backward()
+    leaves_h = [t.clone().to(cuda_device).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yh = HF.mlp2(*leaves_h, mask=mask.to(cuda_device) if mask is not None else None, act1=cfg["act1"], act2=cfg["act2"], hgroup=hg)
+    (yh * gup.to(cuda_device)).sum().backward()
+    H.assert_close(yh.detach().cpu(), yr.detach(), 2e-6, "mlp2 y")
+    for name, a, r in zip(("dx", "dW1", "db1", "dW2", "db2"), leaves_h, leaves_r):
+        H.assert_close(a.grad.cpu(), r.grad, 5e-6, f"mlp2 {name}")
