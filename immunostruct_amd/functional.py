@@ -857,10 +857,11 @@ class VaeLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_terms):
         d_recon, d_mu, d_lv, d_logit = ctx.saved_tensors
-        gr = d_recon * g if ctx.seq else None
-        gm = d_mu * g if ctx.seq else None
-        gl = d_lv * g if ctx.seq else None
-        return gr, None, gm, gl, (d_logit * g).reshape(ctx.logit_shape), None, None, None, None, None, None
+        if ctx.seq:
+            gr, gm, gl, gz = torch._foreach_mul([d_recon, d_mu, d_lv, d_logit], g)     # one multi-tensor launch
+        else:
+            gr, gm, gl, gz = None, None, None, d_logit * g
+        return gr, None, gm, gl, gz.reshape(ctx.logit_shape), None, None, None, None, None, None
 
 
 def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):
