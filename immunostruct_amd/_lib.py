@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libimmunostruct_hip.so")
 _P, _I, _F, _LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 # symbol -> argtypes ; keep in sync with include/immunostruct_hip.h
-_RETURNS_LONGLONG = {"is_attn_colmean_probs_floats"}
+_RETURNS_LONGLONG = {"is_attn_colmean_probs_floats", "is_contrastive_scratch_floats", "is_contrastive_work_floats"}
 SIGNATURES = {
     "is_version": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
@@ -54,6 +54,10 @@ SIGNATURES = {
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
+    "is_contrastive_scratch_floats": [_I],
+    "is_contrastive_work_floats": [_I],
+    "is_contrastive_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _I, _P],
+    "is_contrastive_bwd": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_mlp2_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "is_mlp2_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "is_mlp2_bwd_records": [_I],

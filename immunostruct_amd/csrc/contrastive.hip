@@ -1,0 +1,365 @@
+// Paired (cancer / wild-type) contrastive loss, forward and backward, as five launches.
+//
+// Reference: utils/contrastive.py:18-83 (PairedContrastiveLoss): both embeddings go through the projector
+//   Linear(E -> Z, no bias) -> BatchNorm1d(Z) on BATCH statistics (the module is never put in eval mode,
+//   procedures/train.py:76) -> ReLU -> Linear(Z -> Z, no bias),          Z = 128, E = 104
+// are centred over the batch, and
+//   loss = sum_ij w_ij (zc zw^T / Z - diag(pos))_ij^2 + sum_kl w_kl (zc^T zw / B - I)_kl^2
+//          + 1/2 [ mean_k relu(1 - sqrt(var_k(zc) + 1e-4)) + (same for zw) ],     w = 1 on the diagonal, lambda elsewhere
+// (the reference writes the two weighted sums with boolean-mask in-place scaling, :62-81; same values).
+// The projector is random and frozen (it is not handed to the optimizer, procedures/train.py:76-83) but gradients
+// flow through it to the embeddings: the backward returns d loss / d emb_c and d loss / d emb_w only.
+// BatchNorm's running statistics are not maintained (nothing ever reads them: the module stays in train mode).
+//
+//   contr_side_fwd  (grid 2, one workgroup of 16 waves per side): y1 = emb W1^T -> batch statistics -> a1 -> z0 = a1 W2^T
+//                   -> centre -> per-column std -> hinge.  Intermediates live in a global scratch that stays in L1/L2
+//                   (the whole problem is ~0.5 MB); phases are separated by workgroup barriers.
+//   contr_pair_fwd  pair = zc zw^T / Z and corr = zc^T zw / B tile by tile (32 x 32 per wave) + the weighted squared
+//                   deviations -> one partial per tile;   contr_finish sums the partials in tile order.
+//   contr_pair_bwd  dzc = dPair zw / Z + zw dCorr^T / B,  dzw = dPair^T zc / Z + zc dCorr / B   (tiles of B x Z)
+//   contr_side_bwd  (grid 2): hinge + centring backward -> da1 = dz0 W2 -> ReLU / BatchNorm backward (batch statistics)
+//                   -> d emb = dy1 W1.
+// All matrix products run on v_mfma_f32_32x32x2_f32 with operands read straight from global memory (L1 hits), every
+// reduction has a fixed order -> bitwise reproducible.  B <= 256 pairs, E <= 256, Z = 128.
+#include "common.h"
+
+namespace is {
+
+constexpr int CZ = 128;          // projector width
+constexpr int C_WAVES = 16;      // waves of a side workgroup
+constexpr float BN_EPS = 1e-5f;
+
+// acc (32 x 32) += sum_k a(row r, k) * b(k, col r); K rounded up to even, accessors return 0 past the end.
+template <typename FA, typename FB>
+__device__ __forceinline__ void tile32(f32x16& acc, int K, FA a, FB b, int lane) {
+  const int r = lane & 31, hf = lane >> 5;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 2 * u + hf;
+      av[u] = (k < K) ? a(r, k) : 0.0f;
+      bv[u] = (k < K) ? b(k, r) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) z[t] = 0.0f;
+  return z;
+}
+
+// scratch layout per side (floats): Y [B][Z] | A1 [B][Z] | Zc [B][Z] | stats: mu[Z] inv[Z] colmean[Z] std[Z]
+__host__ __device__ inline long long side_floats(int B) { return 3LL * B * CZ + 4 * CZ; }
+
+__global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
+    const float* __restrict__ emb_c, const float* __restrict__ emb_w, int ld_e, int E,
+    const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ W2, float* __restrict__ scratch, float* __restrict__ hinge, int B) {
+  const int side = blockIdx.x;
+  const float* emb = side == 0 ? emb_c : emb_w;
+  float* S = scratch + (size_t)side * side_floats(B);
+  float* Y = S; float* A1 = Y + (size_t)B * CZ; float* Zc = A1 + (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
+  __shared__ float red[CZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int row_tiles = (B + 31) / 32, ntiles = row_tiles * (CZ / 32);
+  // ---- y1 = emb W1^T ----
+  for (int tl = wave; tl < ntiles; tl += C_WAVES) {
+    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
+    f32x16 acc = zero16();
+    tile32(acc, E, [&](int rr, int k) { return (i0 + rr < B) ? emb[(size_t)(i0 + rr) * ld_e + k] : 0.0f; },
+           [&](int k, int cc) { return W1[(size_t)(j0 + cc) * E + k]; }, lane);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = i0 + tile_row(t, hf);
+      if (i < B) Y[(size_t)i * CZ + j0 + r] = acc[t];
+    }
+  }
+  __syncthreads();
+  // ---- batch statistics of every column (biased variance), a1 = relu(gamma xhat + beta) ----
+  if (tid < CZ) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += Y[(size_t)b * CZ + tid];
+    const float mu = s / (float)B;
+    float v = 0.0f;
+    for (int b = 0; b < B; ++b) { const float d = Y[(size_t)b * CZ + tid] - mu; v += d * d; }
+    st[tid] = mu;
+    st[CZ + tid] = 1.0f / sqrtf(v / (float)B + BN_EPS);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
+    const int k = idx % CZ;
+    const float xh = (Y[idx] - st[k]) * st[CZ + k];
+    Y[idx] = xh;                                     // Y now holds xhat (needed by the backward)
+    A1[idx] = fmaxf(gamma[k] * xh + beta[k], 0.0f);
+  }
+  __syncthreads();
+  // ---- z0 = a1 W2^T ----
+  for (int tl = wave; tl < ntiles; tl += C_WAVES) {
+    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
+    f32x16 acc = zero16();
+    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? A1[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
+           [&](int k, int cc) { return W2[(size_t)(j0 + cc) * CZ + k]; }, lane);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = i0 + tile_row(t, hf);
+      if (i < B) Zc[(size_t)i * CZ + j0 + r] = acc[t];
+    }
+  }
+  __syncthreads();
+  // ---- centre, unbiased variance, hinge ----
+  if (tid < CZ) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += Zc[(size_t)b * CZ + tid];
+    const float m = s / (float)B;
+    float v = 0.0f;
+    for (int b = 0; b < B; ++b) {
+      const float d = Zc[(size_t)b * CZ + tid] - m;
+      Zc[(size_t)b * CZ + tid] = d;
+      v += d * d;
+    }
+    const float sd = sqrtf(v / (float)(B - 1) + 1e-4f);
+    st[2 * CZ + tid] = m;
+    st[3 * CZ + tid] = sd;
+    red[tid] = fmaxf(1.0f - sd, 0.0f);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.0f;
+    for (int k = 0; k < CZ; ++k) s += red[k];
+    hinge[side] = s / (float)CZ;
+  }
+}
+
+// tiles: [0, rt*rt) pair tiles (B x B), then 16 corr tiles (Z x Z).  PAIR [B][B], CORR [Z][Z] are kept for the backward.
+__global__ __launch_bounds__(256) void contr_pair_fwd_kernel(
+    const float* __restrict__ scratch, const float* __restrict__ pos, float lambda, float* __restrict__ PAIR,
+    float* __restrict__ CORR, float* __restrict__ partials, int B) {
+  const float* Zc = scratch + 2LL * B * CZ;
+  const float* Zw = scratch + side_floats(B) + 2LL * B * CZ;
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int rt = (B + 31) / 32, npair = rt * rt, ntiles = npair + 16;
+  const int tl = blockIdx.x * 4 + wave;
+  float part = 0.0f;
+  if (tl < ntiles) {
+    f32x16 acc = zero16();
+    if (tl < npair) {
+      const int i0 = (tl / rt) * 32, j0 = (tl % rt) * 32;
+      tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? Zc[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
+             [&](int k, int cc) { return (j0 + cc < B) ? Zw[(size_t)(j0 + cc) * CZ + k] : 0.0f; }, lane);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = i0 + tile_row(t, hf), j = j0 + r;
+        if (i < B && j < B) {
+          const float v = acc[t] * (1.0f / (float)CZ);
+          PAIR[(size_t)i * B + j] = v;
+          const float d = (i == j) ? v - pos[i] : v;
+          part += ((i == j) ? 1.0f : lambda) * d * d;
+        }
+      }
+    } else {
+      const int c = tl - npair, i0 = (c / 4) * 32, j0 = (c % 4) * 32;
+      tile32(acc, B, [&](int rr, int k) { return Zc[(size_t)k * CZ + i0 + rr]; },
+             [&](int k, int cc) { return Zw[(size_t)k * CZ + j0 + cc]; }, lane);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = i0 + tile_row(t, hf), j = j0 + r;
+        const float v = acc[t] / (float)B;
+        CORR[(size_t)i * CZ + j] = v;
+        const float d = (i == j) ? v - 1.0f : v;
+        part += ((i == j) ? 1.0f : lambda) * d * d;
+      }
+    }
+  }
+  red[wave][lane] = part;
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.0f;
+    for (int l = 0; l < 64; ++l) s += red[tid][l];
+    partials[blockIdx.x * 4 + tid] = s;
+  }
+}
+
+__global__ void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ hinge,
+                                    float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < nparts; ++i) s += partials[i];
+    loss[0] = s + 0.5f * (hinge[0] + hinge[1]);
+  }
+}
+
+// DZ [2][B][Z]: gradient w.r.t. the centred projections (pair / corr terms only; the hinge is added by the side kernel)
+__global__ __launch_bounds__(256) void contr_pair_bwd_kernel(
+    const float* __restrict__ scratch, const float* __restrict__ pos, float lambda, const float* __restrict__ PAIR,
+    const float* __restrict__ CORR, float* __restrict__ DZ, int B) {
+  const float* Zc = scratch + 2LL * B * CZ;
+  const float* Zw = scratch + side_floats(B) + 2LL * B * CZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int rt = (B + 31) / 32, per_side = rt * 4;
+  const int tl = blockIdx.x * 4 + wave;
+  if (tl >= 2 * per_side) return;
+  const int side = tl / per_side, q = tl % per_side;
+  const int i0 = (q / 4) * 32, j0 = (q % 4) * 32;
+  const float invz = 1.0f / (float)CZ, invb = 1.0f / (float)B;
+  auto dpair = [&](int i, int j) {          // d loss / d pair_ij
+    if (i >= B || j >= B) return 0.0f;
+    const float v = PAIR[(size_t)i * B + j];
+    return (i == j) ? 2.0f * (v - pos[i]) : 2.0f * lambda * v;
+  };
+  auto dcorr = [&](int k, int l) {
+    const float v = CORR[(size_t)k * CZ + l];
+    return (k == l) ? 2.0f * (v - 1.0f) : 2.0f * lambda * v;
+  };
+  f32x16 acc = zero16(), acc2 = zero16();
+  if (side == 0) {
+    // dzc[b][k] = sum_j dpair[b][j] zw[j][k] / Z + sum_l zw[b][l] dcorr[k][l] / B
+    tile32(acc, B, [&](int rr, int j) { return dpair(i0 + rr, j); },
+           [&](int j, int cc) { return Zw[(size_t)j * CZ + j0 + cc]; }, lane);
+    tile32(acc2, CZ, [&](int rr, int l) { return (i0 + rr < B) ? Zw[(size_t)(i0 + rr) * CZ + l] : 0.0f; },
+           [&](int l, int cc) { return dcorr(j0 + cc, l); }, lane);
+  } else {
+    // dzw[j][l] = sum_b dpair[b][j] zc[b][l] / Z + sum_k zc[j][k] dcorr[k][l] / B
+    tile32(acc, B, [&](int rr, int b) { return dpair(b, i0 + rr); },
+           [&](int b, int cc) { return Zc[(size_t)b * CZ + j0 + cc]; }, lane);
+    tile32(acc2, CZ, [&](int rr, int k) { return (i0 + rr < B) ? Zc[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
+           [&](int k, int cc) { return dcorr(k, j0 + cc); }, lane);
+  }
+  float* out = DZ + (size_t)side * B * CZ;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = i0 + tile_row(t, hf);
+    if (i < B) out[(size_t)i * CZ + j0 + r] = acc[t] * invz + acc2[t] * invb;
+  }
+}
+
+__global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
+    const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ W2,
+    const float* __restrict__ scratch, float* __restrict__ DZ, float* __restrict__ work, const float* __restrict__ g_loss,
+    float* __restrict__ demb_c, float* __restrict__ demb_w, int ld_d, int E, int B) {
+  const int side = blockIdx.x;
+  const float* S = scratch + (size_t)side * side_floats(B);
+  const float* XH = S; const float* A1 = XH + (size_t)B * CZ; const float* Zc = A1 + (size_t)B * CZ;
+  const float* st = Zc + (size_t)B * CZ;
+  float* dz = DZ + (size_t)side * B * CZ;
+  float* wk = work + (size_t)side * B * CZ;                  // da1, then dy1
+  float* demb = side == 0 ? demb_c : demb_w;
+  __shared__ float s1[CZ], s2[CZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const float g = g_loss[0];
+  // ---- hinge gradient + centring backward (per column) ----
+  if (tid < CZ) {
+    const float sd = st[3 * CZ + tid];
+    // d hinge / d var_k = -(1/2) * (1/Z) * [sd < 1] / (2 sd);  d var_k / d z_bk = 2 z_bk / (B - 1)
+    const float dv = (sd < 1.0f) ? -0.5f / (float)CZ / (2.0f * sd) : 0.0f;
+    const float coef = dv * 2.0f / (float)(B - 1);
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+      const float v = dz[(size_t)b * CZ + tid] + coef * Zc[(size_t)b * CZ + tid];
+      dz[(size_t)b * CZ + tid] = v;
+      s += v;
+    }
+    const float m = s / (float)B;
+    for (int b = 0; b < B; ++b) dz[(size_t)b * CZ + tid] -= m;
+  }
+  __syncthreads();
+  // ---- da1 = dz0 W2 ----
+  const int row_tiles = (B + 31) / 32;
+  for (int tl = wave; tl < row_tiles * 4; tl += C_WAVES) {
+    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
+    f32x16 acc = zero16();
+    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? dz[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
+           [&](int k, int cc) { return W2[(size_t)k * CZ + j0 + cc]; }, lane);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = i0 + tile_row(t, hf);
+      if (i < B) wk[(size_t)i * CZ + j0 + r] = acc[t];
+    }
+  }
+  __syncthreads();
+  // ---- ReLU backward, BatchNorm backward on batch statistics ----
+  if (tid < CZ) {
+    const float gm = gamma[tid];
+    float a = 0.0f, c = 0.0f;
+    for (int b = 0; b < B; ++b) {
+      const size_t idx = (size_t)b * CZ + tid;
+      const float dxh = (A1[idx] > 0.0f) ? wk[idx] * gm : 0.0f;
+      wk[idx] = dxh;
+      a += dxh;
+      c += dxh * XH[idx];
+    }
+    s1[tid] = a; s2[tid] = c;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
+    const int k = idx % CZ;
+    wk[idx] = st[CZ + k] / (float)B * ((float)B * wk[idx] - s1[k] - XH[idx] * s2[k]);     // dy1
+  }
+  __syncthreads();
+  // ---- d emb = dy1 W1, scaled by the upstream gradient ----
+  const int col_tiles = (E + 31) / 32;
+  for (int tl = wave; tl < row_tiles * col_tiles; tl += C_WAVES) {
+    const int i0 = (tl / col_tiles) * 32, j0 = (tl % col_tiles) * 32;
+    f32x16 acc = zero16();
+    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? wk[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
+           [&](int k, int cc) { return (j0 + cc < E) ? W1[(size_t)k * E + j0 + cc] : 0.0f; }, lane);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = i0 + tile_row(t, hf), j = j0 + r;
+      if (i < B && j < E) demb[(size_t)i * ld_d + j] = acc[t] * g;
+    }
+  }
+}
+
+}  // namespace is
+
+// floats of `scratch` (kept from forward to backward): two sides + PAIR [B][B] + CORR [Z][Z] + hinge[2] + partials
+extern "C" long long is_contrastive_scratch_floats(int B) {
+  const long long rt = (B + 31) / 32;
+  return 2 * is::side_floats(B) + (long long)B * B + is::CZ * is::CZ + 2 + (rt * rt + 16 + 3) / 4 * 4;
+}
+// floats of the backward work buffer (DZ [2][B][Z] + work [2][B][Z])
+extern "C" long long is_contrastive_work_floats(int B) { return 4LL * B * is::CZ; }
+
+// emb_c, emb_w [B, ld_e] (E valid columns), pos [B] (1.0 = immunogenic), W1 [128, E], gamma, beta [128], W2 [128, 128];
+// loss [1].  2 <= B <= 256, E <= 256.
+extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld_e, int E, const float* pos, const float* W1,
+                                  const float* gamma, const float* beta, const float* W2, float lambda, float* scratch,
+                                  float* loss, int B, void* stream) {
+  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_e < E) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long sides = 2 * is::side_floats(B);
+  float* PAIR = scratch + sides;
+  float* CORR = PAIR + (long long)B * B;
+  float* hinge = CORR + is::CZ * is::CZ;
+  float* partials = hinge + 2;
+  const int rt = (B + 31) / 32, ntiles = rt * rt + 16, nblocks = (ntiles + 3) / 4;
+  hipLaunchKernelGGL(is::contr_side_fwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, emb_c, emb_w, ld_e, E, W1, gamma, beta, W2,
+                     scratch, hinge, B);
+  hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
+  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, hinge, loss);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// g_loss [1] = upstream gradient of the scalar loss; demb_c, demb_w [B, ld_d] (E columns written).
+extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, const float* W2, float lambda,
+                                  const float* scratch, float* work, const float* g_loss, float* demb_c, float* demb_w,
+                                  int ld_d, int E, int B, void* stream) {
+  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_d < E) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long sides = 2 * is::side_floats(B);
+  const float* PAIR = scratch + sides;
+  const float* CORR = PAIR + (long long)B * B;
+  float* DZ = work;
+  float* wk = work + 2LL * B * is::CZ;
+  const int rt = (B + 31) / 32, ntiles = 2 * rt * 4;
+  hipLaunchKernelGGL(is::contr_pair_bwd_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, DZ, B);
+  hipLaunchKernelGGL(is::contr_side_bwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, W1, gamma, W2, scratch, DZ, wk, g_loss,
+                     demb_c, demb_w, ld_d, E, B);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -756,6 +756,52 @@ def sequential_mlp2(seq, x):
     return mlp2(x, l1.weight, l1.bias, l2.weight, l2.bias, mask=mask, act1=1, act2=1 if len(mods) == 5 else 0)
 
 
+class PairedContrastiveFn(torch.autograd.Function):
+    """``PairedContrastiveLoss`` value and embedding gradients on ``csrc/contrastive.hip`` (5 launches).  The projector
+    (w1, gamma, beta, w2) is frozen in the reference (never handed to the optimizer): no parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
+        lib = _lib.load()
+        _lib.require_device(emb_c, emb_w, pos, w1, gamma, beta, w2)
+        if emb_c.shape != emb_w.shape or emb_c.dim() != 2:
+            raise AssertionError("cancer / wild-type embeddings must have equal (batch, features) shapes")
+        b, e = int(emb_c.shape[0]), int(emb_c.shape[1])
+        if not (2 <= b <= 256) or e > 256 or tuple(w1.shape) != (128, e) or tuple(w2.shape) != (128, 128):
+            raise NotImplementedError("contrastive kernel: 2 <= batch <= 256, embedding <= 256, projector width 128")
+        emb_c, emb_w, pos, w1, gamma, beta, w2 = (_lib.f32c(t) for t in (emb_c, emb_w, pos, w1, gamma, beta, w2))
+        dev = emb_c.device
+        scratch = torch.empty(lib.is_contrastive_scratch_floats(b), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with KernelTimer.span("contrastive_fwd"):
+            _lib.check(lib.is_contrastive_fwd(_lib.ptr(emb_c), _lib.ptr(emb_w), e, e, _lib.ptr(pos), _lib.ptr(w1), _lib.ptr(gamma),
+                                              _lib.ptr(beta), _lib.ptr(w2), float(lam), _lib.ptr(scratch), _lib.ptr(loss), b,
+                                              _lib.stream_ptr()), "is_contrastive_fwd")
+        ctx.cfg = (b, e, float(lam))
+        ctx.save_for_backward(pos, w1, gamma, w2, scratch)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pos, w1, gamma, w2, scratch = ctx.saved_tensors
+        b, e, lam = ctx.cfg
+        dev = scratch.device
+        work = torch.empty(lib.is_contrastive_work_floats(b), dtype=torch.float32, device=dev)
+        dc = torch.empty(b, e, dtype=torch.float32, device=dev)
+        dw = torch.empty(b, e, dtype=torch.float32, device=dev)
+        gl = _lib.f32c(g.reshape(1))
+        with KernelTimer.span("contrastive_bwd"):
+            _lib.check(lib.is_contrastive_bwd(_lib.ptr(pos), _lib.ptr(w1), _lib.ptr(gamma), _lib.ptr(w2), lam, _lib.ptr(scratch),
+                                              _lib.ptr(work), _lib.ptr(gl), _lib.ptr(dc), _lib.ptr(dw), e, e, b, _lib.stream_ptr()),
+                       "is_contrastive_bwd")
+        return dc, dw, None, None, None, None, None, None
+
+
+def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
+    return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam)
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """Per-segment mean and/or max over rows (``csrc/segment_ops.hip``).
 

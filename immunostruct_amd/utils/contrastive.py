@@ -18,7 +18,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 __all__ = ["PairedContrastiveLoss"]
+
+USE_HIP_KERNEL = os.environ.get("IMMUNOSTRUCT_CONTRASTIVE_KERNEL", "1") != "0"
 
 
 def _weighted_sq(m, ideal_diag, off_weight):
@@ -50,6 +54,15 @@ class PairedContrastiveLoss(nn.Module):
         pos = (is_immunogenic > is_immunogenic.mean()).to(embedding_cancer.dtype)
         if embedding_cancer.shape != embedding_wt.shape:
             raise AssertionError("cancer / wild-type embeddings must have equal shapes")
+        if (embedding_cancer.is_cuda and self.z_dim == 128 and 2 <= embedding_cancer.shape[0] <= 256
+                and embedding_cancer.dim() == 2 and embedding_cancer.shape[1] <= 256 and USE_HIP_KERNEL):
+            # fused HIP path (csrc/contrastive.hip): the projector is frozen in the reference, so only the embedding
+            # gradients are produced; BatchNorm running statistics are not maintained (never read: train mode only)
+            from .. import functional as HF
+            bn = self.projector[1]
+            return HF.paired_contrastive(embedding_cancer, embedding_wt, pos, self.projector[0].weight.detach(),
+                                         bn.weight.detach(), bn.bias.detach(), self.projector[3].weight.detach(),
+                                         self.lambda_off_diag)
         zc = self.projector(embedding_cancer)
         zw = self.projector(embedding_wt)
         b = zc.shape[0]

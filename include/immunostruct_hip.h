@@ -186,6 +186,22 @@ int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
                           float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
 
+/* Paired cancer / wild-type contrastive loss (utils/contrastive.py:18-83), forward and backward.
+ * emb_c, emb_w [B, ld_e] (E valid columns; E = 104), pos [B] (1.0 where the pair is immunogenic), projector
+ * W1 [128, E] (Linear, no bias), gamma / beta [128] (BatchNorm1d on batch statistics), W2 [128, 128]; lambda = weight of
+ * the off-diagonal terms.  loss [1].  scratch (is_contrastive_scratch_floats(B) floats) is kept for the backward,
+ * which needs a work buffer of is_contrastive_work_floats(B) floats and the upstream gradient g_loss [1] on the device,
+ * and writes d loss / d emb_c, d loss / d emb_w [B, ld_d] (the projector is frozen: no parameter gradients).
+ * 2 <= B <= 256, E <= 256.                                                                                     */
+long long is_contrastive_scratch_floats(int B);
+long long is_contrastive_work_floats(int B);
+int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld_e, int E, const float* pos, const float* W1,
+                       const float* gamma, const float* beta, const float* W2, float lambda, float* scratch,
+                       float* loss, int B, void* stream);
+int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, const float* W2, float lambda,
+                       const float* scratch, float* work, const float* g_loss, float* demb_c, float* demb_w,
+                       int ld_d, int E, int B, void* stream);
+
 /* Two-layer per-sample MLP for the small dense heads (classifier Linear(F,32)-ReLU-Dropout-Linear(32,1),
  * models/hybrid_models.py:288-295; property embedding :280-286; the pooled attention's W_v / w_concat tail,
  * models/layers.py:74-77):

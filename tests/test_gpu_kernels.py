@@ -424,3 +424,30 @@ def test_mlp2_matches_torch(cuda_device, cfg):
     H.assert_close(yh.detach().cpu(), yr.detach(), 2e-6, "mlp2 y")
     for name, a, r in zip(("dx", "dW1", "db1", "dW2", "db2"), leaves_h, leaves_r):
         H.assert_close(a.grad.cpu(), r.grad, 5e-6, f"mlp2 {name}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,e", [(16, 104), (37, 104), (128, 104), (200, 208)])
+def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
+    """csrc/contrastive.hip (value + both embedding gradients) vs oracle/functional_ref.paired_contrastive_loss in fp64,
+    ragged and multi-tile batch sizes; north-star tolerance 1e-4 relative on the loss."""
+    from immunostruct_amd.utils import PairedContrastiveLoss
+    g = torch.Generator().manual_seed(100 + b)
+    pcl = PairedContrastiveLoss(embedding_dim=e, device=cuda_device)
+    sd = H.det_sd({k: tuple(v.shape) for k, v in pcl.state_dict().items()}, seed=b)
+    pcl.load_state_dict(sd)
+    ec, ew = torch.randn(b, e, generator=g), torch.randn(b, e, generator=g)
+    y = (torch.rand(b, generator=g) < 0.3).float()
+    y[0], y[1] = 0.0, 1.0
+    gup = 1.7
+    # fp64 oracle
+    sd64 = {k: v.double() for k, v in sd.items() if v.is_floating_point()}
+    ec64, ew64 = ec.double().requires_grad_(True), ew.double().requires_grad_(True)
+    ref = FR.paired_contrastive_loss(sd64, ec64, ew64, y.double())
+    (ref * gup).backward()
+    ecd, ewd = ec.to(cuda_device).requires_grad_(True), ew.to(cuda_device).requires_grad_(True)
+    val = pcl(ecd, ewd, y.to(cuda_device))
+    (val * gup).backward()
+    assert abs(float(val) - float(ref)) <= 1e-4 * abs(float(ref)), (float(val), float(ref))
+    H.assert_close(ecd.grad.cpu(), ec64.grad, 1e-4, "d emb cancer")
+    H.assert_close(ewd.grad.cpu(), ew64.grad, 1e-4, "d emb wt")
