@@ -53,6 +53,7 @@ SIGNATURES = {
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
+    "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P],
     "is_adam_step": [_P, _I, _P, _P, _P],
     "is_contrastive_scratch_floats": [_I],
     "is_contrastive_work_floats": [_I],

@@ -175,3 +175,74 @@ extern "C" int is_multi_copy(const void* jobs, int njobs, void* stream) {
   hipLaunchKernelGGL(is::multi_copy_kernel, dim3(blocks, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------
+// On-device batcher: assemble the block-diagonal batch of B graphs (reference data/utils.py:160-176, dgl.batch in
+// `collate`) from a device-resident dataset of per-graph CSR pieces -- no host work, no sort: every graph's edges are
+// already in destination order, so the batch's CSR is the concatenation of the pieces with node / edge offsets added.
+// Workgroup i assembles graph slot i (graph id idx[i]); its edge offset is the sum of the edge counts of slots < i.
+namespace is {
+struct BatchSrc {     // dataset, all graphs padded to n nodes
+  const float* x;               // [G][n][F]
+  const int* eoff;              // [G + 1]  edge offset of every graph in the concatenated edge arrays
+  const int* rowptr_dst;        // [G][n + 1]  local (0-based per graph)
+  const int* rowptr_src;        // [G][n + 1]
+  const int* src;               // [Etot]  local node ids, destination order
+  const int* dst;               // [Etot]
+  const int* pos;               // [Etot]  local slot ids, source order
+  const float* ea;              // [Etot][Fe]
+};
+struct BatchDst {
+  float* x; int* rowptr_dst; int* rowptr_src; int* src; int* dst; int* pos; float* ea;
+};
+
+__global__ __launch_bounds__(256) void batch_gather_kernel(const long long* __restrict__ idx, int B, int n, int F, int Fe,
+                                                           BatchSrc S, BatchDst D) {
+  __shared__ int red[256];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  int part = 0;
+  for (int j = tid; j < i; j += 256) {
+    const long long gj = idx[j];
+    part += S.eoff[gj + 1] - S.eoff[gj];
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const int off = red[0];
+  const long long g = idx[i];
+  const int e0 = S.eoff[g], cnt = S.eoff[g + 1] - e0, v0 = i * n;
+  for (int k = tid; k < n * F; k += 256) D.x[(size_t)v0 * F + k] = S.x[(size_t)g * n * F + k];
+  for (int v = tid; v < n; v += 256) {
+    D.rowptr_dst[v0 + v] = S.rowptr_dst[(size_t)g * (n + 1) + v] + off;
+    D.rowptr_src[v0 + v] = S.rowptr_src[(size_t)g * (n + 1) + v] + off;
+  }
+  if (i == B - 1 && tid == 0) {
+    D.rowptr_dst[v0 + n] = off + cnt;
+    D.rowptr_src[v0 + n] = off + cnt;
+  }
+  for (int e = tid; e < cnt; e += 256) {
+    D.src[off + e] = S.src[e0 + e] + v0;
+    D.dst[off + e] = S.dst[e0 + e] + v0;
+    D.pos[off + e] = S.pos[e0 + e] + off;
+  }
+  for (int k = tid; k < cnt * Fe; k += 256) D.ea[(size_t)off * Fe + k] = S.ea[(size_t)e0 * Fe + k];
+}
+}  // namespace is
+
+// idx [B] int64 (device): graph ids.  Dataset arrays as documented in is::BatchSrc; destination arrays of a batch with
+// B * n nodes and room for the selected graphs' edges (caller guarantees the capacity: B * max edges per graph).
+extern "C" int is_batch_gather(const long long* idx, int B, int n, int F, int Fe, const float* x_all, const int32_t* eoff,
+                               const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all, const int32_t* src_all,
+                               const int32_t* dst_all, const int32_t* pos_all, const float* ea_all, float* x,
+                               int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* src_sorted, int32_t* dst_sorted,
+                               int32_t* pos_by_src, float* ea, void* stream) {
+  if (B <= 0) return 0;
+  if (n <= 0 || F <= 0 || Fe < 0) return -22;
+  is::BatchSrc S{x_all, eoff, rowptr_dst_all, rowptr_src_all, src_all, dst_all, pos_all, ea_all};
+  is::BatchDst D{x, rowptr_dst, rowptr_src, src_sorted, dst_sorted, pos_by_src, ea};
+  hipLaunchKernelGGL(is::batch_gather_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), idx, B, n, F, Fe, S, D);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

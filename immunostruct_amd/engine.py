@@ -81,6 +81,16 @@ class StaticGraphBatch(PackedGraphBatch):
     def load(self, g: PackedGraphBatch):
         multi_copy(self.copy_pairs(g))
 
+    def refresh_partitions(self):
+        """Recompute the edge kernels' work partitions from the rowptr currently in the buffers (after the on-device
+        batcher wrote a new batch): vectorised torch ops on the device, no host sync, capturable."""
+        from .graph import balanced_node_chunks, greedy_node_tiles
+        for k, dst in self._csr._chunks.items():
+            dst.copy_(balanced_node_chunks(self._csr.rowptr_dst, k))
+        for key, dst in self._csr._tiles.items():
+            t = greedy_node_tiles(self._csr.rowptr_dst, self.edge_capacity, *key)
+            dst[:t.numel()].copy_(t)
+
 
 def multi_copy(pairs):
     """All (source, destination) copies of one batch hand-over as ONE kernel launch
@@ -106,6 +116,36 @@ def multi_copy(pairs):
         _lib.check(lib.is_multi_copy(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _lib.stream_ptr()), "is_multi_copy")
 
 
+def _optimizer_tensors(optimizer):
+    out = []
+    for p, st in optimizer.state.items():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                out.append((id(p), k, v))
+    for gs in getattr(optimizer, "_groups", {}).values():      # immunostruct_amd.optim: device-side step counter
+        out.append((id(gs), "state", gs["state"]))
+    return out
+
+
+def _snapshot(model, optimizer):
+    return ({k: v.detach().clone() for k, v in model.state_dict().items()},
+            {(a, k): v.detach().clone() for a, k, v in _optimizer_tensors(optimizer)})
+
+
+def _restore(model, optimizer, snap):
+    """in place (the captured graph and the optimizer's chunk table hold these addresses): values from before the
+    warm-up; optimizer tensors that the warm-up created (fresh optimizer) go back to zero"""
+    msnap, osnap = snap
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(msnap[k])
+        for a, k, v in _optimizer_tensors(optimizer):
+            if (a, k) in osnap:
+                v.copy_(osnap[(a, k)])
+            else:
+                v.zero_()
+
+
 class CapturedTrainStep:
     """``step(graph, seq, prop, y) -> loss`` replaying captured HIP graphs.
 
@@ -114,7 +154,7 @@ class CapturedTrainStep:
     eager train steps on the template batch (they update the model like any other step), then captures.
     """
 
-    def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3):
+    def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3, preserve_state=False):
         if warmup < 1:
             raise ValueError("warmup must be >= 1: optimizer state and BLAS handles have to be created by an eager "
                              "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
@@ -130,6 +170,7 @@ class CapturedTrainStep:
         fe = int(g.edata["edge_attr"].shape[1])
         for din in (20, HF.HIDDEN):
             HF.layer_plan(din, fe, g.device)
+        snap = _snapshot(model, optimizer) if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -137,6 +178,8 @@ class CapturedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            _restore(model, optimizer, snap)      # the warm-up steps leave no trace: training starts from the caller's state
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
@@ -173,9 +216,14 @@ class CapturedTrainStep:
         return loss
 
     def __call__(self, g, seq, prop, y):
+        self._load(g, seq, prop, y)
+        return self.replay()
+
+    def replay(self):
+        """Run the captured step on whatever the static buffers (``sgraph``, ``seq``, ``prop``, ``y``) hold -- the
+        on-device batcher (``data.DeviceResidentDataset.gather_into``) writes them directly."""
         if hasattr(self.optimizer, "refresh"):
             self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
-        self._load(g, seq, prop, y)
         self.graph_a.replay()
         if self.graph_b is not None:
             self.reducer.all_reduce_mean()

@@ -20,7 +20,7 @@ try:  # optional, exactly as inert as a disabled wandb run when missing
 except Exception:  # pragma: no cover
     wandb = None
 
-__all__ = ["train_model", "train_model_comparative"]
+__all__ = ["train_model", "train_model_comparative", "train_model_device"]
 
 
 def _to(device, obj):
@@ -99,3 +99,84 @@ def train_model_comparative(config, device, model, train_loader, val_loader, opt
     contrastive = PairedContrastiveLoss(device=device, embedding_dim=104) if coeff > 0 else None
     return _fit(config, model, train_loader, val_loader, optimizer, scheduler, stage,
                 lambda batch: _paired_loss(model, loss_function, batch, device, contrastive, coeff))
+
+
+def train_model_device(config, device, model, dataset, train_index, val_index, optimizer, loss_function, scheduler=None,
+                       stage="pretrain", seed=0):
+    """``train_model`` on a :class:`~immunostruct_amd.data.DeviceResidentDataset`: same epoch
+    loop, loss, best-validation checkpoint and printed / returned values as :func:`train_model` with a shuffling
+    ``DataLoader(batch_size=config.batch_size)``, but batches are assembled on the GPU from graph ids
+    (``dataset.gather_into``) and every full batch runs as one replay of the captured HIP graph
+    (``engine.CapturedTrainStep``); a trailing partial batch is run eagerly.  ``train_index`` / ``val_index``: graph
+    ids (any integer sequence)."""
+    from ..distributed import FlatGradReducer
+    from ..engine import CapturedTrainStep
+    device = dataset.device
+    bsz = int(config.batch_size)
+    train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
+    val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
+    gen = torch.Generator(device="cpu").manual_seed(int(seed))
+
+    def forward_loss(m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return loss_function(recon, seq, mu, logvar, final, y)
+
+    captured = None
+    if train_index.numel() >= bsz:
+        buf = dataset.new_batch(bsz)
+        dataset.gather_into(train_index[:bsz], *buf)
+        model.train()
+        reducer = FlatGradReducer(model.parameters(), world=1)
+        # the engine's construction runs one eager warm-up step on this batch and then restores model + optimizer
+        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=bsz * dataset.max_edges,
+                                     warmup=1, preserve_state=True)
+    tails = {}
+
+    def eager_batch(idx):
+        b = int(idx.numel())
+        if b not in tails:
+            tails[b] = dataset.new_batch(b)
+        return dataset.gather_into(idx, *tails[b])
+
+    train_losses, val_losses = [], []
+    best = float("inf")
+    for epoch in range(config.num_epochs):
+        model.train()
+        perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
+        running, steps = None, 0
+        for at in range(0, perm.numel(), bsz):
+            idx = perm[at:at + bsz]
+            if idx.numel() == bsz and captured is not None:
+                dataset.gather_into(idx, captured.sgraph, captured.seq, captured.prop, captured.y)
+                loss = captured.replay().clone()
+            else:
+                g, seq, prop, y = eager_batch(idx)
+                optimizer.zero_grad(set_to_none=True)
+                loss = forward_loss(model, g, seq, prop, y)
+                loss.backward()
+                optimizer.step()
+                loss = loss.detach()
+            running = loss if running is None else running + loss
+            steps += 1
+        train_loss = float(running) / max(steps, 1)
+        train_losses.append(train_loss)
+        if scheduler is not None:
+            scheduler.step()
+        model.eval()
+        running, vsteps = None, 0
+        with torch.no_grad():
+            for at in range(0, val_index.numel(), bsz):
+                g, seq, prop, y = eager_batch(val_index[at:at + bsz])
+                loss = forward_loss(model, g, seq, prop, y).detach()
+                running = loss if running is None else running + loss
+                vsteps += 1
+        val_total = float(running) if running is not None else 0.0
+        if val_total < best:
+            _save_best(config, model, stage)
+            best = val_total
+        val_loss = val_total / max(vsteps, 1)
+        val_losses.append(val_loss)
+        if wandb is not None and getattr(wandb, "run", None) is not None:
+            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
+        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
+    return train_losses, val_losses

@@ -237,6 +237,18 @@ int is_debug_timestamp(long long* slot, void* stream);
  * bytes a multiple of 4.                                                                                   */
 int is_multi_copy(const void* jobs, int njobs, void* stream);
 
+/* On-device batcher (reference data/utils.py:160-176: `collate` -> dgl.batch): assemble the block-diagonal batch of the
+ * B graphs idx[0..B) (int64, device) from a device-resident dataset of per-graph CSR pieces, all graphs padded to n
+ * nodes: x_all [G][n][F]; eoff [G+1] edge offsets; rowptr_dst_all / rowptr_src_all [G][n+1] (0-based per graph);
+ * src_all / dst_all [Etot] local node ids in destination order; pos_all [Etot] local slot ids in source order;
+ * ea_all [Etot][Fe].  Writes the batch arrays (node ids + slot*n, edge slots + running edge offset); the destination
+ * edge arrays must hold the selected graphs' edges (B * max edges per graph is always enough).                   */
+int is_batch_gather(const long long* idx, int B, int n, int F, int Fe, const float* x_all, const int32_t* eoff,
+                    const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all, const int32_t* src_all,
+                    const int32_t* dst_all, const int32_t* pos_all, const float* ea_all, float* x,
+                    int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* src_sorted, int32_t* dst_sorted,
+                    int32_t* pos_by_src, float* ea, void* stream);
+
 /* Per-segment mean and/or max over rows seg_ptr[s] .. seg_ptr[s+1] of x [rows, ld_x] (C channels).
  * out_mean / out_max [num_segments, C] may each be NULL.  Empty segment: mean 0, max 0.            */
 int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_ptr, float* out_mean, float* out_max,

@@ -210,5 +210,61 @@ def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "48",
               "--model-save-dir", str(tmp_path)]
     train_IEDB_wFT.main(["--model", "HybridModelv2"] + common)
+    train_IEDB_wFT.main(["--model", "HybridModelv2", "--device-dataset", "--seed", "3"] + common)      # on-GPU batcher + captured step
     train_Cancer_wFT.main(["--use-wt-for-downstream", "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common)
-    assert len(list(tmp_path.glob("*_finetune.pt"))) == 2
+    assert len(list(tmp_path.glob("*_finetune.pt"))) == 3
+
+
+def test_device_batcher_matches_collate(cuda_device):
+    """data.DeviceResidentDataset.gather_into (one HIP launch from graph ids) builds exactly the batch that the reference
+    pipeline builds on the host: collate -> graph.batch -> CSR index construction (data/utils.py:160-176)."""
+    from immunostruct_amd.data import DeviceResidentDataset, SyntheticImmunoDataset, collate
+    ds = SyntheticImmunoDataset(14, seed=3, deg_extra=3)
+    dds = DeviceResidentDataset(ds, cuda_device)
+    buf = dds.new_batch(5)
+    for ids in ([5, 2, 9, 0, 13], [1, 1, 7, 3, 12]):        # a second load overwrites the first (fewer / more edges)
+        idx = torch.tensor(ids, dtype=torch.int64, device=cuda_device)
+        sg, seq, prop, y = dds.gather_into(idx, *buf)
+        g_ref, seq_ref, y_ref, prop_ref = collate([ds[i] for i in ids])
+        c_ref, c = g_ref.csr(), sg.csr()
+        e = g_ref.num_edges()
+        assert torch.equal(sg.ndata["x"].cpu(), g_ref.ndata["x"])
+        assert torch.equal(c.rowptr_dst.cpu(), c_ref.rowptr_dst) and torch.equal(c.rowptr_src.cpu(), c_ref.rowptr_src)
+        assert torch.equal(c.src_sorted[:e].cpu(), c_ref.src_sorted) and torch.equal(c.dst_sorted[:e].cpu(), c_ref.dst_sorted)
+        assert torch.equal(c.pos_by_src[:e].cpu(), c_ref.pos_by_src)
+        assert torch.equal(sg.edge_feat_csr(None)[:e].cpu(), g_ref.edge_feat_csr(g_ref.edata["edge_attr"]))
+        assert torch.equal(seq.cpu(), seq_ref) and torch.equal(prop.cpu(), prop_ref) and torch.equal(y.cpu(), y_ref.float())
+        # the work partitions follow the new rowptr
+        for k in (8, 64):
+            assert torch.equal(c.chunks(k).cpu(), c_ref.chunks(k))
+        sg.refresh_partitions()
+        assert torch.equal(c.chunks(8).cpu(), c_ref.chunks(8))
+        tc = c.tiles(64, 24).cpu()
+        tr = c_ref.tiles(64, 24)
+        cnt = int(tr[0])
+        assert int(tc[0]) == cnt and torch.equal(tc[1:cnt + 2], tr[1:cnt + 2])
+
+
+def test_train_model_device_runs_and_preserves_the_start_state(cuda_device, tmp_path):
+    """procedures.train_model_device: device-resident dataset + on-GPU batcher + captured step.  With zero epochs the
+    engine's warm-up must leave model and optimizer untouched; with two epochs it trains (finite, improving loss)."""
+    from types import SimpleNamespace
+    from immunostruct_amd import optim
+    from immunostruct_amd.data import DeviceResidentDataset, SyntheticImmunoDataset
+    from immunostruct_amd.procedures import train_model_device
+    dev = cuda_device
+    ds = SyntheticImmunoDataset(44, seed=5)
+    dds = DeviceResidentDataset(ds, dev)
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+    torch.manual_seed(0)
+    model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = SimpleNamespace(batch_size=8, num_epochs=0, model_save_path_pretrain=str(tmp_path / "m.pt"), model_save_path_finetune=str(tmp_path / "f.pt"))
+    train_model_device(cfg, dev, model, dds, range(36), range(36, 44), opt, losses.regression_loss)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    cfg.num_epochs = 3
+    tl, vl = train_model_device(cfg, dev, model, dds, range(36), range(36, 44), opt, losses.regression_loss)
+    assert len(tl) == 3 and all(np.isfinite(tl)) and all(np.isfinite(vl)) and tl[-1] < tl[0]
+    assert (tmp_path / "m.pt").exists()
