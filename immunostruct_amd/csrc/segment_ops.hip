@@ -16,33 +16,45 @@
 
 namespace is {
 
+// 16 lanes per node (one float4 = 4 channels per lane, a 256-byte row per 16-lane group), 16 nodes per workgroup:
+// a quarter of the waves of a wave-per-node mapping, so the whole batch is resident at once and the three dependent
+// latencies (rowptr -> slot ids -> rows) are paid once instead of once per round.  Per-node summation order unchanged.
 __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
     const float* __restrict__ rows, const float* __restrict__ vec3,
     const int* __restrict__ ptr, const int* __restrict__ pos,
     float* __restrict__ out_rows, int ld_out, float* __restrict__ out_vec3, int N) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sub = threadIdx.x & 15;
+  const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (v >= N) return;
   const int lo = ptr[v], hi = ptr[v + 1];
-  float acc = 0.0f, acc3 = 0.0f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float acc3 = 0.0f;
+  const bool has3 = vec3 != nullptr && sub < 3;
   int p = lo;
   for (; p + 4 <= hi; p += 4) {
     const int e0 = pos[p], e1 = pos[p + 1], e2 = pos[p + 2], e3 = pos[p + 3];
-    const float a0 = rows[(size_t)e0 * H + lane], a1 = rows[(size_t)e1 * H + lane];
-    const float a2 = rows[(size_t)e2 * H + lane], a3 = rows[(size_t)e3 * H + lane];
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(rows + (size_t)e0 * H + sub * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(rows + (size_t)e1 * H + sub * 4);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(rows + (size_t)e2 * H + sub * 4);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(rows + (size_t)e3 * H + sub * 4);
     acc += a0; acc += a1; acc += a2; acc += a3;
-    if (vec3 != nullptr && lane < 3) {
-      acc3 += vec3[(size_t)e0 * 3 + lane]; acc3 += vec3[(size_t)e1 * 3 + lane];
-      acc3 += vec3[(size_t)e2 * 3 + lane]; acc3 += vec3[(size_t)e3 * 3 + lane];
+    if (has3) {
+      acc3 += vec3[(size_t)e0 * 3 + sub]; acc3 += vec3[(size_t)e1 * 3 + sub];
+      acc3 += vec3[(size_t)e2 * 3 + sub]; acc3 += vec3[(size_t)e3 * 3 + sub];
     }
   }
   for (; p < hi; ++p) {
     const int e0 = pos[p];
-    acc += rows[(size_t)e0 * H + lane];
-    if (vec3 != nullptr && lane < 3) acc3 += vec3[(size_t)e0 * 3 + lane];
+    acc += *reinterpret_cast<const f32x4*>(rows + (size_t)e0 * H + sub * 4);
+    if (has3) acc3 += vec3[(size_t)e0 * 3 + sub];
   }
-  out_rows[(size_t)v * ld_out + lane] = acc;
-  if (vec3 != nullptr && lane < 3) out_vec3[v * 3 + lane] += acc3;
+  float* o = out_rows + (size_t)v * ld_out + sub * 4;
+  if ((ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out_rows) & 15) == 0) {
+    *reinterpret_cast<f32x4*>(o) = acc;
+  } else {
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+  }
+  if (has3) out_vec3[v * 3 + sub] += acc3;
 }
 
 // one workgroup per (segment, 64-channel slab)
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
 extern "C" int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
                                      float* out_rows, int ld_out, float* out_vec3, int N, void* stream) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(is::gather_segment_sum_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(is::gather_segment_sum_kernel, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
                      rows, vec3, ptr, pos, out_rows, ld_out, out_vec3, N);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
