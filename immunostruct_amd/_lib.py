@@ -35,6 +35,8 @@ SIGNATURES = {
     "is_egnn_edge_fwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
     "is_egnn_edge_fwd_v3": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
                             _I, _P],
+    "is_egnn_edge_fwd_v3x": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
+                             _I, _P],
     "is_egnn_edge_bwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P,
                             _I, _I, _I, _P],
     "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P],

@@ -35,10 +35,49 @@ __device__ long long g_stamps3[64];
 #define STAMP3(k) do { } while (0)
 #endif
 
-template <int FE_MAX>
+// ---- optional split-bf16 matrix path (X3) -----------------------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): x*y ~ hi*hi' + hi*lo' + lo*hi' (three v_mfma_f32_16x16x32_bf16 with
+// fp32 accumulation; the dropped lo*lo' term is 2^-16 relative).  One 16x16x32 bf16 MFMA replaces eight 16x16x4 fp32
+// MFMAs at 1/16 of their cycles, so a 64x64 layer costs 24 x 16 instead of 64 x 32 SIMD cycles.  Opt-in
+// (IMMUNOSTRUCT_EDGE_FWD=v3x): NOT bit-identical to the fp32 kernels, measured error in tests/test_gpu_kernels.py.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDB = H + 8;      // bf16 row stride of the split weight tiles (144 bytes: 16-byte aligned rows)
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (__bf16)a[i]; lo[i] = (__bf16)(a[i] - (float)hi[i]);
+    hi[4 + i] = (__bf16)b[i]; lo[4 + i] = (__bf16)(b[i] - (float)hi[4 + i]);
+  }
+}
+
+// acc[nt] (16 x 16) += A[16 x 64] * W[nt*16 .., 64]^T with A fp32 in LDS (row stride LD), W split bf16 in LDS
+__device__ __forceinline__ void mm16_rows_x3(f32x4 (&acc)[4], const float* a_lds, const __bf16* w_hi, const __bf16* w_lo, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* ap = a_lds + r * LD + c * 32 + q * 8;
+    bf16x8 ah, al;
+    split8(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), ah, al);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int off = (nt * 16 + r) * LDB + c * 32 + q * 8;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+template <bool X3> struct Fwd3Weights;
+template <> struct Fwd3Weights<false> { float w2[H * LD]; float wc1[H * LD]; };
+template <> struct Fwd3Weights<true> { __bf16 w2h[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1l[H * LDB]; };
+
+template <int FE_MAX, bool X3 = false>
 struct Fwd3Smem {
-  float w2[H * LD];
-  float wc1[H * LD];
+  Fwd3Weights<X3> w;
   float act[W3][TE16 * LD];
   float e_rad[W3][TE16];
   float e_xd[W3][3][TE16];
@@ -102,7 +141,7 @@ __device__ __forceinline__ void load_fwd_rows(FwdRows& rw, const EdgeIds<FE_MAX>
   }
 }
 
-template <int FE_MAX, bool SAVE>
+template <int FE_MAX, bool SAVE, bool X3 = false>
 __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
@@ -113,7 +152,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     const float* __restrict__ Wc1, const float* __restrict__ bc1, const float* __restrict__ wc2,
     float* __restrict__ h_neigh, int ld_hn, float* __restrict__ x_out,
     float* __restrict__ z2s, float* __restrict__ z3s, int E, int Fe) {
-  __shared__ Fwd3Smem<FE_MAX> sm;
+  __shared__ Fwd3Smem<FE_MAX, X3> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   STAMP3(0);
@@ -153,8 +192,20 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int idx = tid + (j & 3) * 256;
-      float* dst = (j < 4) ? sm.w2 : sm.wc1;
-      *reinterpret_cast<f32x4*>(dst + (idx / (H / 4)) * LD + (idx % (H / 4)) * 4) = wreg[j];
+      const int row = idx / (H / 4), c4 = (idx % (H / 4)) * 4;
+      if constexpr (X3) {
+        __bf16* dh = (j < 4) ? sm.w.w2h : sm.w.wc1h;
+        __bf16* dl = (j < 4) ? sm.w.w2l : sm.w.wc1l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const __bf16 hv = (__bf16)wreg[j][k];
+          dh[row * LDB + c4 + k] = hv;
+          dl[row * LDB + c4 + k] = (__bf16)(wreg[j][k] - (float)hv);
+        }
+      } else {
+        float* dst = (j < 4) ? sm.w.w2 : sm.w.wc1;
+        *reinterpret_cast<f32x4*>(dst + row * LD + c4) = wreg[j];
+      }
     }
   }
   const float wr_c = W1[lane * ldw + 2 * din];
@@ -238,7 +289,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
-      mm16_rows<4, H>(acc, act, sm.w2, lane);
+      if constexpr (X3) mm16_rows_x3(acc, act, sm.w.w2h, sm.w.w2l, lane);
+      else mm16_rows<4, H>(acc, act, sm.w.w2, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -255,7 +307,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
-      mm16_rows<4, H>(acc, act, sm.wc1, lane);
+      if constexpr (X3) mm16_rows_x3(acc, act, sm.w.wc1h, sm.w.wc1l, lane);
+      else mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float part = 0.0f;
@@ -325,12 +378,12 @@ extern "C" int is_debug_stamps3(long long* out) {
 }
 #endif
 
-extern "C" int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                                   const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                                   const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                                   const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                                   const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                                   float* z3s, int N, int E, int Fe, void* stream) {
+static int edge_fwd_v3_launch(bool x3, const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                              const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                              const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                              const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                              const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                              float* z3s, int N, int E, int Fe, void* stream) {
   if (N <= 0 || nchunks <= 0) return 0;
   if (Fe < 0 || Fe > 8 || (z2s == nullptr) != (z3s == nullptr)) return -22;
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
@@ -340,14 +393,39 @@ extern "C" int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, c
   const dim3 grid((nchunks + is::W3 - 1) / is::W3), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool save = z2s != nullptr;
-#define IS_LAUNCH_FWD3(FE, SV)                                                                                       \
-  hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
+#define IS_LAUNCH_FWD3(FE, SV, XX)                                                                                       \
+  hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV, XX>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe)
-  if (Fe <= 1) {
-    if (save) IS_LAUNCH_FWD3(1, true); else IS_LAUNCH_FWD3(1, false);
+  if (x3) {
+    if (Fe > 1) return -22;
+    if (save) IS_LAUNCH_FWD3(1, true, true); else IS_LAUNCH_FWD3(1, false, true);
+  } else if (Fe <= 1) {
+    if (save) IS_LAUNCH_FWD3(1, true, false); else IS_LAUNCH_FWD3(1, false, false);
   } else {
-    if (save) IS_LAUNCH_FWD3(8, true); else IS_LAUNCH_FWD3(8, false);
+    if (save) IS_LAUNCH_FWD3(8, true, false); else IS_LAUNCH_FWD3(8, false, false);
   }
 #undef IS_LAUNCH_FWD3
   return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                                   const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                                   const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                                   const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                                   const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                                   float* z3s, int N, int E, int Fe, void* stream) {
+  return edge_fwd_v3_launch(false, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
+                            wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
+}
+
+// Same pass with the two 64 x 64 layers on split-bf16 MFMA (three v_mfma_f32_16x16x32_bf16 per product term, fp32
+// accumulation): opt-in, Fe <= 1, not bit-identical to the fp32 kernels (relative error of a product ~2^-16).
+extern "C" int is_egnn_edge_fwd_v3x(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                                    const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                                    const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                                    const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                                    const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                                    float* z3s, int N, int E, int Fe, void* stream) {
+  return edge_fwd_v3_launch(true, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
+                            wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
 }

@@ -277,10 +277,11 @@ class EGNNStackFn(torch.autograd.Function):
             z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # v3 stores full 16-row tiles
             z3s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None
             edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
-            if EDGE_FWD == "v3" and EDGE_KERNELS == "v2":
+            if EDGE_FWD in ("v3", "v3x") and EDGE_KERNELS == "v2":
                 kf = fwd_chunk_count(e)
+                fwd3 = lib.is_egnn_edge_fwd_v3x if (EDGE_FWD == "v3x" and fe <= 1) else lib.is_egnn_edge_fwd_v3
                 with KernelTimer.span("egnn_edge_fwd"):
-                    _lib.check(lib.is_egnn_edge_fwd_v3(
+                    _lib.check(fwd3(
                         _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
                         _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted),
                         _lib.ptr(csr.chunks(kf)), kf, _lib.ptr(W1), ldw, din,

@@ -451,3 +451,24 @@ def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
     assert abs(float(val) - float(ref)) <= 1e-4 * abs(float(ref)), (float(val), float(ref))
     H.assert_close(ecd.grad.cpu(), ec64.grad, 1e-4, "d emb cancer")
     H.assert_close(ewd.grad.cpu(), ew64.grad, 1e-4, "d emb wt")
+
+
+@pytest.mark.gpu
+def test_edge_forward_split_bf16_option_error_budget(cuda_device, monkeypatch):
+    """The opt-in split-bf16 forward (IMMUNOSTRUCT_EDGE_FWD=v3x: x = hi + lo in bf16, three bf16 MFMAs per product) stays
+    inside the forward tolerance of the fp32 kernels over a 6-layer stack; it is NOT the default because it is an order of
+    magnitude less accurate than fp32 arithmetic (measured ~1e-5 vs ~6e-7 against fp64)."""
+    raw = synthetic.make_batch(4, seed=8)
+    out = {}
+    for mode in ("v3", "v3x"):
+        monkeypatch.setattr(HF, "EDGE_FWD", mode)
+        torch.manual_seed(4)
+        layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(cuda_device) for i in range(6)]
+        g = H.product_graph(raw, cuda_device)
+        with torch.no_grad():
+            h, x = egnn_stack_forward(layers, g, g.ndata["x"][:, :20], g.ndata["x"][:, 20:], g.edata["edge_attr"])
+        out[mode] = (h.cpu(), x.cpu())
+    eh = H.assert_close(out["v3x"][0], out["v3"][0], FWD_TOL, "split-bf16 h")
+    ex = H.assert_close(out["v3x"][1], out["v3"][1], FWD_TOL, "split-bf16 x")
+    assert eh > 0.0      # it really is a different arithmetic
+    print(f"split-bf16 vs fp32 after 6 layers: h {eh:.1e}, x {ex:.1e}")

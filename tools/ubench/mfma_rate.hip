@@ -4,6 +4,7 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ void kern(float* out, long long* cycles, int iters) {
@@ -38,6 +39,12 @@ __global__ void kern(float* out, long long* cycles, int iters) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int n = 0; n < 8; ++n) v[n] = __builtin_amdgcn_exp2f(v[n]);
+    } else if (MODE == 5) {   // 16 MFMA 16x16x16 bf16, 4 independent accumulators
+      const s16x4 ab = {(short)lane, (short)(lane + 1), (short)(lane + 2), (short)(lane + 3)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, ab, acc[n], 0, 0, 0);
     } else if (MODE == 4) {   // 8 x (mfma + 4 fma): overlap test
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
@@ -85,5 +92,6 @@ int main() {
   run<2>("v_fma_f32", 16);
   run<3>("v_exp_f32", 16);
   run<4>("mfma16 + 4 fma (per group)", 8);
+  run<5>("mfma_f32_16x16x16_bf16", 16);
   return 0;
 }
