@@ -276,11 +276,11 @@ class EGNNStackFn(torch.autograd.Function):
             x_out = torch.empty(n, 3, **f32)
             z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # v3 stores full 16-row tiles
             z3s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None
-            edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
-            if EDGE_FWD in ("v3", "v3x") and EDGE_KERNELS == "v2":
-                kf = fwd_chunk_count(e)
-                fwd3 = lib.is_egnn_edge_fwd_v3x if (EDGE_FWD == "v3x" and fe <= 1) else lib.is_egnn_edge_fwd_v3
-                with KernelTimer.span("egnn_edge_fwd"):
+            with KernelTimer.span("egnn_edge_fwd"):
+                if EDGE_FWD in ("v3", "v3x") and EDGE_KERNELS == "v2":
+                    # wave-autonomous, software-pipelined mapping (v3x: its opt-in split-bf16 variant)
+                    kf = fwd_chunk_count(e)
+                    fwd3 = lib.is_egnn_edge_fwd_v3x if (EDGE_FWD == "v3x" and fe <= 1) else lib.is_egnn_edge_fwd_v3
                     _lib.check(fwd3(
                         _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
                         _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted),
@@ -288,13 +288,13 @@ class EGNNStackFn(torch.autograd.Function):
                         _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
                         _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe, st),
                         "is_egnn_edge_fwd_v3")
-            else:
-              with KernelTimer.span("egnn_edge_fwd"):
-                _lib.check(edge_fwd(
-                    _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
-                    _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
-                    _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-                    _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, st), "is_egnn_edge_fwd")
+                else:
+                    edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
+                    _lib.check(edge_fwd(
+                        _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
+                        _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
+                        _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+                        _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, st), "is_egnn_edge_fwd")
             last = i == n_layers - 1
             zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
             h_out = torch.empty(n, HIDDEN, **f32)
