@@ -20,7 +20,7 @@ try:  # optional, exactly as inert as a disabled wandb run when missing
 except Exception:  # pragma: no cover
     wandb = None
 
-__all__ = ["train_model", "train_model_comparative", "train_model_device"]
+__all__ = ["train_model", "train_model_comparative", "train_model_device", "train_model_comparative_device"]
 
 
 def _to(device, obj):
@@ -168,6 +168,68 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
             for at in range(0, val_index.numel(), bsz):
                 g, seq, prop, y = eager_batch(val_index[at:at + bsz])
                 loss = forward_loss(model, g, seq, prop, y).detach()
+                running = loss if running is None else running + loss
+                vsteps += 1
+        val_total = float(running) if running is not None else 0.0
+        if val_total < best:
+            _save_best(config, model, stage)
+            best = val_total
+        val_loss = val_total / max(vsteps, 1)
+        val_losses.append(val_loss)
+        if wandb is not None and getattr(wandb, "run", None) is not None:
+            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
+        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
+    return train_losses, val_losses
+
+
+def train_model_comparative_device(config, device, model, dataset_cancer, dataset_wt, train_index, val_index, optimizer,
+                                   loss_function, scheduler=None, stage="pretrain", seed=0):
+    """``train_model_comparative`` with both members of every (cancer, wild-type) pair in device-resident datasets
+    (same graph ids in both; targets are the cancer dataset's): batches are assembled on the GPU, the loss is the
+    reference's (``procedures/train.py:97-114``: shared prediction term, averaged reconstruction terms, ``coeff_contrastive``
+    x paired contrastive loss).  Steps run eagerly -- the contrastive loss' class-count early-out
+    (``utils/contrastive.py:38-43``) needs a host decision per batch, so this loop is not captured."""
+    device = dataset_cancer.device
+    bsz = int(config.batch_size)
+    coeff = float(getattr(config, "coeff_contrastive", 0) or 0)
+    contrastive = PairedContrastiveLoss(device=device, embedding_dim=104) if coeff > 0 else None
+    train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
+    val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
+    gen = torch.Generator(device="cpu").manual_seed(int(seed))
+    bufs = {}
+
+    def batch(idx):
+        b = int(idx.numel())
+        if b not in bufs:
+            bufs[b] = (dataset_cancer.new_batch(b), dataset_wt.new_batch(b))
+        (gc, sc, pc, y), (gw, sw, pw, _) = (dataset_cancer.gather_into(idx, *bufs[b][0]), dataset_wt.gather_into(idx, *bufs[b][1]))
+        return (gc, gw), (sc, sw), y, (pc, pw)
+
+    def step_loss(idx):
+        return _paired_loss(model, loss_function, batch(idx), device, contrastive, coeff)
+
+    train_losses, val_losses = [], []
+    best = float("inf")
+    for epoch in range(config.num_epochs):
+        model.train()
+        perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
+        running, steps = None, 0
+        for at in range(0, perm.numel(), bsz):
+            optimizer.zero_grad(set_to_none=True)
+            loss = step_loss(perm[at:at + bsz])
+            loss.backward()
+            optimizer.step()
+            running = loss.detach() if running is None else running + loss.detach()
+            steps += 1
+        train_loss = float(running) / max(steps, 1)
+        train_losses.append(train_loss)
+        if scheduler is not None:
+            scheduler.step()
+        model.eval()
+        running, vsteps = None, 0
+        with torch.no_grad():
+            for at in range(0, val_index.numel(), bsz):
+                loss = step_loss(val_index[at:at + bsz]).detach()
                 running = loss if running is None else running + loss
                 vsteps += 1
         val_total = float(running) if running is not None else 0.0

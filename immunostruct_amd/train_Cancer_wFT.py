@@ -13,9 +13,10 @@ import torch
 from torch.utils.data import DataLoader, random_split
 
 from . import optim
-from .data import SyntheticImmunoDataset, SyntheticPairedDataset, collate
+from .data import DeviceResidentDataset, SyntheticImmunoDataset, SyntheticPairedDataset, collate
 from .models.mapping import model_map
-from .procedures import binary_metrics, predict_proba, train_model, train_model_comparative
+from .procedures import (binary_metrics, predict_proba, train_model, train_model_comparative, train_model_comparative_device,
+                         train_model_device)
 from .utils import Losses, seed_everything
 
 
@@ -35,6 +36,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", default=1, type=int)
     p.add_argument("--coeff-contrastive", default=0, type=float)
     p.add_argument("--synthetic", default=0, type=int)
+    p.add_argument("--device-dataset", action="store_true",
+                   help="keep the datasets in HBM and assemble batches on the GPU (data.DeviceResidentDataset)")
     return p.parse_args(argv)
 
 
@@ -75,14 +78,28 @@ def main(argv=None):
     tr, va, _ = random_split(ds1, [0.8, 0.1, 0.1], gen)
     losses = Losses(input_dim, ds1.class_weights, sequence=config.sequence_loss)
     opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
-    train_model(config, device, model, mk(tr, True), mk(va, False), opt, losses.regression_loss)
+    if config.device_dataset:
+        train_model_device(config, device, model, DeviceResidentDataset(ds1, device), tr.indices, va.indices, opt,
+                           losses.regression_loss, seed=config.seed)
+    else:
+        train_model(config, device, model, mk(tr, True), mk(va, False), opt, losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
     # stage 2: comparative pretraining on (cancer, wild-type) pairs, continuous target
     ds2 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=False)
     tr2, va2, te2 = random_split(ds2, [0.8, 0.1, 0.1], gen)
     opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
-    train_model_comparative(config, device, model, mk(tr2, True), mk(va2, False), opt, losses.regression_loss)
+    def fit_pairs(ds, tr_, va_, opt_, loss_fn, sched_=None, stage="pretrain"):
+        if config.device_dataset:
+            # graph ids of a random_split subset, or of its modulo-oversampled extension (reference ExtendedDataset)
+            idx = lambda sub: ([sub.dataset.indices[i % len(sub.dataset)] for i in range(len(sub))]
+                               if isinstance(sub, _Extended) else sub.indices)
+            return train_model_comparative_device(config, device, model, DeviceResidentDataset(ds.c, device),
+                                                  DeviceResidentDataset(ds.w, device), idx(tr_), idx(va_), opt_, loss_fn,
+                                                  sched_, stage=stage, seed=config.seed)
+        return train_model_comparative(config, device, model, mk(tr_, True), mk(va_, False), opt_, loss_fn, sched_, stage=stage)
+
+    fit_pairs(ds2, tr2, va2, opt, losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
     # stage 3: comparative finetuning, BCE (+ coeff * paired contrastive loss)
@@ -95,7 +112,7 @@ def main(argv=None):
         torch.optim.lr_scheduler.LinearLR(opt, 0.01, 1.0, total_iters=max(config.num_epochs // 4, 1)),
         torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(config.num_epochs - config.num_epochs // 4, 1))],
         milestones=[max(config.num_epochs // 4, 1)])
-    train_model_comparative(config, device, model, mk(tr3, True), mk(va3, False), opt, losses.BCE_loss, sched, stage="finetune")
+    fit_pairs(ds3, tr3, va3, opt, losses.BCE_loss, sched, stage="finetune")
     model.load_trained(config.model_save_path_finetune, new_head=False)
     prob, y = predict_proba(model, mk(te3, False), device, comparative=True)
     print("test metrics:", binary_metrics(y, prob))

@@ -212,7 +212,9 @@ def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     train_IEDB_wFT.main(["--model", "HybridModelv2"] + common)
     train_IEDB_wFT.main(["--model", "HybridModelv2", "--device-dataset", "--seed", "3"] + common)      # on-GPU batcher + captured step
     train_Cancer_wFT.main(["--use-wt-for-downstream", "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common)
-    assert len(list(tmp_path.glob("*_finetune.pt"))) == 3
+    train_Cancer_wFT.main(["--use-wt-for-downstream", "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2",
+                           "--device-dataset", "--seed", "3"] + common)
+    assert len(list(tmp_path.glob("*_finetune.pt"))) == 4
 
 
 def test_device_batcher_matches_collate(cuda_device):
