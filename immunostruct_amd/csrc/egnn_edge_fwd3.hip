@@ -23,6 +23,7 @@
 // and skipped by the segment scan.  Only a graph with fewer than 16 edges in total has rows past the end
 // (clamped loads, stores into the >= 16-row padding of z2s / z3s).
 #include "common.h"
+#include <stdlib.h>
 
 namespace is {
 
@@ -42,6 +43,44 @@ __device__ long long g_stamps3[64];
 // (IMMUNOSTRUCT_EDGE_FWD=v3x): NOT bit-identical to the fp32 kernels, measured error in tests/test_gpu_kernels.py.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDB = H + 8;      // bf16 row stride of the split weight tiles (144 bytes: 16-byte aligned rows)
+
+__device__ __forceinline__ void split8_3(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = i < 4 ? a[i] : b[i - 4];
+    hi[i] = (__bf16)v;
+    const float r1 = v - (float)hi[i];
+    mid[i] = (__bf16)r1;
+    lo[i] = (__bf16)(r1 - (float)mid[i]);
+  }
+}
+
+// three-piece variant: x = hi + mid + lo exactly (3 x 8 mantissa bits); the six largest cross terms are kept
+// (hh, hm, mh, hl, lh, mm): what is dropped is O(2^-24) relative, i.e. fp32-class accuracy at 6 x 16 cycles per 32 k.
+__device__ __forceinline__ void mm16_rows_x6(f32x4 (&acc)[4], const float* a_lds, const __bf16* w_hi, const __bf16* w_mid,
+                                             const __bf16* w_lo, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* ap = a_lds + r * LD + c * 32 + q * 8;
+    bf16x8 ah, am, al;
+    split8_3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), ah, am, al);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int off = (nt * 16 + r) * LDB + c * 32 + q * 8;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(w_mid + off);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
+      // smallest terms first
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
+    }
+  }
+}
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -71,11 +110,12 @@ __device__ __forceinline__ void mm16_rows_x3(f32x4 (&acc)[4], const float* a_lds
   }
 }
 
-template <bool X3> struct Fwd3Weights;
-template <> struct Fwd3Weights<false> { float w2[H * LD]; float wc1[H * LD]; };
-template <> struct Fwd3Weights<true> { __bf16 w2h[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1l[H * LDB]; };
+template <int X3> struct Fwd3Weights;
+template <> struct Fwd3Weights<0> { float w2[H * LD]; float wc1[H * LD]; };
+template <> struct Fwd3Weights<2> { __bf16 w2h[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1l[H * LDB]; };
+template <> struct Fwd3Weights<3> { __bf16 w2h[H * LDB], w2m[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1m[H * LDB], wc1l[H * LDB]; };
 
-template <int FE_MAX, bool X3 = false>
+template <int FE_MAX, int X3 = 0>
 struct Fwd3Smem {
   Fwd3Weights<X3> w;
   float act[W3][TE16 * LD];
@@ -141,7 +181,7 @@ __device__ __forceinline__ void load_fwd_rows(FwdRows& rw, const EdgeIds<FE_MAX>
   }
 }
 
-template <int FE_MAX, bool SAVE, bool X3 = false>
+template <int FE_MAX, bool SAVE, int X3 = 0>
 __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
@@ -193,7 +233,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     for (int j = 0; j < 8; ++j) {
       const int idx = tid + (j & 3) * 256;
       const int row = idx / (H / 4), c4 = (idx % (H / 4)) * 4;
-      if constexpr (X3) {
+      if constexpr (X3 == 2) {
         __bf16* dh = (j < 4) ? sm.w.w2h : sm.w.wc1h;
         __bf16* dl = (j < 4) ? sm.w.w2l : sm.w.wc1l;
 #pragma unroll
@@ -201,6 +241,19 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
           const __bf16 hv = (__bf16)wreg[j][k];
           dh[row * LDB + c4 + k] = hv;
           dl[row * LDB + c4 + k] = (__bf16)(wreg[j][k] - (float)hv);
+        }
+      } else if constexpr (X3 == 3) {
+        __bf16* dh = (j < 4) ? sm.w.w2h : sm.w.wc1h;
+        __bf16* dm = (j < 4) ? sm.w.w2m : sm.w.wc1m;
+        __bf16* dl = (j < 4) ? sm.w.w2l : sm.w.wc1l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const __bf16 hv = (__bf16)wreg[j][k];
+          const float r1 = wreg[j][k] - (float)hv;
+          const __bf16 mv = (__bf16)r1;
+          dh[row * LDB + c4 + k] = hv;
+          dm[row * LDB + c4 + k] = mv;
+          dl[row * LDB + c4 + k] = (__bf16)(r1 - (float)mv);
         }
       } else {
         float* dst = (j < 4) ? sm.w.w2 : sm.w.wc1;
@@ -289,7 +342,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
-      if constexpr (X3) mm16_rows_x3(acc, act, sm.w.w2h, sm.w.w2l, lane);
+      if constexpr (X3 == 2) mm16_rows_x3(acc, act, sm.w.w2h, sm.w.w2l, lane);
+      else if constexpr (X3 == 3) mm16_rows_x6(acc, act, sm.w.w2h, sm.w.w2m, sm.w.w2l, lane);
       else mm16_rows<4, H>(acc, act, sm.w.w2, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -307,7 +361,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
-      if constexpr (X3) mm16_rows_x3(acc, act, sm.w.wc1h, sm.w.wc1l, lane);
+      if constexpr (X3 == 2) mm16_rows_x3(acc, act, sm.w.wc1h, sm.w.wc1l, lane);
+      else if constexpr (X3 == 3) mm16_rows_x6(acc, act, sm.w.wc1h, sm.w.wc1m, sm.w.wc1l, lane);
       else mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -378,7 +433,7 @@ extern "C" int is_debug_stamps3(long long* out) {
 }
 #endif
 
-static int edge_fwd_v3_launch(bool x3, const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+static int edge_fwd_v3_launch(int x3, const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                               const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                               const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
                               const float* W2, const float* b2, const float* Wc1, const float* bc1,
@@ -396,13 +451,16 @@ static int edge_fwd_v3_launch(bool x3, const float* ps, const float* pd, int ld_
 #define IS_LAUNCH_FWD3(FE, SV, XX)                                                                                       \
   hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV, XX>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe)
-  if (x3) {
+  if (x3 == 2) {
     if (Fe > 1) return -22;
-    if (save) IS_LAUNCH_FWD3(1, true, true); else IS_LAUNCH_FWD3(1, false, true);
+    if (save) IS_LAUNCH_FWD3(1, true, 2); else IS_LAUNCH_FWD3(1, false, 2);
+  } else if (x3 == 3) {
+    if (Fe > 1) return -22;
+    if (save) IS_LAUNCH_FWD3(1, true, 3); else IS_LAUNCH_FWD3(1, false, 3);
   } else if (Fe <= 1) {
-    if (save) IS_LAUNCH_FWD3(1, true, false); else IS_LAUNCH_FWD3(1, false, false);
+    if (save) IS_LAUNCH_FWD3(1, true, 0); else IS_LAUNCH_FWD3(1, false, 0);
   } else {
-    if (save) IS_LAUNCH_FWD3(8, true, false); else IS_LAUNCH_FWD3(8, false, false);
+    if (save) IS_LAUNCH_FWD3(8, true, 0); else IS_LAUNCH_FWD3(8, false, 0);
   }
 #undef IS_LAUNCH_FWD3
   return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -414,7 +472,7 @@ extern "C" int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, c
                                    const float* W2, const float* b2, const float* Wc1, const float* bc1,
                                    const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                                    float* z3s, int N, int E, int Fe, void* stream) {
-  return edge_fwd_v3_launch(false, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
+  return edge_fwd_v3_launch(0, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
                             wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
 }
 
@@ -426,6 +484,7 @@ extern "C" int is_egnn_edge_fwd_v3x(const float* ps, const float* pd, int ld_p, 
                                     const float* W2, const float* b2, const float* Wc1, const float* bc1,
                                     const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                                     float* z3s, int N, int E, int Fe, void* stream) {
-  return edge_fwd_v3_launch(true, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
+  static const int pieces = (getenv("IMMUNOSTRUCT_SPLIT_PIECES") != nullptr && atoi(getenv("IMMUNOSTRUCT_SPLIT_PIECES")) == 3) ? 3 : 2;
+  return edge_fwd_v3_launch(pieces, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
                             wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
 }

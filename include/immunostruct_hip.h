@@ -109,8 +109,9 @@ int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float*
                         const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                         float* z3s, int N, int E, int Fe, void* stream);
 /* is_egnn_edge_fwd_v3 with the two 64 x 64 layers on split-bf16 MFMA (x = hi + lo in bf16, three
- * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation).  Opt-in (IMMUNOSTRUCT_EDGE_FWD=v3x), Fe <= 1;
- * not bit-identical to the fp32 kernels: a product carries ~2^-16 relative error.                     */
+ * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; with IMMUNOSTRUCT_SPLIT_PIECES=3 in the environment
+ * x = hi + mid + lo and six MFMAs per product: fp32-class accuracy).  Opt-in (IMMUNOSTRUCT_EDGE_FWD=v3x), Fe <= 1;
+ * not bit-identical to the fp32 kernels (two pieces: ~2^-16 relative error per product).               */
 int is_egnn_edge_fwd_v3x(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                          const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                          const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
