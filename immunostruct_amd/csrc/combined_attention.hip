@@ -24,6 +24,8 @@
 namespace is {
 
 constexpr int CA_HEADS = 8;
+constexpr int CA_THREADS = 1024;   // one (token, head) item per thread for T <= 128: the block is pure latency (one workgroup per
+                                   // graph, 128 graphs on 256 CUs), so the serial exp loops per thread are what it costs
 constexpr int CA_TMAX = 256;
 constexpr int CA_NSTAT = 5;   // gamma, mx, 1/den, m, second moment
 constexpr int CA_PART = 3 * CA_HEADS + 1;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void ca_coefficients(CaCoef& co, const float* wq, con
 }
 
 template <int F>
-__global__ __launch_bounds__(256) void comb_attn_fwd_kernel(
+__global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bq,
     const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ bv,
     const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ z,
@@ -69,11 +71,11 @@ __global__ __launch_bounds__(256) void comb_attn_fwd_kernel(
   constexpr int D = F / CA_HEADS;
   __shared__ float c[CA_TMAX];
   __shared__ CaCoef co;
-  __shared__ float red[2][4];
+  __shared__ float red[2][CA_THREADS / 64];
   const int tid = threadIdx.x, b = blockIdx.x;
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   float lo = INFINITY, hi = -INFINITY;
-  for (int j = tid; j < T; j += 256) {
+  for (int j = tid; j < T; j += CA_THREADS) {
     const float v = x[(size_t)b * T + j];
     c[j] = v;
     lo = fminf(lo, v); hi = fmaxf(hi, v);
@@ -82,11 +84,12 @@ __global__ __launch_bounds__(256) void comb_attn_fwd_kernel(
   for (int m = 32; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m, 64)); hi = fmaxf(hi, __shfl_xor(hi, m, 64)); }
   if ((tid & 63) == 0) { red[0][tid >> 6] = lo; red[1][tid >> 6] = hi; }
   __syncthreads();
-  const float cmin = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
-  const float cmax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  float cmin = red[0][0], cmax = red[1][0];
+#pragma unroll
+  for (int k = 1; k < CA_THREADS / 64; ++k) { cmin = fminf(cmin, red[0][k]); cmax = fmaxf(cmax, red[1][k]); }
   const float rs = rsqrtf((float)D);
   const int items = CA_HEADS * T;
-  for (int w0 = 0; w0 < items; w0 += 256) {
+  for (int w0 = 0; w0 < items; w0 += CA_THREADS) {
     const int w = w0 + tid;
     const bool on = w < items;
     const int i = on ? (w >> 3) : 0, hd = tid & 7;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void comb_attn_fwd_kernel(
 }
 
 template <int F>
-__global__ __launch_bounds__(256) void comb_attn_bwd_kernel(
+__global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dz,
     const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ Wc,
@@ -126,16 +129,16 @@ __global__ __launch_bounds__(256) void comb_attn_bwd_kernel(
   __shared__ float s_gamma[CA_HEADS * CA_TMAX], s_mx[CA_HEADS * CA_TMAX], s_inv[CA_HEADS * CA_TMAX],
       s_m[CA_HEADS * CA_TMAX], s_dm[CA_HEADS * CA_TMAX];
   __shared__ CaCoef co;
-  __shared__ float acc[4][256];
+  __shared__ float acc[4][CA_THREADS];
   const int tid = threadIdx.x, b = blockIdx.x;
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
-  for (int j = tid; j < T; j += 256) c[j] = x[(size_t)b * T + j];
+  for (int j = tid; j < T; j += CA_THREADS) c[j] = x[(size_t)b * T + j];
   __syncthreads();
   const float rs = rsqrtf((float)D);
   const int items = CA_HEADS * T, hd = tid & 7;
   float dA2 = 0.f, dC2 = 0.f, dAl = 0.f, dBe = 0.f;
   // ---- phase 1: per (token i, head) item ----
-  for (int w0 = 0; w0 < items; w0 += 256) {
+  for (int w0 = 0; w0 < items; w0 += CA_THREADS) {
     const int w = w0 + tid;
     const bool on = w < items;
     const int i = on ? (w >> 3) : 0;
@@ -164,20 +167,20 @@ __global__ __launch_bounds__(256) void comb_attn_bwd_kernel(
   if (tid < 3 * CA_HEADS) {
     const int which = tid / CA_HEADS, h = tid % CA_HEADS;
     float s = 0.f;
-    for (int t = h; t < 256; t += CA_HEADS) s += acc[which][t];
+    for (int t = h; t < CA_THREADS; t += CA_HEADS) s += acc[which][t];
     partials[(size_t)b * CA_PART + tid] = s;
   }
   if (tid == 3 * CA_HEADS) {
     float s = 0.f;
-    for (int t = 0; t < 256; t += CA_HEADS) s += acc[3][t];
+    for (int t = 0; t < CA_THREADS; t += CA_HEADS) s += acc[3][t];
     partials[(size_t)b * CA_PART + 3 * CA_HEADS] = s;
   }
   // ---- phase 2: per key token j: dc_j = sum_{i,h} dm p_{ih}(j) (1 + gamma (c_j - m)) + direct ----
-  // the (i,h) items are split over SPLIT thread groups so that all 256 threads work; the group partial
+  // the (i,h) items are split over SPLIT thread groups so that (nearly) all threads work; the group partial
   // sums are combined in a fixed order through LDS (deterministic)
   __syncthreads();   // acc[][] has been consumed by the per-head sums above
   {
-    const int split = (T <= 64) ? 4 : (T <= 128 ? 2 : 1);      // T * split <= 256
+    const int split = CA_THREADS / T >= 8 ? 8 : (CA_THREADS / T >= 4 ? 4 : CA_THREADS / T);      // T * split <= CA_THREADS
     const int grp = tid / T, j = tid - grp * T;
     float a = 0.f;
     if (grp < split) {
@@ -189,12 +192,12 @@ __global__ __launch_bounds__(256) void comb_attn_bwd_kernel(
         const float p = __expf(gam * cj - s_mx[w]) * s_inv[w];
         a += s_dm[w] * p * (1.0f + gam * (cj - s_m[w]));
       }
-      acc[grp][j] = a;
+      (&acc[0][0])[grp * CA_TMAX + j] = a;      // acc viewed as [8][CA_TMAX]
     }
     __syncthreads();
     if (tid < T) {
       float v = dxi[tid];
-      for (int k = 0; k < split; ++k) v += acc[k][tid];
+      for (int k = 0; k < split; ++k) v += (&acc[0][0])[k * CA_TMAX + tid];
       dx[(size_t)b * T + tid] = v;
     }
   }
@@ -259,8 +262,8 @@ extern "C" int is_comb_attn_fwd(const float* x, const float* wq, const float* bq
   if (B <= 0) return 0;
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (F == 16) hipLaunchKernelGGL(is::comb_attn_fwd_kernel<16>, dim3(B), dim3(256), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
-  else hipLaunchKernelGGL(is::comb_attn_fwd_kernel<32>, dim3(B), dim3(256), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
+  if (F == 16) hipLaunchKernelGGL(is::comb_attn_fwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
+  else hipLaunchKernelGGL(is::comb_attn_fwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -271,10 +274,10 @@ extern "C" int is_comb_attn_bwd(const float* x, const float* stats, const float*
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (F == 16) {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(256), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
+    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   } else {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(256), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
+    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;
