@@ -57,6 +57,7 @@ SIGNATURES = {
     "is_multi_copy": [_P, _I, _P],
     "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P],
     "is_adam_step": [_P, _I, _P, _P, _P],
+    "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_contrastive_scratch_floats": [_I],
     "is_contrastive_work_floats": [_I],
     "is_contrastive_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _I, _P],

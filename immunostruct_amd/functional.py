@@ -803,6 +803,42 @@ def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
     return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam)
 
 
+class LinearSmallBatchFn(torch.autograd.Function):
+    """``F.linear(x, w, b)`` whose weight / bias gradients come from ``csrc/dense.hip`` (contraction over the small batch);
+    forward and input gradient are the library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        gy = _lib.f32c(gy)
+        xc = _lib.f32c(x)
+        n, k, bsz = int(w.shape[0]), int(w.shape[1]), int(xc.shape[0])
+        dw = torch.empty(n, k, dtype=torch.float32, device=w.device)
+        db = torch.empty(n, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        with KernelTimer.span("linear_wgrad"):
+            _lib.check(lib.is_linear_wgrad(_lib.ptr(gy), n, _lib.ptr(xc), k, _lib.ptr(dw), _lib.ptr(db), bsz, n, k, _lib.stream_ptr()),
+                       "is_linear_wgrad")
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        return gx, dw, db
+
+
+def linear_small_batch(x, weight, bias):
+    """nn.Linear forward for (batch, features) inputs on a GPU; plain F.linear otherwise"""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and DENSE_WGRAD:
+        return LinearSmallBatchFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+DENSE_WGRAD = os.environ.get("IMMUNOSTRUCT_DENSE_WGRAD", "1") != "0"
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """Per-segment mean and/or max over rows (``csrc/segment_ops.hip``).
 

@@ -112,7 +112,7 @@ class MultimodalNet(nn.Module):
         return nn.Sequential(*mods)
 
     def encode_vae(self, x):
-        h1 = F.relu(self.vae_fc1(x))
+        h1 = F.relu(HF.linear_small_batch(x, self.vae_fc1.weight, self.vae_fc1.bias))
         return self.vae_fc21(h1), self.vae_fc22(h1)
 
     def reparameterize(self, mu, logvar):
@@ -120,7 +120,7 @@ class MultimodalNet(nn.Module):
         return mu + torch.randn_like(mu) * torch.exp(0.5 * logvar)
 
     def decode_vae(self, z):
-        return self.vae_fc4(F.relu(self.vae_fc3(z)))
+        return HF.linear_small_batch(F.relu(self.vae_fc3(z)), self.vae_fc4.weight, self.vae_fc4.bias)
 
     def load_trained(self, path, new_head=False, map_location=None):
         self.load_state_dict(torch.load(path, map_location=map_location))

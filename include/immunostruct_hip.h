@@ -231,6 +231,13 @@ int is_mlp2_bwd(const float* x, int ld_x, const float* W1, const float* W2, cons
                 const float* y, const float* gy, float* gx, float* partials, int B, int in, int hid, int out,
                 int hgroup, int act1, int act2, void* stream);
 
+/* Weight / bias gradient of a Linear layer whose contraction dimension is the (small) batch: dW [N, K] = gy^T x,
+ * db [N] = sum_b gy (db may be NULL) for gy [B, ld_g] (N columns), x [B, ld_x] (K columns).  Used for the two large
+ * matrices of the sequence VAE (vae_fc1 512 x 5943, vae_fc4 5943 x 512; models/hybrid_models.py:297-308); forward and
+ * input gradient stay on the library GEMMs.                                                                   */
+int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld_x, float* dW, float* db, int B, int N, int K,
+                    void* stream);
+
 /* Multi-tensor Adam / AdamW step with torch.optim semantics (reference: torch.optim.Adam in train_IEDB_wFT.py:69-74,
  * torch.optim.AdamW in train_Cancer_wFT.py:76-92).  `chunks` = DEVICE array of nchunks records
  * { float* p; const float* g; float* m; float* v; long long n; } (one workgroup each), `state` = device float[3]

@@ -472,3 +472,19 @@ def test_edge_forward_split_bf16_option_error_budget(cuda_device, monkeypatch):
     ex = H.assert_close(out["v3x"][1], out["v3"][1], FWD_TOL, "split-bf16 x")
     assert eh > 0.0      # it really is a different arithmetic
     print(f"split-bf16 vs fp32 after 6 layers: h {eh:.1e}, x {ex:.1e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,k", [(128, 512, 5943), (128, 5943, 512), (37, 100, 70), (1, 64, 64)])
+def test_linear_small_batch_weight_gradient(cuda_device, b, n, k):
+    """csrc/dense.hip: dW = gy^T x, db = sum gy (the VAE's two large layers) vs torch in fp64; dx through the library GEMM."""
+    g = torch.Generator().manual_seed(b + n)
+    x, w, bias, gup = (torch.randn(b, k, generator=g), torch.randn(n, k, generator=g) * 0.05, torch.randn(n, generator=g),
+                       torch.randn(b, n, generator=g))
+    ref = [t.double().requires_grad_(True) for t in (x, w, bias)]
+    (torch.nn.functional.linear(*ref) * gup.double()).sum().backward()
+    hip = [t.to(cuda_device).requires_grad_(True) for t in (x, w, bias)]
+    y = HF.linear_small_batch(*hip)
+    (y * gup.to(cuda_device)).sum().backward()
+    for name, a, r in zip(("dx", "dW", "db"), hip, ref):
+        H.assert_close(a.grad.cpu(), r.grad, 1e-5, f"linear {name}")
