@@ -216,13 +216,19 @@ def main():
     if not args.eager and not args.no_kernel_timers:
         # the timed region replays a captured HIP graph (individual launches cannot be bracketed there):
         # measure per-kernel durations with HIP events on an eager re-run of the same steps
+        # (sequence branch on the SAME stream for this re-run: a kernel's duration is then its own, not the co-run slow-down
+        #  by whatever the forked branch happens to execute next to it; the in-situ averages are in profiles/)
+        from immunostruct_amd.models import _core as model_core
+        overlap_saved, model_core.OVERLAP_BRANCHES = model_core.OVERLAP_BRANCHES, False
         HF.KernelTimer.reset()
         HF.KernelTimer.enabled = True
         for i in range(min(args.steps, 10)):
             eager_step(args.warmup + i)
         torch.cuda.synchronize()
         HF.KernelTimer.enabled = False
-        timers_mode = "HIP events around each launch, eager re-run of the timed steps (the timed region replays a HIP graph)"
+        model_core.OVERLAP_BRANCHES = overlap_saved
+        timers_mode = ("HIP events around each launch, eager single-stream re-run of the timed steps "
+                       "(the timed region replays a HIP graph)")
 
     if rank == 0:
         graphs = args.batch * world * args.steps
