@@ -220,6 +220,9 @@ def main():
         #  by whatever the forked branch happens to execute next to it; the in-situ averages are in profiles/)
         from immunostruct_amd.models import _core as model_core
         overlap_saved, model_core.OVERLAP_BRANCHES = model_core.OVERLAP_BRANCHES, False
+        for i in range(2):      # untimed: the first eager steps after the replays grow the allocator's pool (hipMalloc stalls)
+            eager_step(args.warmup + i)
+        torch.cuda.synchronize()
         HF.KernelTimer.reset()
         HF.KernelTimer.enabled = True
         for i in range(min(args.steps, 10)):

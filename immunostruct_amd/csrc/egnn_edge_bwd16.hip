@@ -11,7 +11,7 @@
 //     2 x 64 and no cross-wave reduction is needed at the end;
 //   * a workgroup owns one node tile per pass: either NV16 = 16 consecutive destination nodes (~48 edges on
 //     degree-3 graphs: the fourth wave of the 64-edge window idles in the row phases), or -- when the caller
-//     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= NVB = 24 nodes per tile) -- a
+//     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= 24 nodes per tile) -- a
 //     node range that fills the window (63 of 64 rows on the same graphs, 24 % fewer passes).
 #include "common.h"
 
@@ -26,9 +26,9 @@ __device__ long long g_stamps_b[24];
 
 constexpr int WB16 = 4;
 constexpr int NV16 = 16;   // nodes per tile without a tile list
-constexpr int NVB = 24;    // most nodes a listed tile may hold
+constexpr int NVB_LISTED = 24;    // most nodes a listed tile may hold
 
-template <int FE_MAX>
+template <int FE_MAX, int NVB>
 struct Bwd16Smem {
   float w2t[H * LD];
   float wc1t[H * LD];
@@ -52,7 +52,7 @@ struct Bwd16Smem {
 
 constexpr int PART16_STRIDE = 8448 + 64 * 8;  // identical to the v1 record
 
-template <int FE_MAX>
+template <int FE_MAX, int NVB>
 __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, int ld_dpd, float* __restrict__ dx,
     float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe) {
-  __shared__ Bwd16Smem<FE_MAX> sm;
+  __shared__ Bwd16Smem<FE_MAX, NVB> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
 
@@ -446,12 +446,15 @@ extern "C" int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, c
   if (Fe < 0 || Fe > 8 || grid <= 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
+#define IS_LAUNCH_BWD16(FE, NVB)                                                                                          \
+  hipLaunchKernelGGL((is::egnn_edge_bwd16_kernel<FE, NVB>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1, \
+                     ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe)
   if (Fe <= 1) {
-    hipLaunchKernelGGL(is::egnn_edge_bwd16_kernel<1>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
-                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe);
+    if (tiles != nullptr) IS_LAUNCH_BWD16(1, is::NVB_LISTED); else IS_LAUNCH_BWD16(1, is::NV16);
   } else {
-    hipLaunchKernelGGL(is::egnn_edge_bwd16_kernel<8>, dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1,
-                       ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe);
+    if (tiles != nullptr) return -22;      // listed tiles: Fe <= 1 only (the Fe = 8 instantiation has no LDS left)
+    IS_LAUNCH_BWD16(8, is::NV16);
   }
+#undef IS_LAUNCH_BWD16
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -117,11 +117,16 @@ class KernelTimer:
 
     @classmethod
     def summary(cls):
-        """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
+        """name -> (launches kept, mean milliseconds); call after torch.cuda.synchronize()."""
         out = {}
         for name, evs in cls.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+            ms = sorted(a.elapsed_time(b) for a, b in evs)
+            # eager launches: an event pair also brackets the HOST time between the two records when the GPU is idle, so a
+            # garbage-collection pause or an allocator hipMalloc shows up as a 10-100 ms "launch": drop such stalls
+            # (> 5x the median) before averaging
+            med = ms[len(ms) // 2] if ms else 0.0
+            kept = [t for t in ms if t <= 5.0 * med] or ms
+            out[name] = (len(kept), sum(kept) / max(len(kept), 1))
         return out
 
 
