@@ -27,6 +27,9 @@ from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
+if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 _side_streams = {}
 
 
