@@ -47,8 +47,10 @@ SIGNATURES = {
     "is_egnn_node_bwd": [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_reduce_partials_scratch_floats": [_I],
     "is_reduce_partials": [_P, _I, _I, _I, _P, _P, _P, _P],
-    "is_egnn_node_fwd_v2": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
-    "is_egnn_node_bwd_data": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "is_egnn_node_fwd_v2": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
+    "is_node_pack_floats": [],
+    "is_node_pack_weights": [_P, _I, _P],
+    "is_egnn_node_bwd_data": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],
     "is_egnn_node_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
@@ -88,6 +90,12 @@ class WgradLayer(ctypes.Structure):
     """one layer of is_egnn_node_wgrad_batched (mirrors `WgradLayer` in csrc/egnn_node16.hip)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("g_psd", "h_out", "dh", "zn1", "dzn1", "h", "h_neigh", "partials")] + \
                [(n, ctypes.c_int) for n in ("ld_h", "din", "ld_hn", "ld_ho", "dho", "pad")]
+
+
+class NodePackJob(ctypes.Structure):
+    """one layer of is_node_pack_weights (mirrors `NodePackJob` in csrc/egnn_node16.hip)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Wn1", "Wn2", "W1n", "fpack", "bpack")] + \
+               [(n, ctypes.c_int) for n in ("din", "ldw_n", "pad0", "pad1")]
 
 
 class ReduceJob(ctypes.Structure):

@@ -15,6 +15,13 @@
 
 namespace is {
 
+#ifdef IS_STAGE_STAMPS
+__device__ long long g_stamps_node[16];
+#define STAMPN(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps_node[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMPN(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x4 ldg4(const float* p, int align) {
   if (align >= 4) return *reinterpret_cast<const f32x4*>(p);
   if (align == 2) {
@@ -55,12 +62,100 @@ struct Node16Dims {
   static constexpr int KQ1 = KP / 4;                        // k per quarter: 24 / 32
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Operand packs.  The node kernels keep their MFMA B operands in registers; fetched from the NATIVE parameter tensors
+// every wave-level load touches 64 different cache lines (16 rows x 4 k-quarters, 16 bytes used of each 64-byte line) --
+// stage stamps showed that phase to be 60 % (forward) / 37 % (backward) of the kernels.  A tiny kernel run once per
+// step and layer rewrites the weights in exactly the order the lanes consume them (pack[wave][slot][lane][4 floats]):
+// each operand load of the node kernels is then one fully coalesced 1 KB access.
+//   forward slots : b1 (KQ1/4 groups) | b2 (4) | b3 (2 x 4)                         -> NODE_FWD_SLOTS = 20
+//   backward slots: bp (8 groups = 32 k) | ba (4) | bx (2 x 4)                      -> NODE_BWD_SLOTS = 20
+constexpr int NODE_FWD_SLOTS = 20, NODE_BWD_SLOTS = 20;
+constexpr int NODE_PACK_FLOATS = 4 * 20 * 64 * 4;     // per direction and layer
+
+struct NodePackJob {
+  const float *Wn1, *Wn2, *W1n;     // W1n may be NULL (last layer without a projection head)
+  float *fpack, *bpack;
+  int din, ldw_n, pad0, pad1;
+};
+constexpr int NODE_PACK_MAX = 8;
+struct NodePackBatch { NodePackJob job[NODE_PACK_MAX]; };
+
+template <int DIN>
+__device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, int lane) {
+  using D = Node16Dims<DIN>;
+  const int r = lane & 15, q = lane >> 4;
+  const int col = wave * 16 + r;
+  f32x4* fp = reinterpret_cast<f32x4*>(J.fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
+  f32x4* bp = reinterpret_cast<f32x4*>(J.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
+  int slot = 0;
+  // ---- forward ----
+  for (int g = 0; g < D::KQ1 / 4; ++g, ++slot) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int k = q * D::KQ1 + 4 * g + j; v[j] = (k < D::KV) ? J.Wn1[(size_t)col * D::KV + k] : 0.0f; }
+    fp[slot * 64] = v;
+  }
+  for (int g = 0; g < 4; ++g, ++slot) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = J.Wn2[(size_t)col * H + q * 16 + 4 * g + j];
+    fp[slot * 64] = v;
+  }
+  for (int nt = 0; nt < 2; ++nt)
+    for (int g = 0; g < 4; ++g, ++slot) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (J.W1n != nullptr) {
+        const int c = wave * 32 + nt * 16 + r;
+        const float* row = (c < 64) ? J.W1n + (size_t)c * J.ldw_n : J.W1n + (size_t)(c - 64) * J.ldw_n + 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = row[q * 16 + 4 * g + j];
+      }
+      fp[slot * 64] = v;
+    }
+  // ---- backward (transposed operands) ----
+  slot = 0;
+  for (int g = 0; g < 8; ++g, ++slot) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (J.W1n != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = q * 32 + 4 * g + j;
+        v[j] = (c < 64) ? J.W1n[(size_t)c * J.ldw_n + col] : J.W1n[(size_t)(c - 64) * J.ldw_n + 64 + col];
+      }
+    }
+    bp[slot * 64] = v;
+  }
+  for (int g = 0; g < 4; ++g, ++slot) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = J.Wn2[(size_t)(q * 16 + 4 * g + j) * H + col];
+    bp[slot * 64] = v;
+  }
+  for (int nt = 0; nt < 2; ++nt) {
+    const int xc = (wave * 2 + nt) * 16 + r;
+    for (int g = 0; g < 4; ++g, ++slot) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (xc < D::KV) ? J.Wn1[(size_t)(q * 16 + 4 * g + j) * D::KV + xc] : 0.0f;
+      bp[slot * 64] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void node_pack_kernel(NodePackBatch batch) {
+  const NodePackJob& J = batch.job[blockIdx.y];
+  if (J.din == 20) node_pack_body<20>(J, blockIdx.x, threadIdx.x);
+  else node_pack_body<64>(J, blockIdx.x, threadIdx.x);
+}
+
 template <int DIN>
 __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
     const float* __restrict__ h, int ld_h, const float* __restrict__ h_neigh, int ld_hn,
     const float* __restrict__ Wn1, const float* __restrict__ bn1, const float* __restrict__ Wn2,
     const float* __restrict__ bn2, const float* __restrict__ W1n, int ldw_n, const float* __restrict__ b0n,
-    const float* __restrict__ b1n, float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N) {
+    const float* __restrict__ b1n, float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N,
+    const float* __restrict__ fpack) {
   using D = Node16Dims<DIN>;
   __shared__ float xs[32 * D::LD1];
   __shared__ float a1s[32 * LD];
@@ -69,11 +164,24 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
   const int r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * 32;
   const bool has_next = W1n != nullptr;
+  STAMPN(0);
 
   // ---- B operands of all three layers for this wave's output columns (independent of the tile data) ----
   const int col = wave * 16 + r;                       // output column of MM_a / MM_b
   f32x4 b1[D::KQ1 / 4], b2[4], b3[2][4];
-  {
+  if (fpack != nullptr) {      // operand pack: every load is one coalesced 1 KB access
+    const f32x4* fp = reinterpret_cast<const f32x4*>(fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < D::KQ1 / 4; ++g) b1[g] = fp[g * 64];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b2[g] = fp[(D::KQ1 / 4 + g) * 64];
+    if (has_next) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b3[nt][g] = fp[(D::KQ1 / 4 + 4 + nt * 4 + g) * 64];
+    }
+  } else {
     const float* wrow = Wn1 + (size_t)col * D::KV;
     const int al = align_of(Wn1, D::KV);
 #pragma unroll
@@ -107,15 +215,28 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
   }
 
   // ---- X = [h | h_neigh | 0] rows of the tile -> LDS (wave w stages rows 8w .. 8w+7) ----
+  {
+    // all 16 row loads first (unconditional: clamped row / column), then the LDS stores: one memory round trip instead of
+    // a load -> store chain per row (the predicated form kept the compiler from hoisting the loads)
+    float hv[8], nv[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, row = row0 + lr;
-    const bool valid = row < N;
-    if (lane < DIN) xs[lr * D::LD1 + lane] = valid ? h[(size_t)row * ld_h + lane] : 0.0f;
-    xs[lr * D::LD1 + DIN + lane] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
-    if (lane < D::KP - D::KV) xs[lr * D::LD1 + D::KV + lane] = 0.0f;
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(row0 + wave * 8 + i, N - 1);
+      hv[i] = h[(size_t)row * ld_h + min(lane, DIN - 1)];
+      nv[i] = h_neigh[(size_t)row * ld_hn + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int lr = wave * 8 + i;
+      const bool valid = row0 + lr < N;
+      if (lane < DIN) xs[lr * D::LD1 + lane] = valid ? hv[i] : 0.0f;
+      xs[lr * D::LD1 + DIN + lane] = valid ? nv[i] : 0.0f;
+      if (lane < D::KP - D::KV) xs[lr * D::LD1 + D::KV + lane] = 0.0f;
+    }
   }
+  STAMPN(1);
   __syncthreads();
+  STAMPN(2);
 
   // ---- zn1 = X Wn1^T + bn1 ; a1 = SiLU(zn1) ----
   {
@@ -132,7 +253,9 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
         a1s[lr * LD + col] = silu_f(z);
       }
   }
+  STAMPN(3);
   __syncthreads();
+  STAMPN(4);
   // ---- h' = a1 Wn2^T + bn2 ----
   {
     f32x4 acc[2];
@@ -148,8 +271,10 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
         hps[lr * LD + col] = v;
       }
   }
+  STAMPN(5);
   if (!has_next) return;
   __syncthreads();
+  STAMPN(6);
   // ---- next layer's node pre-projection: wave w produces psd columns [32w, 32w + 32) ----
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -165,6 +290,7 @@ __global__ __launch_bounds__(256) void egnn_node_fwd16_kernel(
         if (row0 + lr < N) psd_next[(size_t)(row0 + lr) * 128 + c] = acc[mt][t] + b1n_c[nt];
       }
   }
+  STAMPN(7);
 }
 
 
@@ -195,7 +321,7 @@ __global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
     const float* __restrict__ g_h, const float* __restrict__ g_psd, const float* __restrict__ W1n, int ldw_n,
     const float* __restrict__ zn1, const float* __restrict__ Wn1, const float* __restrict__ Wn2,
     float* __restrict__ dh_total, float* __restrict__ dzn1, float* __restrict__ d_h, float* __restrict__ d_hneigh,
-    int N) {
+    int N, const float* __restrict__ bpack) {
   using D = Node16Dims<DIN>;
   constexpr int LDP = 132;
   __shared__ float ps_[32 * LDP];
@@ -206,38 +332,91 @@ __global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
   const int row0 = blockIdx.x * 32;
   const bool has_psd = g_psd != nullptr;
   const int col = wave * 16 + r;
+  STAMPN(8);
 
   // ---- transposed-weight operands (independent of the tile data) ----
   float bp[32], ba[16], bx[2][16];
-  if (has_psd) {
+  if (bpack != nullptr) {      // operand pack: 20 coalesced 16-byte loads per lane instead of 80 scattered dwords
+    const f32x4* pk = reinterpret_cast<const f32x4*>(bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
+    if (has_psd) {
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int c = q * 32 + s;   // psd column; quarters 0,1 -> Ps rows, 2,3 -> Pd rows
-      bp[s] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1n[(size_t)(c - 64) * ldw_n + 64 + col];
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 v = pk[g * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bp[4 * g + j] = v[j];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = pk[(8 + g) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ba[4 * g + j] = v[j];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = pk[(12 + nt * 4 + g) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bx[nt][4 * g + j] = v[j];
+      }
+  } else {
+    if (has_psd) {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int c = q * 32 + s;   // psd column; quarters 0,1 -> Ps rows, 2,3 -> Pd rows
+        bp[s] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1n[(size_t)(c - 64) * ldw_n + 64 + col];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ba[s] = Wn2[(size_t)(q * 16 + s) * H + col];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int xc = (wave * 2 + nt) * 16 + r;      // column of dX = [d_h | d_hneigh]
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bx[nt][s] = (xc < D::KV) ? Wn1[(size_t)(q * 16 + s) * D::KV + xc] : 0.0f;
     }
   }
+  // the epilogue inputs of this lane (rows mt*16 + 4q + t, column col): fetched now, consumed two / three stages later
+  float zpre[2][4], gpre[2][4];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) ba[s] = Wn2[(size_t)(q * 16 + s) * H + col];
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int xc = (wave * 2 + nt) * 16 + r;      // column of dX = [d_h | d_hneigh]
-#pragma unroll
-    for (int s = 0; s < 16; ++s) bx[nt][s] = (xc < D::KV) ? Wn1[(size_t)(q * 16 + s) * D::KV + xc] : 0.0f;
-  }
+    for (int t = 0; t < 4; ++t) {
+      const int row = min(row0 + mt * 16 + tile16_row(t, q), N - 1);
+      zpre[mt][t] = zn1[(size_t)row * H + col];
+      gpre[mt][t] = (has_psd && g_h != nullptr) ? g_h[(size_t)row * H + col] : 0.0f;
+    }
 
   // ---- stage g_psd (or g_h) rows: wave w stages rows 8w .. 8w+7 ----
+  {
+    float v0[8], v1[8];       // loads first (clamped rows), LDS stores afterwards: one memory round trip
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, row = row0 + lr;
-    const bool valid = row < N;
-    if (has_psd) {
-      ps_[lr * LDP + lane] = valid ? g_psd[(size_t)row * 128 + lane] : 0.0f;
-      ps_[lr * LDP + 64 + lane] = valid ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
-    } else {
-      gs[lr * LD + lane] = valid ? g_h[(size_t)row * H + lane] : 0.0f;
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(row0 + wave * 8 + i, N - 1);
+      if (has_psd) {
+        v0[i] = g_psd[(size_t)row * 128 + lane];
+        v1[i] = g_psd[(size_t)row * 128 + 64 + lane];
+      } else {
+        v0[i] = g_h[(size_t)row * H + lane];
+        v1[i] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int lr = wave * 8 + i;
+      const bool valid = row0 + lr < N;
+      if (has_psd) {
+        ps_[lr * LDP + lane] = valid ? v0[i] : 0.0f;
+        ps_[lr * LDP + 64 + lane] = valid ? v1[i] : 0.0f;
+      } else {
+        gs[lr * LD + lane] = valid ? v0[i] : 0.0f;
+      }
     }
   }
+  STAMPN(9);
   __syncthreads();
+  STAMPN(10);
   if (has_psd) {
     f32x4 acc[2];
     zero_acc4(acc);
@@ -249,7 +428,7 @@ __global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
         const int lr = mt * 16 + tile16_row(t, q), row = row0 + lr;
         float v = 0.0f;
         if (row < N) {
-          v = acc[mt][t] + (g_h != nullptr ? g_h[(size_t)row * H + col] : 0.0f);
+          v = acc[mt][t] + gpre[mt][t];
           dh_total[(size_t)row * H + col] = v;
         }
         gs[lr * LD + col] = v;
@@ -269,13 +448,14 @@ __global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
         float dz = 0.0f;
         if (row < N) {
           float y, dy;
-          silu_fg(zn1[(size_t)row * H + col], y, dy);
+          silu_fg(zpre[mt][t], y, dy);
           dz = acc[mt][t] * dy;
           dzn1[(size_t)row * H + col] = dz;
         }
         zs[lr * LD + col] = dz;
       }
   }
+  STAMPN(11);
   __syncthreads();
   // ---- dX = dzn1 Wn1 ----
 #pragma unroll
@@ -297,6 +477,7 @@ __global__ __launch_bounds__(256) void egnn_node_bwd_data16_kernel(
         }
     }
   }
+  STAMPN(12);
 }
 
 // Streaming weight-gradient kernel of one layer's node block (outer products over the N rows):
@@ -460,29 +641,50 @@ __global__ __launch_bounds__(256, 2) void egnn_node_wgrad16_batched_kernel(Wgrad
 
 }  // namespace is
 
+#ifdef IS_STAGE_STAMPS
+extern "C" int is_debug_stamps_node(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_node), sizeof(long long) * 16) == hipSuccess ? 0 : -5;
+}
+#endif
+
 extern "C" int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                                    const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
                                    const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
-                                   void* stream) {
+                                   const float* fpack, void* stream) {
   if (N <= 0) return 0;
   const dim3 grid((N + 31) / 32), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<20>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N);
-  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<64>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<20>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N, fpack);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd16_kernel<64>, grid, block, 0, st, h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b0n, b1n, zn1, h_out, psd_next, N, fpack);
   else return -22;
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 extern "C" int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
                                      int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
-                                     float* d_h, float* d_hneigh, int N, void* stream) {
+                                     float* d_h, float* d_hneigh, int N, const float* bpack, void* stream) {
   if (N <= 0) return 0;
   if (g_psd == nullptr && g_h == nullptr) return -22;
   const dim3 grid((N + 31) / 32), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (din == 20) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<20>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N);
-  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<64>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N);
+  if (din == 20) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<20>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N, bpack);
+  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_bwd_data16_kernel<64>, grid, block, 0, st, g_h, g_psd, W1n, ldw_n, zn1, Wn1, Wn2, dh_total, dzn1, d_h, d_hneigh, N, bpack);
   else return -22;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// jobs: host array of njobs (<= 8) records { const float *Wn1, *Wn2, *W1n; float *fpack, *bpack; int din, ldw_n, pad0, pad1; }
+// (W1n NULL: no next projection); fpack / bpack: is_node_pack_floats() floats each.  One launch for a whole stack.
+extern "C" int is_node_pack_floats(void) { return is::NODE_PACK_FLOATS; }
+extern "C" int is_node_pack_weights(const void* jobs, int njobs, void* stream) {
+  if (njobs <= 0 || njobs > is::NODE_PACK_MAX) return -22;
+  is::NodePackBatch batch;
+  const is::NodePackJob* src = static_cast<const is::NodePackJob*>(jobs);
+  for (int i = 0; i < njobs; ++i) {
+    batch.job[i] = src[i];
+    if (src[i].din != 20 && src[i].din != 64) return -22;
+  }
+  hipLaunchKernelGGL(is::node_pack_kernel, dim3(4, njobs), dim3(64), 0, static_cast<hipStream_t>(stream), batch);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

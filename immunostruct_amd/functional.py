@@ -20,6 +20,7 @@ _NODES_PER_TILE = 32
 # edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
 EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
 EDGE_FWD = os.environ.get("IMMUNOSTRUCT_EDGE_FWD", "v3")          # v3: wave-autonomous pipelined forward
+NODE_PACKS = os.environ.get("IMMUNOSTRUCT_NODE_PACKS", "1") != "0"     # lane-ordered operand packs for the node kernels
 WGRAD_ROWS = int(os.environ.get("IMMUNOSTRUCT_WGRAD_ROWS", "96"))     # rows per workgroup of a single-layer weight-gradient launch
 WGRAD_GRID = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID", "64"))     # workgroups per layer of the batched launch (x up to 8 layers)
 BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "auto")   # greedy 64-edge node tiles for the v2 backward: 1 | 0 | auto
@@ -272,6 +273,21 @@ class EGNNStackFn(torch.autograd.Function):
             _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0),
                                             _lib.ptr(psd), n, st), "is_node_proj_fwd")
         h_in, ld_h, din = h0, ld_h0, din0
+        packs = None
+        if NODE_KERNELS == "v2" and NODE_PACKS:
+            # operand packs of the node kernels for every layer, forward + backward order: ONE launch
+            pf = lib.is_node_pack_floats()
+            packs = torch.empty(n_layers, 2, pf, **f32)
+            jobs = []
+            for i in range(n_layers):
+                lp = params[i * P:(i + 1) * P]
+                last_i = i == n_layers - 1
+                w1n = (head[0] if head is not None else None) if last_i else params[(i + 1) * P]
+                jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), w1n.data_ptr() if w1n is not None else None,
+                                             packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN,
+                                             int(w1n.shape[1]) if w1n is not None else 0, 0, 0))
+            jarr = (_lib.NodePackJob * len(jobs))(*jobs)
+            _lib.check(lib.is_node_pack_weights(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_node_pack_weights")
         for i in range(n_layers):
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
             ldw = int(W1.shape[1])
@@ -314,13 +330,15 @@ class EGNNStackFn(torch.autograd.Function):
                 _lib.check(node_fwd(
                     _lib.ptr(h_in), ld_h, din, _lib.ptr(h_neigh), HIDDEN, _lib.ptr(Wn1), _lib.ptr(bn1), _lib.ptr(Wn2),
                     _lib.ptr(bn2), _lib.ptr(W1n), int(W1n.shape[1]) if emit else 0, *((_lib.ptr(b0n),) if NODE_KERNELS == "v2" else ()),
-                    _lib.ptr(b1n), _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), n, st), "is_egnn_node_fwd")
+                    _lib.ptr(b1n), _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), n,
+                    *((_lib.ptr(packs[i, 0]) if packs is not None else None,) if NODE_KERNELS == "v2" else ()), st), "is_egnn_node_fwd")
             layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
                                h_out=h_out))
             psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
         ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers = layers, params, csr, ea, fe, n_layers
         ctx.h0_needs_grad, ctx.x0_needs_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         ctx.head = head
+        ctx.packs = packs
         if head is not None:
             return h_in, x, psd
         return h_in, x
@@ -397,7 +415,9 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.check(lib.is_egnn_node_bwd_data(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(W1n),
                                                          int(W1n.shape[1]) if has_psd else 0, _lib.ptr(lay["zn1"]), din,
                                                          _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(dh_total) if has_psd else None,
-                                                         _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n, st), "is_egnn_node_bwd_data")
+                                                         _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n,
+                                                         _lib.ptr(ctx.packs[i, 1]) if ctx.packs is not None else None, st),
+                           "is_egnn_node_bwd_data")
                 keep.extend([dh_total, dzn1, g_psd_next, g_hd])
                 if batched:
                     pw = torch.empty(grid_w * wg_stride, **f32)

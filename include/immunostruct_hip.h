@@ -165,13 +165,21 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
  *                           partial record per workgroup = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out,
  *                           present when g_psd != NULL; is_egnn_node_wgrad_proj_floats floats) followed by
  *                           [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride is_egnn_node_wgrad_stride. */
+/* Operand packs of the node kernels: one launch per step rewrites the node-MLP / pre-projection weights of every layer
+ * in the order the lanes of is_egnn_node_fwd_v2 (fpack) and is_egnn_node_bwd_data (bpack) consume them, so each of
+ * their register operand loads is one coalesced 1 KB access (NULL pack: the kernels read the native tensors).
+ * jobs: host array of njobs (<= 8) records
+ *   { const float *Wn1, *Wn2, *W1n; float *fpack, *bpack; int din, ldw_n, pad0, pad1; }      (W1n may be NULL)
+ * with fpack / bpack of is_node_pack_floats() floats each.                                                  */
+int is_node_pack_floats(void);
+int is_node_pack_weights(const void* jobs, int njobs, void* stream);
 int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                         const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
                         const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
-                        void* stream);
+                        const float* fpack, void* stream);
 int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
                           int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
-                          float* d_h, float* d_hneigh, int N, void* stream);
+                          float* d_h, float* d_hneigh, int N, const float* bpack, void* stream);
 int is_egnn_node_wgrad_stride(void);
 int is_egnn_node_wgrad_proj_floats(void);
 int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, const float* zn1,
