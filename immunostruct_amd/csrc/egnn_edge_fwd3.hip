@@ -3,7 +3,7 @@
 // Same algorithm, inputs, outputs and summation order as egnn_edge_fwd16.hip (results are
 // bit-identical); what changes is how the work is cut and scheduled:
 //   * the destination nodes are cut into `nchunks` contiguous, NODE-ALIGNED ranges with (nearly) equal
-//     edge counts (chunk_ptr, built once per batch next to the CSR index).  One WAVE owns one chunk and
+//     edge counts (chunk_ptr rows = (first node, its first edge), built once per batch next to the CSR index).  One WAVE owns one chunk and
 //     walks its edges in 16-edge tiles that ignore node boundaries, so tiles are full (the node-tiled
 //     kernels left ~25 % of the matrix rows empty on degree-3 graphs) and no wave ever waits for another
 //     one: the only workgroup barrier is the one-time weight staging;
@@ -201,13 +201,12 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
   // ---- chunk of this wave ----
   const int c = blockIdx.x * W3 + wave;
   int va = 0, vb = 0, e0 = 0, e1 = 0;
-  if (c < nchunks) {
-    va = __builtin_amdgcn_readfirstlane(chunk_ptr[c]);
-    vb = __builtin_amdgcn_readfirstlane(chunk_ptr[c + 1]);
-    if (va < vb) {
-      e0 = __builtin_amdgcn_readfirstlane(rowptr[va]);
-      e1 = __builtin_amdgcn_readfirstlane(rowptr[vb]);
-    }
+  if (c < nchunks) {      // chunk_ptr rows = (node boundary, first edge of that node): one load level for both ranges
+    va = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * c]);
+    e0 = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * c + 1]);
+    vb = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * c + 2]);
+    e1 = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * c + 3]);
+    if (va >= vb) { e0 = 0; e1 = 0; }
   }
   FwdBufs B;
   B.ps = make_rsrc(ps); B.pd = make_rsrc(pd); B.x = make_rsrc(x); B.srcs = make_rsrc(srcs); B.dsts = make_rsrc(dsts);

@@ -62,8 +62,8 @@ class CSRIndex:
         return self._tiles[key]
 
     def chunks(self, k):
-        """``chunk_ptr`` (k+1,) int32: the destination nodes cut into k contiguous ranges with (nearly) equal
-        in-edge counts -- the unit of work of one wave of the v3 edge kernels."""
+        """``chunk_ptr`` (k+1, 2) int32 = (node boundary b_j, rowptr[b_j]): the destination nodes cut into k contiguous
+        ranges with (nearly) equal in-edge counts -- the unit of work of one wave of the v3 edge kernels."""
         k = int(k)
         if k not in self._chunks:
             self._chunks[k] = balanced_node_chunks(self.rowptr_dst, k)
@@ -101,7 +101,7 @@ def greedy_node_tiles(rowptr, num_edges, cap_edges, max_nodes):
 
 
 def balanced_node_chunks(rowptr, k):
-    """Boundaries b_0 = 0 <= b_1 <= ... <= b_k = N with b_j = first node whose first in-edge index is
+    """Rows (b_j, rowptr[b_j]) of the boundaries b_0 = 0 <= b_1 <= ... <= b_k = N with b_j = first node whose first in-edge index is
     >= j*E/k: node-aligned chunks of about E/k edges (a node of very high degree leaves its neighbours'
     chunks short or empty; nodes without in-edges ride along with the following node)."""
     n = rowptr.numel() - 1
@@ -111,7 +111,9 @@ def balanced_node_chunks(rowptr, k):
     b = torch.searchsorted(rp, targets, right=False)
     b[0] = 0
     b[-1] = n
-    return torch.clamp(b, max=n).to(torch.int32)
+    b = torch.clamp(b, max=n)
+    # (node boundary, first edge of that node) pairs: the kernel gets a chunk's node AND edge range with one load level
+    return torch.stack([b, rp[b]], dim=1).to(torch.int32).contiguous()
 
 
 def _rowptr(index, n):

@@ -97,8 +97,8 @@ int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float*
                         int Fe, void* stream);
 
 /* Third mapping of the forward edge pass (results bit-identical to v2): wave-autonomous and software-
- * pipelined.  `dsts` [E] = destination of every CSR slot; `chunk_ptr` [nchunks+1] = node-aligned,
- * edge-balanced cut of the destination nodes (b_0 = 0, b_nchunks = N, non-decreasing): one wave walks
+ * pipelined.  `dsts` [E] = destination of every CSR slot; `chunk_ptr` [nchunks+1][2] = rows (b_j, rowptr[b_j]) of the
+ * node-aligned, edge-balanced cut of the destination nodes (b_0 = 0, b_nchunks = N, non-decreasing): one wave walks
  * one chunk in full 16-edge tiles, prefetching the next tile's rows while the current one is on the
  * matrix cores.  E = number of CSR slots (rowptr[N] <= E); z2s / z3s (when not NULL) need at least
  * max(E, 16) rows: tiles are always stored at full width.                                           */

@@ -89,5 +89,7 @@ def test_balanced_node_chunks_cover_all_nodes():
     from immunostruct_amd.graph import balanced_node_chunks
     rowptr = torch.tensor([0, 3, 3, 10, 11, 11, 11, 40, 41], dtype=torch.int32)
     for k in (1, 2, 3, 8, 64):
-        b = balanced_node_chunks(rowptr, k).tolist()
+        t = balanced_node_chunks(rowptr, k)
+        b = t[:, 0].tolist()
         assert b[0] == 0 and b[-1] == 8 and len(b) == k + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        assert t[:, 1].tolist() == [int(rowptr[v]) for v in b]
