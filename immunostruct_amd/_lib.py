@@ -18,7 +18,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libimmunostruct_hip.so")
+LIB_PATH = os.environ.get("IMMUNOSTRUCT_LIB") or os.path.join(_HERE, "csrc", "libimmunostruct_hip.so")   # override: A/B builds
 
 _P, _I, _F, _LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 

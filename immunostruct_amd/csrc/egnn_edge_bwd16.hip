@@ -128,51 +128,53 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
+          // unconditional (row clamped into the tile's edge range; rows past nvalid are masked where they are used):
+          // predicated loads cost the compiler its count of loads in flight, and every later wait becomes vmcnt(0)
           const int row = tile16_row(t, q);
-          const bool rv = row < nvalid;
-          const size_t off = (size_t)(cb + row) * H + nt * 16 + r;
-          z3v[t][nt] = rv ? z3s[off] : 0.0f;
-          z2v[t][nt] = rv ? z2s[off] : 0.0f;
+          const size_t off = (size_t)min(cb + row, e_end - 1) * H + nt * 16 + r;
+          z3v[t][nt] = z3s[off];
+          z2v[t][nt] = z2s[off];
         }
       if (nvalid > 0) {
         // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
-        if (lane < TE16) {
-          const bool valid = lane < nvalid;
-          const int e = cb + lane;
-          int s = v0, dl = 0;
-          float d0 = 0.f, d1 = 0.f, d2 = 0.f, rad = 0.f, rr = 0.f, inv = 0.f;
-          float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-          if (valid) {
-            s = srcs[e];
-            int lo = 0, hi = nv;
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              if (sm.rp[mid] <= e) lo = mid; else hi = mid;
-            }
-            dl = lo;
-            const int v = v0 + dl;
-            d0 = x[s * 3 + 0] - x[v * 3 + 0];
-            d1 = x[s * 3 + 1] - x[v * 3 + 1];
-            d2 = x[s * 3 + 2] - x[v * 3 + 2];
-            rad = radial3(d0, d1, d2);
-            rr = sqrtf(rad);
-            inv = 1.0f / (rr + 1e-30f);
-            const float invdeg = 1.0f / (float)(sm.rp[dl + 1] - sm.rp[dl]);
-            g0 = g_xout[v * 3 + 0] * invdeg;
-            g1 = g_xout[v * 3 + 1] * invdeg;
-            g2 = g_xout[v * 3 + 2] * invdeg;
+        {
+          // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
+          const int l16 = lane & (TE16 - 1);
+          const bool valid = l16 < nvalid;
+          const int e = min(cb + l16, e_end - 1);
+          const int s = srcs[e];
+          int lo = 0, hi = nv;
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sm.rp[mid] <= e) lo = mid; else hi = mid;
           }
-          sm.e_src[wave][lane] = s;
-          sm.e_dl[wave][lane] = dl;
-          sm.e_rad[wave][lane] = rad;
-          sm.e_r[wave][lane] = rr;
-          sm.e_inv[wave][lane] = inv;
-          sm.e_d[wave][0][lane] = d0; sm.e_d[wave][1][lane] = d1; sm.e_d[wave][2][lane] = d2;
-          sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
-          sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+          const int dl = valid ? lo : 0;
+          const int v = v0 + dl;
+          const float xs0 = x[s * 3 + 0], xs1 = x[s * 3 + 1], xs2 = x[s * 3 + 2];
+          const float xv0 = x[v * 3 + 0], xv1 = x[v * 3 + 1], xv2 = x[v * 3 + 2];
+          const float gx0 = g_xout[v * 3 + 0], gx1 = g_xout[v * 3 + 1], gx2 = g_xout[v * 3 + 2];
+          float av[FE_MAX];
 #pragma unroll
-          for (int f = 0; f < FE_MAX; ++f)
-            sm.e_a[wave][f][lane] = (valid && f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;
+          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;      // Fe is kernel-uniform
+          float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
+          float rad = radial3(d0, d1, d2);
+          float rr = sqrtf(rad);
+          float inv = 1.0f / (rr + 1e-30f);
+          const float invdeg = 1.0f / (float)max(sm.rp[dl + 1] - sm.rp[dl], 1);
+          float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
+          if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
+          if (lane < TE16) {
+            sm.e_src[wave][lane] = valid ? s : v0;
+            sm.e_dl[wave][lane] = dl;
+            sm.e_rad[wave][lane] = rad;
+            sm.e_r[wave][lane] = rr;
+            sm.e_inv[wave][lane] = inv;
+            sm.e_d[wave][0][lane] = d0; sm.e_d[wave][1][lane] = d1; sm.e_d[wave][2][lane] = d2;
+            sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
+            sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+#pragma unroll
+            for (int f = 0; f < FE_MAX; ++f) sm.e_a[wave][f][lane] = valid ? av[f] : 0.0f;
+          }
         }
         __builtin_amdgcn_wave_barrier();
         STAMPB(2);
@@ -180,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
-          const int v = v0 + sm.e_dl[wave][row];
+          const int v = v0 + sm.e_dl[wave][row];      // e_dl = 0 for rows past nvalid: a valid node
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) up[t][nt] = (row < nvalid) ? g_hn[(size_t)v * ld_ghn + nt * 16 + r] : 0.0f;
+          for (int nt = 0; nt < 4; ++nt) up[t][nt] = g_hn[(size_t)v * ld_ghn + nt * 16 + r];
         }
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
