@@ -28,6 +28,19 @@ constexpr int MLP_MAX_HID = 64;
 constexpr int MLP_MAX_OUT = 64;
 constexpr int MLP_MAX_XROW = 512; // heads * in for grouped inputs
 
+// copy `count` floats with a per-element index map, 8 loads in flight per thread before the first LDS store
+// (a plain load -> store loop pays the global latency once per element and thread)
+template <typename SrcF, typename DstF>
+__device__ __forceinline__ void stage8(int count, int tid, SrcF src, DstF dst) {
+  for (int i0 = tid; i0 < count; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = (i < count) ? src(i) : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < count) dst(i, v[u]); }
+  }
+}
+
 struct MlpDims {
   int B, in, hid, out, ld_x, xrow, hgroup, act1, act2;
 };
@@ -46,15 +59,11 @@ __global__ __launch_bounds__(256) void mlp2_fwd_kernel(
   float* hs = xs + MLP_SPW * d.xrow;               // [SPW][hid]
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * MLP_SPW;
-  for (int idx = tid; idx < d.hid * d.in; idx += 256) {
-    const int h = idx / d.in, k = idx % d.in;
-    w1t[k * ldw + h] = W1[idx];
-  }
-  for (int idx = tid; idx < d.out * d.hid; idx += 256) w2s[idx] = W2[idx];
-  for (int idx = tid; idx < MLP_SPW * d.xrow; idx += 256) {
-    const int s = idx / d.xrow, c = idx % d.xrow;
-    xs[idx] = (s0 + s < d.B) ? x[(size_t)(s0 + s) * d.ld_x + c] : 0.0f;
-  }
+  stage8(d.hid * d.in, tid, [&](int i) { return W1[i]; }, [&](int i, float v) { w1t[(i % d.in) * ldw + i / d.in] = v; });
+  stage8(d.out * d.hid, tid, [&](int i) { return W2[i]; }, [&](int i, float v) { w2s[i] = v; });
+  stage8(MLP_SPW * d.xrow, tid,
+         [&](int i) { const int s = min(s0 + i / d.xrow, d.B - 1); return x[(size_t)s * d.ld_x + i % d.xrow]; },
+         [&](int i, float v) { xs[i] = (s0 + i / d.xrow < d.B) ? v : 0.0f; });
   __syncthreads();
   const int s = tid >> 5, u = tid & 31;
   const bool live = s0 + s < d.B;
@@ -93,12 +102,11 @@ __global__ __launch_bounds__(256) void mlp2_bwd_kernel(
   float* g2 = gh + MLP_SPW * d.hid;                // [SPW][out]   d loss / d pre-activation 2
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * MLP_SPW;
-  for (int idx = tid; idx < d.hid * d.in; idx += 256) w1s[(idx / d.in) * ldw + idx % d.in] = W1[idx];
-  for (int idx = tid; idx < d.out * d.hid; idx += 256) w2s[idx] = W2[idx];
-  for (int idx = tid; idx < MLP_SPW * d.xrow; idx += 256) {
-    const int s = idx / d.xrow, c = idx % d.xrow;
-    xs[idx] = (s0 + s < d.B) ? x[(size_t)(s0 + s) * d.ld_x + c] : 0.0f;
-  }
+  stage8(d.hid * d.in, tid, [&](int i) { return W1[i]; }, [&](int i, float v) { w1s[(i / d.in) * ldw + i % d.in] = v; });
+  stage8(d.out * d.hid, tid, [&](int i) { return W2[i]; }, [&](int i, float v) { w2s[i] = v; });
+  stage8(MLP_SPW * d.xrow, tid,
+         [&](int i) { const int s = min(s0 + i / d.xrow, d.B - 1); return x[(size_t)s * d.ld_x + i % d.xrow]; },
+         [&](int i, float v) { xs[i] = (s0 + i / d.xrow < d.B) ? v : 0.0f; });
   for (int idx = tid; idx < MLP_SPW * d.out; idx += 256) {
     const int s = idx / d.out, o = idx % d.out;
     float g = 0.0f;
@@ -191,7 +199,7 @@ extern "C" int is_mlp2_fwd(const float* x, int ld_x, const float* W1, const floa
   is::MlpDims d{B, in, hid, out, ld_x, hgroup > 0 ? (hid / (hgroup > 0 ? hgroup : 1)) * in : in, hgroup, act1, act2};
   if (!is::mlp_dims_ok(d)) return -22;
   const size_t lds = sizeof(float) * ((size_t)in * (hid + 1) + (size_t)out * hid + (size_t)is::MLP_SPW * d.xrow + (size_t)is::MLP_SPW * hid);
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)is::mlp2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)is::mlp2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(is::mlp2_fwd_kernel, dim3((B + is::MLP_SPW - 1) / is::MLP_SPW), dim3(256), lds, static_cast<hipStream_t>(stream),
                      x, W1, b1, W2, b2, mask, a1_out, y, d);
   return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -211,7 +219,7 @@ extern "C" int is_mlp2_bwd(const float* x, int ld_x, const float* W1, const floa
   if (!is::mlp_dims_ok(d)) return -22;
   const size_t lds = sizeof(float) * ((size_t)hid * (in + 1) + (size_t)out * hid + (size_t)is::MLP_SPW * d.xrow +
                                       2 * (size_t)is::MLP_SPW * hid + (size_t)is::MLP_SPW * out);
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)is::mlp2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)is::mlp2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(is::mlp2_bwd_kernel, dim3((B + is::MLP_SPW - 1) / is::MLP_SPW), dim3(256), lds, static_cast<hipStream_t>(stream),
                      x, W1, W2, mask, a1, y, gy, gx, partials, d);
   return hipGetLastError() == hipSuccess ? 0 : -5;
