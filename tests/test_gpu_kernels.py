@@ -458,6 +458,8 @@ def test_edge_forward_split_bf16_option_error_budget(cuda_device, monkeypatch):
     """The opt-in split-bf16 forward (IMMUNOSTRUCT_EDGE_FWD=v3x: x = hi + lo in bf16, three bf16 MFMAs per product) stays
     inside the forward tolerance of the fp32 kernels over a 6-layer stack; it is NOT the default because it is an order of
     magnitude less accurate than fp32 arithmetic (measured ~1e-5 vs ~6e-7 against fp64)."""
+    if HF.EDGE_KERNELS != "v2":
+        pytest.skip("the v3 / v3x forward is only selected with the v2 edge-kernel family")
     raw = synthetic.make_batch(4, seed=8)
     out = {}
     for mode in ("v3", "v3x"):
