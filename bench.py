@@ -116,6 +116,17 @@ def cpu_baseline(batch, deg_extra, budget_s=24.0):
                        f"{threads} torch threads of {all_threads} available, {dt:.1f} s; best of the all-threads and 16-thread samples)")
 
 
+def flush_c_stdio():
+    """libraries (RCCL) print through libc's buffered stdout, which would otherwise be flushed at exit -- AFTER the one
+    JSON line this script promises as its last output"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +146,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    if world == 1 and os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1":
+        # debugging aid: a one-rank RCCL group, so that --force-pack issues real (trivial) RCCL collectives on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     if os.environ.get("IMMUNOSTRUCT_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU (gloo)
         local_rank = int(os.environ["IMMUNOSTRUCT_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -179,6 +196,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush_c_stdio()       # RCCL's version banner sits in libc's stdout buffer: push it out now, not after the JSON line
     HF.KernelTimer.reset()
     HF.KernelTimer.enabled = args.eager and not args.no_kernel_timers
 
@@ -220,6 +238,8 @@ def main():
         #  by whatever the forked branch happens to execute next to it; the in-situ averages are in profiles/)
         from immunostruct_amd.models import _core as model_core
         overlap_saved, model_core.OVERLAP_BRANCHES = model_core.OVERLAP_BRANCHES, False
+        for bucket in reducer.buckets:      # the captured graphs are done: pack from the live .grad tensors again
+            bucket["sources"] = None
         for i in range(2):      # untimed: the first eager steps after the replays grow the allocator's pool (hipMalloc stalls)
             eager_step(args.warmup + i)
         torch.cuda.synchronize()
@@ -279,11 +299,16 @@ def main():
                                          f"E~{int(n_edges)} edges/batch (deg_extra={args.deg_extra}), Fe=1",
                                 global_batch=args.batch * world, nodes_per_batch=n_nodes, edges_per_batch=int(n_edges),
                                 parallelism=f"dp{world}", final_loss=round(final_loss, 5),
-                                launch="eager" if args.eager else "hipGraph replay"),
+                                launch="eager" if args.eager else "hipGraph replay",
+                                grad_allreduce=(None if (args.eager or not reducer.packing) else
+                                                dict(form="two-stage backward, bucket 0 overlapped" if captured.two_stage else "serial",
+                                                     buckets=[int(b["flat"].numel()) for b in reducer.buckets],
+                                                     tuned_ms=captured.dp_times))),
                     roofline=roof, cpu_baseline=cpu,
                     kernel_timers_us={k: [v[0], round(v[1] * 1e3, 2)] for k, v in timers.items()})
-        print(json.dumps(line))
-    if world > 1:
+        flush_c_stdio()
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -34,13 +34,17 @@ def init_from_env(backend=None):
 
 
 class FlatGradReducer:
-    """One flat fp32 gradient bucket per step, all-reduced with a single collective.
+    """Flat fp32 gradient buckets, each all-reduced with a single collective.
 
     ``zero()`` drops the gradients (autograd then *assigns* fresh ones: no per-parameter add kernels);
-    ``all_reduce_mean()`` packs them into the persistent flat bucket with ONE concatenation kernel,
-    all-reduces it (RCCL over xGMI: the whole 25 MB model as a single collective) and re-points every
-    ``.grad`` at its slice of the bucket, which is what the optimizer then reads.  With one rank and
-    ``always_pack=False`` both calls are no-ops apart from dropping the gradients.
+    ``all_reduce_mean()`` packs them into the persistent flat bucket(s) with ONE concatenation kernel each,
+    all-reduces (RCCL over xGMI: the whole 25 MB model as one or two collectives) and re-points every
+    ``.grad`` at its slice of a bucket, which is what the optimizer then reads.  With one rank and
+    ``always_pack=False`` all of this is a no-op apart from dropping the gradients.
+
+    ``split(late)`` cuts the parameters into two buckets (everything else / ``late``); ``reduce_bucket(i, async_op)``
+    handles one of them -- the engine all-reduces the first bucket (sequence branch + heads: 96 % of the bytes)
+    asynchronously while the backward of the graph branch, whose gradients form the second bucket, is still running.
     """
 
     def __init__(self, parameters, world=None, always_pack=False):
@@ -49,37 +53,72 @@ class FlatGradReducer:
             raise ValueError("no trainable parameters")
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.always_pack = always_pack
-        dev, total = self.params[0].device, sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev) if (self.world > 1 or always_pack) else None
-        self.sources = None   # gradient tensors to pack (defaults to the parameters' current .grad)
+        self._packing = self.world > 1 or always_pack
+        # debugging aid: issue the collectives even in a one-rank process group (exercises the RCCL launch path on one GPU)
+        self._collective = self.world > 1 or (os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
+        self.buckets = []
+        if self._packing:
+            self._make_buckets([self.params])
+
+    def _make_buckets(self, groups):
+        dev = self.params[0].device
+        self.buckets = [dict(params=g, flat=torch.zeros(sum(p.numel() for p in g), dtype=torch.float32, device=dev), sources=None)
+                        for g in groups if g]
 
     @property
     def packing(self):
-        return self.flat is not None
+        return self._packing
+
+    @property
+    def flat(self):
+        """the (first) flat bucket -- kept for callers that inspect it"""
+        return self.buckets[0]["flat"] if self.buckets else None
+
+    def split(self, late):
+        """two buckets: [parameters not in ``late``] and [``late``]; call before any source binding"""
+        if not self._packing:
+            return
+        late_ids = set(id(p) for p in late)
+        self._make_buckets([[p for p in self.params if id(p) not in late_ids], [p for p in self.params if id(p) in late_ids]])
 
     def zero(self):
         for p in self.params:
             p.grad = None
 
-    def bind_sources(self):
+    def bind_sources(self, bucket=None):
         """Remember the CURRENT .grad tensors as the pack sources (used with captured graphs, where the
         backward always writes the same buffers while ``.grad`` is re-pointed at the bucket)."""
-        self.sources = [p.grad for p in self.params]
+        for i, b in enumerate(self.buckets):
+            if bucket is None or bucket == i:
+                b["sources"] = [p.grad for p in b["params"]]
+
+    def sources(self, value=None):
+        """get (a copy of) / set the bound pack sources of all buckets -- the engine switches between captured forms"""
+        if value is None:
+            return [list(b["sources"]) if b["sources"] is not None else None for b in self.buckets]
+        for b, v in zip(self.buckets, value):
+            b["sources"] = v
+
+    def reduce_bucket(self, i, async_op=False):
+        """pack bucket i, pre-divide by the world size, all-reduce (SUM), re-point the gradients; returns the work handle"""
+        b = self.buckets[i]
+        src = b["sources"] if b["sources"] is not None else [p.grad for p in b["params"]]
+        pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(src, b["params"])]
+        torch.cat(pieces, out=b["flat"])
+        work = None
+        if self._collective:
+            b["flat"].div_(self.world)
+            work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=async_op)
+        off = 0
+        for p in b["params"]:
+            p.grad = b["flat"][off:off + p.numel()].view_as(p)
+            off += p.numel()
+        return work
 
     def all_reduce_mean(self, async_op=False):
-        if not self.packing:
-            return None
-        src = self.sources if self.sources is not None else [p.grad for p in self.params]
-        pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(src, self.params)]
-        torch.cat(pieces, out=self.flat)
         work = None
-        if self.world > 1:
-            self.flat.div_(self.world)
-            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for i in range(len(self.buckets)):
+            work = self.reduce_bucket(i, async_op=async_op)
         return work
 
 

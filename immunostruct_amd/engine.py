@@ -20,6 +20,8 @@ forward + loss + backward, eager all-reduce of the flat bucket, graph B = optimi
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .graph import CSRIndex, PackedGraphBatch
@@ -170,6 +172,17 @@ class CapturedTrainStep:
         fe = int(g.edata["edge_attr"].shape[1])
         for din in (20, HF.HIDDEN):
             HF.layer_plan(din, fe, g.device)
+        # data-parallel runs: backward in two stages so that the all-reduce of the first gradient bucket (everything
+        # above the EGNN stack: 96 % of the bytes) runs under the backward of the stack.  IMMUNOSTRUCT_DP_OVERLAP:
+        # "auto" (default) captures both forms, times them on this machine / process group and keeps the faster one;
+        # "1" / "0" force the two-stage / the serial form.
+        mode = os.environ.get("IMMUNOSTRUCT_DP_OVERLAP", "auto")
+        if mode not in ("auto", "0", "1"):
+            raise ValueError("IMMUNOSTRUCT_DP_OVERLAP must be auto, 0 or 1")
+        self.two_stage = False
+        self._want_two_stage = reducer.packing and mode != "0"
+        self._late = None
+        self.dp_times = None
         snap = _snapshot(model, optimizer) if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -180,21 +193,73 @@ class CapturedTrainStep:
         torch.cuda.synchronize()
         if snap is not None:
             _restore(model, optimizer, snap)      # the warm-up steps leave no trace: training starts from the caller's state
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss = self._fwd_bwd()
-            if self.fused_optimizer:
-                self.optimizer.step()
-                from .functional import Stamps
-                Stamps.mark("optimizer done")
-        self.graph_b = None
+        self.graph_a = self.graph_a1 = self.graph_a2 = self.graph_b = None
+        self._forms = {}
+        if self.two_stage:
+            self.graph_a1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a1):
+                loss = self._stage1()
+            # a graph always writes the gradient buffers it allocated while capturing: pack from those
+            self.reducer.bind_sources(0)
+            self.reducer.reduce_bucket(0)         # .grad of the first bucket now aliases its persistent flat buffer
+            self.graph_a2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a2, pool=self.graph_a1.pool()):
+                self._stage2()
+            self.reducer.bind_sources(1)
+            self.reducer.reduce_bucket(1)
+            self._forms[True] = (loss, self.reducer.sources())
+        if not self.two_stage or mode == "auto":
+            self.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a):
+                loss = self._fwd_bwd()
+                if self.fused_optimizer:
+                    self.optimizer.step()
+                    from .functional import Stamps
+                    Stamps.mark("optimizer done")
+            if not self.fused_optimizer:
+                self.reducer.bind_sources()
+                self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
+            self._forms[False] = (loss, self.reducer.sources())
         if not self.fused_optimizer:
-            # graph A always writes the gradient buffers it allocated while capturing: pack from those
-            self.reducer.bind_sources()
-            self.reducer.all_reduce_mean()        # .grad now aliases the persistent flat bucket
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self.optimizer.step()
+        if len(self._forms) == 2:
+            self._choose_form(model, optimizer)
+        else:
+            self._use_form(self.two_stage)
+
+    def _use_form(self, two_stage):
+        self.two_stage = two_stage
+        self.loss, sources = self._forms[two_stage]
+        self.reducer.sources(sources)
+
+    def _choose_form(self, model, optimizer, steps=8):
+        """time ``steps`` replays of the two-stage and of the serial form (max over ranks) and keep the faster one; the
+        steps taken for this leave no trace in the model or the optimizer"""
+        import time
+        import torch.distributed as dist
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        snap = _snapshot(model, optimizer)
+        times = {}
+        for form in (True, False):
+            self._use_form(form)
+            for k in range(2 + steps):
+                if k == 2:
+                    if multi:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                self.replay()
+            torch.cuda.synchronize()
+            times[form] = time.perf_counter() - t0
+        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.seq.device)
+        if multi:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+        t = t.tolist()
+        self.dp_times = {"two_stage_ms": 1e3 * t[0] / steps, "serial_ms": 1e3 * t[1] / steps}
+        _restore(model, optimizer, snap)
+        self._use_form(t[0] < t[1])
 
     def _load(self, g, seq, prop, y):
         multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
@@ -209,7 +274,77 @@ class CapturedTrainStep:
         Stamps.mark("backward done (main stream)")
         return loss.detach()
 
+    # ---- two-stage backward (data-parallel overlap) ---------------------------------
+    def _classify(self, loss, bnd):
+        """late = the parameters reachable from the loss ONLY through the EGNN stack outputs ``bnd`` (autograd graph walk)"""
+        def leaves(roots, stop):
+            seen, todo, out = set(), [r for r in roots if r is not None], set()
+            while todo:
+                fn = todo.pop()
+                if fn in seen or fn in stop:
+                    continue
+                seen.add(fn)
+                if hasattr(fn, "variable"):
+                    out.add(id(fn.variable))
+                todo.extend(f for f, _ in fn.next_functions if f is not None)
+            return out
+        cut = set(t.grad_fn for t in bnd if t.grad_fn is not None)
+        below = leaves(list(cut), set())
+        above = leaves([loss.grad_fn], cut)
+        late = [p for p in self.reducer.params if id(p) in below and id(p) not in above]
+        if late and len(late) < len(self.reducer.params):
+            self._late = late
+            ids = set(id(p) for p in late)
+            self._early = [p for p in self.reducer.params if id(p) not in ids]
+            self.reducer.split(late)
+            self.two_stage = True
+        else:
+            self._want_two_stage = False
+
+    def _stage1(self):
+        """forward, loss, and the backward of everything ABOVE the EGNN stack(s): gradients of the stack outputs and
+        of the parameters that do not feed the stack (sequence VAE, property MLP, attention values, heads)"""
+        from . import functional as HF
+        self.reducer.zero()
+        HF.StackBoundary.begin()
+        try:
+            loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        finally:
+            bnd = HF.StackBoundary.end()
+        if self._late is None:
+            self._classify(loss, bnd)      # first eager step
+            if not self.two_stage:
+                loss.backward()
+                self._bnd = self._bnd_grads = None
+                return loss.detach()
+        outs = torch.autograd.grad(loss, bnd + self._early, allow_unused=True)
+        pairs = [(t, g) for t, g in zip(bnd, outs[:len(bnd)]) if g is not None]
+        self._bnd, self._bnd_grads = [t for t, _ in pairs], [g for _, g in pairs]
+        for p, g in zip(self._early, outs[len(bnd):]):
+            p.grad = g
+        return loss.detach()
+
+    def _stage2(self):
+        """backward of the EGNN stack(s) from the gradients stage 1 left at their outputs"""
+        if self._bnd:
+            outs = torch.autograd.grad(self._bnd, self._late, grad_outputs=self._bnd_grads, allow_unused=True)
+            for p, g in zip(self._late, outs):
+                p.grad = g
+        self._bnd = self._bnd_grads = None
+
     def _body(self, eager=False):
+        if self._want_two_stage:
+            loss = self._stage1()
+            if self.two_stage:
+                work = self.reducer.reduce_bucket(0, async_op=True)
+                self._stage2()
+                self.reducer.reduce_bucket(1)
+                if work is not None:
+                    work.wait()
+            else:
+                self.reducer.all_reduce_mean()
+            self.optimizer.step()
+            return loss
         loss = self._fwd_bwd()
         self.reducer.all_reduce_mean()
         self.optimizer.step()
@@ -224,6 +359,15 @@ class CapturedTrainStep:
         on-device batcher (``data.DeviceResidentDataset.gather_into``) writes them directly."""
         if hasattr(self.optimizer, "refresh"):
             self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
+        if self.two_stage:
+            self.graph_a1.replay()
+            work = self.reducer.reduce_bucket(0, async_op=True)    # in flight while graph A2 runs the stack backward
+            self.graph_a2.replay()
+            self.reducer.reduce_bucket(1)
+            if work is not None:
+                work.wait()
+            self.graph_b.replay()
+            return self.loss
         self.graph_a.replay()
         if self.graph_b is not None:
             self.reducer.all_reduce_mean()

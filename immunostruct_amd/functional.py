@@ -48,6 +48,26 @@ NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
 BATCH_WGRAD = os.environ.get("IMMUNOSTRUCT_BATCH_WGRAD", "1") != "0"
 
 
+class StackBoundary:
+    """Collects the outputs of the EGNN stack(s) of one forward pass.  The data-parallel engine cuts the backward
+    there: everything above the stack first (its gradients go out on the all-reduce), the stack itself second."""
+    active = None
+
+    @classmethod
+    def begin(cls):
+        cls.active = []
+
+    @classmethod
+    def record(cls, *tensors):
+        if cls.active is not None:
+            cls.active.extend(t for t in tensors if t is not None and t.requires_grad)
+
+    @classmethod
+    def end(cls):
+        out, cls.active = cls.active or [], None
+        return out
+
+
 class Stamps:
     """Debug aid (IMMUNOSTRUCT_STAMPS=1): device wall-clock stamps at named points of a step, also inside a captured
     HIP graph -- the only way to see the schedule of a replayed graph without a profiler's perturbation."""

@@ -145,6 +145,7 @@ class MultimodalNet(nn.Module):
             h, x, qk = egnn_stack_forward(layers, g, h, x, a, head=head)
         else:
             h, x = egnn_stack_forward(layers, g, h, x, a)   # all layers, fused HIP kernels
+        HF.StackBoundary.record(h, x, qk)
         c = self.gat_hidden_channels
         if g.uniform_nodes_per_graph() is None:
             raise ValueError("all graphs of a batch must be padded to the same node count "

@@ -149,8 +149,8 @@ def test_full_train_step_gradients_vs_oracle(cuda_device):
 
 
 @pytest.mark.parametrize("optimizer", ["torch", "hip"])
-@pytest.mark.parametrize("always_pack", [False, True])
-def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimizer):
+@pytest.mark.parametrize("always_pack", [False, True, "serial", "auto"])
+def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimizer, monkeypatch):
     """engine.CapturedTrainStep (HIP-graph replay on static, fixed-capacity buffers) reproduces eager training.
 
     Batches with MORE and with FEWER edges than the captured one are replayed.  (Tolerance, not bit
@@ -158,6 +158,10 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
     from immunostruct_amd.distributed import FlatGradReducer
     from immunostruct_amd.engine import CapturedTrainStep
     dev = cuda_device
+    # True: the data-parallel path (two-stage backward, two gradient buckets, three graphs); "serial": the same
+    # with IMMUNOSTRUCT_DP_OVERLAP=0 (one backward graph, one bucket)
+    # "auto": both forms captured, the faster one (timed at construction, no trace left in the model) is used
+    monkeypatch.setenv("IMMUNOSTRUCT_DP_OVERLAP", {"serial": "0", "auto": "auto"}.get(always_pack, "1"))
     raws = [synthetic.make_batch(6, seed=s, deg_extra=d) for s, d in ((51, 2), (52, 4), (53, 1))]
     batches = [(H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev),
                 torch.from_numpy(r.prop).to(dev), torch.from_numpy(r.y_reg).to(dev)) for r in raws]
@@ -173,7 +177,7 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
         model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=6))
         model.eval()
-        red = FlatGradReducer(model.parameters(), world=1, always_pack=always_pack)   # True: the multi-rank two-graph path
+        red = FlatGradReducer(model.parameters(), world=1, always_pack=bool(always_pack))
         if optimizer == "torch":
             opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True, capturable=True)
         else:
@@ -183,6 +187,16 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         if captured:
             # construction performs one eager step on batches[0] (optimizer state must exist before capture)
             eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1)
+            if always_pack == "auto":
+                assert eng.dp_times is not None and set(eng._forms) == {True, False}
+            else:
+                assert eng.two_stage == (always_pack is True)
+            if eng._late is not None:
+                late = set(id(p) for p in eng._late)
+                names = sorted(k for k, p in model.named_parameters() if id(p) in late)
+                assert names and all(k.startswith("GCN_layers.") or k.startswith("self_attention.w_q") or k.startswith("self_attention.w_k")
+                                     for k in names), names
+                assert len(red.buckets) == 2
             for b in batches:
                 out.append(float(eng(*b)))
         else:
