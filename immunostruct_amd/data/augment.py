@@ -1,0 +1,208 @@
+"""Training-time augmentations and the split wrapper of the reference's loaders.
+
+Host side (per item, as the reference does in DataLoader workers):
+``SplitDataset`` (``data/util_dataloader.py:10-86``) over items ``(graph, sequence, target, property)`` -- or pairs of
+them -- with the reference's rules: only the ``train`` split is augmented; the coordinates get a random orthogonal
+transform (``data/utils.py:148-155``); with ``return_amino_acid`` one real residue has its one-hot replaced by all-ones
+and its index is returned for the self-supervised cross-entropy (``data/immmunopred_dataloader.py:104-115``; pairs:
+the same residue type in both graphs, ``:253-271``); ``structure_pad_count`` residues are blanked (``:91-102``) and
+``sequence_pad_count`` positions of the non-peptide part of the full sequence become the padding symbol (``:83-89``).
+The reference's quirk is kept: WITHOUT ``return_amino_acid`` the item's ORIGINAL graph is returned
+(``util_dataloader.py:82-86``), i.e. plain training sees un-rotated graphs.  ``ExtendedDataset`` (``:88-102``) and
+``collate_amino_acid`` (``data/utils.py:178-196``) complete the loader side.
+
+Device side: :func:`augment_batch_on_device` applies the same transforms to a whole batch assembled by
+``DeviceResidentDataset.gather_into`` -- a handful of batched torch launches on the static buffers, no host sync.
+"""
+from __future__ import annotations
+
+import copy
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ..graph import PackedGraphBatch
+from .utils import AMINO_ACIDS, RandomRotation, collate
+
+__all__ = ["SplitDataset", "ExtendedDataset", "collate_amino_acid", "mask_single_structure", "mask_single_structure_pair",
+           "mask_structure", "mask_sequence", "augment_batch_on_device", "mask_sequence_on_device"]
+
+N_AA = len(AMINO_ACIDS)
+PAD_INDEX = N_AA            # 'J', the last symbol of the 21-letter alphabet
+
+
+# ---- per-item (host) ----------------------------------------------------------------------------------
+def _onehot(graph):
+    return graph.ndata["x"][:, :-3]
+
+
+def mask_single_structure(graph):
+    """all-ones one-hot at one random real residue; returns (graph, residue index as a 1-element tensor)"""
+    feats = _onehot(graph)
+    for _ in range(feats.shape[0]):
+        node = random.randrange(feats.shape[0])
+        amino = torch.nonzero(feats[node], as_tuple=True)[0]
+        if amino.numel():
+            feats[node] = 1
+            return graph, amino
+    print("unmaskable graph: ", graph.ndata["x"])
+    return graph, torch.tensor([0])
+
+
+def mask_single_structure_pair(graph, graph_wt):
+    """one residue in ``graph`` and a residue of the same type in ``graph_wt``"""
+    fa, fb = _onehot(graph), _onehot(graph_wt)
+    order_a, order_b = list(range(fa.shape[0])), list(range(fb.shape[0]))
+    random.shuffle(order_a)
+    random.shuffle(order_b)
+    for i in order_a:
+        amino = torch.nonzero(fa[i], as_tuple=True)[0]
+        if not amino.numel():
+            continue
+        for j in order_b:
+            other = torch.nonzero(fb[j], as_tuple=True)[0]
+            if other.numel() == amino.numel() and bool((other == amino).all()):
+                fa[i] = 1
+                fb[j] = 1
+                return graph, graph_wt, amino
+    print("unmaskable graph: ", graph.ndata["x"], graph_wt.ndata["x"])
+    return graph, graph_wt, torch.tensor([0])
+
+
+def mask_structure(graph, count):
+    """blank the residue type of ``count`` random nodes (the self-supervision node, all ones, is left alone)"""
+    feats = _onehot(graph)
+    for node in random.sample(range(feats.shape[0]), count):
+        if float(feats[node].sum()) <= 1:
+            feats[node] = 0
+    return graph
+
+
+def mask_sequence(full, peptide, count):
+    """``count`` random positions before the trailing peptide become the padding symbol"""
+    pad = torch.zeros(full.shape[1], dtype=full.dtype)
+    pad[PAD_INDEX] = 1
+    for pos in random.sample(range(len(full) - len(peptide)), count):
+        full[pos] = pad
+    return full
+
+
+class SplitDataset:
+    """``dataset[idx]`` -> ``(graph, sequence, target, property)`` or the same with (cancer, wild-type) pairs;
+    ``peptide_length`` tells ``mask_sequence`` how many trailing positions belong to the peptide."""
+
+    def __init__(self, dataset, split, comparative=False, return_amino_acid=False, structure_pad_count=0,
+                 sequence_pad_count=0, peptide_length=11):
+        self.dataset, self.split, self.comparative = dataset, split, comparative
+        self.return_amino_acid = return_amino_acid
+        self.structure_pad_count, self.sequence_pad_count, self.peptide_length = structure_pad_count, sequence_pad_count, peptide_length
+
+    def __len__(self):
+        return len(self.dataset)
+
+    @staticmethod
+    def _rotated(graph):
+        g = copy.deepcopy(graph)
+        coords = g.ndata["x"][:, -3:]
+        g.ndata["x"][:, -3:] = torch.as_tensor(RandomRotation()(coords.numpy()), dtype=coords.dtype)
+        return g
+
+    def __getitem__(self, idx):
+        graph, sequence, target, prop = self.dataset[idx]
+        updated, amino = graph, None
+        if self.split == "train":
+            if not self.comparative:
+                updated = self._rotated(graph)
+                if self.return_amino_acid:
+                    updated, amino = mask_single_structure(updated)
+                if self.structure_pad_count > 0:
+                    updated = mask_structure(updated, self.structure_pad_count)
+            else:
+                assert len(graph) == 2
+                a, b = self._rotated(graph[0]), self._rotated(graph[1])
+                if self.return_amino_acid:
+                    a, b, amino = mask_single_structure_pair(a, b)
+                if self.structure_pad_count > 0:
+                    a, b = mask_structure(a, self.structure_pad_count), mask_structure(b, self.structure_pad_count)
+                updated = (a, b)
+            if self.sequence_pad_count > 0:
+                tail = slice(-self.peptide_length, None)
+                if not self.comparative:
+                    sequence = mask_sequence(sequence.clone(), sequence[tail], self.sequence_pad_count)
+                else:
+                    sequence = tuple(mask_sequence(s.clone(), s[tail], self.sequence_pad_count) for s in sequence)
+        if self.return_amino_acid:
+            return updated, sequence, target, prop, (amino if self.split == "train" else torch.tensor([0]))
+        return graph, sequence, target, prop          # the reference returns the ORIGINAL graph here
+
+
+class ExtendedDataset(Dataset):
+    """cycles through ``dataset`` until ``desired_len`` items were served (oversampling of the small cancer set)"""
+
+    def __init__(self, dataset, desired_len):
+        self.dataset, self.desired_len = dataset, desired_len
+
+    def __len__(self):
+        return self.desired_len
+
+    def __getitem__(self, idx):
+        return self.dataset[idx % len(self.dataset)]
+
+
+def collate_amino_acid(samples):
+    amino = torch.stack([s[4] for s in samples], dim=0).flatten()
+    return collate([s[:4] for s in samples]) + (amino,)
+
+
+# ---- whole batch (device) --------------------------------------------------------------------------------
+def _random_orthogonal(batch, device, generator):
+    """Haar-distributed 3x3 orthogonal matrices (Gram-Schmidt of Gaussian columns), no solver library involved"""
+    a = torch.randn(batch, 3, 3, device=device, generator=generator)
+    q1 = torch.nn.functional.normalize(a[:, :, 0], dim=1)
+    u2 = a[:, :, 1] - (q1 * a[:, :, 1]).sum(1, keepdim=True) * q1
+    q2 = torch.nn.functional.normalize(u2, dim=1)
+    u3 = a[:, :, 2] - (q1 * a[:, :, 2]).sum(1, keepdim=True) * q1 - (q2 * a[:, :, 2]).sum(1, keepdim=True) * q2
+    q3 = torch.nn.functional.normalize(u3, dim=1)
+    return torch.stack([q1, q2, q3], dim=2)
+
+
+def augment_batch_on_device(x, batch_size, generator=None, rotate=True, mask_single=True, structure_pad_count=0):
+    """In place on the node-feature buffer ``x`` ((batch_size * n) x (20 + 3)) of an assembled batch: per-graph random
+    orthogonal transform of the coordinates, one masked real residue per graph (all-ones one-hot), ``structure_pad_count``
+    blanked residues per graph.  Returns the masked residues' types (int64, one per graph; 0 for a graph with no real
+    residue, which is left unmasked -- the reference's fallback)."""
+    b = int(batch_size)
+    feats = x.view(b, x.shape[0] // b, x.shape[1])
+    n = feats.shape[1]
+    rows = torch.arange(b, device=x.device)
+    if rotate:
+        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], _random_orthogonal(b, x.device, generator))
+    onehot = feats[:, :, :-3]
+    amino = torch.zeros(b, dtype=torch.int64, device=x.device)
+    if mask_single:
+        valid = onehot.sum(-1) > 0
+        score = torch.rand(b, n, device=x.device, generator=generator).masked_fill(~valid, -1.0)
+        node = score.argmax(1)
+        picked = onehot[rows, node]
+        found = valid.any(1)
+        amino = torch.where(found, picked.argmax(1), amino)
+        onehot[rows, node] = torch.where(found[:, None], torch.ones_like(picked), picked)
+    if structure_pad_count > 0:
+        nodes = torch.rand(b, n, device=x.device, generator=generator).topk(structure_pad_count, dim=1).indices
+        r = rows[:, None].expand_as(nodes)
+        keep = (onehot[r, nodes].sum(-1, keepdim=True) > 1).to(x.dtype)      # the self-supervision node stays
+        onehot[r, nodes] = onehot[r, nodes] * keep
+    return amino
+
+
+def mask_sequence_on_device(seq, count, peptide_length=11, generator=None):
+    """In place on the one-hot sequences ``seq`` (B x L x 21): ``count`` random non-peptide positions -> padding symbol"""
+    if count <= 0:
+        return seq
+    b, length = seq.shape[0], seq.shape[1] - peptide_length
+    pos = torch.rand(b, length, device=seq.device, generator=generator).topk(count, dim=1).indices
+    r = torch.arange(b, device=seq.device)[:, None].expand_as(pos)
+    seq[r, pos] = torch.nn.functional.one_hot(torch.tensor(PAD_INDEX, device=seq.device), seq.shape[2]).to(seq.dtype)
+    return seq

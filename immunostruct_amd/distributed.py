@@ -1,4 +1,4 @@
-"""Data-parallel training: one process per GPU, RCCL all-reduce of ONE flat gradient bucket.
+"""Data-parallel training: one process per GPU, RCCL all-reduce of one or two flat gradient buckets.
 
 The reference is single-process; graphs are independent units, so the batched-graph
 train step shards over ranks with no data-path collective: rank r trains on ``perm[r::world]`` of each

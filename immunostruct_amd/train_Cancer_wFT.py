@@ -13,11 +13,12 @@ import torch
 from torch.utils.data import DataLoader, random_split
 
 from . import optim
-from .data import DeviceResidentDataset, SyntheticImmunoDataset, SyntheticPairedDataset, collate
+from .data import (DeviceResidentDataset, ExtendedDataset, SplitDataset, SyntheticImmunoDataset, SyntheticPairedDataset,
+                   collate, collate_amino_acid)
 from .models.mapping import model_map
-from .procedures import (binary_metrics, predict_proba, train_model, train_model_comparative, train_model_comparative_device,
-                         train_model_device)
-from .utils import Losses, seed_everything
+from .procedures import (inference_comparative, inference_comparative_SSL, train_model, train_model_comparative,
+                         train_model_comparative_device, train_model_comparative_SSL, train_model_device, train_model_SSL)
+from .utils import LinearWarmupCosineAnnealingLR, Losses, seed_everything
 
 
 def parse_args(argv=None):
@@ -35,23 +36,16 @@ def parse_args(argv=None):
     p.add_argument("--model-save-dir", default="./checkpoints/comparative/", type=str)
     p.add_argument("--seed", default=1, type=int)
     p.add_argument("--coeff-contrastive", default=0, type=float)
+    p.add_argument("--sequence-pad-count", default=0, type=int)
+    p.add_argument("--structure-pad-count", default=0, type=int)
+    p.add_argument("--self-supervision", action="store_true")   # for the *_SSL models: masked-residue prediction
     p.add_argument("--synthetic", default=0, type=int)
     p.add_argument("--device-dataset", action="store_true",
                    help="keep the datasets in HBM and assemble batches on the GPU (data.DeviceResidentDataset)")
     return p.parse_args(argv)
 
 
-class _Extended(torch.utils.data.Dataset):
-    """modulo oversampling to at least ``desired_len`` items (reference ``data/util_dataloader.py:91-102``)."""
-
-    def __init__(self, dataset, desired_len):
-        self.dataset, self.desired_len = dataset, desired_len
-
-    def __len__(self):
-        return self.desired_len
-
-    def __getitem__(self, idx):
-        return self.dataset[idx % len(self.dataset)]
+_Extended = ExtendedDataset      # modulo oversampling (reference data/util_dataloader.py:88-102)
 
 
 def main(argv=None):
@@ -71,7 +65,16 @@ def main(argv=None):
     input_dim = 283 * 21
     model = model_map[config.model](vae_input_dim=input_dim, device=device,
                                     use_wt_for_downstream=config.use_wt_for_downstream).to(device)
-    mk = lambda d, sh: DataLoader(d, batch_size=config.batch_size, collate_fn=collate, shuffle=sh, num_workers=config.num_workers)
+    ssl = config.self_supervision
+    if ssl and config.device_dataset:
+        raise SystemExit("--self-supervision with --device-dataset is implemented for the single-graph entry point only")
+    pads = dict(structure_pad_count=config.structure_pad_count, sequence_pad_count=config.sequence_pad_count)
+
+    def mk(d, split, comparative=False):
+        # the reference's split wrapper: train-time augmentation; with --self-supervision a fifth field (masked residue)
+        wrapped = SplitDataset(d, split, comparative=comparative, return_amino_acid=ssl, **pads)
+        return DataLoader(wrapped, batch_size=config.batch_size, collate_fn=collate_amino_acid if ssl else collate,
+                          shuffle=split == "train", num_workers=config.num_workers)
 
     # stage 1: IEDB-style single-graph pretraining through the plain forward
     ds1 = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=False)
@@ -82,7 +85,8 @@ def main(argv=None):
         train_model_device(config, device, model, DeviceResidentDataset(ds1, device), tr.indices, va.indices, opt,
                            losses.regression_loss, seed=config.seed)
     else:
-        train_model(config, device, model, mk(tr, True), mk(va, False), opt, losses.regression_loss)
+        (train_model_SSL if ssl else train_model)(config, device, model, mk(tr, "train"), mk(va, "val"), opt,
+                                                  losses.regression_loss_SSL if ssl else losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
     # stage 2: comparative pretraining on (cancer, wild-type) pairs, continuous target
@@ -97,9 +101,10 @@ def main(argv=None):
             return train_model_comparative_device(config, device, model, DeviceResidentDataset(ds.c, device),
                                                   DeviceResidentDataset(ds.w, device), idx(tr_), idx(va_), opt_, loss_fn,
                                                   sched_, stage=stage, seed=config.seed)
-        return train_model_comparative(config, device, model, mk(tr_, True), mk(va_, False), opt_, loss_fn, sched_, stage=stage)
+        run = train_model_comparative_SSL if ssl else train_model_comparative
+        return run(config, device, model, mk(tr_, "train", True), mk(va_, "val", True), opt_, loss_fn, sched_, stage=stage)
 
-    fit_pairs(ds2, tr2, va2, opt, losses.regression_loss)
+    fit_pairs(ds2, tr2, va2, opt, losses.regression_loss_SSL if ssl else losses.regression_loss)
     model.load_trained(config.model_save_path_pretrain, new_head=True)
 
     # stage 3: comparative finetuning, BCE (+ coeff * paired contrastive loss)
@@ -108,14 +113,15 @@ def main(argv=None):
     want = config.min_finetuning_batches * config.batch_size
     tr3 = _Extended(tr3, want) if len(tr3) < want else tr3
     opt = optim.AdamW(model.parameters(), lr=config.learning_rate_finetune, weight_decay=1e-6)
-    sched = torch.optim.lr_scheduler.SequentialLR(opt, [
-        torch.optim.lr_scheduler.LinearLR(opt, 0.01, 1.0, total_iters=max(config.num_epochs // 4, 1)),
-        torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(config.num_epochs - config.num_epochs // 4, 1))],
-        milestones=[max(config.num_epochs // 4, 1)])
-    fit_pairs(ds3, tr3, va3, opt, losses.BCE_loss, sched, stage="finetune")
+    sched = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=config.num_epochs // 4,
+                                          warmup_start_lr=config.learning_rate_finetune / 100, max_epochs=config.num_epochs)
+    fit_pairs(ds3, tr3, va3, opt, losses.BCE_loss_SSL if ssl else losses.BCE_loss, sched, stage="finetune")
     model.load_trained(config.model_save_path_finetune, new_head=False)
-    prob, y = predict_proba(model, mk(te3, False), device, comparative=True)
-    print("test metrics:", binary_metrics(y, prob))
+    # metrics as the reference reports them (train_Cancer_wFT.py:178-190): threshold from the train pairs, applied to the test pairs
+    infer = inference_comparative_SSL if ssl else inference_comparative
+    train_stats = infer(config, model, mk(tr3, "train", True), device)
+    test_stats = infer(config, model, mk(te3, "test", True), device, optimal_threshold=train_stats["optimal_threshold"])
+    return train_stats, test_stats
 
 
 if __name__ == "__main__":

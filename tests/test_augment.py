@@ -1,0 +1,123 @@
+"""Loader-side augmentations: per-item host functions with the reference's rules
+(``data/util_dataloader.py:10-86``, ``data/immmunopred_dataloader.py:83-115,232-271``) and the batched on-device form."""
+import random
+
+import numpy as np
+import torch
+
+from immunostruct_amd import data as D
+from immunostruct_amd.data import augment as A
+
+
+def dataset(n=6, seed=11):
+    return D.SyntheticImmunoDataset(n, seed=seed)
+
+
+def real_rows(g):
+    return (g.ndata["x"][:, :-3].sum(1) > 0).nonzero().flatten()
+
+
+def test_mask_single_structure_marks_one_real_residue():
+    random.seed(0)
+    g0 = dataset()[0][0]
+    for _ in range(5):
+        g = A.SplitDataset._rotated(g0)
+        before = g.ndata["x"].clone()
+        g, amino = A.mask_single_structure(g)
+        changed = (g.ndata["x"] != before).any(1).nonzero().flatten()
+        assert changed.numel() == 1 and int(changed) in set(real_rows(g0).tolist())
+        node = int(changed)
+        assert bool((g.ndata["x"][node, :-3] == 1).all())
+        assert amino.shape == (1,) and int(before[node, :-3].argmax()) == int(amino)
+        assert torch.equal(g.ndata["x"][node, -3:], before[node, -3:])
+    empty = A.SplitDataset._rotated(g0)
+    empty.ndata["x"][:, :-3] = 0
+    _, amino = A.mask_single_structure(empty)
+    assert amino.tolist() == [0] and float(empty.ndata["x"][:, :-3].sum()) == 0      # the reference's fallback
+
+
+def test_pair_mask_picks_the_same_residue_type():
+    random.seed(1)
+    ds = D.SyntheticPairedDataset(4, seed=5)
+    (ga, gb), _, _, _ = ds[1]
+    a, b = A.SplitDataset._rotated(ga), A.SplitDataset._rotated(gb)
+    a, b, amino = A.mask_single_structure_pair(a, b)
+    for g, orig in ((a, ga), (b, gb)):
+        node = (g.ndata["x"][:, :-3].sum(1) > 1).nonzero().flatten()
+        assert node.numel() == 1 and int(orig.ndata["x"][int(node), :-3].argmax()) == int(amino)
+
+
+def test_mask_structure_and_sequence():
+    random.seed(2)
+    g0, seq, _, _ = dataset()[2]
+    g = A.SplitDataset._rotated(g0)
+    g, _ = A.mask_single_structure(g)
+    g = A.mask_structure(g, 7)
+    rows = g.ndata["x"][:, :-3].sum(1)
+    assert int((rows > 1).sum()) == 1                                     # the self-supervision node survives
+    assert int((rows == 0).sum()) >= int((g0.ndata["x"][:, :-3].sum(1) == 0).sum())
+    assert int((rows == 1).sum()) >= real_rows(g0).numel() - 8
+    s = A.mask_sequence(seq.clone(), seq[-11:], 9)
+    diff = (s != seq).any(1).nonzero().flatten()
+    assert diff.numel() <= 9 and (diff.numel() == 0 or int(diff.max()) < len(seq) - 11)
+    assert bool((s[diff].argmax(1) == A.PAD_INDEX).all())
+
+
+def test_split_dataset_rules():
+    random.seed(3)
+    np.random.seed(3)
+    ds = dataset()
+    plain = A.SplitDataset(ds, "train")
+    assert plain[0][0] is ds[0][0] and len(plain[0]) == 4                # the reference's quirk: the ORIGINAL graph
+    ssl = A.SplitDataset(ds, "train", return_amino_acid=True)
+    g, seq, y, prop, amino = ssl[0]
+    orig = ds[0][0]
+    assert g is not orig and amino.shape == (1,)
+    rows = real_rows(orig)
+    d0 = torch.cdist(orig.ndata["x"][rows, -3:], orig.ndata["x"][rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
+    d1 = torch.cdist(g.ndata["x"][rows, -3:], g.ndata["x"][rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
+    assert torch.allclose(d0, d1, atol=1e-3) and not torch.allclose(orig.ndata["x"][rows, -3:], g.ndata["x"][rows, -3:])
+    assert float(orig.ndata["x"][:, :-3].max()) == 1 and int((orig.ndata["x"][:, :-3].sum(1) > 1).sum()) == 0   # untouched
+    val = A.SplitDataset(ds, "val", return_amino_acid=True)[0]
+    assert val[0] is orig and val[4].tolist() == [0]
+    batch = D.collate_amino_acid([ssl[i] for i in range(4)])
+    assert len(batch) == 5 and batch[4].shape == (4,) and batch[0].batch_size == 4 and batch[1].shape[0] == 4
+    pairs = D.SyntheticPairedDataset(4, seed=5)
+    item = A.SplitDataset(pairs, "train", comparative=True, return_amino_acid=True, structure_pad_count=2, sequence_pad_count=3)[0]
+    assert len(item[0]) == 2 and len(item[1]) == 2 and item[4].shape == (1,)
+    pb = D.collate_amino_acid([item, item])
+    assert pb[0][0].batch_size == 2 and pb[4].shape == (2,)
+    ext = D.ExtendedDataset(ds, 15)
+    assert len(ext) == 15 and ext[13][0] is ds[13 % len(ds)][0]
+
+
+def test_augment_batch_on_device_form():
+    ds = dataset(8, seed=4)
+    x0 = torch.cat([ds[i][0].ndata["x"] for i in range(8)]).clone()
+    n = ds[0][0].num_nodes()
+    x0.view(8, n, -1)[5, :, :-3] = 0                                          # a graph with no real residue
+    x = x0.clone()
+    gen = torch.Generator().manual_seed(9)
+    amino = A.augment_batch_on_device(x, 8, gen, structure_pad_count=3)
+    f0, f1 = x0.view(8, n, -1), x.view(8, n, -1)
+    for b in range(8):
+        marked = (f1[b, :, :-3].sum(1) > 1).nonzero().flatten()
+        if b == 5:
+            assert marked.numel() == 0 and int(amino[b]) == 0
+            continue
+        assert marked.numel() == 1
+        node = int(marked)
+        assert float(f0[b, node, :-3].sum()) == 1 and int(f0[b, node, :-3].argmax()) == int(amino[b])
+        blanked = ((f0[b, :, :-3].sum(1) == 1) & (f1[b, :, :-3].sum(1) == 0)).sum()
+        assert int(blanked) <= 3
+        rows = (f0[b, :, :-3].sum(1) > 0).nonzero().flatten()
+        d0, d1 = torch.cdist(f0[b, rows, -3:], f0[b, rows, -3:], compute_mode="donot_use_mm_for_euclid_dist"), torch.cdist(f1[b, rows, -3:], f1[b, rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
+        assert torch.allclose(d0, d1, atol=2e-3)
+        assert not torch.allclose(f0[b, rows, -3:], f1[b, rows, -3:])
+    q = A._random_orthogonal(16, torch.device("cpu"), gen)
+    assert torch.allclose(q.transpose(1, 2) @ q, torch.eye(3).expand(16, 3, 3), atol=1e-5)
+    seq = torch.stack([ds[i][1] for i in range(8)]).clone()
+    s = A.mask_sequence_on_device(seq.clone(), 5, generator=gen)
+    changed = (s != seq).any(2)
+    assert int(changed[:, -11:].sum()) == 0 and bool((changed.sum(1) <= 5).all())
+    assert bool((s[changed].argmax(1) == A.PAD_INDEX).all())

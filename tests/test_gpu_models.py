@@ -221,7 +221,7 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
 def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     """both entry points: pretrain -> new head -> finetune -> inference on a small synthetic set (1 epoch)."""
     from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
-    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "48",
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160",
               "--model-save-dir", str(tmp_path)]
     train_IEDB_wFT.main(["--model", "HybridModelv2"] + common)
     train_IEDB_wFT.main(["--model", "HybridModelv2", "--device-dataset", "--seed", "3"] + common)      # on-GPU batcher + captured step
@@ -229,6 +229,61 @@ def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     train_Cancer_wFT.main(["--use-wt-for-downstream", "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2",
                            "--device-dataset", "--seed", "3"] + common)
     assert len(list(tmp_path.glob("*_finetune.pt"))) == 4
+
+
+def test_entry_scripts_self_supervision(cuda_device, tmp_path):
+    """--self-supervision: masked-residue augmentation -> 5-field batches -> *_SSL models and losses ->
+    inference with the train-set Youden threshold; loader path, on-device (captured) path, and the paired script."""
+    from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160",
+              "--self-supervision", "--structure-pad-count", "2", "--sequence-pad-count", "3", "--model-save-dir", str(tmp_path)]
+    keys = {"optimal_threshold", "accuracy", "accuracy_op", "f1", "f1_op", "precision", "precision_op", "recall", "recall_op",
+            "roc_auc", "pr_auc", "ppvn", "ppvn_op", "ppv30", "ppv30_op"}
+    for extra in ([], ["--device-dataset", "--seed", "3"]):
+        train_stats, test_stats = train_IEDB_wFT.main(["--model", "HybridModelv2_SSL"] + common + extra)
+        assert set(train_stats) == keys and set(test_stats) == keys
+        assert test_stats["optimal_threshold"] == train_stats["optimal_threshold"]
+        assert all(np.isfinite(float(v)) for v in train_stats.values())
+    train_stats, test_stats = train_Cancer_wFT.main(["--model", "HybridModelv2_Comparative_SSL", "--use-wt-for-downstream",
+                                                     "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common)
+    assert set(test_stats) == keys and 0.0 <= test_stats["roc_auc"] <= 1.0
+
+
+def test_inference_matches_host_loop(cuda_device):
+    """procedures.inference: probabilities collected on the device == per-batch sigmoid of the model's logits; metric
+    dictionary == metric functions on those arrays (reference procedures/infer.py:9-50)."""
+    from torch.utils.data import DataLoader
+    from immunostruct_amd.data import SyntheticImmunoDataset, SyntheticPairedDataset, collate
+    from immunostruct_amd.procedures import evaluate_metrics, find_optimal_threshold, inference, inference_comparative
+    dev = cuda_device
+    ds = SyntheticImmunoDataset(40, seed=8, binary=True)
+    model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+    loader = DataLoader(ds, batch_size=16, collate_fn=collate)
+    torch.manual_seed(77)          # the VAE samples eps in eval mode too (reference hybrid_models.py:297-300)
+    out = inference(None, model, loader, dev, return_raw_preds=True, optimal_threshold=0.5322)
+    probs = []
+    model.eval()
+    torch.manual_seed(77)
+    with torch.no_grad():
+        for g, seq, y, prop in loader:
+            probs.append(torch.sigmoid(model(g.to(dev), seq.to(dev), prop.to(dev))[3]).reshape(-1).cpu())
+    probs = torch.cat(probs).numpy().astype(np.float64)
+    np.testing.assert_allclose(out["predicted_probs"], probs, rtol=1e-6)
+    np.testing.assert_array_equal(out["true_targets"], ds.y.numpy())
+    want = evaluate_metrics(out["true_targets"], out["predicted_probs"], 0.5322)
+    assert all(out[k] == want[k] for k in want) and out["optimal_threshold"] == 0.5322
+    # without a given threshold: Youden's J on this very set (an untrained model can sit below chance, where the
+    # reference's assertion on the threshold fires -- same behaviour here)
+    flipped = 1.0 - out["true_targets"] if out["roc_auc"] < 0.5 else out["true_targets"]
+    thr = find_optimal_threshold(flipped, out["predicted_probs"])
+    assert thr in out["predicted_probs"]
+    with pytest.raises(NotImplementedError):
+        inference(None, model, loader, dev, clinical_loader=loader)
+    pairs = SyntheticPairedDataset(24, seed=9, binary=True)
+    pm = model_map["HybridModelv2_Comparative"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+    pout = inference_comparative(None, pm, DataLoader(pairs, batch_size=8, collate_fn=collate), dev, return_raw_preds=True,
+                                 optimal_threshold=0.5)
+    assert pout["predicted_probs"].shape == (24,) and 0 <= pout["roc_auc"] <= 1
 
 
 def test_device_batcher_matches_collate(cuda_device):
