@@ -61,6 +61,27 @@ class DeviceResidentDataset:
         self.prop = torch.stack([torch.as_tensor(it[3]).float() for it in items]).contiguous().to(device)
         self.device = self.x.device          # canonical form ("cuda" -> "cuda:0")
 
+    @classmethod
+    def from_packed(cls, packed, device, binary=None):
+        """straight from a :class:`~immunostruct_amd.data.PackedDataset` (``.npz`` of ``data.convert_pyg_directory``): the file
+        already holds this class' arrays, so loading is a handful of H2D copies -- no per-graph Python objects, no sorting"""
+        if packed.seq is None:
+            raise ValueError("the packed dataset has no labels attached")
+        device = torch.device(device)
+        self = object.__new__(cls)
+        self.num_graphs, self.nodes_per_graph, self.node_feats = (int(v) for v in packed.x.shape)
+        self.edge_feats = int(packed.ea.shape[1])
+        self.max_edges = int((packed.eoff[1:] - packed.eoff[:-1]).max())
+        for name, value in (("x", packed.x), ("eoff", packed.eoff), ("rowptr_dst", packed.rowptr_dst), ("rowptr_src", packed.rowptr_src),
+                            ("src", packed.src), ("dst", packed.dst), ("pos", packed.pos), ("ea", packed.ea), ("prop", packed.prop)):
+            setattr(self, name, value.contiguous().to(device))
+        # tokens -> one-hot on the device (the file stores one byte per position)
+        self.seq = torch.nn.functional.one_hot(packed.seq.to(device).long(), 21).float()
+        binary = packed.binary if binary is None else binary
+        self.y = (packed.y_bin if binary else packed.y_reg).contiguous().to(device)
+        self.device = self.x.device
+        return self
+
     def __len__(self):
         return self.num_graphs
 

@@ -249,6 +249,39 @@ def test_entry_scripts_self_supervision(cuda_device, tmp_path):
     assert set(test_stats) == keys and 0.0 <= test_stats["roc_auc"] <= 1.0
 
 
+def test_entry_script_on_packed_file(cuda_device, tmp_path):
+    """--packed: the .npz of data.PackedDataset feeds the host loader path and, array for array, the
+    on-GPU batcher; the device path assembles the same batches as collate on the items of the same file."""
+    from immunostruct_amd import train_IEDB_wFT
+    from immunostruct_amd.data import DeviceResidentDataset, PackedDataset, collate
+    raw = synthetic.make_batch(96, seed=21)
+    n = int(raw.batch_num_nodes[0])
+    gid = raw.dst // n
+    graphs = [(torch.from_numpy(raw.x[i * n:(i + 1) * n]), torch.from_numpy(raw.src[gid == i] - i * n),
+               torch.from_numpy(raw.dst[gid == i] - i * n)) for i in range(96)]
+    tokens = raw.one_hot_sequence().argmax(-1)
+    alphabet = "ACDEFGHIKLMNPQRSTVWYJ"
+    names = [f"s{i}" for i in range(96)]
+    labels = {nm: ("".join(alphabet[t] for t in tokens[i]), float(raw.prop[i, 0]), float(raw.prop[i, 1]), float(raw.y_bin[i]),
+                   float(raw.y_reg[i])) for i, nm in enumerate(names)}
+    path = str(tmp_path / "iedb_packed.npz")
+    PackedDataset.from_graphs(graphs, names, labels=labels).save(path)
+    packed = PackedDataset.load(path)
+    dds = DeviceResidentDataset.from_packed(packed, cuda_device)
+    idx = torch.tensor([5, 90, 17, 3], device=cuda_device)
+    g, seq, prop, y = dds.gather_into(idx, *dds.new_batch(4))
+    hg, hseq, hy, hprop = collate([packed[int(i)] for i in idx])
+    assert torch.equal(g.ndata["x"].cpu(), hg.ndata["x"]) and torch.equal(seq.cpu(), hseq) and torch.equal(y.cpu(), hy)
+    hc = hg.csr()
+    e = hc.num_edges
+    assert torch.equal(g._csr.src_sorted[:e].cpu(), hc.src_sorted) and torch.equal(g._csr.rowptr_dst.cpu(), hc.rowptr_dst)
+    common = ["--model", "HybridModelv2", "--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16",
+              "--packed", path, "--model-save-dir", str(tmp_path)]
+    for extra in ([], ["--device-dataset", "--seed", "3"]):
+        train_stats, test_stats = train_IEDB_wFT.main(common + extra)
+        assert np.isfinite(test_stats["roc_auc"])
+
+
 def test_inference_matches_host_loop(cuda_device):
     """procedures.inference: probabilities collected on the device == per-batch sigmoid of the model's logits; metric
     dictionary == metric functions on those arrays (reference procedures/infer.py:9-50)."""
