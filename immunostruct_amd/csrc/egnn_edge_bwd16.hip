@@ -52,7 +52,7 @@ struct Bwd16Smem {
 
 constexpr int PART16_STRIDE = 8448 + 64 * 8;  // identical to the v1 record
 
-template <int FE_MAX, int NVB>
+template <int FE_MAX, int NVB, bool GX>
 __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
   const int r = lane & 15, q = lane >> 4;
 
   load_matrix_lds_t(sm.w2t, W2, tid, 256);
-  load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
+  if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
 
   const float wr_c = W1[lane * ldw + 2 * din];
   float wa_c[FE_MAX];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
   float wc2_c[4], wr_t[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    wc2_c[nt] = wc2[nt * 16 + r];
+    wc2_c[nt] = GX ? wc2[nt * 16 + r] : 0.0f;
     wr_t[nt] = W1[(nt * 16 + r) * ldw + 2 * din];
   }
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           // predicated loads cost the compiler its count of loads in flight, and every later wait becomes vmcnt(0)
           const int row = tile16_row(t, q);
           const size_t off = (size_t)min(cb + row, e_end - 1) * H + nt * 16 + r;
-          z3v[t][nt] = z3s[off];
+          if constexpr (GX) z3v[t][nt] = z3s[off];
           z2v[t][nt] = z2s[off];
         }
       if (nvalid > 0) {
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           const int v = v0 + dl;
           const float xs0 = x[s * 3 + 0], xs1 = x[s * 3 + 1], xs2 = x[s * 3 + 2];
           const float xv0 = x[v * 3 + 0], xv1 = x[v * 3 + 1], xv2 = x[v * 3 + 2];
-          const float gx0 = g_xout[v * 3 + 0], gx1 = g_xout[v * 3 + 1], gx2 = g_xout[v * 3 + 2];
+          float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
+          if constexpr (GX) { gx0 = g_xout[v * 3 + 0]; gx1 = g_xout[v * 3 + 1]; gx2 = g_xout[v * 3 + 2]; }
           float av[FE_MAX];
 #pragma unroll
           for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;      // Fe is kernel-uniform
@@ -170,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
             sm.e_r[wave][lane] = rr;
             sm.e_inv[wave][lane] = inv;
             sm.e_d[wave][0][lane] = d0; sm.e_d[wave][1][lane] = d1; sm.e_d[wave][2][lane] = d2;
-            sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
-            sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+            if constexpr (GX) {
+              sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
+              sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+            }
 #pragma unroll
             for (int f = 0; f < FE_MAX; ++f) sm.e_a[wave][f][lane] = valid ? av[f] : 0.0f;
           }
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
         }
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
-        {
+        if constexpr (GX) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int row = tile16_row(t, q);
@@ -214,6 +217,15 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
               bufA[row * LD + nt * 16 + r] = dz3;
             }
           }
+        } else {
+          // no gradient arrives at the coordinate branch: dz3 = 0, so only SiLU'(z2) is needed
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              float mh;
+              silu_fg(z2v[t][nt], mh, dy[t][nt]);
+            }
         }
         // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
 #pragma unroll
@@ -222,20 +234,22 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           gth[i] = ps[(size_t)s * ld_p + lane];      // raw: not consumed before SA
         }
       }
-      STAMPB(3);
-      __syncthreads();   // every wave's dz3 / mh tiles are staged
-      STAMPB(4);
+      if constexpr (GX) {
+        STAMPB(3);
+        __syncthreads();   // every wave's dz3 / mh tiles are staged
+        STAMPB(4);
 
-      // ---- WG1: dWc1[16w.., :] += sum over the window's edge tiles of dz3^T mh ----
+        // ---- WG1: dWc1[16w.., :] += sum over the window's edge tiles of dz3^T mh ----
 #pragma unroll
-      for (int wt = 0; wt < WB16; ++wt)
-        if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.bufA[wt], sm.bufB[wt], wave, lane);
+        for (int wt = 0; wt < WB16; ++wt)
+          if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.bufA[wt], sm.bufB[wt], wave, lane);
+      }
 
       if (nvalid > 0) {
         // ---- MM3: dmh = dz3 Wc1 + g_hn[dst] ; dz2 = dmh * SiLU'(z2) ----
         f32x4 acc[4];
         zero_acc4(acc);
-        mm16_rows<4, H>(acc, bufA, sm.wc1t, lane);
+        if constexpr (GX) mm16_rows<4, H>(acc, bufA, sm.wc1t, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
@@ -248,9 +262,11 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           }
         }
       }
-      STAMPB(5);
-      __syncthreads();   // WG1 + MM3 reads of bufA / bufB are complete in all waves
-      STAMPB(6);
+      if constexpr (GX) {
+        STAMPB(5);
+        __syncthreads();   // WG1 + MM3 reads of bufA / bufB are complete in all waves
+        STAMPB(6);
+      }
 
       if (nvalid > 0) {
 #pragma unroll
@@ -338,10 +354,13 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
           const bool valid = lane < nvalid;
           float q0 = 0.f, q1 = 0.f, q2 = 0.f;
           if (valid) {
-            const float s = sm.e_s[wave][lane];
             const float inv = sm.e_inv[wave][lane], rr = sm.e_r[wave][lane];
             const float d0 = sm.e_d[wave][0][lane], d1 = sm.e_d[wave][1][lane], d2 = sm.e_d[wave][2][lane];
-            const float u0 = s * sm.e_gx[wave][0][lane], u1 = s * sm.e_gx[wave][1][lane], u2 = s * sm.e_gx[wave][2][lane];
+            float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+            if constexpr (GX) {
+              const float s = sm.e_s[wave][lane];
+              u0 = s * sm.e_gx[wave][0][lane]; u1 = s * sm.e_gx[wave][1][lane]; u2 = s * sm.e_gx[wave][2][lane];
+            }
             const float ddot = d0 * u0 + d1 * u1 + d2 * u2;
             const float k = rr > 0.0f ? ddot * inv * inv / rr : 0.0f;
             const float dr2 = 2.0f * sm.e_drad[wave][lane];
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void egnn_edge_bwd16_kernel(
       if (nl < nv) {
         const int v = v0 + nl;
         dPd[(size_t)v * ld_dpd + lane] = acc_h[i];
-        if (lane < 3) dx[v * 3 + lane] = g_xout[v * 3 + lane] - acc_x[i];
+        if (lane < 3) dx[v * 3 + lane] = (GX ? g_xout[v * 3 + lane] : 0.0f) - acc_x[i];
       }
     }
   }
@@ -448,15 +467,22 @@ extern "C" int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, c
   if (Fe < 0 || Fe > 8 || grid <= 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
-#define IS_LAUNCH_BWD16(FE, NVB)                                                                                          \
-  hipLaunchKernelGGL((is::egnn_edge_bwd16_kernel<FE, NVB>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1, \
+  // g_xout == nullptr: no gradient arrives at this layer's coordinate output (the last layer of a stack whose final
+  // coordinates are not used): the coordinate-MLP half of the pass (z3s reads, dz3, dWc1, dz3 Wc1) is skipped, its
+  // weight-gradient entries of the partial record are zero; z3s / Wc1 / wc2 are not read
+  if (g_xout != nullptr && z3s == nullptr) return -22;
+#define IS_LAUNCH_BWD16(FE, NVB, GXF)                                                                                           \
+  hipLaunchKernelGGL((is::egnn_edge_bwd16_kernel<FE, NVB, GXF>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, W1, \
                      ldw, din, W2, Wc1, wc2, z2s, z3s, g_hn, ld_ghn, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe)
+#define IS_LAUNCH_BWD16_GX(FE, NVB) \
+  do { if (g_xout != nullptr) IS_LAUNCH_BWD16(FE, NVB, true); else IS_LAUNCH_BWD16(FE, NVB, false); } while (0)
   if (Fe <= 1) {
-    if (tiles != nullptr) IS_LAUNCH_BWD16(1, is::NVB_LISTED); else IS_LAUNCH_BWD16(1, is::NV16);
+    if (tiles != nullptr) IS_LAUNCH_BWD16_GX(1, is::NVB_LISTED); else IS_LAUNCH_BWD16_GX(1, is::NV16);
   } else {
     if (tiles != nullptr) return -22;      // listed tiles: Fe <= 1 only (the Fe = 8 instantiation has no LDS left)
-    IS_LAUNCH_BWD16(8, is::NV16);
+    IS_LAUNCH_BWD16_GX(8, is::NV16);
   }
+#undef IS_LAUNCH_BWD16_GX
 #undef IS_LAUNCH_BWD16
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

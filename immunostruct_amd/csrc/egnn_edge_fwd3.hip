@@ -181,7 +181,9 @@ __device__ __forceinline__ void load_fwd_rows(FwdRows& rw, const EdgeIds<FE_MAX>
   }
 }
 
-template <int FE_MAX, bool SAVE, int X3 = 0>
+// COORD = false: the layer's coordinate output is not wanted (last layer of a stack whose final coordinates are unused):
+// the coordinate MLP (z3 = mh Wc1^T + bc1, s = SiLU(z3) . wc2), the z3s store and the x_out update are skipped.
+template <int FE_MAX, bool SAVE, int X3 = 0, bool COORD = true>
 __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
@@ -222,14 +224,15 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
   }
   {
     f32x4 wreg[8];
+    constexpr int NW = COORD ? 8 : 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NW; ++j) {
       const int idx = tid + (j & 3) * 256;                      // 1024 float4 per matrix, 256 threads
       const float* src = (j < 4) ? W2 : Wc1;
       wreg[j] = *reinterpret_cast<const f32x4*>(src + idx * 4);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NW; ++j) {
       const int idx = tid + (j & 3) * 256;
       const int row = idx / (H / 4), c4 = (idx % (H / 4)) * 4;
       if constexpr (X3 == 2) {
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     b2_c[nt] = b2[nt * 16 + r];
-    bc1_c[nt] = bc1[nt * 16 + r];
-    wc2_c[nt] = wc2[nt * 16 + r];
+    bc1_c[nt] = COORD ? bc1[nt * 16 + r] : 0.0f;
+    wc2_c[nt] = COORD ? wc2[nt * 16 + r] : 0.0f;
   }
   FwdRows r0 = {};
   if (has_edges) load_fwd_rows<FE_MAX>(r0, id0, B, ld_p_bytes, lane);
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     STAMP3(stamp_k); ++stamp_k;
 
     // ---- MM2: z3 = mh Wc1^T + bc1 ; s = SiLU(z3) . wc2 ----
-    {
+    if constexpr (COORD) {
       f32x4 acc[4];
       zero_acc4(acc);
       if constexpr (X3 == 2) mm16_rows_x3(acc, act, sm.w.wc1h, sm.w.wc1l, lane);
@@ -386,26 +389,26 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
 #pragma unroll
       for (int i = 0; i < TE16; ++i) {
         hv[i] = act[i * LD + lane];
-        cs[i] = sm.e_s[wave][i];
-        cd[i] = sm.e_xd[wave][lane < 3 ? lane : 0][i];
+        cs[i] = COORD ? sm.e_s[wave][i] : 0.0f;
+        cd[i] = COORD ? sm.e_xd[wave][lane < 3 ? lane : 0][i] : 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < TE16; ++i) {
         if (i >= lo && i < hi) {
           acc_h += hv[i];
-          acc_x = __builtin_fmaf(cs[i], cd[i], acc_x);
+          if constexpr (COORD) acc_x = __builtin_fmaf(cs[i], cd[i], acc_x);
           cnt += 1;
           if ((fm >> i) & 1ull) {
             const int v = __builtin_amdgcn_readlane(id0.d, i);
             for (int u = vnext; u < v; ++u) {   // nodes without in-edges (none on residue graphs)
               h_neigh[(size_t)u * ld_hn + lane] = 0.0f;
-              if (lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
+              if (COORD && lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
             }
             buf_store(acc_h, B.hn, lane * 4, v * ld_hn_bytes);
             const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[0]), i));
             const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[1]), i));
             const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[2]), i));
-            if (lane < 3) x_out[v * 3 + lane] = (lane == 0 ? x0 : (lane == 1 ? x1 : x2)) + acc_x / (float)cnt;
+            if (COORD && lane < 3) x_out[v * 3 + lane] = (lane == 0 ? x0 : (lane == 1 ? x1 : x2)) + acc_x / (float)cnt;
             acc_h = 0.0f; acc_x = 0.0f; cnt = 0;
             vnext = v + 1;
           }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
   }
   for (int u = vnext; u < vb; ++u) {
     h_neigh[(size_t)u * ld_hn + lane] = 0.0f;
-    if (lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
+    if (COORD && lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
   }
 }
 
@@ -439,7 +442,9 @@ static int edge_fwd_v3_launch(int x3, const float* ps, const float* pd, int ld_p
                               const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                               float* z3s, int N, int E, int Fe, void* stream) {
   if (N <= 0 || nchunks <= 0) return 0;
-  if (Fe < 0 || Fe > 8 || (z2s == nullptr) != (z3s == nullptr)) return -22;
+  // x_out == nullptr: the coordinate branch is not evaluated (fp32 kernels only); z3s is then not written and may be null
+  const bool coord = x_out != nullptr;
+  if (Fe < 0 || Fe > 8 || (coord && (z2s == nullptr) != (z3s == nullptr)) || (!coord && x3 != 0)) return -22;
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
   const long long lim = 0x7fffffffLL;
   if ((long long)N * ld_p * 4 > lim || (long long)N * ld_hn * 4 > lim || (long long)(E + 16) * 64 * 4 > lim) return -22;
@@ -447,19 +452,22 @@ static int edge_fwd_v3_launch(int x3, const float* ps, const float* pd, int ld_p
   const dim3 grid((nchunks + is::W3 - 1) / is::W3), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool save = z2s != nullptr;
-#define IS_LAUNCH_FWD3(FE, SV, XX)                                                                                       \
-  hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV, XX>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
+#define IS_LAUNCH_FWD3(FE, SV, XX, CO)                                                                                       \
+  hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV, XX, CO>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe)
   if (x3 == 2) {
     if (Fe > 1) return -22;
-    if (save) IS_LAUNCH_FWD3(1, true, 2); else IS_LAUNCH_FWD3(1, false, 2);
+    if (save) IS_LAUNCH_FWD3(1, true, 2, true); else IS_LAUNCH_FWD3(1, false, 2, true);
   } else if (x3 == 3) {
     if (Fe > 1) return -22;
-    if (save) IS_LAUNCH_FWD3(1, true, 3); else IS_LAUNCH_FWD3(1, false, 3);
+    if (save) IS_LAUNCH_FWD3(1, true, 3, true); else IS_LAUNCH_FWD3(1, false, 3, true);
+  } else if (!coord) {
+    if (Fe <= 1) { if (save) IS_LAUNCH_FWD3(1, true, 0, false); else IS_LAUNCH_FWD3(1, false, 0, false); }
+    else { if (save) IS_LAUNCH_FWD3(8, true, 0, false); else IS_LAUNCH_FWD3(8, false, 0, false); }
   } else if (Fe <= 1) {
-    if (save) IS_LAUNCH_FWD3(1, true, 0); else IS_LAUNCH_FWD3(1, false, 0);
+    if (save) IS_LAUNCH_FWD3(1, true, 0, true); else IS_LAUNCH_FWD3(1, false, 0, true);
   } else {
-    if (save) IS_LAUNCH_FWD3(8, true, 0); else IS_LAUNCH_FWD3(8, false, 0);
+    if (save) IS_LAUNCH_FWD3(8, true, 0, true); else IS_LAUNCH_FWD3(8, false, 0, true);
   }
 #undef IS_LAUNCH_FWD3
   return hipGetLastError() == hipSuccess ? 0 : -5;

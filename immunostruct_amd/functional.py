@@ -251,11 +251,15 @@ class EGNNStackFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h0, x0, ea, csr, n_layers, *params):
+    def forward(ctx, h0, x0, ea, csr, n_layers, final_coords, *params):
         """params = 11 tensors per layer [+ (Wa, ba, Wb, bb) of an optional 128-wide projection head of the final h:
-        the node attention's query / key projection, emitted by the last layer's node kernel]"""
+        the node attention's query / key projection, emitted by the last layer's node kernel].
+        ``final_coords=False``: the caller does not use the last layer's coordinates (the reference's models never do:
+        ``hybrid_models.py:323-324`` keeps only h) -- that layer's coordinate MLP is then not evaluated, forward or
+        backward, and None is returned in place of x."""
         lib = _lib.load()
         _lib.require_device(h0, x0, ea, csr.rowptr_dst, *params)
+        ctx.set_materialize_grads(False)      # an unused output (the final coordinates) reaches backward as None, not as zeros
         has_head = len(params) == PARAMS_PER_LAYER * n_layers + 4
         if not has_head and len(params) != PARAMS_PER_LAYER * n_layers:
             raise ValueError("expected 11 parameter tensors per layer (+ 4 for the projection head)")
@@ -314,10 +318,12 @@ class EGNNStackFn(torch.autograd.Function):
             if ldw != 2 * din + 1 + fe:
                 raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
             h_neigh = torch.empty(n, HIDDEN, **f32)
-            x_out = torch.empty(n, 3, **f32)
+            # (kernels that can skip the coordinate branch: fp32 v3 forward, v2-family backward)
+            no_coords = (not final_coords) and i == n_layers - 1 and EDGE_FWD == "v3" and EDGE_KERNELS == "v2" and fe <= 1
+            x_out = torch.empty(n, 3, **f32) if not no_coords else None
             z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # v3 stores full 16-row tiles
-            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None
-            with KernelTimer.span("egnn_edge_fwd"):
+            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
+            with KernelTimer.span("egnn_edge_fwd_nocoord" if no_coords else "egnn_edge_fwd"):
                 if EDGE_FWD in ("v3", "v3x") and EDGE_KERNELS == "v2":
                     # wave-autonomous, software-pipelined mapping (v3x: its opt-in split-bf16 variant)
                     kf = fwd_chunk_count(e)
@@ -364,7 +370,7 @@ class EGNNStackFn(torch.autograd.Function):
         return h_in, x
 
     @staticmethod
-    def backward(ctx, g_h, g_x, g_head=None):
+    def backward(ctx, g_h, g_x=None, g_head=None):
         lib = _lib.load()
         layers, params, csr, ea, fe, L = ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers
         n, e = csr.num_nodes, csr.num_edges
@@ -373,10 +379,15 @@ class EGNNStackFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         P = PARAMS_PER_LAYER
         g_hd = _lib.f32c(g_h) if g_h is not None else torch.zeros(n, HIDDEN, **f32)
-        g_xc = _lib.f32c(g_x) if g_x is not None else torch.zeros(n, 3, **f32)
         plans = [layer_plan(layers[i]["din"], fe, dev) for i in range(L)]
         gflat = [torch.empty(pl.total, **f32) for pl in plans]
         use_v2 = EDGE_KERNELS == "v2" and fe <= 1   # (the Fe = 8 instantiation of the v2 backward spills)
+        # no gradient at the final coordinates (unused, or never produced): the last layer's backward skips its
+        # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
+        if g_x is not None:
+            g_xc = _lib.f32c(g_x)
+        else:
+            g_xc = None if use_v2 else torch.zeros(n, 3, **f32)
         edge_bwd = lib.is_egnn_edge_bwd_v2 if use_v2 else lib.is_egnn_edge_bwd
         # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
         tiles = csr.tiles(64, 24) if (use_v2 and use_bwd_tiles(n, e, 2 * _MAX_BWD_GRID)) else None
@@ -485,7 +496,7 @@ class EGNNStackFn(torch.autograd.Function):
             dx = torch.empty(n, 3, **f32)
             psd = lay["psd"]
             extra = (_lib.ptr(tiles),) if use_v2 else ()
-            with KernelTimer.span("egnn_edge_bwd"):
+            with KernelTimer.span("egnn_edge_bwd_nocoord" if g_xc is None else "egnn_edge_bwd"):
                 _lib.check(edge_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
@@ -551,7 +562,7 @@ class EGNNStackFn(torch.autograd.Function):
             hh = HIDDEN * HIDDEN
             grads.extend([head_flat[0:hh].view(HIDDEN, HIDDEN), head_flat[2 * hh + HIDDEN:2 * hh + 2 * HIDDEN],
                           head_flat[hh:2 * hh].view(HIDDEN, HIDDEN), head_flat[2 * hh:2 * hh + HIDDEN]])
-        return (g_h0, g_x0, None, None, None) + tuple(grads)
+        return (g_h0, g_x0, None, None, None, None) + tuple(grads)
 
 
 class PairLinearFn(torch.autograd.Function):
@@ -707,13 +718,14 @@ def fused_head_available(n_layers):
     return NODE_KERNELS == "v2" and BATCH_WGRAD and n_layers <= 6
 
 
-def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None):
+def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None, final_coords=True):
     """layer_params: list (one entry per layer) of the 11 native parameter tensors; ``head`` = optional
-    (Wa, ba, Wb, bb), 64x64 each: the call then also returns [h Wa^T + ba | h Wb^T + bb] (N, 128) of the final h."""
+    (Wa, ba, Wb, bb), 64x64 each: the call then also returns [h Wa^T + ba | h Wb^T + bb] (N, 128) of the final h.
+    ``final_coords=False``: the last layer's coordinates are not needed; None may be returned in their place."""
     flat = [p for lp in layer_params for p in lp]
     if head is not None:
         flat = flat + list(head)
-    return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), *flat)
+    return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), bool(final_coords), *flat)
 
 
 class Mlp2Fn(torch.autograd.Function):

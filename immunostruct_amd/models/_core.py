@@ -142,9 +142,11 @@ class MultimodalNet(nn.Module):
         head = self.self_attention.qk_head() if (self.SPEC.pool == "mean" and HF.fused_head_available(len(layers))) else None
         if head is not None:
             # the node attention's query / key projection rides on the last EGNN layer's node kernel
-            h, x, qk = egnn_stack_forward(layers, g, h, x, a, head=head)
+            h, x, qk = egnn_stack_forward(layers, g, h, x, a, head=head, final_coords=False)
         else:
-            h, x = egnn_stack_forward(layers, g, h, x, a)   # all layers, fused HIP kernels
+            # all layers, fused HIP kernels; the models keep only h (reference hybrid_models.py:323-324), so the last
+            # layer's coordinate update is not evaluated
+            h, x = egnn_stack_forward(layers, g, h, x, a, final_coords=False)
         HF.StackBoundary.record(h, x, qk)
         c = self.gat_hidden_channels
         if g.uniform_nodes_per_graph() is None:

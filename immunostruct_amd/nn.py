@@ -61,11 +61,13 @@ class EGNNConv(nn.Module):
         return h, x
 
 
-def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None):
+def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True):
     """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``).
 
     ``head`` = optional (Wa, ba, Wb, bb): also return the 128-wide projection [h Wa^T + ba | h Wb^T + bb] of the
-    final node features (the node attention's query / key projection), computed by the last layer's node kernel."""
+    final node features (the node attention's query / key projection), computed by the last layer's node kernel.
+    ``final_coords=False``: the caller ignores the last layer's coordinates; its coordinate MLP is then skipped and the
+    returned x may be None."""
     if not isinstance(graph, PackedGraphBatch):
         raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
     fe = layers[0].edge_feat_size
@@ -77,7 +79,8 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, hea
     if edge_feat is not None and edge_feat.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
     ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
-    return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head)
+    return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head,
+                         final_coords=final_coords)
 
 
 def _seg_ptr_from_batch(batch_index, size=None):

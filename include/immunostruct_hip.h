@@ -82,7 +82,9 @@ int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x,
  * layout): 16-edge tiles on v_mfma_f32_16x16x4_f32, 2-4 waves per SIMD; the default for Fe <= 1.
  * is_egnn_edge_bwd_v2 takes grid <= number of tiles; `tiles` is NULL (tiles of 16 consecutive
  * nodes) or the greedy tile list [count, b_0, ..., b_count, ...] (int32, <= 64 in-edges and <= 24
- * nodes per tile, immunostruct_amd/graph.py greedy_node_tiles) that fills the 64-edge windows.    */
+ * nodes per tile, immunostruct_amd/graph.py greedy_node_tiles) that fills the 64-edge windows.
+ * is_egnn_edge_bwd_v2 with g_xout == NULL: no gradient arrives at the layer's coordinate output; the coordinate-MLP half of the pass is
+ * skipped (z3s / Wc1 / wc2 are not read, their entries of the partial record are zero).                          */
 int is_egnn_edge_fwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                         const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                         const float* W2, const float* b2, const float* Wc1, const float* bc1,
@@ -101,7 +103,9 @@ int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float*
  * node-aligned, edge-balanced cut of the destination nodes (b_0 = 0, b_nchunks = N, non-decreasing): one wave walks
  * one chunk in full 16-edge tiles, prefetching the next tile's rows while the current one is on the
  * matrix cores.  E = number of CSR slots (rowptr[N] <= E); z2s / z3s (when not NULL) need at least
- * max(E, 16) rows: tiles are always stored at full width.                                           */
+ * max(E, 16) rows: tiles are always stored at full width.
+ * x_out == NULL: the layer's coordinate output is not wanted (the last layer of a stack whose final coordinates are
+ * unused, reference hybrid_models.py:323-324): the coordinate MLP is not evaluated, z3s is not written (may be NULL). */
 int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                         const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                         const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,

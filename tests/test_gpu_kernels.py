@@ -361,6 +361,46 @@ def test_edge_forward_v3_is_bit_identical_to_v2(cuda_device, monkeypatch, case, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["padded190_deg3", "hub", "ragged_nodes"])
+def test_unused_final_coordinates_are_skipped_exactly(cuda_device, case):
+    """The models never use the last EGNN layer's coordinates (reference hybrid_models.py:323-324).  Skipping that layer's
+    coordinate MLP -- in the backward when no gradient arrives at x (null g_xout), in the forward with final_coords=False --
+    leaves h bit-identical and every gradient equal to what pushing zeros through the branch gives (to fp32 round-off);
+    the skipped weights get exact zeros."""
+    raw = _hub_graph() if case == "hub" else _raw_cases()[case]
+    fe = raw.edge_attr.shape[1]
+    res = {}
+    for mode in ("zeros_through", "no_grad_at_x", "not_evaluated"):
+        torch.manual_seed(5)
+        layers = [EGNNConv(20 if i == 0 else 64, 64, 64, fe).to(cuda_device) for i in range(3)]
+        g = H.product_graph(raw, cuda_device)
+        x0 = g.ndata["x"][:, 20:].clone().requires_grad_(True)
+        h, x = egnn_stack_forward(layers, g, g.ndata["x"][:, :20], x0, g.edata["edge_attr"] if fe else None,
+                                  final_coords=mode != "not_evaluated")
+        assert (x is None) == (mode == "not_evaluated")
+        w = torch.linspace(-1, 1, h.numel(), device=cuda_device).view_as(h)
+        loss = (h * w).sum()
+        if mode == "zeros_through":
+            loss = loss + (x * 0.0).sum()
+        loss.backward()
+        res[mode] = [h.detach().cpu(), x0.grad.cpu()] + [p.grad.cpu() for lay in layers for p in lay.parameters()]
+    names = ["h", "dx0"] + [f"layer{i}.{k}" for i, lay in enumerate(layers) for k, _ in lay.named_parameters()]
+    assert torch.equal(res["zeros_through"][0], res["not_evaluated"][0])            # h: same bits
+    for nm, a, b in zip(names, res["no_grad_at_x"], res["not_evaluated"]):
+        assert torch.equal(a, b), f"{nm}: skipping in the forward too changed a gradient bit"
+    # against pushing zeros through the coordinate branch: same values up to the compiler's fma contraction of the
+    # two instantiations of the backward kernel (a few ulp of the sums)
+    for nm, a, b in zip(names, res["zeros_through"], res["not_evaluated"]):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * max(scale, 1e-30), f"{nm}: {float((a - b).abs().max()):.3e} vs scale {scale:.3e}"
+    for nm, t in zip(names, res["not_evaluated"]):
+        if nm.startswith("layer2.coord_mlp"):
+            assert float(t.abs().max()) == 0.0
+        elif nm.startswith("layer"):
+            assert float(t.abs().max()) > 0.0, nm
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,wd", [("Adam", 0.0), ("Adam", 1e-6), ("AdamW", 1e-2)])
 def test_hip_adam_matches_torch_optim(cuda_device, kind, wd):
     """csrc/optimizer.hip vs torch.optim.Adam / AdamW over several steps, ragged tensor sizes, a changing lr."""
