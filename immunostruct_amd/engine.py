@@ -149,7 +149,8 @@ def _restore(model, optimizer, snap):
 
 
 class CapturedTrainStep:
-    """``step(graph, seq, prop, y) -> loss`` replaying captured HIP graphs.
+    """``step(graph, seq, prop, y) -> loss`` replaying captured HIP graphs (``graph`` / ``seq`` / ``prop`` may be
+    (cancer, wild-type) pairs: ``forward_loss`` then receives pairs of static buffers).
 
     ``forward_loss(model, graph, seq, prop, y) -> scalar loss`` defines the step body (so the same
     engine serves the regression / BCE / comparative stages).  Construction runs ``warmup`` (>= 1) REAL
@@ -162,9 +163,19 @@ class CapturedTrainStep:
                              "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
         g, seq, prop, y = template
         self.model, self.optimizer, self.reducer, self.forward_loss = model, optimizer, reducer, forward_loss
-        self.sgraph = StaticGraphBatch(g, edge_capacity)
-        self.seq, self.prop, self.y = torch.zeros_like(seq), torch.zeros_like(prop), torch.zeros_like(y)
-        self._load(g, seq, prop, y)
+        # paired (cancer, wild-type) batches: graph / sequence / property are 2-tuples, one static buffer set per member
+        self.paired = isinstance(g, (tuple, list))
+        if self.paired:
+            caps = edge_capacity if isinstance(edge_capacity, (tuple, list)) else (edge_capacity,) * len(g)
+            self.sgraph = tuple(StaticGraphBatch(gi, ci) for gi, ci in zip(g, caps))
+            self.seq = tuple(torch.zeros_like(t) for t in seq)
+            self.prop = tuple(torch.zeros_like(t) for t in prop)
+            g = g[0]
+        else:
+            self.sgraph = StaticGraphBatch(g, edge_capacity)
+            self.seq, self.prop = torch.zeros_like(seq), torch.zeros_like(prop)
+        self.y = torch.zeros_like(y)
+        self._load(*template)
         self.fused_optimizer = not reducer.packing   # single rank: optimizer inside the same graph
         # host->device uploads must not happen inside the capture: build the (cached) gradient scatter
         # maps of both layer shapes now, even when no eager warm-up step is requested
@@ -253,7 +264,7 @@ class CapturedTrainStep:
                 self.replay()
             torch.cuda.synchronize()
             times[form] = time.perf_counter() - t0
-        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.seq.device)
+        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.y.device)
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
         t = t.tolist()
@@ -262,7 +273,13 @@ class CapturedTrainStep:
         self._use_form(t[0] < t[1])
 
     def _load(self, g, seq, prop, y):
-        multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
+        if self.paired:
+            pairs = [(y, self.y)]
+            for sg, gi, si, ss, pi, ps in zip(self.sgraph, g, seq, self.seq, prop, self.prop):
+                pairs += sg.copy_pairs(gi) + [(si, ss), (pi, ps)]
+            multi_copy(pairs)
+        else:
+            multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
 
     def _fwd_bwd(self):
         from .functional import Stamps

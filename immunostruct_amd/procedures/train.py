@@ -187,8 +187,11 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
     """``train_model_comparative`` with both members of every (cancer, wild-type) pair in device-resident datasets
     (same graph ids in both; targets are the cancer dataset's): batches are assembled on the GPU, the loss is the
     reference's (``procedures/train.py:97-114``: shared prediction term, averaged reconstruction terms, ``coeff_contrastive``
-    x paired contrastive loss).  Steps run eagerly -- the contrastive loss' class-count early-out
-    (``utils/contrastive.py:38-43``) needs a host decision per batch, so this loop is not captured."""
+    x paired contrastive loss).  Every full batch is one replay of the captured HIP graph of the paired step; the
+    contrastive loss' class-count early-out (``utils/contrastive.py:38-43``) is evaluated on the device there
+    (``PairedContrastiveLoss.capturable``).  ``IMMUNOSTRUCT_CAPTURE_PAIRED=0`` runs every step eagerly."""
+    from ..distributed import FlatGradReducer
+    from ..engine import CapturedTrainStep
     device = dataset_cancer.device
     bsz = int(config.batch_size)
     coeff = float(getattr(config, "coeff_contrastive", 0) or 0)
@@ -198,15 +201,35 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
     bufs = {}
 
+    def gather(idx, cancer, wt):
+        dataset_cancer.gather_into(idx, *cancer)
+        dataset_wt.gather_into(idx, *wt)
+
     def batch(idx):
         b = int(idx.numel())
         if b not in bufs:
             bufs[b] = (dataset_cancer.new_batch(b), dataset_wt.new_batch(b))
-        (gc, sc, pc, y), (gw, sw, pw, _) = (dataset_cancer.gather_into(idx, *bufs[b][0]), dataset_wt.gather_into(idx, *bufs[b][1]))
+        gather(idx, *bufs[b])
+        (gc, sc, pc, y), (gw, sw, pw, _) = bufs[b]
         return (gc, gw), (sc, sw), y, (pc, pw)
 
     def step_loss(idx):
         return _paired_loss(model, loss_function, batch(idx), device, contrastive, coeff)
+
+    def forward_loss(m, graphs, seqs, props, y):
+        return _paired_loss(m, loss_function, (graphs, seqs, y, props), device, contrastive, coeff)
+
+    captured, wt_y = None, None
+    if train_index.numel() >= bsz and os.environ.get("IMMUNOSTRUCT_CAPTURE_PAIRED", "1") != "0":
+        graphs, seqs, y, props = batch(train_index[:bsz])
+        model.train()
+        if contrastive is not None:
+            contrastive.capturable = True
+        reducer = FlatGradReducer(model.parameters(), world=1)
+        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, (graphs, seqs, props, y),
+                                     edge_capacity=(bsz * dataset_cancer.max_edges, bsz * dataset_wt.max_edges),
+                                     warmup=1, preserve_state=True)
+        wt_y = torch.zeros_like(captured.y)       # the wild-type dataset's targets are not used
 
     train_losses, val_losses = [], []
     best = float("inf")
@@ -215,11 +238,18 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
         perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
         running, steps = None, 0
         for at in range(0, perm.numel(), bsz):
-            optimizer.zero_grad(set_to_none=True)
-            loss = step_loss(perm[at:at + bsz])
-            loss.backward()
-            optimizer.step()
-            running = loss.detach() if running is None else running + loss.detach()
+            idx = perm[at:at + bsz]
+            if captured is not None and idx.numel() == bsz:
+                gather(idx, (captured.sgraph[0], captured.seq[0], captured.prop[0], captured.y),
+                       (captured.sgraph[1], captured.seq[1], captured.prop[1], wt_y))
+                loss = captured.replay().clone()
+            else:
+                optimizer.zero_grad(set_to_none=True)
+                loss = step_loss(idx)
+                loss.backward()
+                optimizer.step()
+                loss = loss.detach()
+            running = loss if running is None else running + loss
             steps += 1
         train_loss = float(running) / max(steps, 1)
         train_losses.append(train_loss)

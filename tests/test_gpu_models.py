@@ -218,6 +218,69 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 3 captured steps")
 
 
+def test_captured_paired_step_matches_eager(cuda_device):
+    """The paired (cancer, wild-type) train step -- two encoder passes, fused head, BCE + reconstruction terms, paired
+    contrastive loss -- as one captured HIP graph (engine.CapturedTrainStep on pairs of static buffers) reproduces eager
+    training, including a single-class batch, where the contrastive term must vanish (reference utils/contrastive.py:38-43:
+    host early-out; here a device-side gate, PairedContrastiveLoss.capturable)."""
+    from immunostruct_amd.distributed import FlatGradReducer
+    from immunostruct_amd.engine import CapturedTrainStep
+    from immunostruct_amd import optim
+    from immunostruct_amd.procedures.train import _paired_loss
+    dev = cuda_device
+    nb = 6
+    raws = [(synthetic.make_batch(nb, seed=s, deg_extra=d), synthetic.make_batch(nb, seed=s + 100, deg_extra=d2))
+            for s, d, d2 in ((61, 2, 3), (62, 4, 1), (63, 1, 2), (64, 3, 3))]
+    targets = [torch.tensor(t, dtype=torch.float32, device=dev) for t in
+               ([0, 1, 0, 0, 1, 0], [1, 1, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 0])]      # third: single class
+    def tens(r):
+        return H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev), torch.from_numpy(r.prop).to(dev)
+    batches = []
+    for (rc, rw), y in zip(raws, targets):
+        (gc, sc, pc), (gw, sw, pw) = tens(rc), tens(rw)
+        batches.append(((gc, gw), (sc, sw), (pc, pw), y))
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+    eps = [H.make_eps(19, nb).to(dev), H.make_eps(20, nb).to(dev)]
+    caps = (max(rc.num_edges for rc, _ in raws), max(rw.num_edges for _, rw in raws))
+
+    def run(captured):
+        model = model_map["HybridModelv2_Comparative"](vae_input_dim=H.VAE_IN, device=dev, use_wt_for_downstream=True).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
+        model.eval()        # dropout off: the two runs draw no random masks
+        torch.manual_seed(0)
+        contrastive = PairedContrastiveLoss(device=dev, embedding_dim=104)
+        contrastive.capturable = captured
+        opt = optim.AdamW(model.parameters(), lr=1e-5, weight_decay=1e-6)
+
+        def forward_loss(m, graphs, seqs, props, y):
+            it = iter(eps * 8)
+            with mock.patch("torch.randn_like", lambda t: next(it).to(t.dtype)):
+                return _paired_loss(m, losses.BCE_loss, (graphs, seqs, y, props), dev, contrastive, 0.05)
+
+        out = []
+        if captured:
+            red = FlatGradReducer(model.parameters(), world=1)
+            eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=caps, warmup=1)
+            assert eng.paired and len(eng.sgraph) == 2
+            for b in batches:
+                out.append(float(eng(*b)))
+        else:
+            for b in [batches[0]] + batches:
+                opt.zero_grad(set_to_none=True)
+                loss = forward_loss(model, *b)
+                loss.backward()
+                opt.step()
+                out.append(float(loss.detach()))
+        return out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    l_e, sd_e = run(False)
+    l_c, sd_c = run(True)
+    for a, b in zip(l_e[1:], l_c):
+        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
+    for k in sd_e:
+        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 4 captured paired steps")
+
+
 def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     """both entry points: pretrain -> new head -> finetune -> inference on a small synthetic set (1 epoch)."""
     from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
