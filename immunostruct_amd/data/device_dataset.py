@@ -82,6 +82,26 @@ class DeviceResidentDataset:
         self.device = self.x.device
         return self
 
+    @classmethod
+    def concat(cls, first, second):
+        """the graphs of ``first`` followed by those of ``second`` (same node count / feature widths): ids of ``second``
+        are shifted by ``len(first)``.  Used for (cancer, wild-type) pairs: ONE gather with ids [idx, idx + len(first)]
+        assembles the merged batch the paired models encode in a single pass."""
+        for k in ("nodes_per_graph", "node_feats", "edge_feats", "device"):
+            if getattr(first, k) != getattr(second, k):
+                raise ValueError(f"datasets differ in {k}")
+        if first.seq.shape[1:] != second.seq.shape[1:] or first.prop.shape[1:] != second.prop.shape[1:]:
+            raise ValueError("datasets differ in sequence / property shape")
+        self = object.__new__(cls)
+        self.device = first.device
+        self.num_graphs = first.num_graphs + second.num_graphs
+        self.nodes_per_graph, self.node_feats, self.edge_feats = first.nodes_per_graph, first.node_feats, first.edge_feats
+        self.max_edges = max(first.max_edges, second.max_edges)
+        for k in ("x", "rowptr_dst", "rowptr_src", "src", "dst", "pos", "ea", "seq", "prop", "y"):
+            setattr(self, k, torch.cat([getattr(first, k), getattr(second, k)], dim=0))
+        self.eoff = torch.cat([first.eoff, second.eoff[1:] + first.eoff[-1]])      # slot offsets; the ids inside a graph stay local
+        return self
+
     def __len__(self):
         return self.num_graphs
 

@@ -241,4 +241,32 @@ def batch(graphs):
         out.ndata[key] = torch.cat([g.ndata[key] for g in graphs], dim=0)
     for key in graphs[0].edata:
         out.edata[key] = torch.cat([g.edata[key] for g in graphs], dim=0)
+    if len(graphs) > 1 and all(g._csr is not None for g in graphs):
+        out._csr = _concat_csr([g._csr for g in graphs])     # block-diagonal: the union's indices are the pieces' + offsets
+    return out
+
+
+def _concat_csr(parts):
+    """CSR indices of the block-diagonal union of graphs whose own indices exist: every piece is already sorted by
+    destination (stable), so the union's arrays are the pieces' arrays with node / slot offsets added -- no sort.
+    Equal to ``CSRIndex(src, dst, n)`` of the union (``tests/test_graph_index.py``)."""
+    out = object.__new__(CSRIndex)
+    n_off, e_off = 0, 0
+    cols = {k: [] for k in ("src_sorted", "dst_sorted", "eperm", "pos_by_src")}
+    rp_d, rp_s = [], []
+    for i, c in enumerate(parts):
+        cols["src_sorted"].append(c.src_sorted + n_off)
+        cols["dst_sorted"].append(c.dst_sorted + n_off)
+        cols["eperm"].append(c.eperm + e_off)
+        cols["pos_by_src"].append(c.pos_by_src + e_off)
+        last = i == len(parts) - 1
+        rp_d.append((c.rowptr_dst if last else c.rowptr_dst[:-1]) + e_off)
+        rp_s.append((c.rowptr_src if last else c.rowptr_src[:-1]) + e_off)
+        n_off += c.num_nodes
+        e_off += c.num_edges
+    for k, v in cols.items():
+        setattr(out, k, torch.cat(v))
+    out.rowptr_dst, out.rowptr_src = torch.cat(rp_d).to(torch.int32), torch.cat(rp_s).to(torch.int32)
+    out.num_nodes, out.num_edges = n_off, e_off
+    out._chunks, out._tiles = {}, {}
     return out

@@ -22,11 +22,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as HF
+from ..graph import PackedGraphBatch
+from ..graph import batch as graph_batch
 from ..nn import EGNNConv, egnn_stack_forward
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
+MERGE_PAIRS = os.environ.get("IMMUNOSTRUCT_MERGE_PAIRS", "1") != "0"      # paired models: one encoder pass over [cancer; wild-type]
 if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -68,6 +71,7 @@ class MultimodalNet(nn.Module):
         self.property_embedding_dim = property_embedding_dim
         self.use_wt_for_downstream = use_wt_for_downstream
         self.mlp_features = mlp_features
+        self._pair_rows = 0       # > 0 while a merged (cancer; wild-type) batch is being encoded: rows of one member
         c = gat_hidden_channels
 
         if sp.graph:
@@ -120,7 +124,13 @@ class MultimodalNet(nn.Module):
 
     def reparameterize(self, mu, logvar):
         # sampled on every call, also in eval mode (reference hybrid_models.py:301-304)
-        return mu + torch.randn_like(mu) * torch.exp(0.5 * logvar)
+        if self._pair_rows:
+            # merged (cancer; wild-type) batch: two draws in the reference's order (cancer first), one per member
+            b = self._pair_rows
+            eps = torch.cat([torch.randn_like(mu[:b]), torch.randn_like(mu[b:])], dim=0)
+        else:
+            eps = torch.randn_like(mu)
+        return mu + eps * torch.exp(0.5 * logvar)
 
     def decode_vae(self, z):
         return HF.linear_small_batch(F.relu(self.vae_fc3(z)), self.vae_fc4.weight, self.vae_fc4.bias)
@@ -259,12 +269,45 @@ class MultimodalNet(nn.Module):
         o = self._encode(graph_data, sequence_data, peptide_property, need_attention=True)
         return o["mu"], o["logvar"], o["x_gat_node"], o["z_vae"], o["attention"], o["recon_x"]
 
+    def _encode_pair(self, graphs, seqs, props, need_attention):
+        """Encoder outputs of the cancer and of the wild-type member.  The encoder treats every graph / sample on its
+        own (block-diagonal batch, per-graph attention, per-sample VAE and property MLP) and both members share its
+        weights, so the pair is encoded as ONE batch of 2B graphs [cancer; wild-type] -- half the launches, and no
+        gradient-accumulation kernels for the twice-used parameters -- and the outputs are split afterwards.
+        Inputs: the reference's 2-tuples (merged here when both graphs are plain batches with the same node layout), or
+        an already merged batch (one graph of 2B graphs, sequences / properties with 2B rows: what the on-GPU batcher
+        delivers).  Static (capacity-padded) buffers and IMMUNOSTRUCT_MERGE_PAIRS=0 take two encoder passes."""
+        merged = None
+        if isinstance(graphs, PackedGraphBatch):
+            if graphs.batch_size % 2 or seqs.shape[0] != graphs.batch_size:
+                raise ValueError("a merged pair batch holds 2B graphs and 2B sequence / property rows")
+            merged = (graphs, seqs, props)
+        elif (MERGE_PAIRS and self.SPEC.graph and self.SPEC.vae and type(graphs[0]) is PackedGraphBatch
+              and type(graphs[1]) is PackedGraphBatch and graphs[0].batch_size == graphs[1].batch_size
+              and graphs[0].num_nodes() == graphs[1].num_nodes() and seqs[0].shape == seqs[1].shape):
+            graphs[0].csr(), graphs[1].csr()
+            merged = (graph_batch([graphs[0], graphs[1]]), torch.cat([seqs[0], seqs[1]], dim=0), torch.cat([props[0], props[1]], dim=0))
+        if merged is None:
+            oc = self._encode(graphs[0], seqs[0], props[0], need_attention=need_attention)
+            ow = self._encode(graphs[1], seqs[1], props[1])
+            return oc, ow
+        b = merged[0].batch_size // 2
+        self._pair_rows = b
+        try:
+            o = self._encode(*merged, need_attention=need_attention)
+        finally:
+            self._pair_rows = 0
+        halves = ({}, {})
+        for k, v in o.items():
+            for i, h in enumerate(halves):
+                h[k] = v[i * b:(i + 1) * b] if torch.is_tensor(v) else v
+        return halves
+
     def forward_comparative(self, graph_data_pair, sequence_data_pair, peptide_property_pair,
                             return_embedding=False, return_attention=False):
         if not self.SPEC.paired:
             raise AttributeError(f"{type(self).__name__} has no comparative forward")
-        oc = self._encode(graph_data_pair[0], sequence_data_pair[0], peptide_property_pair[0], need_attention=return_attention)
-        ow = self._encode(graph_data_pair[1], sequence_data_pair[1], peptide_property_pair[1])
+        oc, ow = self._encode_pair(graph_data_pair, sequence_data_pair, peptide_property_pair, return_attention)
         emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)
         emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)
         fused = torch.cat([emb_c, emb_w], dim=1) if self.use_wt_for_downstream else emb_c

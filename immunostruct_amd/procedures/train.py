@@ -44,6 +44,9 @@ def _single_loss(model, loss_function, batch, device, extra=None):
 def _paired_loss(model, loss_function, batch, device, contrastive, coeff):
     graphs, seqs, target, props = _to(device, batch)
     emb, recon, mu, logvar, final = model.forward_comparative(graphs, seqs, props)
+    if torch.is_tensor(seqs):       # merged batch [cancer; wild-type] (the on-GPU batcher's form)
+        half = seqs.shape[0] // 2
+        seqs = (seqs[:half], seqs[half:])
     # the prediction term is shared, the reconstruction terms are averaged (reference :107-114)
     loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
                   + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
@@ -185,11 +188,14 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
 def train_model_comparative_device(config, device, model, dataset_cancer, dataset_wt, train_index, val_index, optimizer,
                                    loss_function, scheduler=None, stage="pretrain", seed=0):
     """``train_model_comparative`` with both members of every (cancer, wild-type) pair in device-resident datasets
-    (same graph ids in both; targets are the cancer dataset's): batches are assembled on the GPU, the loss is the
-    reference's (``procedures/train.py:97-114``: shared prediction term, averaged reconstruction terms, ``coeff_contrastive``
-    x paired contrastive loss).  Every full batch is one replay of the captured HIP graph of the paired step; the
-    contrastive loss' class-count early-out (``utils/contrastive.py:38-43``) is evaluated on the device there
-    (``PairedContrastiveLoss.capturable``).  ``IMMUNOSTRUCT_CAPTURE_PAIRED=0`` runs every step eagerly."""
+    (same graph ids in both; targets are the cancer dataset's).  A batch of B pairs is assembled on the GPU as ONE merged
+    batch of 2B graphs [cancer; wild-type] (one gather from the concatenated dataset) which the paired model encodes in a
+    single pass (``MultimodalNet._encode_pair``); the loss is the reference's (``procedures/train.py:97-114``: shared
+    prediction term, averaged reconstruction terms, ``coeff_contrastive`` x paired contrastive loss).  Every full batch is
+    one replay of the captured HIP graph of that step; the contrastive loss' class-count early-out
+    (``utils/contrastive.py:38-43``) is evaluated on the device there (``PairedContrastiveLoss.capturable``).
+    ``IMMUNOSTRUCT_CAPTURE_PAIRED=0`` runs every step eagerly."""
+    from ..data import DeviceResidentDataset
     from ..distributed import FlatGradReducer
     from ..engine import CapturedTrainStep
     device = dataset_cancer.device
@@ -199,37 +205,36 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
     train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
     val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
+    both = DeviceResidentDataset.concat(dataset_cancer, dataset_wt)
+    shift = len(dataset_cancer)
     bufs = {}
 
-    def gather(idx, cancer, wt):
-        dataset_cancer.gather_into(idx, *cancer)
-        dataset_wt.gather_into(idx, *wt)
+    def gather(idx, buf):
+        return both.gather_into(torch.cat([idx, idx + shift]), *buf)
 
     def batch(idx):
         b = int(idx.numel())
         if b not in bufs:
-            bufs[b] = (dataset_cancer.new_batch(b), dataset_wt.new_batch(b))
-        gather(idx, *bufs[b])
-        (gc, sc, pc, y), (gw, sw, pw, _) = bufs[b]
-        return (gc, gw), (sc, sw), y, (pc, pw)
+            bufs[b] = both.new_batch(2 * b)
+        return gather(idx, bufs[b])
+
+    def forward_loss(m, g2, seq2, prop2, y2):
+        # y2 holds the targets of both members; the pair's label is the cancer member's
+        return _paired_loss(m, loss_function, (g2, seq2, y2[:y2.numel() // 2], prop2), device, contrastive, coeff)
 
     def step_loss(idx):
-        return _paired_loss(model, loss_function, batch(idx), device, contrastive, coeff)
+        return forward_loss(model, *batch(idx))
 
-    def forward_loss(m, graphs, seqs, props, y):
-        return _paired_loss(m, loss_function, (graphs, seqs, y, props), device, contrastive, coeff)
-
-    captured, wt_y = None, None
+    captured = None
     if train_index.numel() >= bsz and os.environ.get("IMMUNOSTRUCT_CAPTURE_PAIRED", "1") != "0":
-        graphs, seqs, y, props = batch(train_index[:bsz])
+        buf = both.new_batch(2 * bsz)
+        gather(train_index[:bsz], buf)
         model.train()
         if contrastive is not None:
             contrastive.capturable = True
         reducer = FlatGradReducer(model.parameters(), world=1)
-        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, (graphs, seqs, props, y),
-                                     edge_capacity=(bsz * dataset_cancer.max_edges, bsz * dataset_wt.max_edges),
+        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=2 * bsz * both.max_edges,
                                      warmup=1, preserve_state=True)
-        wt_y = torch.zeros_like(captured.y)       # the wild-type dataset's targets are not used
 
     train_losses, val_losses = [], []
     best = float("inf")
@@ -240,8 +245,7 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
         for at in range(0, perm.numel(), bsz):
             idx = perm[at:at + bsz]
             if captured is not None and idx.numel() == bsz:
-                gather(idx, (captured.sgraph[0], captured.seq[0], captured.prop[0], captured.y),
-                       (captured.sgraph[1], captured.seq[1], captured.prop[1], wt_y))
+                gather(idx, (captured.sgraph, captured.seq, captured.prop, captured.y))
                 loss = captured.replay().clone()
             else:
                 optimizer.zero_grad(set_to_none=True)

@@ -218,30 +218,44 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 3 captured steps")
 
 
-def test_captured_paired_step_matches_eager(cuda_device):
-    """The paired (cancer, wild-type) train step -- two encoder passes, fused head, BCE + reconstruction terms, paired
-    contrastive loss -- as one captured HIP graph (engine.CapturedTrainStep on pairs of static buffers) reproduces eager
-    training, including a single-class batch, where the contrastive term must vanish (reference utils/contrastive.py:38-43:
-    host early-out; here a device-side gate, PairedContrastiveLoss.capturable)."""
+@pytest.mark.parametrize("form", ["two_pass", "merged"])
+def test_captured_paired_step_matches_eager(cuda_device, form, monkeypatch):
+    """The paired (cancer, wild-type) train step -- encoder on both members, fused head, BCE + reconstruction terms, paired
+    contrastive loss -- as one captured HIP graph reproduces eager training, including a single-class batch, where the
+    contrastive term must vanish (reference utils/contrastive.py:38-43: host early-out; here a device-side gate,
+    PairedContrastiveLoss.capturable).  ``two_pass``: pairs of static buffers, one encoder pass per member;
+    ``merged``: one batch of 2B graphs [cancer; wild-type], one encoder pass (what the on-GPU batcher delivers)."""
     from immunostruct_amd.distributed import FlatGradReducer
     from immunostruct_amd.engine import CapturedTrainStep
     from immunostruct_amd import optim
+    from immunostruct_amd.graph import batch as graph_batch
+    from immunostruct_amd.models import _core
     from immunostruct_amd.procedures.train import _paired_loss
     dev = cuda_device
     nb = 6
+    monkeypatch.setattr(_core, "MERGE_PAIRS", form == "merged")
     raws = [(synthetic.make_batch(nb, seed=s, deg_extra=d), synthetic.make_batch(nb, seed=s + 100, deg_extra=d2))
             for s, d, d2 in ((61, 2, 3), (62, 4, 1), (63, 1, 2), (64, 3, 3))]
     targets = [torch.tensor(t, dtype=torch.float32, device=dev) for t in
                ([0, 1, 0, 0, 1, 0], [1, 1, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 0])]      # third: single class
+
     def tens(r):
         return H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev), torch.from_numpy(r.prop).to(dev)
+
     batches = []
     for (rc, rw), y in zip(raws, targets):
         (gc, sc, pc), (gw, sw, pw) = tens(rc), tens(rw)
-        batches.append(((gc, gw), (sc, sw), (pc, pw), y))
+        if form == "merged":
+            gc.csr(), gw.csr()
+            batches.append((graph_batch([gc, gw]), torch.cat([sc, sw]), torch.cat([pc, pw]), torch.cat([y, y])))
+        else:
+            batches.append(((gc, gw), (sc, sw), (pc, pw), y))
     losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
     eps = [H.make_eps(19, nb).to(dev), H.make_eps(20, nb).to(dev)]
-    caps = (max(rc.num_edges for rc, _ in raws), max(rw.num_edges for _, rw in raws))
+    if form == "merged":
+        caps = max(rc.num_edges + rw.num_edges for rc, rw in raws)
+    else:
+        caps = (max(rc.num_edges for rc, _ in raws), max(rw.num_edges for _, rw in raws))
 
     def run(captured):
         model = model_map["HybridModelv2_Comparative"](vae_input_dim=H.VAE_IN, device=dev, use_wt_for_downstream=True).to(dev)
@@ -254,6 +268,8 @@ def test_captured_paired_step_matches_eager(cuda_device):
 
         def forward_loss(m, graphs, seqs, props, y):
             it = iter(eps * 8)
+            if form == "merged":
+                y = y[:nb]
             with mock.patch("torch.randn_like", lambda t: next(it).to(t.dtype)):
                 return _paired_loss(m, losses.BCE_loss, (graphs, seqs, y, props), dev, contrastive, 0.05)
 
@@ -261,7 +277,7 @@ def test_captured_paired_step_matches_eager(cuda_device):
         if captured:
             red = FlatGradReducer(model.parameters(), world=1)
             eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=caps, warmup=1)
-            assert eng.paired and len(eng.sgraph) == 2
+            assert eng.paired == (form == "two_pass")
             for b in batches:
                 out.append(float(eng(*b)))
         else:
@@ -278,7 +294,40 @@ def test_captured_paired_step_matches_eager(cuda_device):
     for a, b in zip(l_e[1:], l_c):
         assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
     for k in sd_e:
-        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 4 captured paired steps")
+        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 4 captured paired steps ({form})")
+
+
+def test_merged_pair_encoding_equals_two_passes(cuda_device, monkeypatch):
+    """forward_comparative on the reference's 2-tuples: encoding [cancer; wild-type] as one batch (default) gives the
+    outputs and parameter gradients of two encoder passes with shared weights (reference comparative_models.py:463-496)."""
+    from immunostruct_amd.models import _core
+    dev = cuda_device
+    nb = 5
+    rc, rw = synthetic.make_batch(nb, seed=71, deg_extra=2), synthetic.make_batch(nb, seed=72, deg_extra=4)
+    args = ((H.product_graph(rc, dev), H.product_graph(rw, dev)),
+            (torch.from_numpy(rc.one_hot_sequence()).to(dev), torch.from_numpy(rw.one_hot_sequence()).to(dev)),
+            (torch.from_numpy(rc.prop).to(dev), torch.from_numpy(rw.prop).to(dev)))
+    eps = [H.make_eps(3, nb).to(dev), H.make_eps(4, nb).to(dev)]
+    res = {}
+    for merge in (False, True):
+        monkeypatch.setattr(_core, "MERGE_PAIRS", merge)
+        model = model_map["HybridModelv2_Comparative"](vae_input_dim=H.VAE_IN, device=dev, use_wt_for_downstream=True).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=4))
+        model.eval()
+        it = iter(eps)
+        with mock.patch("torch.randn_like", lambda t: next(it).to(t.dtype)):
+            emb, recon, mu, logvar, final = model.forward_comparative(*args)
+        outs = [emb[0], emb[1], recon[0], recon[1], mu[0], mu[1], logvar[0], logvar[1], final]
+        w = [torch.linspace(-1, 1, t.numel(), device=dev).view_as(t) for t in outs]
+        sum((t * wi).sum() for t, wi in zip(outs, w)).backward()
+        res[merge] = ([t.detach().cpu() for t in outs], {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None})
+    for i, (a, b) in enumerate(zip(*[res[m][0] for m in (False, True)])):
+        H.assert_close(b, a, 2e-6, f"output {i}")
+    gmax = max(float(g.abs().max()) for g in res[False][1].values())
+    for k, g in res[False][1].items():
+        if float(g.abs().max()) < 1e-6 * gmax:
+            continue                      # analytically zero (key bias): round-off on both sides
+        H.assert_close(res[True][1][k], g, GRAD_TOL, f"grad {k}")
 
 
 def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):

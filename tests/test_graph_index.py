@@ -93,3 +93,28 @@ def test_balanced_node_chunks_cover_all_nodes():
         b = t[:, 0].tolist()
         assert b[0] == 0 and b[-1] == 8 and len(b) == k + 1 and all(x <= y for x, y in zip(b, b[1:]))
         assert t[:, 1].tolist() == [int(rowptr[v]) for v in b]
+
+
+def test_batch_concatenates_existing_csr_pieces():
+    """graph.batch of graphs whose CSR indices exist (DataLoader workers build them per graph; a (cancer, wild-type) pair
+    of batches) = the indices of the union built from scratch, without a sort."""
+    import numpy as np
+    from immunostruct_amd.graph import CSRIndex, batch, graph
+    rs = np.random.RandomState(2)
+    parts = []
+    for n, e in ((7, 20), (5, 0), (9, 31), (4, 6)):
+        g = graph((torch.from_numpy(rs.randint(0, n, size=e)), torch.from_numpy(rs.randint(0, n, size=e))), num_nodes=n)
+        g.ndata["x"] = torch.from_numpy(rs.normal(size=(n, 3)).astype(np.float32))
+        g.edata["edge_attr"] = torch.from_numpy(rs.rand(e, 2).astype(np.float32))
+        g.csr()
+        parts.append(g)
+    left, right = batch(parts[:2]), batch(parts[2:])
+    assert left._csr is not None and right._csr is not None
+    union = batch([left, right])                      # batches of batches: the paired forward's merge
+    assert union._csr is not None and union.batch_num_nodes().tolist() == [7, 5, 9, 4]
+    s, d = union.edges()
+    want = CSRIndex(s, d, union.num_nodes())
+    for k in ("rowptr_dst", "src_sorted", "dst_sorted", "eperm", "rowptr_src", "pos_by_src"):
+        assert torch.equal(getattr(union._csr, k), getattr(want, k)), k
+        assert getattr(union._csr, k).dtype == getattr(want, k).dtype, k
+    assert torch.equal(union.edge_feat_csr(union.edata["edge_attr"]), union.edata["edge_attr"][want.eperm])

@@ -60,6 +60,22 @@ def eager(i):
 contrastive.capturable = True
 eng = CapturedTrainStep(model, opt, FlatGradReducer(model.parameters(), world=1), forward_loss, batches[0][:4], edge_capacity=caps)
 t_c = timed(lambda i: eng(*batches[i % 3][:4]))
+# merged form: one batch of 2B graphs [cancer; wild-type], one encoder pass
+from immunostruct_amd.graph import batch as graph_batch  # noqa: E402
+merged = []
+for (gc, gw), (sc, sw), (pc, pw), y, (ec, ew) in batches:
+    gc.csr(), gw.csr()
+    merged.append((graph_batch([gc, gw]), torch.cat([sc, sw]), torch.cat([pc, pw]), torch.cat([y, y]), ec + ew))
+
+
+def forward_loss_merged(m, g2, seq2, prop2, y2):
+    return _paired_loss(m, losses.BCE_loss, (g2, seq2, y2[:y2.numel() // 2], prop2), dev, contrastive, 0.01)
+
+
+eng2 = CapturedTrainStep(model, opt, FlatGradReducer(model.parameters(), world=1), forward_loss_merged, merged[0][:4],
+                         edge_capacity=max(m[4] for m in merged))
+t_m = timed(lambda i: eng2(*merged[i % 3][:4]))
+print(f"captured, merged pair batch: {t_m:.3f} ms ({2 * B / t_m:.1f} k graphs/s)")
 contrastive.capturable = False
 t_e = timed(eager)
 print(f"paired step, B = {B} pairs ({2 * B} graphs): eager {t_e:.3f} ms ({2 * B / t_e:.1f} k graphs/s), "
