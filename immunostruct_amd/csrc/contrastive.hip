@@ -28,6 +28,14 @@ namespace is {
 constexpr int CZ = 128;          // projector width
 constexpr int C_WAVES = 16;      // waves of a side workgroup
 constexpr float BN_EPS = 1e-5f;
+constexpr int C_GROUPS = 64 * C_WAVES / CZ;     // row stripes of a column pass (8)
+
+__device__ __forceinline__ float group_sum(const float (*part)[CZ], int c) {
+  float t = part[0][c];
+#pragma unroll
+  for (int g = 1; g < C_GROUPS; ++g) t += part[g][c];
+  return t;
+}
 
 // acc (32 x 32) += sum_k a(row r, k) * b(k, col r); K rounded up to even, accessors return 0 past the end.
 template <typename FA, typename FB>
@@ -65,7 +73,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
   float* S = scratch + (size_t)side * side_floats(B);
   float* Y = S; float* A1 = Y + (size_t)B * CZ; float* Zc = A1 + (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
   __shared__ float red[CZ];
+  __shared__ float part[C_GROUPS][CZ];      // column passes: C_GROUPS row stripes per column, combined in a fixed order
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int col = tid & (CZ - 1), grp = tid / CZ;
   const int row_tiles = (B + 31) / 32, ntiles = row_tiles * (CZ / 32);
   // ---- y1 = emb W1^T ----
   for (int tl = wave; tl < ntiles; tl += C_WAVES) {
@@ -81,14 +91,22 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
   }
   __syncthreads();
   // ---- batch statistics of every column (biased variance), a1 = relu(gamma xhat + beta) ----
-  if (tid < CZ) {
+  {
     float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += Y[(size_t)b * CZ + tid];
-    const float mu = s / (float)B;
+    for (int b = grp; b < B; b += C_GROUPS) s += Y[(size_t)b * CZ + col];
+    part[grp][col] = s;
+    __syncthreads();
+    if (tid < CZ) red[tid] = group_sum(part, tid) / (float)B;
+    __syncthreads();
+    const float mu = red[col];
     float v = 0.0f;
-    for (int b = 0; b < B; ++b) { const float d = Y[(size_t)b * CZ + tid] - mu; v += d * d; }
-    st[tid] = mu;
-    st[CZ + tid] = 1.0f / sqrtf(v / (float)B + BN_EPS);
+    for (int b = grp; b < B; b += C_GROUPS) { const float d = Y[(size_t)b * CZ + col] - mu; v += d * d; }
+    part[grp][col] = v;
+    __syncthreads();
+    if (tid < CZ) {
+      st[tid] = red[tid];
+      st[CZ + tid] = 1.0f / sqrtf(group_sum(part, tid) / (float)B + BN_EPS);
+    }
   }
   __syncthreads();
   for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
@@ -112,20 +130,28 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
   }
   __syncthreads();
   // ---- centre, unbiased variance, hinge ----
-  if (tid < CZ) {
+  {
     float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += Zc[(size_t)b * CZ + tid];
-    const float m = s / (float)B;
+    for (int b = grp; b < B; b += C_GROUPS) s += Zc[(size_t)b * CZ + col];
+    part[grp][col] = s;
+    __syncthreads();
+    if (tid < CZ) red[tid] = group_sum(part, tid) / (float)B;
+    __syncthreads();
+    const float m = red[col];
     float v = 0.0f;
-    for (int b = 0; b < B; ++b) {
-      const float d = Zc[(size_t)b * CZ + tid] - m;
-      Zc[(size_t)b * CZ + tid] = d;
+    for (int b = grp; b < B; b += C_GROUPS) {
+      const float d = Zc[(size_t)b * CZ + col] - m;
+      Zc[(size_t)b * CZ + col] = d;
       v += d * d;
     }
-    const float sd = sqrtf(v / (float)(B - 1) + 1e-4f);
-    st[2 * CZ + tid] = m;
-    st[3 * CZ + tid] = sd;
-    red[tid] = fmaxf(1.0f - sd, 0.0f);
+    part[grp][col] = v;
+    __syncthreads();
+    if (tid < CZ) {
+      const float sd = sqrtf(group_sum(part, tid) / (float)(B - 1) + 1e-4f);
+      st[2 * CZ + tid] = red[tid];
+      st[3 * CZ + tid] = sd;
+      red[tid] = fmaxf(1.0f - sd, 0.0f);
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -250,22 +276,28 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   float* wk = work + (size_t)side * B * CZ;                  // da1, then dy1
   float* demb = side == 0 ? demb_c : demb_w;
   __shared__ float s1[CZ], s2[CZ];
+  __shared__ float part[C_GROUPS][CZ], part2[C_GROUPS][CZ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int col = tid & (CZ - 1), grp = tid / CZ;
   const float g = g_loss[0];
   // ---- hinge gradient + centring backward (per column) ----
-  if (tid < CZ) {
-    const float sd = st[3 * CZ + tid];
+  {
+    const float sd = st[3 * CZ + col];
     // d hinge / d var_k = -(1/2) * (1/Z) * [sd < 1] / (2 sd);  d var_k / d z_bk = 2 z_bk / (B - 1)
     const float dv = (sd < 1.0f) ? -0.5f / (float)CZ / (2.0f * sd) : 0.0f;
     const float coef = dv * 2.0f / (float)(B - 1);
     float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-      const float v = dz[(size_t)b * CZ + tid] + coef * Zc[(size_t)b * CZ + tid];
-      dz[(size_t)b * CZ + tid] = v;
+    for (int b = grp; b < B; b += C_GROUPS) {
+      const float v = dz[(size_t)b * CZ + col] + coef * Zc[(size_t)b * CZ + col];
+      dz[(size_t)b * CZ + col] = v;
       s += v;
     }
-    const float m = s / (float)B;
-    for (int b = 0; b < B; ++b) dz[(size_t)b * CZ + tid] -= m;
+    part[grp][col] = s;
+    __syncthreads();
+    if (tid < CZ) s1[tid] = group_sum(part, tid) / (float)B;
+    __syncthreads();
+    const float m = s1[col];
+    for (int b = grp; b < B; b += C_GROUPS) dz[(size_t)b * CZ + col] -= m;
   }
   __syncthreads();
   // ---- da1 = dz0 W2 ----
@@ -283,17 +315,19 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   }
   __syncthreads();
   // ---- ReLU backward, BatchNorm backward on batch statistics ----
-  if (tid < CZ) {
-    const float gm = gamma[tid];
+  {
+    const float gm = gamma[col];
     float a = 0.0f, c = 0.0f;
-    for (int b = 0; b < B; ++b) {
-      const size_t idx = (size_t)b * CZ + tid;
+    for (int b = grp; b < B; b += C_GROUPS) {
+      const size_t idx = (size_t)b * CZ + col;
       const float dxh = (A1[idx] > 0.0f) ? wk[idx] * gm : 0.0f;
       wk[idx] = dxh;
       a += dxh;
       c += dxh * XH[idx];
     }
-    s1[tid] = a; s2[tid] = c;
+    part[grp][col] = a; part2[grp][col] = c;
+    __syncthreads();
+    if (tid < CZ) { s1[tid] = group_sum(part, tid); s2[tid] = group_sum(part2, tid); }
   }
   __syncthreads();
   for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
