@@ -417,6 +417,21 @@ __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __res
   if (d >= 0) dst[d] = v;
 }
 
+// nparts <= RED_SPLIT: one launch.  Same summation order as the two stages (stage 1 then only copies record p to slot p,
+// stage 2 adds the slots in ascending order), hence the same bits.
+__global__ __launch_bounds__(256) void reduce_partials_direct(const float* __restrict__ partials, int nparts, int stride,
+                                                              int count, const int* __restrict__ map, float* __restrict__ dst) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= count) return;
+  float r[RED_SPLIT];
+#pragma unroll
+  for (int s = 0; s < RED_SPLIT; ++s) r[s] = (s < nparts) ? partials[(size_t)s * stride + idx] : 0.0f;   // issued together
+  float v = 0.0f;
+#pragma unroll
+  for (int s = 0; s < RED_SPLIT; ++s) v += r[s];
+  const int d = map != nullptr ? map[idx] : idx;
+  if (d >= 0) dst[d] = v;
+}
 
 // Batched form: up to RED_MAX_JOBS independent reductions (one per kernel's partial records) in two launches.
 struct ReduceJob {
@@ -510,6 +525,10 @@ extern "C" int is_reduce_partials(const float* partials, int nparts, int stride,
                                   float* dst, float* scratch, void* stream) {
   if (nparts <= 0 || stride <= 0 || count <= 0 || count > stride) return -22;
   const dim3 block(256);
+  if (nparts <= is::RED_SPLIT) {
+    hipLaunchKernelGGL(is::reduce_partials_direct, dim3((count + 255) / 256), block, 0, IS_STREAM(stream), partials, nparts, stride, count, map, dst);
+    IS_RET();
+  }
   hipLaunchKernelGGL(is::reduce_partials_stage1, dim3((count + 255) / 256, is::RED_SPLIT), block, 0, IS_STREAM(stream), partials, nparts, stride, count, scratch);
   hipLaunchKernelGGL(is::reduce_partials_stage2, dim3((count + 255) / 256), block, 0, IS_STREAM(stream), scratch, count, map, dst);
   IS_RET();

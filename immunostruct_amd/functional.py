@@ -989,6 +989,7 @@ class VaeLossFn(torch.autograd.Function):
         _lib.check(code, "is_vae_loss")
         ctx.seq = seq
         ctx.logit_shape = logit.shape
+        ctx.set_materialize_grads(False)       # no zero-fill launch for the (non-differentiable) term vector's gradient
         ctx.save_for_backward(d_recon, d_mu, d_lv, d_logit)
         total = out[0].clone()
         ctx.mark_non_differentiable(out)
@@ -997,6 +998,8 @@ class VaeLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_terms):
         d_recon, d_mu, d_lv, d_logit = ctx.saved_tensors
+        if g is None:
+            return (None,) * 11
         if ctx.seq:
             gr, gm, gl, gz = torch._foreach_mul([d_recon, d_mu, d_lv, d_logit], g)     # one multi-tensor launch
         else:
