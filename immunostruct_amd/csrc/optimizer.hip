@@ -18,7 +18,8 @@ struct AdamChunk {
 };
 
 // state: [0] step count (as float, exact below 2^24), [1] lr / (1 - beta1^t), [2] sqrt(1 - beta2^t)
-// hyper: [0] lr, [1] beta1, [2] beta2, [3] eps, [4] weight_decay, [5] decoupled (AdamW) flag
+// hyper: [0] lr, [1] beta1, [2] beta2, [3] eps, [4] weight_decay, [5] decoupled (AdamW) flag, [6] gradient scale
+//        (1 = none; 1 / world size when the summed data-parallel gradient bucket is averaged here instead of by its own pass)
 __global__ void adam_prepare_kernel(float* __restrict__ state, const float* __restrict__ hyper) {
   const double t = (double)state[0] + 1.0;
   state[0] = (float)t;
@@ -41,13 +42,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunk* __restr
   const AdamChunk c = chunks[blockIdx.x];
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
   const bool decoupled = hyper[5] != 0.0f;
+  const float gs = hyper[6];
   const float step_size = state[1], bc2s = state[2];
   const bool vec = ((reinterpret_cast<uintptr_t>(c.p) | reinterpret_cast<uintptr_t>(c.g) | reinterpret_cast<uintptr_t>(c.m) |
                      reinterpret_cast<uintptr_t>(c.v)) & 15) == 0;
   const long long n4 = vec ? (c.n >> 2) : 0;
   for (long long i = threadIdx.x; i < n4; i += 256) {
     float4 p = reinterpret_cast<float4*>(c.p)[i];
-    const float4 g = reinterpret_cast<const float4*>(c.g)[i];
+    float4 g = reinterpret_cast<const float4*>(c.g)[i];
+    g.x *= gs; g.y *= gs; g.z *= gs; g.w *= gs;
     float4 m = reinterpret_cast<float4*>(c.m)[i];
     float4 v = reinterpret_cast<float4*>(c.v)[i];
     adam_one(p.x, g.x, m.x, v.x, lr, b1, b2, eps, wd, decoupled, step_size, bc2s);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunk* __restr
   }
   for (long long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
     float p = c.p[i], m = c.m[i], v = c.v[i];
-    adam_one(p, c.g[i], m, v, lr, b1, b2, eps, wd, decoupled, step_size, bc2s);
+    adam_one(p, c.g[i] * gs, m, v, lr, b1, b2, eps, wd, decoupled, step_size, bc2s);
     c.p[i] = p; c.m[i] = m; c.v[i] = v;
   }
 }
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunk* __restr
 }  // namespace is
 
 // chunks: DEVICE array of nchunks records { float* p; const float* g; float* m; float* v; long long n; };
-// state: device float[3] (step, derived step size, derived sqrt bias correction); hyper: device float[6]
-// (lr, beta1, beta2, eps, weight_decay, decoupled flag).  Two launches: a one-thread prepare + the streaming update.
+// state: device float[3] (step, derived step size, derived sqrt bias correction); hyper: device float[8]
+// (lr, beta1, beta2, eps, weight_decay, decoupled flag, gradient scale, unused).  Two launches: a one-thread prepare + the streaming update.
 extern "C" int is_adam_step(const void* chunks, int nchunks, float* state, const float* hyper, void* stream) {
   if (nchunks <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);

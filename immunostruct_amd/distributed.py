@@ -57,13 +57,27 @@ class FlatGradReducer:
         # debugging aid: issue the collectives even in a one-rank process group (exercises the RCCL launch path on one GPU)
         self._collective = self.world > 1 or (os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
         self.buckets = []
+        # True: reduce_bucket divides by the world size (its own pass over the bucket); the engine switches it off when
+        # the optimizer applies 1 / world itself (immunostruct_amd.optim: ``grad_scale``)
+        self.divide = True
         if self._packing:
             self._make_buckets([self.params])
 
     def _make_buckets(self, groups):
         dev = self.params[0].device
-        self.buckets = [dict(params=g, flat=torch.zeros(sum(p.numel() for p in g), dtype=torch.float32, device=dev), sources=None)
-                        for g in groups if g]
+        self.buckets = []
+        for g in groups:
+            if not g:
+                continue
+            flat = torch.zeros(sum(p.numel() for p in g), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in g:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                # gradient producers that own their output buffer (functional.LinearSmallBatchFn: the two VAE matrices,
+                # 96 % of the bytes) write straight into the bucket: no copy for them when the bucket is packed
+                p._grad_dest = views[-1]
+            self.buckets.append(dict(params=g, flat=flat, views=views, sources=None))
 
     @property
     def packing(self):
@@ -100,19 +114,26 @@ class FlatGradReducer:
             b["sources"] = v
 
     def reduce_bucket(self, i, async_op=False):
-        """pack bucket i, pre-divide by the world size, all-reduce (SUM), re-point the gradients; returns the work handle"""
+        """pack bucket i (one multi-tensor copy of the gradients that are not already in place), all-reduce (SUM; divided
+        by the world size here unless ``divide`` is off), re-point the gradients; returns the work handle"""
         b = self.buckets[i]
         src = b["sources"] if b["sources"] is not None else [p.grad for p in b["params"]]
-        pieces = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(src, b["params"])]
-        torch.cat(pieces, out=b["flat"])
+        dsts, srcs = [], []
+        for g, v in zip(src, b["views"]):
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                dsts.append(v)
+                srcs.append(g.view_as(v) if g.is_contiguous() else g.contiguous().view_as(v))
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
         work = None
         if self._collective:
-            b["flat"].div_(self.world)
+            if self.divide:
+                b["flat"].div_(self.world)
             work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=async_op)
-        off = 0
-        for p in b["params"]:
-            p.grad = b["flat"][off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, v in zip(b["params"], b["views"]):
+            p.grad = v
         return work
 
     def all_reduce_mean(self, async_op=False):

@@ -177,6 +177,10 @@ class CapturedTrainStep:
         self.y = torch.zeros_like(y)
         self._load(*template)
         self.fused_optimizer = not reducer.packing   # single rank: optimizer inside the same graph
+        if getattr(reducer, "_collective", False) and hasattr(optimizer, "grad_scale") and reducer.divide:
+            # the summed gradient bucket is averaged inside the optimizer kernel instead of by a pass of its own
+            reducer.divide = False
+            optimizer.grad_scale = 1.0 / reducer.world
         # host->device uploads must not happen inside the capture: build the (cached) gradient scatter
         # maps of both layer shapes now, even when no eager warm-up step is requested
         from . import functional as HF

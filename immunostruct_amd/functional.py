@@ -868,6 +868,9 @@ class LinearSmallBatchFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        # data-parallel runs: the reducer's slice of the flat gradient bucket for this weight (distributed.FlatGradReducer);
+        # the weight gradient is then written there directly instead of being copied in when the bucket is packed
+        ctx.dest = getattr(w, "_grad_dest", None)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -877,7 +880,10 @@ class LinearSmallBatchFn(torch.autograd.Function):
         gy = _lib.f32c(gy)
         xc = _lib.f32c(x)
         n, k, bsz = int(w.shape[0]), int(w.shape[1]), int(xc.shape[0])
-        dw = torch.empty(n, k, dtype=torch.float32, device=w.device)
+        dest = ctx.dest
+        # (not while a gradient is being accumulated over several backward passes: the slice IS the accumulator then)
+        direct = (dest is not None and w.grad is None and dest.shape == w.shape and dest.is_contiguous() and dest.device == w.device)
+        dw = dest if direct else torch.empty(n, k, dtype=torch.float32, device=w.device)
         db = torch.empty(n, dtype=torch.float32, device=w.device) if ctx.has_bias else None
         with KernelTimer.span("linear_wgrad"):
             _lib.check(lib.is_linear_wgrad(_lib.ptr(gy), n, _lib.ptr(xc), k, _lib.ptr(dw), _lib.ptr(db), bsz, n, k, _lib.stream_ptr()),

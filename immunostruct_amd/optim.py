@@ -31,18 +31,21 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._groups = {}       # id(group) -> dict(table, key, state, hyper, hyper_host)
+        # every gradient is multiplied by this inside the update kernel: 1 / world size when the data-parallel reducer
+        # hands over the SUM of the ranks' gradients (saves its own pass over the 25 MB bucket)
+        self.grad_scale = 1.0
 
     # ---- helpers -------------------------------------------------------------
     def _hyper_host(self, group):
         return (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
-                float(group["weight_decay"]), 1.0 if self.decoupled_weight_decay else 0.0)
+                float(group["weight_decay"]), 1.0 if self.decoupled_weight_decay else 0.0, float(self.grad_scale), 0.0)
 
     def _group_state(self, group, params):
         dev = params[0].device
         gs = self._groups.get(id(group))
         if gs is None:
             gs = dict(key=None, table=None, hyper_host=None,
-                      state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(6, dtype=torch.float32, device=dev))
+                      state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(8, dtype=torch.float32, device=dev))
             self._groups[id(group)] = gs
         return gs
 

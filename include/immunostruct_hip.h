@@ -253,8 +253,9 @@ int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld_x, float* 
 /* Multi-tensor Adam / AdamW step with torch.optim semantics (reference: torch.optim.Adam in train_IEDB_wFT.py:69-74,
  * torch.optim.AdamW in train_Cancer_wFT.py:76-92).  `chunks` = DEVICE array of nchunks records
  * { float* p; const float* g; float* m; float* v; long long n; } (one workgroup each), `state` = device float[3]
- * {step count, derived step size, derived sqrt(1 - beta2^t)} updated by the call, `hyper` = device float[6]
- * {lr, beta1, beta2, eps, weight_decay, decoupled (AdamW) flag}.  Capturable in a HIP graph.                   */
+ * {step count, derived step size, derived sqrt(1 - beta2^t)} updated by the call, `hyper` = device float[8]
+ * {lr, beta1, beta2, eps, weight_decay, decoupled (AdamW) flag, gradient scale (1 = none), unused}.
+ * Capturable in a HIP graph.                                                                                   */
 int is_adam_step(const void* chunks, int nchunks, float* state, const float* hyper, void* stream);
 
 /* Debug aid: one single-thread launch that writes the device wall clock (100 MHz) to *slot; can be captured in a
