@@ -144,9 +144,9 @@ class MultimodalNet(nn.Module):
                 self.classifier = self.get_classifier().to(self.device)
 
     # ---- encoders ------------------------------------------------------------
-    def _encode_graph(self, g, need_attention=False, x0=None):
+    def _encode_graph(self, g, need_attention=False):
         feats = g.ndata["x"]
-        h, x, a = feats[:, :NODE_ONEHOT], (feats[:, NODE_ONEHOT:] if x0 is None else x0), g.edata["edge_attr"]
+        h, x, a = feats[:, :NODE_ONEHOT], feats[:, NODE_ONEHOT:], g.edata["edge_attr"]
         layers = list(self.GCN_layers)
         qk = None
         head = self.self_attention.qk_head() if (self.SPEC.pool == "mean" and HF.fused_head_available(len(layers))) else None
@@ -198,10 +198,7 @@ class MultimodalNet(nn.Module):
         sp = self.SPEC
         o = {}
         overlap = sp.graph and sp.vae and seq.is_cuda and OVERLAP_BRANCHES
-        x0 = None
         if overlap:
-            if os.environ.get("IMMUNOSTRUCT_GRAPH_FIRST", "0") == "1":
-                x0 = g.ndata["x"][:, NODE_ONEHOT:].contiguous()     # first node of the graph branch, created before the fork
             main = torch.cuda.current_stream()
             side = _side_stream(seq.device)
             side.wait_stream(main)
@@ -212,7 +209,7 @@ class MultimodalNet(nn.Module):
                 HF.Stamps.hook(o["recon_x"], "bwd seq-branch start (d recon)")
         if sp.graph:
             HF.Stamps.mark("fwd graph-branch start")
-            o["x_gat_node"], o["attention"] = self._encode_graph(g, need_attention, x0=x0)
+            o["x_gat_node"], o["attention"] = self._encode_graph(g, need_attention)
             HF.Stamps.mark("fwd graph-branch end")
             HF.Stamps.hook(o["x_gat_node"], "bwd graph-branch start (d x_gat)")
         if overlap:
