@@ -43,6 +43,17 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+class PairList(list):
+    """[cancer, wild-type] as the reference returns it; ``merged`` = the tensor of the one encoder pass both are slices
+    of (None after two passes).  The reconstruction / KLD terms of a pair, 0.5 * (term(cancer) + term(wild-type)) with
+    equal member sizes, are the same means taken over ``merged`` -- one loss launch instead of two, and no slice
+    backward (procedures.train._paired_loss)."""
+
+    def __init__(self, items, merged=None):
+        super().__init__(items)
+        self.merged = merged
+
+
 @dataclass(frozen=True)
 class Spec:
     graph: bool = True          # EGNN + node attention + pooling branch
@@ -294,7 +305,7 @@ class MultimodalNet(nn.Module):
             o = self._encode(*merged, need_attention=need_attention)
         finally:
             self._pair_rows = 0
-        halves = ({}, {})
+        halves = ({"_merged": o}, {"_merged": o})
         for k, v in o.items():
             for i, h in enumerate(halves):
                 h[k] = v[i * b:(i + 1) * b] if torch.is_tensor(v) else v
@@ -314,5 +325,5 @@ class MultimodalNet(nn.Module):
             return (oc["x_gat_node"], oc["mu"], oc["logvar"], final) + tail
         if return_attention:
             return (oc["attention"], oc["mu"], oc["logvar"], final) + tail
-        return ([emb_c, emb_w], [oc["recon_x"], ow["recon_x"]], [oc["mu"], ow["mu"]],
-                [oc["logvar"], ow["logvar"]], final) + tail
+        pair = lambda k: PairList([oc[k], ow[k]], oc.get("_merged", {}).get(k))
+        return ([emb_c, emb_w], pair("recon_x"), pair("mu"), pair("logvar"), final) + tail

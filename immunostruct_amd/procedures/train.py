@@ -44,12 +44,19 @@ def _single_loss(model, loss_function, batch, device, extra=None):
 def _paired_loss(model, loss_function, batch, device, contrastive, coeff):
     graphs, seqs, target, props = _to(device, batch)
     emb, recon, mu, logvar, final = model.forward_comparative(graphs, seqs, props)
-    if torch.is_tensor(seqs):       # merged batch [cancer; wild-type] (the on-GPU batcher's form)
-        half = seqs.shape[0] // 2
-        seqs = (seqs[:half], seqs[half:])
-    # the prediction term is shared, the reconstruction terms are averaged (reference :107-114)
-    loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
-                  + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
+    merged = [getattr(t, "merged", None) for t in (recon, mu, logvar)]
+    if all(m is not None for m in merged) and merged[0].shape[0] == 2 * recon[0].shape[0]:
+        # one encoder pass produced both members (equal sizes): 0.5 * (loss(cancer) + loss(wild-type)) -- shared
+        # prediction term, averaged reconstruction / KLD means (reference :107-114) -- is the loss over the merged rows
+        seq2 = seqs if torch.is_tensor(seqs) else torch.cat([seqs[0], seqs[1]], dim=0)
+        loss = loss_function(merged[0], seq2, merged[1], merged[2], final, target)
+    else:
+        if torch.is_tensor(seqs):       # merged batch [cancer; wild-type] (the on-GPU batcher's form)
+            half = seqs.shape[0] // 2
+            seqs = (seqs[:half], seqs[half:])
+        # the prediction term is shared, the reconstruction terms are averaged (reference :107-114)
+        loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
+                      + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
     if coeff > 0:
         loss = loss + coeff * contrastive(emb[0], emb[1], target)
     return loss

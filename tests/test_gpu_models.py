@@ -323,6 +323,26 @@ def test_merged_pair_encoding_equals_two_passes(cuda_device, monkeypatch):
         res[merge] = ([t.detach().cpu() for t in outs], {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None})
     for i, (a, b) in enumerate(zip(*[res[m][0] for m in (False, True)])):
         H.assert_close(b, a, 2e-6, f"output {i}")
+    # the paired loss: one launch over the merged rows == 0.5 * (loss(cancer) + loss(wild-type)) of two passes
+    from immunostruct_amd.procedures.train import _paired_loss
+    y = torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0], device=dev)
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+    vals = {}
+    for merge in (False, True):
+        monkeypatch.setattr(_core, "MERGE_PAIRS", merge)
+        model = model_map["HybridModelv2_Comparative"](vae_input_dim=H.VAE_IN, device=dev, use_wt_for_downstream=True).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=4))
+        model.eval()
+        it = iter(eps)
+        with mock.patch("torch.randn_like", lambda t: next(it).to(t.dtype)):
+            loss = _paired_loss(model, losses.BCE_loss, (args[0], args[1], y, args[2]), dev, None, 0.0)
+        loss.backward()
+        vals[merge] = (float(loss.detach()), {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None})
+    assert abs(vals[True][0] - vals[False][0]) <= 2e-6 * abs(vals[False][0]), vals
+    gmax = max(float(g.abs().max()) for g in vals[False][1].values())
+    for k, g in vals[False][1].items():
+        if float(g.abs().max()) >= 1e-6 * gmax:
+            H.assert_close(vals[True][1][k], g, GRAD_TOL, f"paired-loss grad {k}")
     gmax = max(float(g.abs().max()) for g in res[False][1].values())
     for k, g in res[False][1].items():
         if float(g.abs().max()) < 1e-6 * gmax:
