@@ -220,6 +220,37 @@ __global__ void contr_finish_kernel(const float* __restrict__ partials, int npar
   }
 }
 
+__global__ __launch_bounds__(256) void contr_targets_kernel(const float* __restrict__ target, float* __restrict__ pos,
+                                                            float* __restrict__ gate, int B) {
+  __shared__ float s_sum[256], s_lo[256], s_hi[256];
+  __shared__ int s_other[256];
+  const int tid = threadIdx.x;
+  float sum = 0.0f, lo = INFINITY, hi = -INFINITY;
+  for (int b = tid; b < B; b += 256) { const float v = target[b]; sum += v; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  s_sum[tid] = sum; s_lo[tid] = lo; s_hi[tid] = hi;
+  __syncthreads();
+  if (tid == 0) {          // fixed order: deterministic mean
+    float t = 0.0f, l = INFINITY, h = -INFINITY;
+    for (int i = 0; i < 256; ++i) { t += s_sum[i]; l = fminf(l, s_lo[i]); h = fmaxf(h, s_hi[i]); }
+    s_sum[0] = t / (float)B; s_lo[0] = l; s_hi[0] = h;
+  }
+  __syncthreads();
+  const float mean = s_sum[0], l = s_lo[0], h = s_hi[0];
+  int other = 0;
+  for (int b = tid; b < B; b += 256) {
+    const float v = target[b];
+    pos[b] = v > mean ? 1.0f : 0.0f;
+    other |= (v != l && v != h) ? 1 : 0;
+  }
+  s_other[tid] = other;
+  __syncthreads();
+  if (tid == 0) {
+    int any = 0;
+    for (int i = 0; i < 256; ++i) any |= s_other[i];
+    gate[0] = (any == 0 && l != h) ? 1.0f : 0.0f;
+  }
+}
+
 // DZ [2][B][Z]: gradient w.r.t. the centred projections (pair / corr terms only; the hinge is added by the side kernel)
 __global__ __launch_bounds__(256) void contr_pair_bwd_kernel(
     const float* __restrict__ scratch, const float* __restrict__ pos, float lambda, const float* __restrict__ PAIR,
@@ -377,6 +408,15 @@ extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld
                      scratch, hinge, B);
   hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
   hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, hinge, loss);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// target [B] -> pos [B] = (target > mean(target)) as 1.0 / 0.0 (reference utils/contrastive.py:45) and gate [1] = 1.0 if the
+// target holds exactly two distinct values else 0.0 (the reference's early-out, :38-43, as a device-side factor).  One
+// launch instead of ~11 elementwise / reduction launches.  1 <= B <= 1024.
+extern "C" int is_contrastive_targets(const float* target, float* pos, float* gate, int B, void* stream) {
+  if (B < 1 || B > 1024) return -22;
+  hipLaunchKernelGGL(is::contr_targets_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), target, pos, gate, B);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -856,6 +856,20 @@ class PairedContrastiveFn(torch.autograd.Function):
         return dc, dw, None, None, None, None, None, None
 
 
+def contrastive_targets(target):
+    """(pos, gate): pos = (target > mean) as floats, gate = [exactly two distinct values] as a 0-d float tensor; one launch"""
+    lib = _lib.load()
+    _lib.require_device(target)
+    t = _lib.f32c(target.reshape(-1).to(torch.float32))
+    b = int(t.numel())
+    if not 1 <= b <= 1024:
+        raise NotImplementedError("contrastive_targets: 1 <= batch <= 1024")
+    pos = torch.empty(b, dtype=torch.float32, device=t.device)
+    gate = torch.empty(1, dtype=torch.float32, device=t.device)
+    _lib.check(lib.is_contrastive_targets(_lib.ptr(t), _lib.ptr(pos), _lib.ptr(gate), b, _lib.stream_ptr()), "is_contrastive_targets")
+    return pos, gate[0]
+
+
 def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
     return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam)
 

@@ -50,21 +50,22 @@ class PairedContrastiveLoss(nn.Module):
         self.capturable = False      # True: no host-side early-out (engine.CapturedTrainStep on paired batches)
 
     def forward(self, embedding_cancer, embedding_wt, is_immunogenic):
-        gate = None
+        gate = pos = None
         if self.capturable and is_immunogenic.is_cuda:
             # same rule without a host decision (a captured HIP graph cannot branch on data): the loss is always
             # evaluated -- it is finite for any target -- and multiplied by [the target holds exactly two distinct
-            # values], computed on the device; value and gradients are then exactly the reference's 0 otherwise
-            lo, hi = is_immunogenic.min(), is_immunogenic.max()
-            two = ((is_immunogenic == lo) | (is_immunogenic == hi)).all() & (lo != hi)
-            gate = two.to(embedding_cancer.dtype)
+            # values], computed on the device (one launch, csrc/contrastive.hip is_contrastive_targets, together with the
+            # positive mask); value and gradients are then exactly the reference's 0 otherwise
+            from .. import functional as HF
+            pos, gate = HF.contrastive_targets(is_immunogenic)
         elif is_immunogenic.unique().numel() != 2:
             return 0  # nothing to contrast (continuous target, or a single-class batch)
-        loss = self._loss(embedding_cancer, embedding_wt, is_immunogenic)
+        loss = self._loss(embedding_cancer, embedding_wt, is_immunogenic, pos)
         return loss if gate is None else loss * gate
 
-    def _loss(self, embedding_cancer, embedding_wt, is_immunogenic):
-        pos = (is_immunogenic > is_immunogenic.mean()).to(embedding_cancer.dtype)
+    def _loss(self, embedding_cancer, embedding_wt, is_immunogenic, pos=None):
+        if pos is None:
+            pos = (is_immunogenic > is_immunogenic.mean()).to(embedding_cancer.dtype)
         if embedding_cancer.shape != embedding_wt.shape:
             raise AssertionError("cancer / wild-type embeddings must have equal shapes")
         if (embedding_cancer.is_cuda and self.z_dim == 128 and 2 <= embedding_cancer.shape[0] <= 256

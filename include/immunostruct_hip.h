@@ -224,6 +224,11 @@ int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, co
                        const float* scratch, float* work, const float* g_loss, float* demb_c, float* demb_w,
                        int ld_d, int E, int B, void* stream);
 
+/* target [B] -> pos [B] = (target > mean(target)) as 1.0 / 0.0 (reference utils/contrastive.py:45) and gate [1] = 1.0 when
+ * the target holds exactly two distinct values, else 0.0: the reference's host-side early-out (utils/contrastive.py:38-43)
+ * as a device-side factor, for captured graphs.  1 <= B <= 1024.                                                       */
+int is_contrastive_targets(const float* target, float* pos, float* gate, int B, void* stream);
+
 /* Two-layer per-sample MLP for the small dense heads (classifier Linear(F,32)-ReLU-Dropout-Linear(32,1),
  * models/hybrid_models.py:288-295; property embedding :280-286; the pooled attention's W_v / w_concat tail,
  * models/layers.py:74-77):

@@ -530,3 +530,21 @@ def test_linear_small_batch_weight_gradient(cuda_device, b, n, k):
     (y * gup.to(cuda_device)).sum().backward()
     for name, a, r in zip(("dx", "dW", "db"), hip, ref):
         H.assert_close(a.grad.cpu(), r.grad, 1e-5, f"linear {name}")
+
+
+@pytest.mark.gpu
+def test_contrastive_targets_kernel(cuda_device):
+    """is_contrastive_targets: positive mask and the two-distinct-values gate of utils/contrastive.py:38-45 in one launch."""
+    from immunostruct_amd import functional as HF
+    g = torch.Generator().manual_seed(5)
+    cases = [torch.tensor([0.0, 1.0]), torch.zeros(7), torch.ones(130), (torch.rand(128, generator=g) < 0.19).float(),
+             torch.rand(64, generator=g) * 2 - 1, torch.tensor([0.0, 1.0, 2.0, 1.0]), torch.tensor([-3.5, 2.25] * 300),
+             (torch.rand(1000, generator=g) < 0.5).float() * 0.3 - 0.1]
+    for y in cases:
+        pos, gate = HF.contrastive_targets(y.to(cuda_device))
+        want_pos = (y > y.mean()).float()
+        want_gate = 1.0 if y.unique().numel() == 2 else 0.0
+        assert torch.equal(pos.cpu(), want_pos), y
+        assert float(gate) == want_gate, (y, float(gate))
+    with pytest.raises(NotImplementedError):
+        HF.contrastive_targets(torch.zeros(2000, device=cuda_device))
