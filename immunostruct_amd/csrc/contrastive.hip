@@ -61,6 +61,58 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+
+// C[i][c] = sum_k A(i, k) * W(k, c) for i < B (<= 256), c < N (<= 128), all 16 waves of the workgroup: 32-wide K slabs of both
+// operands are staged through LDS with coalesced loads (WKC: W(k, c) is contiguous in k, else in c), each wave owns the
+// 32 x 32 output tiles tl = wave, wave + 16, ... (at most two).  Same k order and MFMA mapping as tile32: same bits.
+constexpr int SLAB = 32, SLD = SLAB + 1, SLAB_ROWS = 256, SLAB_COLS = 128;
+struct SlabSmem { float a[SLAB_ROWS * SLD]; float w[SLAB_COLS * SLD]; };
+
+template <bool WKC, typename FA, typename FW, typename FOUT>
+__device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int row_tiles = (B + 31) / 32, col_tiles = (N + 31) / 32, ntiles = row_tiles * col_tiles;
+  f32x16 acc[2] = {zero16(), zero16()};
+  for (int k0 = 0; k0 < K; k0 += SLAB) {
+    __syncthreads();
+    // A slab: rows x 32 k (k fastest: 128-byte row segments)
+    for (int idx = tid; idx < row_tiles * 32 * SLAB; idx += 64 * C_WAVES) {
+      const int i = idx / SLAB, kk = idx % SLAB;
+      sm.a[i * SLD + kk] = (i < B && k0 + kk < K) ? a_elem(i, k0 + kk) : 0.0f;
+    }
+    for (int idx = tid; idx < col_tiles * 32 * SLAB; idx += 64 * C_WAVES) {
+      int c, kk;
+      if (WKC) { c = idx / SLAB; kk = idx % SLAB; } else { kk = idx / (col_tiles * 32); c = idx % (col_tiles * 32); }
+      sm.w[c * SLD + kk] = (c < N && k0 + kk < K) ? w_elem(k0 + kk, c) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int own = 0; own < 2; ++own) {
+      const int tl = wave + own * C_WAVES;
+      if (tl < ntiles) {
+        const float* ap = sm.a + ((tl / col_tiles) * 32 + r) * SLD;
+        const float* wp = sm.w + ((tl % col_tiles) * 32 + r) * SLD;
+#pragma unroll
+        for (int kk = 0; kk < SLAB; kk += 2)
+          acc[own] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk + hf], wp[kk + hf], acc[own], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int own = 0; own < 2; ++own) {
+    const int tl = wave + own * C_WAVES;
+    if (tl < ntiles) {
+      const int i0 = (tl / col_tiles) * 32, j0 = (tl % col_tiles) * 32;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = i0 + tile_row(t, hf), c = j0 + r;
+        if (i < B && c < N) out(i, c, acc[own][t]);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // scratch layout per side (floats): Y [B][Z] | A1 [B][Z] | Zc [B][Z] | stats: mu[Z] inv[Z] colmean[Z] std[Z]
 __host__ __device__ inline long long side_floats(int B) { return 3LL * B * CZ + 4 * CZ; }
 
@@ -73,23 +125,14 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
   float* S = scratch + (size_t)side * side_floats(B);
   float* Y = S; float* A1 = Y + (size_t)B * CZ; float* Zc = A1 + (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
   __shared__ float red[CZ];
+  __shared__ SlabSmem slab;
   __shared__ float part[C_GROUPS][CZ];      // column passes: C_GROUPS row stripes per column, combined in a fixed order
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int tid = threadIdx.x;
   const int col = tid & (CZ - 1), grp = tid / CZ;
-  const int row_tiles = (B + 31) / 32, ntiles = row_tiles * (CZ / 32);
   // ---- y1 = emb W1^T ----
-  for (int tl = wave; tl < ntiles; tl += C_WAVES) {
-    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
-    f32x16 acc = zero16();
-    tile32(acc, E, [&](int rr, int k) { return (i0 + rr < B) ? emb[(size_t)(i0 + rr) * ld_e + k] : 0.0f; },
-           [&](int k, int cc) { return W1[(size_t)(j0 + cc) * E + k]; }, lane);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = i0 + tile_row(t, hf);
-      if (i < B) Y[(size_t)i * CZ + j0 + r] = acc[t];
-    }
-  }
-  __syncthreads();
+  gemm_slabs<true>(slab, B, CZ, E, [&](int i, int k) { return emb[(size_t)i * ld_e + k]; },
+                   [&](int k, int c) { return W1[(size_t)c * E + k]; },
+                   [&](int i, int c, float v) { Y[(size_t)i * CZ + c] = v; }, tid);
   // ---- batch statistics of every column (biased variance), a1 = relu(gamma xhat + beta) ----
   {
     float s = 0.0f;
@@ -117,18 +160,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
   }
   __syncthreads();
   // ---- z0 = a1 W2^T ----
-  for (int tl = wave; tl < ntiles; tl += C_WAVES) {
-    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
-    f32x16 acc = zero16();
-    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? A1[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
-           [&](int k, int cc) { return W2[(size_t)(j0 + cc) * CZ + k]; }, lane);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = i0 + tile_row(t, hf);
-      if (i < B) Zc[(size_t)i * CZ + j0 + r] = acc[t];
-    }
-  }
-  __syncthreads();
+  gemm_slabs<true>(slab, B, CZ, CZ, [&](int i, int k) { return A1[(size_t)i * CZ + k]; },
+                   [&](int k, int c) { return W2[(size_t)c * CZ + k]; },
+                   [&](int i, int c, float v) { Zc[(size_t)i * CZ + c] = v; }, tid);
   // ---- centre, unbiased variance, hinge ----
   {
     float s = 0.0f;
@@ -307,8 +341,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   float* wk = work + (size_t)side * B * CZ;                  // da1, then dy1
   float* demb = side == 0 ? demb_c : demb_w;
   __shared__ float s1[CZ], s2[CZ];
+  __shared__ SlabSmem slab;
   __shared__ float part[C_GROUPS][CZ], part2[C_GROUPS][CZ];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int tid = threadIdx.x;
   const int col = tid & (CZ - 1), grp = tid / CZ;
   const float g = g_loss[0];
   // ---- hinge gradient + centring backward (per column) ----
@@ -332,19 +367,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   }
   __syncthreads();
   // ---- da1 = dz0 W2 ----
-  const int row_tiles = (B + 31) / 32;
-  for (int tl = wave; tl < row_tiles * 4; tl += C_WAVES) {
-    const int i0 = (tl / 4) * 32, j0 = (tl % 4) * 32;
-    f32x16 acc = zero16();
-    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? dz[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
-           [&](int k, int cc) { return W2[(size_t)k * CZ + j0 + cc]; }, lane);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = i0 + tile_row(t, hf);
-      if (i < B) wk[(size_t)i * CZ + j0 + r] = acc[t];
-    }
-  }
-  __syncthreads();
+  gemm_slabs<false>(slab, B, CZ, CZ, [&](int i, int k) { return dz[(size_t)i * CZ + k]; },
+                    [&](int k, int c) { return W2[(size_t)k * CZ + c]; },
+                    [&](int i, int c, float v) { wk[(size_t)i * CZ + c] = v; }, tid);
   // ---- ReLU backward, BatchNorm backward on batch statistics ----
   {
     const float gm = gamma[col];
@@ -367,18 +392,10 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   }
   __syncthreads();
   // ---- d emb = dy1 W1, scaled by the upstream gradient ----
-  const int col_tiles = (E + 31) / 32;
-  for (int tl = wave; tl < row_tiles * col_tiles; tl += C_WAVES) {
-    const int i0 = (tl / col_tiles) * 32, j0 = (tl % col_tiles) * 32;
-    f32x16 acc = zero16();
-    tile32(acc, CZ, [&](int rr, int k) { return (i0 + rr < B) ? wk[(size_t)(i0 + rr) * CZ + k] : 0.0f; },
-           [&](int k, int cc) { return (j0 + cc < E) ? W1[(size_t)k * E + j0 + cc] : 0.0f; }, lane);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = i0 + tile_row(t, hf), j = j0 + r;
-      if (i < B && j < E) demb[(size_t)i * ld_d + j] = acc[t] * g;
-    }
-  }
+  for (int c0 = 0; c0 < E; c0 += SLAB_COLS)       // E <= 256: at most two column blocks of the slab width
+    gemm_slabs<false>(slab, B, min(SLAB_COLS, E - c0), CZ, [&](int i, int k) { return wk[(size_t)i * CZ + k]; },
+                      [&](int k, int c) { return W1[(size_t)k * E + c0 + c]; },
+                      [&](int i, int c, float v) { demb[(size_t)i * ld_d + c0 + c] = v * g; }, tid);
 }
 
 }  // namespace is
