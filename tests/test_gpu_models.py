@@ -106,11 +106,14 @@ def test_comparative_train_step_matches_reference_golden(cuda_device, name, wt):
     print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
 
 
-def test_full_train_step_gradients_vs_oracle(cuda_device):
-    """HybridModelv2, B=8, train-mode dropout with shared keep-masks: every parameter gradient vs oracle autograd."""
+@pytest.mark.parametrize("n_pad,b", [(190, 8), (40, 5), (100, 3), (150, 4), (250, 2)])
+def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
+    """HybridModelv2: loss and every parameter gradient vs oracle autograd -- at the reference's padded node count (190) and
+    at other dataset-wide node counts (the node-attention kernels have one instantiation per 64 nodes, the edge / node
+    kernels tile by 16 / 32 rows: 40, 100, 150 and 250 nodes hit every variant and ragged last tiles)."""
     dev = cuda_device
-    b = 8
-    raw = synthetic.make_batch(b, seed=33, deg_extra=5)
+    reals = (n_pad - 2, n_pad - 1, n_pad)
+    raw = synthetic.make_batch(b, seed=33, deg_extra=5, n_pad=n_pad, n_real_choices=reals)
     sd = H.det_sd(H.model_shapes("HybridModelv2"), seed=14)
     eps = H.make_eps(5, b)
     y = torch.from_numpy(raw.y_reg)
