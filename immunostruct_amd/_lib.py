@@ -74,6 +74,7 @@ SIGNATURES = {
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_attn_colmean_fwd_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_attn_colmean_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_probs_floats": [_I, _I, _I],
     "is_comb_attn_stats_floats": [_I, _I],

@@ -105,7 +105,8 @@ __device__ __forceinline__ void attn_stage_qk(AttnSmem<NT, D>& sm, const float* 
 template <int NT, int D>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, float* __restrict__ ctx, float* __restrict__ abar_out,
-    float* __restrict__ probs, int n, int heads) {
+    float* __restrict__ probs, int n, int heads, const float* __restrict__ wv, const float* __restrict__ bv,
+    const float* __restrict__ wc, const float* __restrict__ bc, float* __restrict__ a1_out, float* __restrict__ y_out) {
   constexpr int LDQ = AttnSmem<NT, D>::LDQ;
   __shared__ AttnSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -190,6 +191,35 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
 #pragma unroll
       for (int w = 0; w < NT; ++w) v += sm.cpart[w][tid];
       ctx[(size_t)(b * heads + hd) * 64 + tid] = v;
+      sm.cpart[0][tid] = v;      // (own column: read above by this thread only)
+    }
+  }
+  if constexpr (D == 64) {
+    if (wv != nullptr) {
+      // pooled tail of a single head (models/layers.py:74-77 on the mean-pooled vector): hid = W_v ctx + b_v,
+      // y = W_c hid + b_c, the arithmetic of csrc/mlp_head.hip (k ascending from the bias) on LDS-staged transposed
+      // weights; the Q / K tiles are dead by now and lend their space
+      constexpr int LDW = 65;
+      float* wvt = sm.qs;                       // [k][d]
+      float* wct = sm.qs + 64 * LDW;            // [h][o]
+      __syncthreads();
+      for (int i = tid; i < 64 * 64; i += 64 * NT) {
+        wvt[(i & 63) * LDW + (i >> 6)] = wv[i];
+        wct[(i & 63) * LDW + (i >> 6)] = wc[i];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float acc = bv[tid];
+        for (int k = 0; k < 64; ++k) acc += wvt[k * LDW + tid] * sm.cpart[0][k];
+        if (a1_out != nullptr) a1_out[(size_t)b * 64 + tid] = acc;
+        sm.dab[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float acc = bc[tid];
+        for (int h = 0; h < 64; ++h) acc += wct[h * LDW + tid] * sm.dab[h];
+        y_out[(size_t)b * 64 + tid] = acc;
+      }
     }
   }
 }
@@ -398,7 +428,22 @@ extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, 
                                    int heads, void* stream) {
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
-  ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads);
+  const float* none = nullptr;
+  float* nout = nullptr;
+  ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, none, none, none, none, nout, nout);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// Single head: the same pass followed, in the same launch, by the pooled tail hid = W_v ctx + b_v (a1_out [B,64], may be
+// NULL), y = W_c hid + b_c (y_out [B,64]) -- the value projection and w_concat of models/layers.py:74-77 applied to the
+// mean-pooled vector (what is_mlp2_fwd computes from ctx with hgroup = 64, as one launch less).
+extern "C" int is_attn_colmean_fwd_tail(const float* qk, const float* x, float* ctx, float* abar, float* probs,
+                                        const float* wv, const float* bv, const float* wc, const float* bc, float* a1_out,
+                                        float* y_out, int B, int n, void* stream) {
+  if (B <= 0) return 0;
+  if (n <= 0 || n > 256 || wv == nullptr || bv == nullptr || wc == nullptr || bc == nullptr || y_out == nullptr) return -22;
+  const int heads = 1;
+  ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, wv, bv, wc, bc, a1_out, y_out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

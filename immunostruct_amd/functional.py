@@ -660,6 +660,67 @@ def attn_colmean(qk, x, b, n, heads):
     return AttnColMeanFn.apply(qk, x, b, n, heads)
 
 
+class AttnPooledTailFn(torch.autograd.Function):
+    """Single head: ``AttnColMeanFn`` followed by the pooled tail u = W_c (W_v ctx + b_v) + b_c in the SAME forward launch
+    (``is_attn_colmean_fwd_tail``); the backward is the tail's (``is_mlp2_bwd`` + reduction) followed by the attention's."""
+
+    @staticmethod
+    def forward(ctx_, qk, x, wv, bv, wc, bc, b, n):
+        lib = _lib.load()
+        _lib.require_device(qk, x, wv, bv, wc, bc)
+        if qk.shape != (b * n, 2 * HIDDEN) or x.shape != (b * n, HIDDEN) or tuple(wv.shape) != (HIDDEN, HIDDEN) \
+                or tuple(wc.shape) != (HIDDEN, HIDDEN):
+            raise ValueError("expected qk (B*n,128), x (B*n,64) and 64x64 projections")
+        if n > 256:
+            raise NotImplementedError("attention kernel supports <= 256 nodes per graph")
+        qk, x, wv, bv, wc, bc = (_lib.f32c(t) for t in (qk, x, wv, bv, wc, bc))
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        need = any(ctx_.needs_input_grad)
+        pooled = torch.empty(b, 1, HIDDEN, **f32)
+        y = torch.empty(b, HIDDEN, **f32)
+        a1 = torch.empty(b, HIDDEN, **f32) if need else None
+        abar = torch.empty(b, 1, n, **f32) if need else None
+        probs = torch.empty(lib.is_attn_colmean_probs_floats(b, n, 1), **f32) if need else None
+        with KernelTimer.span("attn_colmean_fwd"):
+            _lib.check(lib.is_attn_colmean_fwd_tail(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(pooled), _lib.ptr(abar), _lib.ptr(probs),
+                                                    _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(a1), _lib.ptr(y),
+                                                    b, n, _lib.stream_ptr()), "is_attn_colmean_fwd_tail")
+        ctx_.dims = (b, n)
+        ctx_.save_for_backward(qk, x, abar, probs, pooled, wv, wc, a1, y)
+        return y
+
+    @staticmethod
+    def backward(ctx_, gy):
+        lib = _lib.load()
+        qk, x, abar, probs, pooled, wv, wc, a1, y = ctx_.saved_tensors
+        b, n = ctx_.dims
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr()
+        gy = _lib.f32c(gy)
+        hid = HIDDEN
+        nrec, rec = lib.is_mlp2_bwd_records(b), lib.is_mlp2_bwd_record_floats(hid, hid, hid)
+        part = torch.empty(nrec * rec, **f32)
+        g_ctx = torch.empty(b, hid, **f32)
+        with KernelTimer.span("mlp2_bwd"):
+            _lib.check(lib.is_mlp2_bwd(_lib.ptr(pooled), hid, _lib.ptr(wv), _lib.ptr(wc), None, _lib.ptr(a1), _lib.ptr(y),
+                                       _lib.ptr(gy), _lib.ptr(g_ctx), _lib.ptr(part), b, hid, hid, hid, hid, 0, 0, st), "is_mlp2_bwd")
+            flat = torch.empty(rec, **f32)
+            scratch = torch.empty(lib.is_reduce_partials_scratch_floats(rec), **f32)
+            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nrec, rec, rec, None, _lib.ptr(flat), _lib.ptr(scratch), st), "is_reduce_partials")
+        dqk, dx = torch.empty_like(qk), torch.empty_like(x)
+        with KernelTimer.span("attn_colmean_bwd"):
+            _lib.check(lib.is_attn_colmean_bwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(probs), _lib.ptr(g_ctx),
+                                               _lib.ptr(dqk), _lib.ptr(dx), b, n, 1, st), "is_attn_colmean_bwd")
+        o1, o2, o3 = hid * hid, hid * hid + hid, 2 * hid * hid + hid
+        return dqk, dx, flat[:o1].view(hid, hid), flat[o1:o2], flat[o2:o3].view(hid, hid), flat[o3:], None, None
+
+
+def attn_pooled_tail(qk, x, wv, bv, wc, bc, b, n):
+    return AttnPooledTailFn.apply(qk, x, wv, bv, wc, bc, b, n)
+
+
 class CombinedAttentionMeanFn(torch.autograd.Function):
     """z (B,T) = mean over features of MultiHeadAttention(F, 8, input_dim=1) applied to the scalar tokens x (B,T)
     (``csrc/combined_attention.hip``, closed form)."""
@@ -787,6 +848,7 @@ def mlp2(x, w1, b1, w2, b2, mask=None, act1=0, act2=0, hgroup=0):
 
 
 MLP_HEADS = os.environ.get("IMMUNOSTRUCT_MLP_HEADS", "1") != "0"
+ATTN_TAIL = os.environ.get("IMMUNOSTRUCT_ATTN_TAIL", "1") != "0"      # single-head pooled tail inside the attention forward launch
 _ones_cache = {}
 
 

@@ -305,6 +305,13 @@ int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const 
 long long is_attn_colmean_probs_floats(int B, int n, int heads);
 int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,
                         int heads, void* stream);
+
+/* Single head: is_attn_colmean_fwd followed, in the same launch, by the pooled tail hid = W_v ctx + b_v (a1_out [B,64], may
+ * be NULL), y = W_c hid + b_c (y_out [B,64]): value projection and w_concat of models/layers.py:74-77 on the mean-pooled
+ * vector.  wv, wc [64,64] row-major (out, in); 1 <= n <= 256.                                                          */
+int is_attn_colmean_fwd_tail(const float* qk, const float* x, float* ctx, float* abar, float* probs, const float* wv,
+                             const float* bv, const float* wc, const float* bc, float* a1_out, float* y_out, int B, int n,
+                             void* stream);
 int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* probs,
                         const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream);
 
