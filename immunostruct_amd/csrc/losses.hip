@@ -50,43 +50,47 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
     float* __restrict__ d_logvar, int latent_total,
     const float* __restrict__ logit, const float* __restrict__ y, float* __restrict__ d_logit, int batch,
     int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ out) {
-  __shared__ float red[LOSS_BLOCK / 64];
+  __shared__ float red[3][LOSS_BLOCK / 64];
   const int tid = threadIdx.x;
-  float mse = 0.0f, kld = 0.0f;
-  if (recon_total > 0) {
-    float acc = 0.0f;
-    for (int i = tid; i < nparts; i += LOSS_BLOCK) acc += partials[i];
-    mse = block_sum(acc, red) / (float)recon_total;
+  // the three per-thread partial sums first (their loads are independent: all in flight together), then ONE pass of
+  // wave reductions and one barrier for all three -- same per-thread order and same reduction tree as three block sums
+  float acc_m = 0.0f, acc_k = 0.0f, acc_p = 0.0f;
+  if (recon_total > 0)
+    for (int i = tid; i < nparts; i += LOSS_BLOCK) acc_m += partials[i];
+  const float inv = latent_total > 0 ? 1.0f / (float)latent_total : 0.0f;
+  for (int i = tid; i < latent_total; i += LOSS_BLOCK) {
+    const float m = mu[i], lv = logvar[i], ev = __expf(lv);
+    acc_k += 1.0f + lv - m * m - ev;
+    d_mu[i] = c_kld * m * inv;
+    d_logvar[i] = c_kld * (-0.5f) * (1.0f - ev) * inv;
   }
-  if (latent_total > 0) {
-    float acc = 0.0f;
-    const float inv = 1.0f / (float)latent_total;
-    for (int i = tid; i < latent_total; i += LOSS_BLOCK) {
-      const float m = mu[i], lv = logvar[i], ev = __expf(lv);
-      acc += 1.0f + lv - m * m - ev;
-      d_mu[i] = c_kld * m * inv;
-      d_logvar[i] = c_kld * (-0.5f) * (1.0f - ev) * inv;
-    }
-    kld = -0.5f * block_sum(acc, red) * inv;
-  }
-  float acc = 0.0f;
   const float invb = 1.0f / (float)batch;
   for (int i = tid; i < batch; i += LOSS_BLOCK) {
     const float z = logit[i], t = y[i];
     if (mode == 0) {
       const float d = z - t;
-      acc += d * d;
+      acc_p += d * d;
       d_logit[i] = c_pred * 2.0f * d * invb;
     } else {
       // -[pw*t*log(sig(z)) + (1-t)*log(1-sig(z))], stable form
       const float lw = 1.0f + (pos_weight - 1.0f) * t;
       const float sp = log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.0f);  // softplus(-z)
-      acc += (1.0f - t) * z + lw * sp;
+      acc_p += (1.0f - t) * z + lw * sp;
       const float sg = 1.0f / (1.0f + __expf(-z));
       d_logit[i] = c_pred * ((1.0f - t) * sg - pos_weight * t * (1.0f - sg)) * invb;
     }
   }
-  const float pred = block_sum(acc, red) * invb;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    acc_m += __shfl_xor(acc_m, m, 64);
+    acc_k += __shfl_xor(acc_k, m, 64);
+    acc_p += __shfl_xor(acc_p, m, 64);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = acc_m; red[1][tid >> 6] = acc_k; red[2][tid >> 6] = acc_p; }
+  __syncthreads();
+  const float mse = recon_total > 0 ? (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)recon_total : 0.0f;
+  const float kld = latent_total > 0 ? -0.5f * (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) * inv : 0.0f;
+  const float pred = (((red[2][0] + red[2][1]) + red[2][2]) + red[2][3]) * invb;
   if (tid == 0) {
     out[0] = c_pred * pred + c_mse * mse + c_kld * kld;
     out[1] = pred; out[2] = mse; out[3] = kld;
