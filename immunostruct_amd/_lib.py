@@ -50,6 +50,7 @@ SIGNATURES = {
     "is_egnn_node_fwd_v2": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "is_node_pack_floats": [],
     "is_node_pack_weights": [_P, _I, _P],
+    "is_stack_prologue": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     "is_egnn_node_bwd_data": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],

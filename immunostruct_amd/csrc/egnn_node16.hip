@@ -11,6 +11,7 @@
 //   * the backward data path (is_egnn_node_bwd_data) carries no weight-gradient accumulators; the
 //     weight gradients of a layer are produced by ONE streaming outer-product kernel
 //     (is_egnn_node_wgrad) from the tensors the data path leaves in HBM.
+#include <algorithm>
 #include "common.h"
 
 namespace is {
@@ -88,65 +89,116 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
   const int col = wave * 16 + r;
   f32x4* fp = reinterpret_cast<f32x4*>(J.fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
   f32x4* bp = reinterpret_cast<f32x4*>(J.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
-  int slot = 0;
+  // every slot is gathered into registers first and stored afterwards: the 160 scattered loads of a lane are then in
+  // flight together (interleaved with the stores they would be serialised by possible aliasing)
+  const float* __restrict__ Wn1 = J.Wn1;
+  const float* __restrict__ Wn2 = J.Wn2;
+  const float* __restrict__ W1n = J.W1n;
+  const int ldw_n = J.ldw_n;
+  f32x4 fv[NODE_FWD_SLOTS], bv[NODE_BWD_SLOTS];
+#pragma unroll
+  for (int i = 0; i < NODE_FWD_SLOTS; ++i) fv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NODE_BWD_SLOTS; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // ---- forward ----
-  for (int g = 0; g < D::KQ1 / 4; ++g, ++slot) {
-    f32x4 v;
+  constexpr int G1 = D::KQ1 / 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int k = q * D::KQ1 + 4 * g + j; v[j] = (k < D::KV) ? J.Wn1[(size_t)col * D::KV + k] : 0.0f; }
-    fp[slot * 64] = v;
-  }
-  for (int g = 0; g < 4; ++g, ++slot) {
-    f32x4 v;
+  for (int g = 0; g < G1; ++g)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = J.Wn2[(size_t)col * H + q * 16 + 4 * g + j];
-    fp[slot * 64] = v;
-  }
-  for (int nt = 0; nt < 2; ++nt)
-    for (int g = 0; g < 4; ++g, ++slot) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (J.W1n != nullptr) {
-        const int c = wave * 32 + nt * 16 + r;
-        const float* row = (c < 64) ? J.W1n + (size_t)c * J.ldw_n : J.W1n + (size_t)(c - 64) * J.ldw_n + 64;
+    for (int j = 0; j < 4; ++j) { const int k = q * D::KQ1 + 4 * g + j; fv[g][j] = (k < D::KV) ? Wn1[(size_t)col * D::KV + k] : 0.0f; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = row[q * 16 + 4 * g + j];
-      }
-      fp[slot * 64] = v;
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fv[G1 + g][j] = Wn2[(size_t)col * H + q * 16 + 4 * g + j];
+  if (W1n != nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c = wave * 32 + nt * 16 + r;
+      const float* row = (c < 64) ? W1n + (size_t)c * ldw_n : W1n + (size_t)(c - 64) * ldw_n + 64;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fv[G1 + 4 + nt * 4 + g][j] = row[q * 16 + 4 * g + j];
     }
+  }
   // ---- backward (transposed operands) ----
-  slot = 0;
-  for (int g = 0; g < 8; ++g, ++slot) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (J.W1n != nullptr) {
+  if (W1n != nullptr) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = q * 32 + 4 * g + j;
-        v[j] = (c < 64) ? J.W1n[(size_t)c * J.ldw_n + col] : J.W1n[(size_t)(c - 64) * J.ldw_n + 64 + col];
+        bv[g][j] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1n[(size_t)(c - 64) * ldw_n + 64 + col];
       }
-    }
-    bp[slot * 64] = v;
   }
-  for (int g = 0; g < 4; ++g, ++slot) {
-    f32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = J.Wn2[(size_t)(q * 16 + 4 * g + j) * H + col];
-    bp[slot * 64] = v;
-  }
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[8 + g][j] = Wn2[(size_t)(q * 16 + 4 * g + j) * H + col];
+#pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int xc = (wave * 2 + nt) * 16 + r;
-    for (int g = 0; g < 4; ++g, ++slot) {
-      f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (xc < D::KV) ? J.Wn1[(size_t)(q * 16 + 4 * g + j) * D::KV + xc] : 0.0f;
-      bp[slot * 64] = v;
-    }
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[12 + nt * 4 + g][j] = (xc < D::KV) ? Wn1[(size_t)(q * 16 + 4 * g + j) * D::KV + xc] : 0.0f;
   }
+  constexpr int NF = G1 + 4 + 8;      // forward slots in use (the rest of the 20 stay unwritten, as before)
+#pragma unroll
+  for (int i = 0; i < NF; ++i) fp[i * 64] = fv[i];
+#pragma unroll
+  for (int i = 0; i < NODE_BWD_SLOTS; ++i) bp[i * 64] = bv[i];
 }
 
 __global__ __launch_bounds__(64) void node_pack_kernel(NodePackBatch batch) {
   const NodePackJob& J = batch.job[blockIdx.y];
   if (J.din == 20) node_pack_body<20>(J, blockIdx.x, threadIdx.x);
   else node_pack_body<64>(J, blockIdx.x, threadIdx.x);
+}
+
+// The stack's prologue in ONE launch: blocks [0, proj_blocks) compute the layer-0 pre-projection psd = [h W1s^T + b0 |
+// h W1d^T + b1] (the body of node_proj_fwd_kernel, csrc/egnn_node.hip: lane = channel, a wave walks nodes), the
+// remaining njobs blocks write the operand packs (wave = former blockIdx.x of node_pack_kernel).  The two are
+// independent -- the packs depend on the weights only -- so they run side by side instead of back to back.
+template <int DIN>
+__device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int ld_h, const float* __restrict__ W1, int ldw,
+                                                const float* __restrict__ b0, const float* __restrict__ b1,
+                                                float* __restrict__ psd, int N, int block, int nblocks) {
+  const int lane = threadIdx.x & 63;
+  float ws[DIN], wd[DIN];
+#pragma unroll
+  for (int k = 0; k < DIN; ++k) {
+    ws[k] = W1[lane * ldw + k];
+    wd[k] = W1[lane * ldw + DIN + k];
+  }
+  const float bias = b1[lane];
+  const float bias0 = b0 != nullptr ? b0[lane] : 0.0f;
+  for (int n = block * 4 + (threadIdx.x >> 6); n < N; n += nblocks * 4) {
+    const float hv = (lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
+    float as = bias0, ad = bias;
+#pragma unroll
+    for (int k = 0; k < DIN; ++k) {
+      const float hk = __shfl(hv, k, 64);
+      as += hk * ws[k];
+      ad += hk * wd[k];
+    }
+    psd[(size_t)n * 128 + lane] = as;
+    psd[(size_t)n * 128 + 64 + lane] = ad;
+  }
+}
+
+__global__ __launch_bounds__(256) void stack_prologue_kernel(NodePackBatch batch, int proj_blocks, const float* __restrict__ h,
+                                                             int ld_h, int din, const float* __restrict__ W1, int ldw,
+                                                             const float* __restrict__ b0, const float* __restrict__ b1,
+                                                             float* __restrict__ psd, int N) {
+  if ((int)blockIdx.x < proj_blocks) {
+    if (din == 20) stack_proj_body<20>(h, ld_h, W1, ldw, b0, b1, psd, N, blockIdx.x, proj_blocks);
+    else stack_proj_body<64>(h, ld_h, W1, ldw, b0, b1, psd, N, blockIdx.x, proj_blocks);
+    return;
+  }
+  const NodePackJob& J = batch.job[blockIdx.x - proj_blocks];
+  if (J.din == 20) node_pack_body<20>(J, threadIdx.x >> 6, threadIdx.x & 63);
+  else node_pack_body<64>(J, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 template <int DIN>
@@ -685,6 +737,23 @@ extern "C" int is_node_pack_weights(const void* jobs, int njobs, void* stream) {
     if (src[i].din != 20 && src[i].din != 64) return -22;
   }
   hipLaunchKernelGGL(is::node_pack_kernel, dim3(4, njobs), dim3(64), 0, static_cast<hipStream_t>(stream), batch);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// is_node_proj_fwd (layer-0 pre-projection: h [N, ld_h] (din = 20 | 64 columns), W1 [64, ldw], b0 (may be NULL), b1 -> psd
+// [N, 128]) and is_node_pack_weights (jobs as there) as ONE launch.
+extern "C" int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
+                                 const float* b0, const float* b1, float* psd, int N, void* stream) {
+  if (njobs <= 0 || njobs > is::NODE_PACK_MAX || N <= 0 || (din != 20 && din != 64)) return -22;
+  is::NodePackBatch batch;
+  const is::NodePackJob* src = static_cast<const is::NodePackJob*>(jobs);
+  for (int i = 0; i < njobs; ++i) {
+    batch.job[i] = src[i];
+    if (src[i].din != 20 && src[i].din != 64) return -22;
+  }
+  const int proj_blocks = std::min((N + 3) / 4, 2048);
+  hipLaunchKernelGGL(is::stack_prologue_kernel, dim3(proj_blocks + njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
+                     proj_blocks, h, ld_h, din, W1, ldw, b0, b1, psd, N);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

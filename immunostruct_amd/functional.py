@@ -293,9 +293,11 @@ class EGNNStackFn(torch.autograd.Function):
         P = PARAMS_PER_LAYER
         w1_0, b1_0 = params[0], params[1]
         psd = torch.empty(n, 2 * HIDDEN, **f32)
-        with KernelTimer.span("node_proj_fwd"):
-            _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0),
-                                            _lib.ptr(psd), n, st), "is_node_proj_fwd")
+        fused_prologue = NODE_KERNELS == "v2" and NODE_PACKS and STACK_PROLOGUE
+        if not fused_prologue:
+            with KernelTimer.span("node_proj_fwd"):
+                _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0),
+                                                _lib.ptr(psd), n, st), "is_node_proj_fwd")
         h_in, ld_h, din = h0, ld_h0, din0
         packs = None
         if NODE_KERNELS == "v2" and NODE_PACKS:
@@ -311,7 +313,14 @@ class EGNNStackFn(torch.autograd.Function):
                                              packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN,
                                              int(w1n.shape[1]) if w1n is not None else 0, 0, 0))
             jarr = (_lib.NodePackJob * len(jobs))(*jobs)
-            _lib.check(lib.is_node_pack_weights(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_node_pack_weights")
+            if fused_prologue:
+                # layer-0 pre-projection and the operand packs of every layer: independent, one launch
+                with KernelTimer.span("stack_prologue"):
+                    _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
+                                                     _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd), n, st),
+                               "is_stack_prologue")
+            else:
+                _lib.check(lib.is_node_pack_weights(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_node_pack_weights")
         for i in range(n_layers):
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
             ldw = int(W1.shape[1])
@@ -849,6 +858,7 @@ def mlp2(x, w1, b1, w2, b2, mask=None, act1=0, act2=0, hgroup=0):
 
 MLP_HEADS = os.environ.get("IMMUNOSTRUCT_MLP_HEADS", "1") != "0"
 ATTN_TAIL = os.environ.get("IMMUNOSTRUCT_ATTN_TAIL", "1") != "0"      # single-head pooled tail inside the attention forward launch
+STACK_PROLOGUE = os.environ.get("IMMUNOSTRUCT_STACK_PROLOGUE", "1") != "0"      # layer-0 projection + operand packs as one launch
 _ones_cache = {}
 
 

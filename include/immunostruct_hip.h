@@ -177,6 +177,12 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
  * with fpack / bpack of is_node_pack_floats() floats each.                                                  */
 int is_node_pack_floats(void);
 int is_node_pack_weights(const void* jobs, int njobs, void* stream);
+
+/* The EGNN stack's prologue as one launch: is_node_proj_fwd for layer 0 (h [N, ld_h] with din = 20 | 64 feature columns,
+ * W1 = edge_mlp.0.weight [64, ldw], b0 may be NULL, b1 = edge_mlp.0.bias -> psd [N, 128]) next to is_node_pack_weights
+ * (same jobs array): the packs depend on the weights only, the two run side by side.                               */
+int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
+                      const float* b0, const float* b1, float* psd, int N, void* stream);
 int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
                         const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
                         const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
