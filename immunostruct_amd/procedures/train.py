@@ -118,25 +118,37 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
     ``DataLoader(batch_size=config.batch_size)``, but batches are assembled on the GPU from graph ids
     (``dataset.gather_into``) and every full batch runs as one replay of the captured HIP graph
     (``engine.CapturedTrainStep``); a trailing partial batch is run eagerly.  ``train_index`` / ``val_index``: graph
-    ids (any integer sequence)."""
-    from ..distributed import FlatGradReducer
+    ids (any integer sequence).
+
+    Data parallel (SURVEY.md section 8 e): when ``torch.distributed`` is initialised (one process per GPU, every rank
+    holding the dataset) rank r trains on ``perm[r::world]`` of each epoch's permutation (the same seeded permutation on
+    all ranks, cut to a multiple of the world size), ``config.batch_size`` graphs per rank and step; the gradients are
+    all-reduced through ``distributed.FlatGradReducer`` (inside the captured step: overlapped with the backward when that
+    measures faster), rank 0's initial weights are broadcast, every rank validates on the full validation set and only
+    rank 0 writes the checkpoint."""
+    import torch.distributed as dist
+    from ..distributed import FlatGradReducer, broadcast_parameters
     from ..engine import CapturedTrainStep
     device = dataset.device
     bsz = int(config.batch_size)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
     train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
     val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
+    if world > 1:
+        broadcast_parameters(model)
 
     def forward_loss(m, g, seq, prop, y):
         recon, mu, logvar, final = m(g, seq, prop)
         return loss_function(recon, seq, mu, logvar, final, y)
 
     captured = None
-    if train_index.numel() >= bsz:
+    reducer = FlatGradReducer(model.parameters(), world=world)
+    if train_index.numel() // world >= bsz:
         buf = dataset.new_batch(bsz)
-        dataset.gather_into(train_index[:bsz], *buf)
+        dataset.gather_into(train_index[rank:rank + bsz * world:world][:bsz], *buf)
         model.train()
-        reducer = FlatGradReducer(model.parameters(), world=1)
         # the engine's construction runs one eager warm-up step on this batch and then restores model + optimizer
         captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=bsz * dataset.max_edges,
                                      warmup=1, preserve_state=True)
@@ -153,6 +165,8 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
     for epoch in range(config.num_epochs):
         model.train()
         perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
+        if world > 1:
+            perm = perm[: (perm.numel() // world) * world][rank::world]      # this rank's shard: equal length on every rank
         running, steps = None, 0
         for at in range(0, perm.numel(), bsz):
             idx = perm[at:at + bsz]
@@ -161,9 +175,10 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
                 loss = captured.replay().clone()
             else:
                 g, seq, prop, y = eager_batch(idx)
-                optimizer.zero_grad(set_to_none=True)
+                reducer.zero()
                 loss = forward_loss(model, g, seq, prop, y)
                 loss.backward()
+                reducer.all_reduce_mean()
                 optimizer.step()
                 loss = loss.detach()
             running = loss if running is None else running + loss
@@ -182,13 +197,15 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
                 vsteps += 1
         val_total = float(running) if running is not None else 0.0
         if val_total < best:
-            _save_best(config, model, stage)
+            if rank == 0:
+                _save_best(config, model, stage)
             best = val_total
         val_loss = val_total / max(vsteps, 1)
         val_losses.append(val_loss)
-        if wandb is not None and getattr(wandb, "run", None) is not None:
-            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
-        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
+        if rank == 0:
+            if wandb is not None and getattr(wandb, "run", None) is not None:
+                wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
+            print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
     return train_losses, val_losses
 
 

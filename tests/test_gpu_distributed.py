@@ -1,0 +1,39 @@
+"""Multi-rank paths on the one GPU of the test box: two processes (torch.distributed.run, gloo backend) share cuda:0.
+The RCCL backend needs one GPU per rank and is exercised by the driver's multi-GPU bench only."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script_args, port):
+    env = dict(os.environ, IMMUNOSTRUCT_DIST_BACKEND="gloo", IMMUNOSTRUCT_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.gpu
+def test_data_parallel_training_loop_two_ranks(cuda_device):
+    """procedures.train_model_device under torch.distributed (SURVEY.md 8 e): rank 0's weights are broadcast, every rank
+    trains on its shard of each epoch's permutation through the captured step with the gradient all-reduce, the ranks'
+    parameters stay bit-identical, only rank 0 writes the checkpoint (tools/dp_train_check.py asserts all of it)."""
+    res = _run([os.path.join("tools", "dp_train_check.py")], 29551)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "DP TRAIN CHECK OK" in res.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_prints_one_json_line(cuda_device):
+    """bench.py as the driver launches it for N = 2: rank 0 prints exactly one JSON line, last, with the whole-job value."""
+    import json
+    res = _run(["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-kernel-timers"], 29552)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["scaling"] == "weak"
+    assert line["config"]["grad_allreduce"]["form"] in ("serial", "two-stage backward, bucket 0 overlapped")
+    assert sum(1 for ln in lines if ln.lstrip().startswith("{")) == 1
