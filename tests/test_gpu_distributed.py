@@ -37,3 +37,14 @@ def test_bench_two_ranks_prints_one_json_line(cuda_device):
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["scaling"] == "weak"
     assert line["config"]["grad_allreduce"]["form"] in ("serial", "two-stage backward, bucket 0 overlapped")
     assert sum(1 for ln in lines if ln.lstrip().startswith("{")) == 1
+
+
+@pytest.mark.gpu
+def test_entry_script_two_ranks(cuda_device, tmp_path):
+    """train_IEDB_wFT under torch.distributed.run with --device-dataset: pretrain -> new head -> finetune -> inference on
+    two ranks; rank 0 writes both checkpoints, every rank loads them after the barrier."""
+    res = _run(["-m", "immunostruct_amd.train_IEDB_wFT", "--model", "HybridModelv2", "--full-sequence", "--sequence-loss",
+                "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160", "--device-dataset", "--seed", "3",
+                "--model-save-dir", str(tmp_path)], 29553)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("DONE FINE TUNING") == 2 and len(list(tmp_path.glob("*.pt"))) == 2
