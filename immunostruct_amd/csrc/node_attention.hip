@@ -224,6 +224,8 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
   }
 }
 
+constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop
+
 template <int NT, int D>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
@@ -250,16 +252,16 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     // lane = channel (one coalesced 256-byte row per load, 8 rows in flight)
     {
       const float g = gc[lane];
-      for (int j0 = wave; j0 < NT * 32; j0 += 8 * NT) {
-        float xv[8], ab[8];
+      for (int j0 = wave; j0 < NT * 32; j0 += DAB_ROWS * NT) {
+        float xv[DAB_ROWS], ab[DAB_ROWS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DAB_ROWS; ++u) {
           const int j = j0 + u * NT;
           xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
           ab[u] = (j < n) ? abar_in[(size_t)(b * heads + hd) * n + j] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DAB_ROWS; ++u) {
           const int j = j0 + u * NT;
           float d = sum_over_r16(xv[u] * g);          // 16-lane rows by DPP, then the four rows
           d += __shfl_xor(d, 16, 64);
