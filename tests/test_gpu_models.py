@@ -356,7 +356,7 @@ def test_merged_pair_encoding_equals_two_passes(cuda_device, monkeypatch):
 def test_training_trajectory_matches_oracle(cuda_device):
     """Ten Adam steps at the reference's learning rate (1e-3, train_IEDB_wFT.py:19) on fresh batches: the HIP path's loss
     follows the CPU oracle's step by step (same initial weights, same reparameterisation noise) -- the whole chain
-    forward / loss / backward / optimizer, compounded.  (B = 128, 20 steps: 5e-6, tools/trajectory_check.py.  The
+    forward / loss / backward / optimizer, compounded.  (B = 128, 20 steps: 5e-6, tests/tools/trajectory_check.py.  The
     un-normalised EGNN is unstable at this learning rate on synthetic data: a few steps later BOTH implementations
     blow up at the same step -- loss 6160 vs 6127 at step 13 of this very sequence -- which is where a trajectory
     comparison stops being meaningful.)"""

@@ -1,12 +1,12 @@
 """Loss trajectory of several Adam steps at the reference's learning rate: HIP path vs the CPU oracle on the same batches,
-same initial weights, same reparameterisation noise.  python tools/trajectory_check.py [steps] [batch] [lr]"""
+same initial weights, same reparameterisation noise.  python tests/tools/trajectory_check.py [steps] [batch] [lr]"""
 import os, sys
 import unittest.mock as mock
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from immunostruct_amd import optim, synthetic  # noqa: E402
 from immunostruct_amd.graph import PackedGraphBatch  # noqa: E402
 from immunostruct_amd.models import model_map  # noqa: E402

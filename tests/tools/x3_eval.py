@@ -1,6 +1,6 @@
 """Accuracy and speed of the split-bf16 forward edge kernel (v3x) against the fp32 kernel (v3) and an fp64 oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from immunostruct_amd import synthetic, functional as HF
 from immunostruct_amd.graph import PackedGraphBatch
