@@ -50,6 +50,8 @@ class PairedContrastiveLoss(nn.Module):
         self.capturable = False      # True: no host-side early-out (engine.CapturedTrainStep on paired batches)
 
     def forward(self, embedding_cancer, embedding_wt, is_immunogenic):
+        from .. import _lib
+        _lib.require_device(embedding_cancer, embedding_wt)      # no CPU path, as everywhere in this package
         gate = pos = None
         if self.capturable and is_immunogenic.is_cuda:
             # same rule without a host decision (a captured HIP graph cannot branch on data): the loss is always
