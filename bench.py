@@ -127,6 +127,46 @@ def flush_c_stdio():
         pass
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without torchrun: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in its environment, the contract torch.distributed.run would provide) BEFORE this process touches a GPU, let rank 0
+    write the single JSON line to our stdout (the other ranks' stdout goes to stderr), and return non-zero when any
+    rank fails -- the survivors are then stopped by PID, never by pattern."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()       # counting devices does not initialise the GPU runtime
+    if have < n and os.environ.get("IMMUNOSTRUCT_FORCE_DEVICE") is None:
+        print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(so.getsockname()[1])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in sorted(pending):
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,9 +181,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain ``python bench.py --gpus N``: become the launcher (no GPU call has happened in this process)
+        raise SystemExit(self_launch(args.gpus))
     rank, local_rank, world = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line printed must describe the run asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     if world == 1 and os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1":
@@ -205,12 +248,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("IMMUNOSTRUCT_STEP_TRACE")     # debugging aid: device time of every timed step (events)
+    marks = []
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if trace:
+            e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
         last = step(args.warmup + i)
+    if trace:
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
     fence()
     dt = time.perf_counter() - t0
+    if trace:
+        print("[step trace] ms per step: " + " ".join(f"{a.elapsed_time(b):.3f}" for a, b in zip(marks, marks[1:])), file=sys.stderr)
+        for blk in range(int(trace)):
+            fence()
+            b0 = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i)
+            fence()
+            print(f"[step trace] extra block {blk}: {1e3 * (time.perf_counter() - b0) / args.steps:.3f} ms/step", file=sys.stderr)
     HF.KernelTimer.enabled = False
     if os.environ.get("IMMUNOSTRUCT_HOST_TIMES"):     # debugging aid: host-side cost of one isolated step vs its GPU time
         for i in range(5):
@@ -300,6 +358,8 @@ def main():
                                          f"E~{int(n_edges)} edges/batch (deg_extra={args.deg_extra}), Fe=1",
                                 global_batch=args.batch * world, nodes_per_batch=n_nodes, edges_per_batch=int(n_edges),
                                 parallelism=f"dp{world}", final_loss=round(final_loss, 5),
+                                rccl_ranks=(torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+                                dist_backend=(torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                                 launch="eager" if args.eager else "hipGraph replay",
                                 grad_allreduce=(None if (args.eager or not reducer.packing) else
                                                 dict(form="two-stage backward, bucket 0 overlapped" if captured.two_stage else "serial",

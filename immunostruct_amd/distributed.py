@@ -10,6 +10,7 @@ single bucket -- one large collective instead of many small ones.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -112,6 +113,18 @@ class FlatGradReducer:
             return [list(b["sources"]) if b["sources"] is not None else None for b in self.buckets]
         for b, v in zip(self.buckets, value):
             b["sources"] = v
+
+    @contextlib.contextmanager
+    def live_gradients(self):
+        """an EAGER step between replays of a captured one (a trailing partial batch): pack from the ``.grad`` tensors the
+        eager backward produces, not from the captured graph's gradient buffers the sources are bound to"""
+        saved = self.sources()
+        for b in self.buckets:
+            b["sources"] = None
+        try:
+            yield self
+        finally:
+            self.sources(saved)
 
     def reduce_bucket(self, i, async_op=False):
         """pack bucket i (one multi-tensor copy of the gradients that are not already in place), all-reduce (SUM; divided

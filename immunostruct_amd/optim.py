@@ -44,17 +44,37 @@ class Adam(torch.optim.Optimizer):
         dev = params[0].device
         gs = self._groups.get(id(group))
         if gs is None:
-            gs = dict(key=None, table=None, hyper_host=None,
+            gs = dict(key=None, table=None, hyper_host=None, captured={}, pending=[], spares=[],
                       state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(8, dtype=torch.float32, device=dev))
             self._groups[id(group)] = gs
         return gs
 
     def refresh(self):
-        """copy changed hyper-parameters (learning-rate schedulers) to their device copies; not capturable"""
+        """copy changed hyper-parameters (learning-rate schedulers) to their device copies and upload the chunk tables of
+        freshly captured steps; call before replaying a captured step (the engine does); not capturable"""
         for group in self.param_groups:
             gs = self._groups.get(id(group))
             if gs is not None:
+                self._flush_group(gs)
                 self.refresh_group(group, gs)
+
+    flush_tables = refresh
+
+    @staticmethod
+    def _flush_group(gs):
+        while gs["pending"]:
+            table, host = gs["pending"].pop()
+            table.copy_(host)
+
+    def _rows(self, params):
+        rows = []
+        for p in params:
+            st = self.state[p]
+            for off in range(0, p.numel(), CHUNK):
+                cnt = min(CHUNK, p.numel() - off)
+                rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
+                             st["exp_avg_sq"].data_ptr() + 4 * off, cnt))
+        return torch.from_numpy(np.asarray(rows, dtype=np.int64))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -80,31 +100,36 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             gs = self._group_state(group, params)
             key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
-            if gs["key"] != key:
-                rows = []
-                for p in params:
-                    st = self.state[p]
-                    for off in range(0, p.numel(), CHUNK):
-                        cnt = min(CHUNK, p.numel() - off)
-                        rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
-                                     st["exp_avg_sq"].data_ptr() + 4 * off, cnt))
-                host = torch.from_numpy(np.asarray(rows, dtype=np.int64))
-                if capturing:
-                    # gradients produced inside a capture live at fixed addresses of the graph's memory pool: the table
-                    # upload becomes a memcpy node of the graph (pinned staging buffer allocated by the eager step --
-                    # no allocation is legal here -- and kept alive, unchanged, with the optimizer)
-                    if gs["table"] is None or gs["table"].shape != host.shape or gs.get("pinned") is None:
-                        raise RuntimeError("the chunk table must have been allocated by an eager step before a capture")
-                    gs["pinned"].copy_(host)
-                    gs["table"].copy_(gs["pinned"], non_blocking=True)
-                else:
-                    gs["table"] = host.to(params[0].device)
-                    if gs.get("pinned") is None or gs["pinned"].shape != host.shape:
-                        gs["pinned"] = torch.empty_like(host).pin_memory()
-                gs["key"] = key
+            if capturing:
+                # gradients produced inside a capture live at fixed addresses of the graph's memory pool.  The step being
+                # captured gets a chunk table of its OWN, kept alive with the optimizer: eager steps before or after never
+                # rebind or overwrite it.  It comes from the spares the last eager step left (memory allocated while
+                # capturing belongs to the graph's pool and may alias a buffer the replayed graph writes earlier in the
+                # step).  Its rows are uploaded by flush_tables() once the capture has ended -- the kernel only reads
+                # them at replay time, so the graph needs no upload node.
+                ent = gs["captured"].get(key)
+                if ent is None:
+                    host = self._rows(params)
+                    ent = next((t for t in gs["spares"] if t.shape == host.shape), None)
+                    if ent is None:
+                        raise RuntimeError("the chunk table of a captured step is allocated by an eager step with the same "
+                                           "parameters: run one eager step before the HIP-graph capture")
+                    gs["spares"] = [t for t in gs["spares"] if t is not ent]
+                    gs["captured"][key] = ent
+                    gs["pending"].append((ent, host))
+                table = ent
+            else:
+                self._flush_group(gs)
+                if gs["key"] != key:
+                    gs["table"] = self._rows(params).to(params[0].device)
+                    gs["key"] = key
+                table = gs["table"]
+                gs["spares"] = [t for t in gs["spares"] if t.shape == table.shape]
+                while len(gs["spares"]) < 3:
+                    gs["spares"].append(torch.empty_like(table))
             if not capturing:
                 self.refresh_group(group, gs)
-            _lib.check(lib.is_adam_step(_lib.ptr(gs["table"]), int(gs["table"].shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+            _lib.check(lib.is_adam_step(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
                                         _lib.stream_ptr()), "is_adam_step")
         return loss
 

@@ -175,11 +175,12 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
                 loss = captured.replay().clone()
             else:
                 g, seq, prop, y = eager_batch(idx)
-                reducer.zero()
-                loss = forward_loss(model, g, seq, prop, y)
-                loss.backward()
-                reducer.all_reduce_mean()
-                optimizer.step()
+                with reducer.live_gradients():      # not the captured graph's (stale) gradient buffers
+                    reducer.zero()
+                    loss = forward_loss(model, g, seq, prop, y)
+                    loss.backward()
+                    reducer.all_reduce_mean()
+                    optimizer.step()
                 loss = loss.detach()
             running = loss if running is None else running + loss
             steps += 1

@@ -48,3 +48,40 @@ def test_entry_script_two_ranks(cuda_device, tmp_path):
                 "--model-save-dir", str(tmp_path)], 29553)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count("DONE FINE TUNING") == 2 and len(list(tmp_path.glob("*.pt"))) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "tail"])
+def test_data_parallel_parity_on_the_hip_model(cuda_device, mode):
+    """SURVEY.md section 4 (iv) on the real model (tools/dp_parity_check.py): ``split`` -- 2 ranks x B/2 through the captured
+    two-stage step (all-reduce of bucket 0 under the stack backward, 1/world inside Adam) == 1 rank x B eager, same
+    weights after 3 Adam steps; ``tail`` -- train_model_device with a shard that is not a multiple of the batch size
+    (replays + one eager trailing step that must pack its OWN gradients) == an all-eager data-parallel loop."""
+    res = _run([os.path.join("tools", "dp_parity_check.py"), mode], 29554 + (mode == "tail"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "DP PARITY OK" in res.stdout
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(cuda_device):
+    """``python bench.py --gpus 2`` WITHOUT torchrun (how the driver starts N = 1): the script becomes the launcher, one
+    child per rank, rank 0's single JSON line on stdout, n_gpus == the number asked for and == the process group's size."""
+    import json
+    env = dict(os.environ, IMMUNOSTRUCT_DIST_BACKEND="gloo", IMMUNOSTRUCT_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-kernel-timers"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["global_batch"] == 256
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """never a line with n_gpus != the number requested: with no (or too few) GPUs the launcher exits non-zero"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMMUNOSTRUCT_FORCE_DEVICE")}
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "{" not in res.stdout
