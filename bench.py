@@ -1,25 +1,33 @@
 #!/usr/bin/env python
 """Throughput of the ImmunoStruct train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload iedb|paired|stress]
 
-A "step" = one pass of the hot path over one batch of synthetic peptide-MHC residue graphs already
-resident in HBM: HybridModelv2 forward (6 EGNN layers -> node attention -> mean-pool, sequence VAE,
-property MLP, fusion head) + regression loss + backward + Adam, i.e. the inner loop of
-``procedures/train.py:18-29`` on BASELINE config 2 (B = 128 graphs of 190 padded nodes per GPU,
-``--full-sequence --sequence-loss``).  N > 1: one process per GPU (launched by torch.distributed.run),
-graphs sharded over ranks (weak scaling), one RCCL all-reduce of the flat gradient per step.
+A "step" = one pass of the hot path over one batch of synthetic peptide-MHC residue graphs already resident in HBM.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline"     -- the dominant HIP kernel (fused EGNN edge backward): algorithmic FLOP / launch divided
-                    by its mean launch duration measured with HIP events inside the timed region,
-                    against the fp32 MFMA peak; the HBM view of the same launches is included.
-  "cpu_baseline" -- the CPU oracle (a port of the reference's un-fused PyTorch path) timed on this
-                    box's host cores on a bounded sample of the same workload (N = 1, rank 0 only).
+``iedb`` (default; BASELINE config 2 / 3): HybridModelv2 forward (6 EGNN layers -> node attention -> mean-pool, sequence
+    VAE, property MLP, fusion head) + regression loss + backward + Adam -- the inner loop of ``procedures/train.py:18-29``
+    with ``--full-sequence --sequence-loss``, B = 128 graphs of 190 padded nodes per GPU.
+``paired`` (config 4): HybridModelv2_Comparative, ``--use-wt-for-downstream``, BCE + 0.01 x paired contrastive loss,
+    AdamW -- ``procedures/train.py:84-123`` / ``utils/contrastive.py:37-83`` -- B = 128 (cancer, wild-type) pairs =
+    256 graphs per GPU and step.
+``stress`` (config 5, one GPU's slice): the 6-layer EGNN stack alone, forward + backward (all weight gradients), on
+    random residue graphs of ~200 nodes (clipped N(200, 15), padded to the slice's maximum), 8 edge features,
+    average in-degree 8, 64 node channels; B = 256 graphs per GPU and step.
+
+N > 1: one process per GPU (``torch.distributed.run``, or this script launches its own ranks when started as plain
+``python bench.py --gpus N``), graphs sharded over ranks (weak scaling), one RCCL all-reduce of the flat gradient per
+step.  Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline"     -- the dominant HIP kernel (fused EGNN layer backward): algorithmic FLOP / launch divided by its mean
+                    launch duration (HIP events on the launching stream), against the fp32 MFMA peak; the HBM view of the
+                    same launches, the forward layer kernel and (when it still runs) the pure gather kernel next to it.
+  "cpu_baseline" -- the CPU oracle (a port of the reference's un-fused PyTorch path) timed on this box's host cores on a
+                    bounded sample of the same workload (N = 1, rank 0 only).
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -44,14 +52,15 @@ VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 H = 64
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
 def edge_pass_algorithmic(n_nodes, n_edges, din, fe):
-    """Algorithmic bytes / FLOP of one fused EGNN edge launch (DESIGN.md section "Roofline accounting").
+    """Algorithmic bytes / FLOP of one fused EGNN edge pass (DESIGN.md section "Roofline accounting").
 
-    bytes follow SURVEY.md section 8(d); FLOP count only the per-edge dense layers the fused kernel
-    actually needs after hoisting the first edge-MLP layer to node level (2 x 64x64 + 64 forward;
-    backward = 2 data-grad + 2 weight-grad 64x64 products).
+    bytes follow SURVEY.md section 8(d); FLOP count only the per-edge dense layers the fused kernel actually needs after
+    hoisting the first edge-MLP layer to node level (2 x 64x64 + 64 forward; backward = 2 data-grad + 2 weight-grad
+    64x64 products).  The node halves fused into the same launches are not counted (they would only raise the figure).
     """
     bytes_fwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + (n_nodes + 1) * 4 + n_nodes * (din * 4 + 12) + n_nodes * (H * 4 + 12)
     bytes_bwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + n_nodes * H * 4 + 2 * n_nodes * (din + 3) * 4
@@ -60,40 +69,47 @@ def edge_pass_algorithmic(n_nodes, n_edges, din, fe):
     return bytes_fwd, bytes_bwd, flop_fwd, flop_bwd
 
 
-def build_batches(n_batches, batch, deg_extra, device, seed0):
-    out = []
-    for i in range(n_batches):
-        raw = synthetic.make_batch(batch, seed=seed0 + i, deg_extra=deg_extra)
-        g = PackedGraphBatch.from_raw(raw, device=device)
-        out.append(dict(g=g, seq=torch.from_numpy(raw.one_hot_sequence()).to(device),
-                        prop=torch.from_numpy(raw.prop).to(device), y=torch.from_numpy(raw.y_reg).to(device),
-                        raw=raw))
-    return out
+def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key):
+    """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included)"""
+    if "egnn_layer_bwd" not in timers or "egnn_layer_fwd" not in timers:
+        return None
+    per = [edge_pass_algorithmic(n_nodes, n_edges, din, fe) for din in dins]
+    b_fwd, b_bwd = np.mean([p[0] for p in per]), np.mean([p[1] for p in per])
+    f_fwd, f_bwd = np.mean([p[2] for p in per]), np.mean([p[3] for p in per])
+    n_b, ms_b = timers["egnn_layer_bwd"]
+    n_f, ms_f = timers["egnn_layer_fwd"]
+    tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
+    if os.path.isfile(tpath) and traffic_key is not None:
+        rec = json.load(open(tpath))
+        ent = rec.get(traffic_key, {}).get("egnn_layer_bwd_kernel")
+        if ent:
+            traffic = ent.get("bytes")
+            traffic_src = f"{TRAFFIC_FILE} ({rec.get('commit', '?')}): separate rocprofv3 --pmc passes of this workload"
+    roof = dict(kernel="egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src, launches=n_b,
+                mean_launch_us=round(ms_b * 1e3, 2), algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
+                hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                              frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
+                forward_kernel=dict(kernel="egnn_layer_fwd_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
+                                    tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
+                                    frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
+    if "gather_segment_sum" in timers:
+        n_g, ms_g = timers["gather_segment_sum"]
+        gbytes = n_edges * (H * 4 + 12 + 4) + n_nodes * (H * 4 + 12 + 4)
+        roof["gather_kernel"] = dict(kernel="gather_segment_sum_kernel", bound="hbm", mean_launch_us=round(ms_g * 1e3, 2),
+                                     launches=n_g, achieved=round(gbytes / (ms_g * 1e-3) / 1e9, 1), unit="GB/s",
+                                     frac=round(gbytes / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                     note="one launch per step (layer 0); the other layers' source gathers run inside "
+                                          "egnn_layer_bwd_kernel")
+    return roof
 
 
-def cpu_baseline(batch, deg_extra, budget_s=24.0):
-    """Oracle train step (forward + loss + backward + Adam) on the host cores; returns graphs/s.
-
-    Two bounded samples (all hardware threads, and 16 threads: these small un-fused ops do not scale to
-    hundreds of threads) -- the faster one is reported together with the thread count it used.
-    """
-    from oracle import functional_ref as FR
-    from oracle import graph_ref
-    raw = synthetic.make_batch(batch, seed=1, deg_extra=deg_extra)
-    shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
-    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
-    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
-    g = graph_ref.RefGraph(raw.src, raw.dst, raw.num_nodes, raw.batch_num_nodes)
-    g.ndata["x"], g.edata["edge_attr"] = torch.from_numpy(raw.x), torch.from_numpy(raw.edge_attr)
-    seq, prop, y = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop), torch.from_numpy(raw.y_reg)
-
-    def step():
-        opt.zero_grad()
-        it = FR.forward("HybridModelv2", sd, g, seq, prop)
-        loss = FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN)
-        loss.backward()
-        opt.step()
-
+def timed_cpu(step, units_per_step, budget_s, what):
+    """best of the all-threads and the 16-thread sample of ``step`` (these small un-fused ops do not scale to hundreds of
+    threads); returns the cpu_baseline object"""
     all_threads = torch.get_num_threads()
     best = None
     for threads in sorted({all_threads, min(16, all_threads)}, reverse=True):
@@ -106,14 +122,342 @@ def cpu_baseline(batch, deg_extra, budget_s=24.0):
             if time.perf_counter() - t0 > budget_s / 2 or n >= 40:
                 break
         dt = time.perf_counter() - t0
-        rate = batch * n / dt
+        rate = units_per_step * n / dt
         if best is None or rate > best[0]:
             best = (rate, threads, n, dt)
     torch.set_num_threads(all_threads)
     rate, threads, n, dt = best
     return dict(value=round(rate, 2), unit="graphs/s", cores=threads, kind="port",
-                sample=f"{n} train steps of B={batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam, "
-                       f"{threads} torch threads of {all_threads} available, {dt:.1f} s; best of the all-threads and 16-thread samples)")
+                sample=f"{n} steps of {what}, {threads} torch threads of {all_threads} available, {dt:.1f} s; best of the "
+                       f"all-threads and 16-thread samples")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: each offers  step(i) / eager_step(i) / graphs_per_step / describe() / roofline(timers) / cpu_baseline() /
+# extra_config() / eager_timers_setup()
+# ---------------------------------------------------------------------------------------------------------------------
+def device_batch(raw, dev, y_key):
+    g = PackedGraphBatch.from_raw(raw, device=dev)
+    return dict(g=g, seq=torch.from_numpy(raw.one_hot_sequence()).to(dev), prop=torch.from_numpy(raw.prop).to(dev),
+                y=torch.from_numpy(getattr(raw, y_key)).to(dev), raw=raw)
+
+
+class TrainStepWorkload:
+    """shared by ``iedb`` and ``paired``: model + loss + optimizer behind the captured HIP-graph step"""
+
+    def _finish(self, args, world, template, edge_capacity):
+        self.reducer = D.FlatGradReducer(self.model.parameters(), world=world, always_pack=args.force_pack)
+        self.captured = None
+        if not args.eager:
+            from immunostruct_amd.engine import CapturedTrainStep
+            self.captured = CapturedTrainStep(self.model, self.opt, self.reducer, self.forward_loss, template,
+                                              edge_capacity=edge_capacity)
+
+    def step(self, i):
+        if self.captured is None:
+            return self.eager_step(i)
+        return self.captured(*self.batch(i))
+
+    def eager_step(self, i):
+        self.reducer.zero()
+        loss = self.forward_loss(self.model, *self.batch(i))
+        loss.backward()
+        self.reducer.all_reduce_mean()
+        self.opt.step()
+        return loss.detach()
+
+    def eager_timers_setup(self):
+        """per-kernel timers run on an eager, single-stream re-run: the sequence branch on the SAME stream (a kernel's
+        duration is then its own, not the co-run slow-down by the forked branch), gradients packed from the live tensors"""
+        from immunostruct_amd.models import _core as model_core
+        saved = model_core.OVERLAP_BRANCHES
+        model_core.OVERLAP_BRANCHES = False
+        for bucket in self.reducer.buckets:
+            bucket["sources"] = None
+
+        def restore():
+            model_core.OVERLAP_BRANCHES = saved
+        return restore
+
+    def extra_config(self):
+        c, r = self.captured, self.reducer
+        return dict(launch="eager" if c is None else "hipGraph replay",
+                    grad_allreduce=(None if (c is None or not r.packing) else
+                                    dict(form="two-stage backward, bucket 0 overlapped" if c.two_stage else "serial",
+                                         buckets=[int(b["flat"].numel()) for b in r.buckets], tuned_ms=c.dp_times)))
+
+
+class IedbWorkload(TrainStepWorkload):
+    name = "iedb"
+
+    def __init__(self, args, dev, rank, world):
+        self.args = args
+        torch.manual_seed(1)
+        self.model = model_map[args.model](vae_input_dim=VAE_IN, device=dev).to(dev)
+        D.broadcast_parameters(self.model)
+        self.model.train()
+        self.opt = optim.Adam(self.model.parameters(), lr=1e-3)      # csrc/optimizer.hip
+        self.losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+        self.pool = [device_batch(synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + i, deg_extra=args.deg_extra), dev, "y_reg")
+                     for i in range(4)]
+        self.graphs_per_step = args.batch
+        self.n_nodes = self.pool[0]["raw"].num_nodes
+        self.n_edges = float(np.mean([b["raw"].num_edges for b in self.pool]))
+        self._finish(args, world, self.batch(0), max(b["raw"].num_edges for b in self.pool))
+
+    def forward_loss(self, m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return self.losses.regression_loss(recon, seq, mu, logvar, final, y)
+
+    def batch(self, i):
+        b = self.pool[i % len(self.pool)]
+        return b["g"], b["seq"], b["prop"], b["y"]
+
+    def describe(self):
+        a = self.args
+        return (f"IEDB pretrain step (BASELINE config 2): {a.model}, full-sequence + sequence-loss, regression loss, Adam; "
+                f"B={a.batch} graphs/GPU x 190 padded nodes, E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}), Fe=1")
+
+    def roofline(self, timers):
+        # the timed launches are the five full ones per step (layer 0: Din = 20, layers 1-4: Din = 64); the last layer's
+        # launch skips the coordinate MLP (its output is unused by the model) and is timed under its own name
+        key = "iedb_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key)
+
+    def cpu_baseline(self, budget_s=24.0):
+        from oracle import functional_ref as FR
+        from oracle import graph_ref
+        a = self.args
+        raw = synthetic.make_batch(a.batch, seed=1, deg_extra=a.deg_extra)
+        shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
+        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
+        opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+        g = graph_ref.RefGraph(raw.src, raw.dst, raw.num_nodes, raw.batch_num_nodes)
+        g.ndata["x"], g.edata["edge_attr"] = torch.from_numpy(raw.x), torch.from_numpy(raw.edge_attr)
+        seq, prop, y = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop), torch.from_numpy(raw.y_reg)
+
+        def step():
+            opt.zero_grad()
+            it = FR.forward("HybridModelv2", sd, g, seq, prop)
+            FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN).backward()
+            opt.step()
+        return timed_cpu(step, a.batch, budget_s, f"B={a.batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam)")
+
+
+class PairedWorkload(TrainStepWorkload):
+    name = "paired"
+
+    def __init__(self, args, dev, rank, world):
+        from immunostruct_amd.graph import batch as graph_batch
+        from immunostruct_amd.procedures.train import _paired_loss
+        from immunostruct_amd.utils import PairedContrastiveLoss
+        self.args, self.dev = args, dev
+        self._paired_loss = _paired_loss
+        torch.manual_seed(1)
+        self.model = model_map["HybridModelv2_Comparative"](vae_input_dim=VAE_IN, device=dev, use_wt_for_downstream=True).to(dev)
+        D.broadcast_parameters(self.model)
+        self.model.train()
+        self.opt = optim.AdamW(self.model.parameters(), lr=1e-4, weight_decay=1e-6)     # train_Cancer_wFT.py:76-92
+        self.losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+        self.contrastive = PairedContrastiveLoss(device=dev, embedding_dim=104)
+        self.contrastive.capturable = True
+        self.coeff = 0.01
+        self.pool = []
+        for i in range(3):
+            rc = synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + 10 + i, deg_extra=args.deg_extra)
+            rw = synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + 50 + i, deg_extra=args.deg_extra)
+            bc, bw = device_batch(rc, dev, "y_bin"), device_batch(rw, dev, "y_bin")
+            bc["g"].csr(), bw["g"].csr()
+            # the merged pair batch [cancer; wild-type] the on-GPU batcher delivers (procedures.train_model_comparative_device)
+            self.pool.append(dict(g=graph_batch([bc["g"], bw["g"]]), seq=torch.cat([bc["seq"], bw["seq"]]),
+                                  prop=torch.cat([bc["prop"], bw["prop"]]), y=torch.cat([bc["y"], bc["y"]]),
+                                  edges=rc.num_edges + rw.num_edges, nodes=rc.num_nodes + rw.num_nodes))
+        self.graphs_per_step = 2 * args.batch
+        self.n_nodes = self.pool[0]["nodes"]
+        self.n_edges = float(np.mean([b["edges"] for b in self.pool]))
+        self._finish(args, world, self.batch(0), max(b["edges"] for b in self.pool))
+
+    def forward_loss(self, m, g2, seq2, prop2, y2):
+        return self._paired_loss(m, self.losses.BCE_loss, (g2, seq2, y2[:y2.numel() // 2], prop2), self.dev, self.contrastive,
+                                 self.coeff)
+
+    def batch(self, i):
+        b = self.pool[i % len(self.pool)]
+        return b["g"], b["seq"], b["prop"], b["y"]
+
+    def describe(self):
+        a = self.args
+        return (f"cancer fine-tune step (BASELINE config 4): HybridModelv2_Comparative, use-wt-for-downstream, BCE + 0.01 x paired "
+                f"contrastive loss, AdamW; B={a.batch} (cancer, wild-type) pairs = {2 * a.batch} graphs/GPU x 190 padded nodes, "
+                f"E~{int(self.n_edges)} edges/step (deg_extra={a.deg_extra}), Fe=1; graphs/s counts both members")
+
+    def roofline(self, timers):
+        key = "paired_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key)
+
+    def cpu_baseline(self, budget_s=24.0):
+        from oracle import functional_ref as FR
+        from oracle import graph_ref
+        a = self.args
+        rc, rw = synthetic.make_batch(a.batch, seed=11, deg_extra=a.deg_extra), synthetic.make_batch(a.batch, seed=51, deg_extra=a.deg_extra)
+        name = "HybridModelv2_Comparative"
+        shapes = {k: tuple(v.shape) for k, v in model_map[name](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
+        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
+        proj = {k: torch.from_numpy(v) for k, v in synthetic.det_state_dict(
+            {"projector.0.weight": (128, 104), "projector.1.weight": (128,), "projector.1.bias": (128,),
+             "projector.3.weight": (128, 128)}, seed=9).items()}
+        opt = torch.optim.AdamW(list(sd.values()), lr=1e-4, weight_decay=1e-6)
+
+        def ref_graph(raw):
+            g = graph_ref.RefGraph(raw.src, raw.dst, raw.num_nodes, raw.batch_num_nodes)
+            g.ndata["x"], g.edata["edge_attr"] = torch.from_numpy(raw.x), torch.from_numpy(raw.edge_attr)
+            return g
+        gs = (ref_graph(rc), ref_graph(rw))
+        seqs = (torch.from_numpy(rc.one_hot_sequence()), torch.from_numpy(rw.one_hot_sequence()))
+        props = (torch.from_numpy(rc.prop), torch.from_numpy(rw.prop))
+        y = torch.from_numpy(rc.y_bin)
+
+        def step():
+            opt.zero_grad()
+            o = FR.forward_comparative(name, sd, gs, seqs, props)
+            c, w = o["cancer"], o["wt"]
+            lc = FR.bce_loss(c["recon_x"], seqs[0], c["mu"], c["logvar"], o["final_output"], y, VAE_IN, 81.0 / 19.0)
+            lw = FR.bce_loss(w["recon_x"], seqs[1], w["mu"], w["logvar"], o["final_output"], y, VAE_IN, 81.0 / 19.0)
+            loss = (lc + lw) / 2 + 0.01 * FR.paired_contrastive_loss(proj, o["embeddings"][0], o["embeddings"][1], y)
+            loss.backward()
+            opt.step()
+        return timed_cpu(step, 2 * a.batch, budget_s,
+                         f"B={a.batch} pairs (oracle/functional_ref.py forward_comparative + BCE + paired contrastive, fwd+bwd+AdamW)")
+
+
+STRESS_N_MIN, STRESS_N_MAX = 155, 245
+
+
+def stress_batch(num_graphs, seed):
+    """config 5: node counts ~ N(200, 15) clipped to [155, 245] and padded to 245, 8 edge features ~ U(0, 1), chain + 7
+    random contacts per node (average in-degree 8)"""
+    choices = np.arange(STRESS_N_MIN, STRESS_N_MAX + 1)
+    w = np.exp(-0.5 * ((choices - 200.0) / 15.0) ** 2)
+    return synthetic.make_batch(num_graphs, seed=seed, n_pad=STRESS_N_MAX, deg_extra=7, edge_feats=8,
+                                n_real_choices=tuple(int(c) for c in choices), n_real_probs=tuple(float(v) for v in w / w.sum()))
+
+
+class StressWorkload:
+    name = "stress"
+    LAYERS = 6
+
+    def __init__(self, args, dev, rank, world):
+        from immunostruct_amd.nn import EGNNConv, egnn_stack_forward
+        self.args, self.dev = args, dev
+        self._stack = egnn_stack_forward
+        torch.manual_seed(1)
+        self.layers = torch.nn.ModuleList([EGNNConv(H, H, H, 8) for _ in range(self.LAYERS)]).to(dev)
+        D.broadcast_parameters(self.layers)
+        self.reducer = D.FlatGradReducer(self.layers.parameters(), world=world, always_pack=args.force_pack)
+        gen = torch.Generator().manual_seed(7 + rank)
+        self.pool = []
+        for i in range(3):
+            raw = stress_batch(args.batch, seed=2000 * (rank + 1) + i)
+            g = PackedGraphBatch.from_raw(raw, device=dev)
+            g.csr()
+            n = raw.num_nodes
+            self.pool.append(dict(g=g, raw=raw, h0=(0.5 * torch.randn(n, H, generator=gen)).to(dev),
+                                  x0=torch.from_numpy(raw.x[:, 20:].copy()).to(dev),
+                                  gh=(torch.randn(n, H, generator=gen) / n).to(dev), gx=(torch.randn(n, 3, generator=gen) / n).to(dev)))
+        self.graphs_per_step = args.batch
+        self.n_nodes = self.pool[0]["raw"].num_nodes
+        self.n_edges = float(np.mean([b["raw"].num_edges for b in self.pool]))
+        self.graphs = None
+        if not args.eager:
+            # one captured HIP graph per resident batch (the batches differ in edge count; nothing is copied per step)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(len(self.pool)):
+                    self._body(i)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graphs = []
+            for i in range(len(self.pool)):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    self._body(i)
+                self.reducer.bind_sources()
+                self.graphs.append((gr, self.reducer.sources()))
+
+    def _body(self, i):
+        b = self.pool[i]
+        self.reducer.zero()
+        h, x = self._stack(list(self.layers), b["g"], b["h0"], b["x0"], b["g"].edata["edge_attr"])
+        torch.autograd.backward([h, x], [b["gh"], b["gx"]])
+
+    def step(self, i):
+        if self.graphs is None:
+            return self.eager_step(i)
+        gr, srcs = self.graphs[i % len(self.pool)]
+        gr.replay()
+        if self.reducer.packing:
+            self.reducer.sources(srcs)
+            self.reducer.all_reduce_mean()
+        return None
+
+    def eager_step(self, i):
+        for bucket in self.reducer.buckets:
+            bucket["sources"] = None
+        self._body(i % len(self.pool))
+        if self.reducer.packing:
+            self.reducer.all_reduce_mean()
+        return None
+
+    def eager_timers_setup(self):
+        return lambda: None
+
+    def describe(self):
+        a = self.args
+        return (f"EGNN-stack stress (BASELINE config 5, one GPU's slice): {self.LAYERS} EGNNConv layers (64 -> 64 channels, 8 edge "
+                f"features) forward + backward with all weight gradients, no optimizer; B={a.batch} graphs/GPU, node counts "
+                f"~N(200,15) clipped to [{STRESS_N_MIN},{STRESS_N_MAX}] padded to {STRESS_N_MAX}, N={self.n_nodes} nodes, "
+                f"E~{int(self.n_edges)} edges/step (average in-degree 8)")
+
+    def extra_config(self):
+        return dict(launch="eager" if self.graphs is None else "hipGraph replay",
+                    grad_allreduce=None if not self.reducer.packing else
+                    dict(form="serial", buckets=[int(b["flat"].numel()) for b in self.reducer.buckets]))
+
+    def roofline(self, timers):
+        key = "stress_B256" if self.args.batch == 256 else None
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (64,) * self.LAYERS, 8, key)
+
+    def cpu_baseline(self, budget_s=24.0):
+        from oracle import graph_ref
+        b = min(self.args.batch, 32)
+        raw = stress_batch(b, seed=1)
+        shapes = {}
+        for i in range(self.LAYERS):
+            p = f"L{i}."
+            shapes.update({p + "edge_mlp.0.weight": (H, 2 * H + 1 + 8), p + "edge_mlp.0.bias": (H,), p + "edge_mlp.2.weight": (H, H),
+                           p + "edge_mlp.2.bias": (H,), p + "node_mlp.0.weight": (H, 2 * H), p + "node_mlp.0.bias": (H,),
+                           p + "node_mlp.2.weight": (H, H), p + "node_mlp.2.bias": (H,), p + "coord_mlp.0.weight": (H, H),
+                           p + "coord_mlp.0.bias": (H,), p + "coord_mlp.2.weight": (1, H)})
+        sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
+        src, dst = torch.from_numpy(raw.src), torch.from_numpy(raw.dst)
+        gen = torch.Generator().manual_seed(7)
+        n = raw.num_nodes
+        h0, x0 = 0.5 * torch.randn(n, H, generator=gen), torch.from_numpy(raw.x[:, 20:].copy())
+        gh, gx = torch.randn(n, H, generator=gen) / n, torch.randn(n, 3, generator=gen) / n
+        ea = torch.from_numpy(raw.edge_attr)
+
+        def step():
+            for v in sd.values():
+                v.grad = None
+            h, x = h0, x0
+            for i in range(self.LAYERS):
+                h, x = graph_ref.egnn_conv(sd, f"L{i}.", src, dst, n, h, x, ea)
+            torch.autograd.backward([h, x], [gh, gx])
+        return timed_cpu(step, b, budget_s, f"B={b} graphs of the same distribution (oracle/graph_ref.py egnn_conv x {self.LAYERS}, fwd+bwd)")
+
+
+WORKLOADS = {"iedb": IedbWorkload, "paired": PairedWorkload, "stress": StressWorkload}
 
 
 def flush_c_stdio():
@@ -172,14 +516,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="graphs per GPU per step")
-    ap.add_argument("--deg-extra", type=int, default=2, help="random contact edges per residue (E/N - 1)")
-    ap.add_argument("--model", default="HybridModelv2")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="iedb")
+    ap.add_argument("--batch", type=int, default=None, help="graphs (paired: pairs) per GPU per step; default 128 (stress: 256)")
+    ap.add_argument("--deg-extra", type=int, default=2, help="iedb / paired: random contact edges per residue (E/N - 1)")
+    ap.add_argument("--model", default="HybridModelv2", help="iedb: the model class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--force-pack", action="store_true", help="exercise the multi-rank gradient-bucket path on one GPU")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 256 if args.workload == "stress" else 128
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain ``python bench.py --gpus N``: become the launcher (no GPU call has happened in this process)
@@ -200,76 +547,54 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    torch.manual_seed(1)
-    model = model_map[args.model](vae_input_dim=VAE_IN, device=dev).to(dev)
-    D.broadcast_parameters(model)
-    model.train()
-    reducer = D.FlatGradReducer(model.parameters(), world=world, always_pack=args.force_pack)
-    if os.environ.get("IMMUNOSTRUCT_TORCH_ADAM", "0") == "1":
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=not args.eager)
-    else:
-        opt = optim.Adam(model.parameters(), lr=1e-3)      # csrc/optimizer.hip
-    losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
-    pool = build_batches(4, args.batch, args.deg_extra, dev, seed0=1000 * (rank + 1))
-
-    def forward_loss(m, g, seq, prop, y):
-        recon, mu, logvar, final = m(g, seq, prop)
-        return losses.regression_loss(recon, seq, mu, logvar, final, y)
-
-    def eager_step(i):
-        b = pool[i % len(pool)]
-        reducer.zero()
-        loss = forward_loss(model, b["g"], b["seq"], b["prop"], b["y"])
-        loss.backward()
-        reducer.all_reduce_mean()
-        opt.step()
-        return loss.detach()
-
-    if args.eager:
-        step = eager_step
-    else:
-        from immunostruct_amd.engine import CapturedTrainStep
-        b0 = pool[0]
-        captured = CapturedTrainStep(model, opt, reducer, forward_loss, (b0["g"], b0["seq"], b0["prop"], b0["y"]),
-                                     edge_capacity=max(b["raw"].num_edges for b in pool))
-
-        def step(i):
-            b = pool[i % len(pool)]
-            return captured(b["g"], b["seq"], b["prop"], b["y"])
-
-    for i in range(args.warmup):
-        step(i)
-    flush_c_stdio()       # RCCL's version banner sits in libc's stdout buffer: push it out now, not after the JSON line
-    HF.KernelTimer.reset()
-    HF.KernelTimer.enabled = args.eager and not args.no_kernel_timers
+    wl = WORKLOADS[args.workload](args, dev, rank, world)
+    step = wl.step
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    trace = os.environ.get("IMMUNOSTRUCT_STEP_TRACE")     # debugging aid: device time of every timed step (events)
-    marks = []
+    for i in range(args.warmup):
+        step(i)
+    # untimed: keep replaying until the step time is stable (clocks / caches / allocator of a cold box), at most ~0.5 s;
+    # every rank runs the same number of blocks (the stop decision is rank 0's)
+    settle, prev = [], None
+    for blk in range(40):
+        fence()
+        s0 = time.perf_counter()
+        for i in range(5):
+            step(args.warmup + i)
+        fence()
+        cur = (time.perf_counter() - s0) / 5
+        settle.append(round(cur * 1e3, 3))
+        stop = (prev is not None and abs(cur - prev) <= 0.02 * prev and blk >= 2) or sum(settle) * 5e-3 > 0.5
+        if world > 1:
+            flag = torch.tensor([1 if stop else 0], device=dev)
+            torch.distributed.broadcast(flag, src=0)
+            stop = bool(flag.item())
+        if stop:
+            break
+        prev = cur
+    flush_c_stdio()       # RCCL's version banner sits in libc's stdout buffer: push it out now, not after the JSON line
+    HF.KernelTimer.reset()
+    HF.KernelTimer.enabled = args.eager and not args.no_kernel_timers
+
+    gc.collect()
+    gc.disable()          # no collector pause inside the (tens of milliseconds long) timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
+    last = None
     for i in range(args.steps):
-        if trace:
-            e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
+        marks[i].record()
         last = step(args.warmup + i)
-    if trace:
-        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
+    marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
-    if trace:
-        print("[step trace] ms per step: " + " ".join(f"{a.elapsed_time(b):.3f}" for a, b in zip(marks, marks[1:])), file=sys.stderr)
-        for blk in range(int(trace)):
-            fence()
-            b0 = time.perf_counter()
-            for i in range(args.steps):
-                step(args.warmup + i)
-            fence()
-            print(f"[step trace] extra block {blk}: {1e3 * (time.perf_counter() - b0) / args.steps:.3f} ms/step", file=sys.stderr)
+    gc.enable()
     HF.KernelTimer.enabled = False
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))      # device time between the steps' first launches
     if os.environ.get("IMMUNOSTRUCT_HOST_TIMES"):     # debugging aid: host-side cost of one isolated step vs its GPU time
         for i in range(5):
             fence()
@@ -287,84 +612,48 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(last.detach())
+    final_loss = float(last.detach()) if last is not None else None
     timers_mode = "HIP events around each launch inside the timed region (eager launches)"
     if not args.eager and not args.no_kernel_timers:
-        # the timed region replays a captured HIP graph (individual launches cannot be bracketed there):
-        # measure per-kernel durations with HIP events on an eager re-run of the same steps
-        # (sequence branch on the SAME stream for this re-run: a kernel's duration is then its own, not the co-run slow-down
-        #  by whatever the forked branch happens to execute next to it; the in-situ averages are in profiles/)
-        from immunostruct_amd.models import _core as model_core
-        overlap_saved, model_core.OVERLAP_BRANCHES = model_core.OVERLAP_BRANCHES, False
-        for bucket in reducer.buckets:      # the captured graphs are done: pack from the live .grad tensors again
-            bucket["sources"] = None
+        # the timed region replays a captured HIP graph (individual launches cannot be bracketed there): measure per-kernel
+        # durations with HIP events on an eager re-run of the same steps (the in-situ averages are in profiles/)
+        restore = wl.eager_timers_setup()
         for i in range(2):      # untimed: the first eager steps after the replays grow the allocator's pool (hipMalloc stalls)
-            eager_step(args.warmup + i)
+            wl.eager_step(args.warmup + i)
         torch.cuda.synchronize()
         HF.KernelTimer.reset()
         HF.KernelTimer.enabled = True
         for i in range(min(args.steps, 10)):
-            eager_step(args.warmup + i)
+            wl.eager_step(args.warmup + i)
         torch.cuda.synchronize()
         HF.KernelTimer.enabled = False
-        model_core.OVERLAP_BRANCHES = overlap_saved
+        restore()
         timers_mode = ("HIP events around each launch, eager single-stream re-run of the timed steps "
                        "(the timed region replays a HIP graph)")
 
     if rank == 0:
-        graphs = args.batch * world * args.steps
-        n_nodes = pool[0]["raw"].num_nodes
-        n_edges = float(np.mean([b["raw"].num_edges for b in pool]))
+        graphs = wl.graphs_per_step * world * args.steps
         timers = HF.KernelTimer.summary()
-        roof = None
-        if "egnn_edge_bwd" in timers:
-            # the timed launches are the five full ones per step (layer 0: Din = 20, layers 1-4: Din = 64); the last layer's
-            # launch skips the coordinate MLP (its output is unused by the model) and is timed under its own name
-            per = [edge_pass_algorithmic(n_nodes, n_edges, din, 1) for din in (20, 64, 64, 64, 64)]
-            b_fwd, b_bwd = np.mean([p[0] for p in per]), np.mean([p[1] for p in per])
-            f_fwd, f_bwd = np.mean([p[2] for p in per]), np.mean([p[3] for p in per])
-            n_b, ms_b = timers["egnn_edge_bwd"]
-            n_f, ms_f = timers["egnn_edge_fwd"]
-            tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.isfile(tpath) and args.batch == 128 and args.deg_extra == 2:
-                # PMC-measured HBM bytes per launch of this kernel on this workload (profiles/README.md)
-                traffic = json.load(open(tpath)).get("egnn_edge_bwd16_kernel", {}).get("bytes")
-            roof = dict(kernel="egnn_edge_bwd16_kernel", bound="mfma", achieved=round(tf_b, 2),
-                        peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4),
-                        traffic=traffic, measured=timers_mode, launches=n_b, mean_launch_us=round(ms_b * 1e3, 2),
-                        algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
-                        hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                      frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
-                        forward_kernel=dict(kernel="egnn_edge_fwd3_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
-                                            tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
-                                            hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
-                                            frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
-            if "gather_segment_sum" in timers:
-                n_g, ms_g = timers["gather_segment_sum"]
-                gbytes = n_edges * (H * 4 + 12 + 4) + n_nodes * (H * 4 + 12 + 4)
-                roof["gather_kernel"] = dict(kernel="gather_segment_sum_kernel", bound="hbm", mean_launch_us=round(ms_g * 1e3, 2),
-                                             launches=n_g, achieved=round(gbytes / (ms_g * 1e-3) / 1e9, 1), unit="GB/s",
-                                             frac=round(gbytes / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+        roof = wl.roofline(timers)
+        if roof is not None:
+            roof["measured"] = timers_mode
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.batch, args.deg_extra)
+            cpu = wl.cpu_baseline()
+        ddp = torch.distributed.is_initialized()
+        config = dict(workload=wl.describe(), global_batch=wl.graphs_per_step * world, nodes_per_batch=wl.n_nodes,
+                      edges_per_batch=int(wl.n_edges), parallelism=f"dp{world}",
+                      final_loss=None if final_loss is None else round(final_loss, 5),
+                      rccl_ranks=torch.distributed.get_world_size() if ddp else 1,
+                      dist_backend=torch.distributed.get_backend() if ddp else None)
+        config.update(wl.extra_config())
         line = dict(metric="peptide-MHC graphs/sec (train step)", value=round(graphs / dt, 1), unit="graphs/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=f"IEDB pretrain step (BASELINE config 2): {args.model}, full-sequence + sequence-loss, "
-                                         f"regression loss, Adam; B={args.batch} graphs/GPU x 190 padded nodes, "
-                                         f"E~{int(n_edges)} edges/batch (deg_extra={args.deg_extra}), Fe=1",
-                                global_batch=args.batch * world, nodes_per_batch=n_nodes, edges_per_batch=int(n_edges),
-                                parallelism=f"dp{world}", final_loss=round(final_loss, 5),
-                                rccl_ranks=(torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
-                                dist_backend=(torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                                launch="eager" if args.eager else "hipGraph replay",
-                                grad_allreduce=(None if (args.eager or not reducer.packing) else
-                                                dict(form="two-stage backward, bucket 0 overlapped" if captured.two_stage else "serial",
-                                                     buckets=[int(b["flat"].numel()) for b in reducer.buckets],
-                                                     tuned_ms=captured.dp_times))),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=config,
+                    step_ms=dict(median=round(per_step[len(per_step) // 2], 3), min=round(per_step[0], 3), max=round(per_step[-1], 3),
+                                 settle_blocks_ms=settle,
+                                 note="device time per step from HIP events between the steps (rank 0); settle_blocks_ms = the "
+                                      "untimed 5-step blocks replayed after the warm-up until two agreed within 2 %"),
                     roofline=roof, cpu_baseline=cpu,
                     kernel_timers_us={k: [v[0], round(v[1] * 1e3, 2)] for k, v in timers.items()})
         flush_c_stdio()

@@ -28,33 +28,17 @@ SIGNATURES = {
     "is_version": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
     "is_mfma_outer_selftest": [_P, _P, _P, _P],
-    "is_egnn_edge_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
-    "is_egnn_edge_bwd_partials_floats": [_I],
-    "is_egnn_edge_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I,
-                         _I, _I, _P],
-    "is_egnn_edge_fwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
-    "is_egnn_edge_fwd_v3": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
-                            _I, _P],
-    "is_egnn_edge_fwd_v3x": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I,
-                             _I, _P],
-    "is_egnn_edge_bwd_v2": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P,
-                            _I, _I, _I, _P],
+    "is_egnn_layer_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
+                          _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "is_egnn_layer_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 9 + [_I, _P, _P, _P, _I, _I, _I] + [_P] * 14 + [_P],
     "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
-    "is_egnn_node_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
-    "is_node_proj_bwd_floats": [_I],
     "is_node_proj_bwd": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P],
-    "is_egnn_node_bwd_floats": [_I],
-    "is_egnn_node_bwd": [_P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_reduce_partials_scratch_floats": [_I],
     "is_reduce_partials": [_P, _I, _I, _I, _P, _P, _P, _P],
-    "is_egnn_node_fwd_v2": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "is_node_pack_floats": [],
-    "is_node_pack_weights": [_P, _I, _P],
     "is_stack_prologue": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
-    "is_egnn_node_bwd_data": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],
-    "is_egnn_node_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _I, _P],
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],

@@ -1,0 +1,768 @@
+// One EGNNConv layer, backward, as ONE launch per layer: for each tile of destination nodes a workgroup runs
+//   P1  (GATHER) the source-side "scatter-add" of the layer ABOVE as a gather over the CSR-by-source index:
+//       dPs[v] = sum_{out-edges of v} dZ1'[slot], g_x[v] = dx'_dst[v] + sum dD'[slot] -- for its OWN nodes only;
+//   P2  the node data path of this layer for those nodes: dh = g_h + g_psd W1sd' ; dzn1 = (dh Wn2) * SiLU'(zn1) ;
+//       [d_h | d_hneigh] = dzn1 Wn1  (MFMA, B operands in registers from the lane-ordered operand pack, node16.h);
+//   P3  the fused edge pass backward over the in-edges of those nodes (what egnn_edge_bwd16 was): recompute z1 from
+//       the gathers, edge / coordinate-MLP backward, geometry backward, dPd / dx by destination, per-edge dZ1 / dD
+//       for the gather of the layer BELOW, weight-gradient outer products distributed by output tile.
+// Everything P1 / P2 need belongs to the tile's own nodes, so no workgroup ever waits for another one; the activation
+// tiles of P2 live in the LDS buffers P3 uses later.  This replaces three launches per layer (node data kernel, edge
+// kernel, source gather) and their round trips of dh / d_hneigh / dpsd through HBM.
+//
+// P3 mapping (unchanged):
+//   * workgroups of 4 waves, one 16-edge tile per wave on v_mfma_f32_16x16x4_f32, two
+//     16x64 LDS buffers per wave => ~78 KB LDS, TWO independent workgroups per CU (2 waves per
+//     SIMD): one workgroup's gathers / SiLU epilogues overlap the other's MFMAs;
+//   * the weight-gradient outer products are distributed by OUTPUT tile instead of by edge
+//     tile: wave w owns rows [16w, 16w+16) of dW2 / dWc1 / [dw_r | dW_a] and contracts over all four edge
+//     tiles of the 64-edge window, so a wave carries 3 x 16 accumulator registers and no cross-wave reduction
+//     is needed at the end;
+//   * a workgroup owns one node tile per pass: either NV16 = 16 consecutive destination nodes (~48 edges on
+//     degree-3 graphs: the fourth wave of the 64-edge window idles in the row phases), or -- when the caller
+//     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= 24 nodes per tile) -- a
+//     node range that fills the window (63 of 64 rows on the same graphs, 24 % fewer passes).
+#include "common.h"
+#include "node16.h"
+
+namespace is {
+
+#ifdef IS_STAGE_STAMPS
+__device__ long long g_stamps_b[24];
+#define STAMPB(k) do { if (blockIdx.x == 300 && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMPB(k) do { } while (0)
+#endif
+
+constexpr int WB16 = 4;
+constexpr int NV16 = 16;   // nodes per tile without a tile list
+constexpr int NVB_LISTED = 24;    // most nodes a listed tile may hold
+
+template <int FE_MAX, int NVB>
+struct Bwd16Smem {
+  float w2t[H * LD];
+  float wc1t[H * LD];
+  float bufA[WB16][TE16 * LD];
+  float bufB[WB16][TE16 * LD];
+  float pdt[NVB * H];   // Pd rows of this tile's destination nodes
+  int rp[NVB + 1];
+  int e_src[WB16][TE16];
+  int e_dl[WB16][TE16];
+  float e_ra[WB16][TE16 * (FE_MAX + 1)];   // per edge: [radial | edge features]: the B operand of the dw_r / dW_a outer product
+  float wa[FE_MAX > 1 ? FE_MAX * H : 1];   // W_a columns, lane = channel (registers when FE_MAX == 1)
+  float e_r[WB16][TE16];
+  float e_inv[WB16][TE16];
+  float e_d[WB16][3][TE16];
+  float e_gx[WB16][3][TE16];   // upstream coordinate gradient / deg; GEO overwrites it with dL/dd (each lane its own entries)
+  float e_gxd[WB16][TE16];
+  float e_s[WB16][TE16];
+  float e_drad[WB16][TE16];
+};
+
+constexpr int PART16_STRIDE = 8448 + 64 * 8;  // identical to the v1 record
+
+struct NodeBwdArgs {
+  // ---- P1 (GATHER): per-edge gradients of the layer above, by CSR-by-source ----
+  const float* dZ1n;        // [E, 64]
+  const float* dDn;         // [E, 3]
+  const float* dxn;         // [N, 3]   destination-side dL/dx of the layer above (identity path included)
+  const int* rowptr_src;    // [N + 1]
+  const int* pos_by_src;    // [E]
+  // ---- P2 ----
+  const float* g_h;         // [N, 64]  direct gradient of this layer's output h (may be NULL: zero)
+  float* g_psd;             // [N, 128] gradient of the next pre-projection of h: GATHER reads the Pd half and WRITES the Ps
+                            //          half (the weight-gradient kernel reads the whole row later); NULL: no such projection
+  const float* zn1;         // [N, 64]  saved node-MLP pre-activation
+  const float* bpack;       // backward operand pack of this layer
+  float* dh_total;          // [N, 64]  out (only with g_psd): g_h + g_psd W1sd
+  float* dzn1;              // [N, 64]  out
+  float* d_h;               // [N, 64]  out, first DIN columns (may be NULL)
+  float* d_hn;              // [N, 64]  out: dL/dh_neigh, read back by P3 (same workgroup)
+  float* gxtot;             // [N, 3]   out (GATHER): dL/dx_out of this layer = dxn + gather(dDn), read back by P3
+};
+
+template <int FE_MAX, int NVB, bool GX, bool GATHER, int DIN>
+__global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
+    const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
+    const float* __restrict__ x, const float* __restrict__ ea,
+    const int* __restrict__ rowptr, const int* __restrict__ srcs,
+    const float* __restrict__ W1, int ldw, int din,
+    const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ wc2,
+    const float* __restrict__ z2s, const float* __restrict__ z3s,
+    const float* __restrict__ g_xout,
+    float* __restrict__ dZ1, float* __restrict__ dD,
+    float* __restrict__ dPd, int ld_dpd, float* __restrict__ dx,
+    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb) {
+  static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
+  using D = Node16Dims<DIN>;
+  constexpr int MT = 4, PROWS = 16 * MT, LDP = 132;          // node phase: up to 64 rows (several tiles) per pass
+  constexpr int PITCH = (NVB + 15) / 16 * 16;                // rows reserved per tile in a pass
+  constexpr int TPP = PROWS / PITCH;                         // tiles per pass
+  static_assert(sizeof(float) * PROWS * (LDP + 2 * LD) <= sizeof(float) * (2 * H * LD + 2 * WB16 * TE16 * LD),
+                "the node phase's tiles must fit the (not yet staged) weight tiles + window buffers");
+  __shared__ Bwd16Smem<FE_MAX, NVB> sm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  constexpr int RA_LD = FE_MAX + 1;
+  const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
+  const float* __restrict__ gxsrc = GATHER ? nb.gxtot : g_xout;
+
+  // ================= P1 + P2: source gather and node data path of ALL tiles of this workgroup =================
+  // (before the persistent edge loop: its weight-gradient accumulators do not exist yet, so the 80 operand registers
+  //  of the node phase cost nothing, they are fetched once per workgroup, and the gathers of several tiles overlap)
+  {
+    float* ps_ = &sm.w2t[0];                  // [PROWS][LDP]  g_psd rows     (w2t | wc1t | bufA | bufB are contiguous)
+    float* gs = ps_ + PROWS * LDP;            // [PROWS][LD]   dh
+    float* zs = gs + PROWS * LD;              // [PROWS][LD]   dzn1
+    int* tv0 = &sm.e_src[0][0];               // [TPP] first node of the pass's tiles | [TPP] their node counts
+    const bool has_psd = nb.g_psd != nullptr;
+    const int col = wave * 16 + r;
+    // transposed-weight operands of this wave's output columns (operand pack: coalesced 16-byte loads, L2)
+    float bp[32], ba[16], bx[2][16];
+    {
+      const f32x4* pk = reinterpret_cast<const f32x4*>(nb.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 v = pk[g * 64];      // (unused without a projection; the pack slots exist either way)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bp[4 * g + j] = v[j];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = pk[(8 + g) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ba[4 * g + j] = v[j];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = pk[(12 + nt * 4 + g) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bx[nt][4 * g + j] = v[j];
+        }
+    }
+    for (int t0 = blockIdx.x; t0 < num_tiles; t0 += TPP * gridDim.x) {
+      const int ntp = min(TPP, (num_tiles - t0 + (int)gridDim.x - 1) / (int)gridDim.x);     // tiles of this pass
+      const int mt_used = ntp * (PITCH / 16);
+      if (tid < TPP) {
+        const int tl = t0 + tid * gridDim.x;
+        int a0 = 0, cnt = 0;
+        if (tid < ntp) {
+          a0 = (tiles != nullptr) ? tiles[1 + tl] : tl * NV16;
+          cnt = (tiles != nullptr) ? min(NVB, tiles[2 + tl] - a0) : min(NV16, N - a0);
+        }
+        tv0[tid] = a0;
+        tv0[TPP + tid] = cnt;
+      }
+      __syncthreads();
+      // node of pass row lr (or -1): tile k = lr / PITCH, i = lr % PITCH
+      auto row_node = [&](int lr) { const int k = lr / PITCH, i = lr % PITCH; return (i < tv0[TPP + k]) ? tv0[k] + i : -1; };
+      // epilogue inputs of this lane (rows mt*16 + 4q + t, column col): consumed two / three stages later
+      float zpre[MT][4], gpre[MT][4];
+      int vrow[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int v = row_node(mt * 16 + tile16_row(t, q));
+          vrow[mt][t] = v;
+          const int vc = max(v, 0);
+          zpre[mt][t] = nb.zn1[(size_t)vc * H + col];
+          gpre[mt][t] = (has_psd && nb.g_h != nullptr) ? nb.g_h[(size_t)vc * H + col] : 0.0f;
+        }
+      if constexpr (GATHER) {
+        // 4 lanes per node (16 floats of the 256-byte row per lane), all 64 rows of the pass at once: the three dependent
+        // latencies (rowptr -> slot ids -> rows) are paid once per pass; per-element summation order = is_gather_segment_sum's
+        const int sub = tid & 3;
+        const int lr = tid >> 2;
+        const int v = (lr < mt_used * 16) ? row_node(lr) : -1;
+        f32x4 acc[4], pdv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; pdv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float acc3 = 0.0f;
+        if (v >= 0) {
+          const int lo = nb.rowptr_src[v], hi = nb.rowptr_src[v + 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pdv[j] = *reinterpret_cast<const f32x4*>(nb.g_psd + (size_t)v * 128 + 64 + sub * 16 + 4 * j);
+          const float x_dst = (sub < 3) ? nb.dxn[v * 3 + sub] : 0.0f;
+          int p = lo;
+          for (; p + 2 <= hi; p += 2) {
+            const int e0 = nb.pos_by_src[p], e1 = nb.pos_by_src[p + 1];
+            f32x4 a0[4], a1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              a0[j] = *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e0 * H + sub * 16 + 4 * j);
+              a1[j] = *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e1 * H + sub * 16 + 4 * j);
+            }
+            float d0 = 0.0f, d1 = 0.0f;
+            if (sub < 3) { d0 = nb.dDn[(size_t)e0 * 3 + sub]; d1 = nb.dDn[(size_t)e1 * 3 + sub]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[j] += a1[j]; }
+            acc3 += d0; acc3 += d1;
+          }
+          if (p < hi) {
+            const int e0 = nb.pos_by_src[p];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e0 * H + sub * 16 + 4 * j);
+            if (sub < 3) acc3 += nb.dDn[(size_t)e0 * 3 + sub];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)      // Ps half, for the weight-gradient kernel
+            *reinterpret_cast<f32x4*>(nb.g_psd + (size_t)v * 128 + sub * 16 + 4 * j) = acc[j];
+          if (sub < 3) nb.gxtot[v * 3 + sub] = x_dst + acc3;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + sub * 16 + 4 * j) = acc[j];
+          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 64 + sub * 16 + 4 * j) = pdv[j];
+        }
+      } else {
+        // stage g_psd (or g_h) rows of the pass: all loads first, LDS stores afterwards
+        constexpr int RPW = PROWS / WB16;
+        float v0r[RPW], v1r[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int vc = max(row_node(wave * RPW + i), 0);
+          if (has_psd) {
+            v0r[i] = nb.g_psd[(size_t)vc * 128 + lane];
+            v1r[i] = nb.g_psd[(size_t)vc * 128 + 64 + lane];
+          } else {
+            v0r[i] = nb.g_h != nullptr ? nb.g_h[(size_t)vc * H + lane] : 0.0f;
+            v1r[i] = 0.0f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int lr = wave * RPW + i;
+          const bool valid = row_node(lr) >= 0;
+          if (has_psd) {
+            ps_[lr * LDP + lane] = valid ? v0r[i] : 0.0f;
+            ps_[lr * LDP + 64 + lane] = valid ? v1r[i] : 0.0f;
+          } else {
+            gs[lr * LD + lane] = valid ? v0r[i] : 0.0f;
+          }
+        }
+      }
+      __syncthreads();
+      if (has_psd) {      // dh = g_h + g_psd W1sd
+        f32x4 acc[MT];
+        zero_acc4(acc);
+        mm16_regBt_used<MT, 32, LDP>(acc, ps_, bp, lane, mt_used);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int lr = mt * 16 + tile16_row(t, q);
+            float v = 0.0f;
+            if (vrow[mt][t] >= 0) {
+              v = acc[mt][t] + gpre[mt][t];
+              nb.dh_total[(size_t)vrow[mt][t] * H + col] = v;
+            }
+            gs[lr * LD + col] = v;
+          }
+        __syncthreads();
+      }
+      {     // da1 = dh Wn2 ; dzn1 = da1 * SiLU'(zn1)
+        f32x4 acc[MT];
+        zero_acc4(acc);
+        mm16_regBt_used<MT, 16, LD>(acc, gs, ba, lane, mt_used);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int lr = mt * 16 + tile16_row(t, q);
+            float dz = 0.0f;
+            if (vrow[mt][t] >= 0) {
+              float y, dyv;
+              silu_fg(zpre[mt][t], y, dyv);
+              dz = acc[mt][t] * dyv;
+              nb.dzn1[(size_t)vrow[mt][t] * H + col] = dz;
+            }
+            zs[lr * LD + col] = dz;
+          }
+      }
+      __syncthreads();
+      // [d_h | d_hneigh] = dzn1 Wn1: wave w produces columns [32w, 32w + 32) of the (DIN + 64)-wide row
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int xc = (wave * 2 + nt) * 16 + r;
+        if ((wave * 2 + nt) * 16 < D::KV) {          // wave-uniform: the column tile exists
+          f32x4 acc[MT];
+          zero_acc4(acc);
+          mm16_regBt_used<MT, 16, LD>(acc, zs, bx[nt], lane, mt_used);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int v = vrow[mt][t];
+              if (v >= 0 && xc < D::KV) {
+                if (xc < DIN) { if (nb.d_h != nullptr) nb.d_h[(size_t)v * H + xc] = acc[mt][t]; }
+                else nb.d_hn[(size_t)v * H + (xc - DIN)] = acc[mt][t];
+              }
+            }
+        }
+      }
+      __syncthreads();     // the pass's tiles are dead; d_hn / gxtot rows of these tiles are visible to the whole workgroup
+    }
+  }
+
+  // P3 reads the node phase's d_hn rows (written above by this workgroup, behind a barrier) through a restrict pointer:
+  // without it every prefetch of the edge loop is ordered against every store of the loop
+  const float* __restrict__ g_hn = nb.d_hn;
+  load_matrix_lds_t(sm.w2t, W2, tid, 256);
+  if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
+
+  const float wr_c = W1[lane * ldw + 2 * din];
+  // W_a: one register when there is a single edge feature, LDS otherwise (eight more live registers spill this kernel)
+  float wa_c = 0.0f;
+  if constexpr (FE_MAX == 1) {
+    wa_c = (Fe > 0) ? W1[lane * ldw + 2 * din + 1] : 0.0f;
+  } else {
+    for (int idx = tid; idx < FE_MAX * H; idx += 256) {
+      const int f = idx / H, c = idx % H;
+      sm.wa[idx] = (f < Fe) ? W1[c * ldw + 2 * din + 1 + f] : 0.0f;
+    }
+  }
+  float wc2_c[4], wr_t[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    wc2_c[nt] = GX ? wc2[nt * 16 + r] : 0.0f;
+    wr_t[nt] = W1[(nt * 16 + r) * ldw + 2 * din];
+  }
+
+  // wave `wave` owns output rows [16*wave, 16*wave+16) of both weight gradients
+  f32x4 dW2[4], dWc1[4];
+  zero_acc4(dW2);
+  zero_acc4(dWc1);
+  float db2_a[4] = {0.f, 0.f, 0.f, 0.f}, dbc1_a[4] = {0.f, 0.f, 0.f, 0.f}, dwc2_a[4] = {0.f, 0.f, 0.f, 0.f};
+  // dw_r / dW_a = sum_e dz1[e][c] * [radial | a][e][j] as a third outer product, distributed by output tile like dW2:
+  // rows [16w, 16w+16) = channels, column 0 = radial weight, columns 1 .. Fe = edge-feature weights
+  f32x4 dWra = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float* bufA = sm.bufA[wave];
+  float* bufB = sm.bufB[wave];
+  constexpr int NPW = NVB / WB16;
+
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    STAMPB(0);
+    const int v0 = (tiles != nullptr) ? tiles[1 + tile] : tile * NV16;
+    const int nv = (tiles != nullptr) ? min(NVB, tiles[2 + tile] - v0) : min(NV16, N - v0);
+    __syncthreads();
+    if (tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
+#pragma unroll
+    for (int i = 0; i < NVB / WB16; ++i) {
+      const int nl = wave * (NVB / WB16) + i;
+      sm.pdt[nl * H + lane] = (nl < nv) ? pd[(size_t)(v0 + nl) * ld_p + lane] : 0.0f;
+    }
+    __syncthreads();
+    const int e_begin = sm.rp[0], e_end = sm.rp[nv];
+    float acc_h[NPW], acc_x[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) { acc_h[i] = 0.0f; acc_x[i] = 0.0f; }
+
+    for (int win = e_begin; win < e_end; win += WB16 * TE16) {
+      const int cb = win + wave * TE16;
+      const int nvalid = max(0, min(TE16, e_end - cb));
+      STAMPB(1);
+      float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
+      float up[4][4];   // dL/dh_neigh[dst] for this tile (prefetched)
+      float gth[TE16];  // Ps[src] gathers for the z1 recompute (prefetched; Pd[dst] comes from the LDS tile)
+      // the saved pre-activation tiles only depend on the window position: issue their loads first so that
+      // they are in flight during S0's dependent (src index -> coordinates) chain
+      float z3v[4][4], z2v[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          // unconditional (row clamped into the tile's edge range; rows past nvalid are masked where they are used):
+          // predicated loads cost the compiler its count of loads in flight, and every later wait becomes vmcnt(0)
+          const int row = tile16_row(t, q);
+          const size_t off = (size_t)min(cb + row, e_end - 1) * H + nt * 16 + r;
+          if constexpr (GX) z3v[t][nt] = z3s[off];
+          z2v[t][nt] = z2s[off];
+        }
+      if (nvalid > 0) {
+        // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
+        {
+          // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
+          const int l16 = lane & (TE16 - 1);
+          const bool valid = l16 < nvalid;
+          const int e = min(cb + l16, e_end - 1);
+          const int s = srcs[e];
+          int lo = 0, hi = nv;
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sm.rp[mid] <= e) lo = mid; else hi = mid;
+          }
+          const int dl = valid ? lo : 0;
+          const int v = v0 + dl;
+          const float xs0 = x[s * 3 + 0], xs1 = x[s * 3 + 1], xs2 = x[s * 3 + 2];
+          const float xv0 = x[v * 3 + 0], xv1 = x[v * 3 + 1], xv2 = x[v * 3 + 2];
+          float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
+          if constexpr (GX) { gx0 = gxsrc[v * 3 + 0]; gx1 = gxsrc[v * 3 + 1]; gx2 = gxsrc[v * 3 + 2]; }
+          float av[FE_MAX];
+#pragma unroll
+          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;      // Fe is kernel-uniform
+          float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
+          float rad = radial3(d0, d1, d2);
+          float rr = sqrtf(rad);
+          float inv = 1.0f / (rr + 1e-30f);
+          const float invdeg = 1.0f / (float)max(sm.rp[dl + 1] - sm.rp[dl], 1);
+          float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
+          if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
+          if (lane < TE16) {
+            sm.e_src[wave][lane] = valid ? s : v0;
+            sm.e_dl[wave][lane] = dl;
+            sm.e_ra[wave][lane * RA_LD] = rad;
+            sm.e_r[wave][lane] = rr;
+            sm.e_inv[wave][lane] = inv;
+            sm.e_d[wave][0][lane] = d0; sm.e_d[wave][1][lane] = d1; sm.e_d[wave][2][lane] = d2;
+            if constexpr (GX) {
+              sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
+              sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+            }
+#pragma unroll
+            for (int f = 0; f < FE_MAX; ++f) sm.e_ra[wave][lane * RA_LD + 1 + f] = valid ? av[f] : 0.0f;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        STAMPB(2);
+        // prefetch dL/dh_neigh rows of this tile's destinations: consumed after WG1 + MM3
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+          const int v = v0 + sm.e_dl[wave][row];      // e_dl = 0 for rows past nvalid: a valid node
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) up[t][nt] = g_hn[(size_t)v * H + nt * 16 + r];      // written by the node phase
+        }
+
+        // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
+        if constexpr (GX) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int row = tile16_row(t, q);
+            const bool rv = row < nvalid;
+            float tt[4], sp[4];
+            float part = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              silu_fg(z3v[t][nt], tt[nt], sp[nt]);
+              part += tt[nt] * wc2_c[nt];
+              float mh;
+              silu_fg(z2v[t][nt], mh, dy[t][nt]);
+              bufB[row * LD + nt * 16 + r] = rv ? mh : 0.0f;
+            }
+            part = sum_over_r16(part);
+            if (r == 0) sm.e_s[wave][row] = part;
+            const float ds = sm.e_gxd[wave][row];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const float dz3 = ds * wc2_c[nt] * sp[nt];
+              dwc2_a[nt] += ds * tt[nt];
+              dbc1_a[nt] += dz3;
+              bufA[row * LD + nt * 16 + r] = dz3;
+            }
+          }
+        } else {
+          // no gradient arrives at the coordinate branch: dz3 = 0, so only SiLU'(z2) is needed
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              float mh;
+              silu_fg(z2v[t][nt], mh, dy[t][nt]);
+            }
+        }
+        // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
+#pragma unroll
+        for (int i = 0; i < TE16; ++i) {
+          const int s = sm.e_src[wave][i];
+          gth[i] = ps[(size_t)s * ld_p + lane];      // raw: not consumed before SA
+        }
+      }
+      if constexpr (GX) {
+        STAMPB(3);
+        __syncthreads();   // every wave's dz3 / mh tiles are staged
+        STAMPB(4);
+
+        // ---- WG1: dWc1[16w.., :] += sum over the window's edge tiles of dz3^T mh ----
+#pragma unroll
+        for (int wt = 0; wt < WB16; ++wt)
+          if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.bufA[wt], sm.bufB[wt], wave, lane);
+      }
+
+      if (nvalid > 0) {
+        // ---- MM3: dmh = dz3 Wc1 + g_hn[dst] ; dz2 = dmh * SiLU'(z2) ----
+        f32x4 acc[4];
+        zero_acc4(acc);
+        if constexpr (GX) mm16_rows<4, H>(acc, bufA, sm.wc1t, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+          const bool rv = row < nvalid;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float dz2 = rv ? (acc[nt][t] + up[t][nt]) * dy[t][nt] : 0.0f;
+            db2_a[nt] += dz2;
+            dy[t][nt] = dz2;   // parked in registers until every wave has finished reading bufA / bufB
+          }
+        }
+      }
+      if constexpr (GX) {
+        STAMPB(5);
+        __syncthreads();   // WG1 + MM3 reads of bufA / bufB are complete in all waves
+        STAMPB(6);
+      }
+
+      if (nvalid > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bufA[tile16_row(t, q) * LD + nt * 16 + r] = dy[t][nt];   // dz2
+
+        // ---- SA: recompute z1 (lane = channel) -> bufB ----
+        {
+#pragma unroll
+          for (int i = 0; i < TE16; ++i) {
+            float z1 = gth[i] + sm.pdt[sm.e_dl[wave][i] * H + lane] + sm.e_ra[wave][i * RA_LD] * wr_c;
+            if constexpr (FE_MAX == 1) {
+              z1 += sm.e_ra[wave][i * RA_LD + 1] * wa_c;
+            } else {
+#pragma unroll
+              for (int f = 0; f < FE_MAX; ++f) z1 += sm.e_ra[wave][i * RA_LD + 1 + f] * sm.wa[f * H + lane];
+            }
+            bufB[i * LD + lane] = (i < nvalid) ? z1 : 0.0f;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- E1: m1 = SiLU(z1) in place (bufB), SiLU'(z1) -> registers ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float z1 = bufB[row * LD + nt * 16 + r];
+            float y;
+            silu_fg(z1, y, dy[t][nt]);
+            bufB[row * LD + nt * 16 + r] = (row < nvalid) ? y : 0.0f;
+          }
+        }
+      }
+      STAMPB(7);
+      __syncthreads();   // every wave's dz2 / m1 tiles are staged
+      STAMPB(8);
+
+      // ---- WG2: dW2[16w.., :] += sum over edge tiles of dz2^T m1 ----
+#pragma unroll
+      for (int wt = 0; wt < WB16; ++wt)
+        if (win + wt * TE16 < e_end) mm16_outer_rows(dW2, sm.bufA[wt], sm.bufB[wt], wave, lane);
+
+      if (nvalid > 0) {
+        // ---- MM4: dm1 = dz2 W2 ; dz1 = dm1 * SiLU'(z1) ----
+        f32x4 acc[4];
+        zero_acc4(acc);
+        mm16_rows<4, H>(acc, bufA, sm.w2t, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+          const bool rv = row < nvalid;
+          float part = 0.0f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float dz1 = rv ? acc[nt][t] * dy[t][nt] : 0.0f;
+            if (rv) dZ1[(size_t)(cb + row) * H + nt * 16 + r] = dz1;
+            dy[t][nt] = dz1;
+            part += dz1 * wr_t[nt];
+          }
+          part = sum_over_r16(part);
+          if (r == 0) sm.e_drad[wave][row] = part;
+        }
+      }
+      STAMPB(9);
+      __syncthreads();   // WG2 + MM4 reads complete in all waves
+      STAMPB(10);
+
+      if (nvalid > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bufA[tile16_row(t, q) * LD + nt * 16 + r] = dy[t][nt];   // dz1
+
+        // ---- GEO: gradient wrt d = x_src - x_dst, lane = edge ----
+        if (lane < TE16) {
+          const bool valid = lane < nvalid;
+          float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+          if (valid) {
+            const float inv = sm.e_inv[wave][lane], rr = sm.e_r[wave][lane];
+            const float d0 = sm.e_d[wave][0][lane], d1 = sm.e_d[wave][1][lane], d2 = sm.e_d[wave][2][lane];
+            float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+            if constexpr (GX) {
+              const float s = sm.e_s[wave][lane];
+              u0 = s * sm.e_gx[wave][0][lane]; u1 = s * sm.e_gx[wave][1][lane]; u2 = s * sm.e_gx[wave][2][lane];
+            }
+            const float ddot = d0 * u0 + d1 * u1 + d2 * u2;
+            const float k = rr > 0.0f ? ddot * inv * inv / rr : 0.0f;
+            const float dr2 = 2.0f * sm.e_drad[wave][lane];
+            q0 = u0 * inv - d0 * k + d0 * dr2;
+            q1 = u1 * inv - d1 * k + d1 * dr2;
+            q2 = u2 * inv - d2 * k + d2 * dr2;
+            const size_t e = (size_t)(cb + lane);
+            dD[e * 3 + 0] = q0; dD[e * 3 + 1] = q1; dD[e * 3 + 2] = q2;
+          }
+          sm.e_gx[wave][0][lane] = q0; sm.e_gx[wave][1][lane] = q1; sm.e_gx[wave][2][lane] = q2;
+        }
+      }
+      __syncthreads();
+
+      STAMPB(11);
+      // ---- WG3: [dw_r | dW_a][16w.., :] += sum over the window's edge tiles of dz1^T [radial | a] ----
+#pragma unroll
+      for (int wt = 0; wt < WB16; ++wt)
+        if (win + wt * TE16 < e_end) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int e = 4 * q + s;
+            const float b = sm.e_ra[wt][e * RA_LD + min(r, FE_MAX)];     // columns past 1 + FE_MAX are zero
+            dWra = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.bufA[wt][e * LD + wave * 16 + r], r <= FE_MAX ? b : 0.0f, dWra, 0, 0, 0);
+          }
+        }
+      // ---- SEG: destination-side segment sums (deterministic, CSR order) ----
+      {
+        const int win_hi = min(win + WB16 * TE16, e_end);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          const int nl = wave + WB16 * i;
+          if (nl < nv) {
+            const int lo = max(sm.rp[nl], win), hi = min(sm.rp[nl + 1], win_hi);
+            float ah = acc_h[i], ax = acc_x[i];
+            for (int e = lo; e < hi; ++e) {
+              const int rel = e - win;
+              const int w = rel >> 4, row = rel & 15;
+              ah += sm.bufA[w][row * LD + lane];
+              if (lane < 3) ax += sm.e_gx[w][lane][row];
+            }
+            acc_h[i] = ah; acc_x[i] = ax;
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    STAMPB(12);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int nl = wave + WB16 * i;
+      if (nl < nv) {
+        const int v = v0 + nl;
+        dPd[(size_t)v * ld_dpd + lane] = acc_h[i];
+        if (lane < 3) dx[v * 3 + lane] = (GX ? gxsrc[v * 3 + lane] : 0.0f) - acc_x[i];
+      }
+    }
+  }
+
+  // ---- write the workgroup's partial record: each wave owns 16 rows of dW2 / dWc1 ----
+  __syncthreads();
+  float* part = partials + (size_t)blockIdx.x * PART16_STRIDE;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = wave * 16 + tile16_row(t, q), i = nt * 16 + r;
+      part[o * H + i] = dW2[nt][t];
+      part[H * H + o * H + i] = dWc1[nt][t];
+    }
+  {
+    float* vec = &sm.bufB[0][0];  // [wave][slot][64]
+    constexpr int SLOTS = 3;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float vals[3] = {db2_a[nt], dbc1_a[nt], dwc2_a[nt]};
+#pragma unroll
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        float v = vals[sidx];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) vec[(wave * SLOTS + sidx) * H + nt * 16 + r] = v;
+      }
+    }
+    // the third outer product: channel o = 16 wave + 4q + t, column j = r (0: dw_r, 1..8: dW_a[o][j-1])
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = wave * 16 + tile16_row(t, q);
+      if (r == 0) part[2 * H * H + 3 * H + o] = dWra[t];
+      else if (r <= 8) part[2 * H * H + 4 * H + o * 8 + (r - 1)] = dWra[t];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SLOTS * H; idx += 256) {
+      const int sidx = idx / H, c = idx % H;
+      float v = 0.0f;
+      for (int w = 0; w < WB16; ++w) v += vec[(w * SLOTS + sidx) * H + c];
+      part[2 * H * H + sidx * H + c] = v;
+    }
+  }
+}
+
+}  // namespace is
+
+#ifdef IS_STAGE_STAMPS
+extern "C" int is_debug_stamps_bwd(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b), sizeof(long long) * 24) == hipSuccess ? 0 : -5;
+}
+#endif
+
+// One EGNNConv layer backward (source gather of the layer above + node data path + edge pass).
+//   edge half: arguments of the forward plus z2s / z3s (saved pre-activations), outputs dZ1 [E,64] / dD [E,3] (per-edge
+//     gradients in CSR slot order, gathered by source by the NEXT call or by is_gather_segment_sum), dPd [N, ld_dpd] and dx
+//     [N,3] (destination-side parts), one partial weight-gradient record per workgroup (`grid` persistent workgroups):
+//       dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
+//     tiles: NULL (16 consecutive nodes per tile) or the greedy tile list (Fe <= 1).
+//   node half: g_h [N,64] direct gradient of the layer's output h (may be NULL); g_psd [N,128] gradient of the next
+//     pre-projection of h (NULL: none; then dh = g_h); zn1 saved; bpack = the layer's backward operand pack; outputs dh_total
+//     (with g_psd), dzn1, d_h (first din columns; may be NULL), d_hn (scratch [N,64] read back by the edge half).
+//   dZ1n != NULL ("gather"): dZ1n / dDn / dxn are dZ1 / dD / dx of the layer ABOVE and rowptr_src / pos_by_src the CSR-by-source
+//     index; the kernel then completes g_psd[:, :64] = gather(dZ1n) (written: the weight-gradient kernel reads it) and uses
+//     dxn + gather(dDn) (written to gxtot [N,3], scratch) as the coordinate gradient; g_xout must be NULL.  Otherwise g_xout [N,3] (or NULL: no coordinate
+//     gradient; the coordinate-MLP half of the pass is skipped, z3s / Wc1 / wc2 are not read).
+extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                                 const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
+                                 const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                                 const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
+                                 float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                                 const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
+                                 const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
+                                 const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
+                                 void* stream) {
+  if (N <= 0) return 0;
+  const bool gather = dZ1n != nullptr;
+  const bool gx = gather || g_xout != nullptr;
+  if (Fe < 0 || Fe > 8 || grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||
+      d_hn == nullptr || (g_psd != nullptr && dh_total == nullptr) || (g_psd == nullptr && g_h == nullptr) ||
+      (gather && (g_xout != nullptr || dDn == nullptr || dxn == nullptr || rowptr_src == nullptr || pos_by_src == nullptr ||
+                  g_psd == nullptr || gxtot == nullptr)) ||
+      (gx && z3s == nullptr) || (tiles != nullptr && Fe > 1))
+    return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 block(256);
+  const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
+#define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                           \
+  hipLaunchKernelGGL((is::egnn_layer_bwd_kernel<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, \
+                     W1, ldw, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb)
+#define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
+#define IS_LAUNCH_LB_G(FE, NVB)                                        \
+  do {                                                                 \
+    if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true);                   \
+    else if (gx) IS_LAUNCH_LB_D(FE, NVB, true, false);                 \
+    else IS_LAUNCH_LB_D(FE, NVB, false, false);                        \
+  } while (0)
+  if (Fe <= 1) {
+    if (tiles != nullptr) IS_LAUNCH_LB_G(1, is::NVB_LISTED); else IS_LAUNCH_LB_G(1, is::NV16);
+  } else {
+    IS_LAUNCH_LB_G(8, is::NV16);
+  }
+#undef IS_LAUNCH_LB_G
+#undef IS_LAUNCH_LB_D
+#undef IS_LAUNCH_LB
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

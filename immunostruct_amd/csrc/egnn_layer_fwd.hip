@@ -1,7 +1,8 @@
-// Fused EGNN edge pass, forward -- wave-autonomous, software-pipelined version (v3).
+// One EGNNConv layer, forward, as ONE launch: the fused edge pass (gather, edge MLP, coordinate MLP, segment sums by
+// destination) followed, inside the same workgroup, by the node MLP of the workgroup's own nodes and the NEXT layer's
+// node pre-projection (or the node attention's query / key projection after the last layer).
 //
-// Same algorithm, inputs, outputs and summation order as egnn_edge_fwd16.hip (results are
-// bit-identical); what changes is how the work is cut and scheduled:
+// Edge half -- wave-autonomous and software-pipelined:
 //   * the destination nodes are cut into `nchunks` contiguous, NODE-ALIGNED ranges with (nearly) equal
 //     edge counts (chunk_ptr rows = (first node, its first edge), built once per batch next to the CSR index).  One WAVE owns one chunk and
 //     walks its edges in 16-edge tiles that ignore node boundaries, so tiles are full (the node-tiled
@@ -22,8 +23,16 @@
 // wave owning the previous chunk); they are recomputed bit-identically, re-stored with the same values,
 // and skipped by the segment scan.  Only a graph with fewer than 16 edges in total has rows past the end
 // (clamped loads, stores into the >= 16-row padding of z2s / z3s).
+//
+// Node half.  The four chunks of a workgroup are consecutive, so together its waves hold the complete h_neigh of one
+// contiguous node range: after ONE workgroup barrier (h_neigh rows are re-read from L2 -- waves of a workgroup share
+// their CU's L1) the workgroup runs zn1 = [h | h_neigh] Wn1^T + bn1, h' = SiLU(zn1) Wn2^T + bn2 and
+// psd' = [h' W1s'^T | h' W1d'^T + b1'] for those nodes, up to 64 rows per pass (empty 16-row tiles are skipped): wave w produces output columns [16w, 16w + 16)
+// with its MFMA B operands in registers, fetched from the lane-ordered operand pack (node16.h) after the edge loop has
+// released its registers; the activation tiles live where the edge half kept its weight tiles.  This replaces the
+// separate node kernel (one launch and one h_neigh round trip through HBM per layer).
 #include "common.h"
-#include <stdlib.h>
+#include "node16.h"
 
 namespace is {
 
@@ -36,88 +45,11 @@ __device__ long long g_stamps3[64];
 #define STAMP3(k) do { } while (0)
 #endif
 
-// ---- optional split-bf16 matrix path (X3) -----------------------------------------------------------------------
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): x*y ~ hi*hi' + hi*lo' + lo*hi' (three v_mfma_f32_16x16x32_bf16 with
-// fp32 accumulation; the dropped lo*lo' term is 2^-16 relative).  One 16x16x32 bf16 MFMA replaces eight 16x16x4 fp32
-// MFMAs at 1/16 of their cycles, so a 64x64 layer costs 24 x 16 instead of 64 x 32 SIMD cycles.  Opt-in
-// (IMMUNOSTRUCT_EDGE_FWD=v3x): NOT bit-identical to the fp32 kernels, measured error in tests/test_gpu_kernels.py.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDB = H + 8;      // bf16 row stride of the split weight tiles (144 bytes: 16-byte aligned rows)
+struct Fwd3Weights { float w2[H * LD]; float wc1[H * LD]; };
 
-__device__ __forceinline__ void split8_3(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float v = i < 4 ? a[i] : b[i - 4];
-    hi[i] = (__bf16)v;
-    const float r1 = v - (float)hi[i];
-    mid[i] = (__bf16)r1;
-    lo[i] = (__bf16)(r1 - (float)mid[i]);
-  }
-}
-
-// three-piece variant: x = hi + mid + lo exactly (3 x 8 mantissa bits); the six largest cross terms are kept
-// (hh, hm, mh, hl, lh, mm): what is dropped is O(2^-24) relative, i.e. fp32-class accuracy at 6 x 16 cycles per 32 k.
-__device__ __forceinline__ void mm16_rows_x6(f32x4 (&acc)[4], const float* a_lds, const __bf16* w_hi, const __bf16* w_mid,
-                                             const __bf16* w_lo, int lane) {
-  const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const float* ap = a_lds + r * LD + c * 32 + q * 8;
-    bf16x8 ah, am, al;
-    split8_3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), ah, am, al);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int off = (nt * 16 + r) * LDB + c * 32 + q * 8;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
-      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(w_mid + off);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
-      // smallest terms first
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
-    }
-  }
-}
-
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)a[i]; lo[i] = (__bf16)(a[i] - (float)hi[i]);
-    hi[4 + i] = (__bf16)b[i]; lo[4 + i] = (__bf16)(b[i] - (float)hi[4 + i]);
-  }
-}
-
-// acc[nt] (16 x 16) += A[16 x 64] * W[nt*16 .., 64]^T with A fp32 in LDS (row stride LD), W split bf16 in LDS
-__device__ __forceinline__ void mm16_rows_x3(f32x4 (&acc)[4], const float* a_lds, const __bf16* w_hi, const __bf16* w_lo, int lane) {
-  const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const float* ap = a_lds + r * LD + c * 32 + q * 8;
-    bf16x8 ah, al;
-    split8(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), ah, al);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int off = (nt * 16 + r) * LDB + c * 32 + q * 8;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w_hi + off);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w_lo + off);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);
-    }
-  }
-}
-
-template <int X3> struct Fwd3Weights;
-template <> struct Fwd3Weights<0> { float w2[H * LD]; float wc1[H * LD]; };
-template <> struct Fwd3Weights<2> { __bf16 w2h[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1l[H * LDB]; };
-template <> struct Fwd3Weights<3> { __bf16 w2h[H * LDB], w2m[H * LDB], w2l[H * LDB], wc1h[H * LDB], wc1m[H * LDB], wc1l[H * LDB]; };
-
-template <int FE_MAX, int X3 = 0>
+template <int FE_MAX>
 struct Fwd3Smem {
-  Fwd3Weights<X3> w;
+  Fwd3Weights w;
   float act[W3][TE16 * LD];
   float e_rad[W3][TE16];
   float e_xd[W3][3][TE16];
@@ -183,8 +115,8 @@ __device__ __forceinline__ void load_fwd_rows(FwdRows& rw, const EdgeIds<FE_MAX>
 
 // COORD = false: the layer's coordinate output is not wanted (last layer of a stack whose final coordinates are unused):
 // the coordinate MLP (z3 = mh Wc1^T + bc1, s = SiLU(z3) . wc2), the z3s store and the x_out update are skipped.
-template <int FE_MAX, bool SAVE, int X3 = 0, bool COORD = true>
-__global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
+template <int FE_MAX, bool SAVE, bool COORD, int DIN>
+__global__ __launch_bounds__(256) void egnn_layer_fwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs, const int* __restrict__ dsts,
@@ -193,8 +125,11 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ Wc1, const float* __restrict__ bc1, const float* __restrict__ wc2,
     float* __restrict__ h_neigh, int ld_hn, float* __restrict__ x_out,
-    float* __restrict__ z2s, float* __restrict__ z3s, int E, int Fe) {
-  __shared__ Fwd3Smem<FE_MAX, X3> sm;
+    float* __restrict__ z2s, float* __restrict__ z3s, int E, int Fe,
+    const float* __restrict__ h, int ld_h, const float* __restrict__ bn1, const float* __restrict__ bn2,
+    const float* __restrict__ b0n, const float* __restrict__ b1n, const float* __restrict__ fpack,
+    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next) {
+  __shared__ Fwd3Smem<FE_MAX> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   STAMP3(0);
@@ -235,32 +170,8 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     for (int j = 0; j < NW; ++j) {
       const int idx = tid + (j & 3) * 256;
       const int row = idx / (H / 4), c4 = (idx % (H / 4)) * 4;
-      if constexpr (X3 == 2) {
-        __bf16* dh = (j < 4) ? sm.w.w2h : sm.w.wc1h;
-        __bf16* dl = (j < 4) ? sm.w.w2l : sm.w.wc1l;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const __bf16 hv = (__bf16)wreg[j][k];
-          dh[row * LDB + c4 + k] = hv;
-          dl[row * LDB + c4 + k] = (__bf16)(wreg[j][k] - (float)hv);
-        }
-      } else if constexpr (X3 == 3) {
-        __bf16* dh = (j < 4) ? sm.w.w2h : sm.w.wc1h;
-        __bf16* dm = (j < 4) ? sm.w.w2m : sm.w.wc1m;
-        __bf16* dl = (j < 4) ? sm.w.w2l : sm.w.wc1l;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const __bf16 hv = (__bf16)wreg[j][k];
-          const float r1 = wreg[j][k] - (float)hv;
-          const __bf16 mv = (__bf16)r1;
-          dh[row * LDB + c4 + k] = hv;
-          dm[row * LDB + c4 + k] = mv;
-          dl[row * LDB + c4 + k] = (__bf16)(r1 - (float)mv);
-        }
-      } else {
-        float* dst = (j < 4) ? sm.w.w2 : sm.w.wc1;
-        *reinterpret_cast<f32x4*>(dst + row * LD + c4) = wreg[j];
-      }
+      float* dst = (j < 4) ? sm.w.w2 : sm.w.wc1;
+      *reinterpret_cast<f32x4*>(dst + row * LD + c4) = wreg[j];
     }
   }
   const float wr_c = W1[lane * ldw + 2 * din];
@@ -276,9 +187,9 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
   }
   FwdRows r0 = {};
   if (has_edges) load_fwd_rows<FE_MAX>(r0, id0, B, ld_p_bytes, lane);
-  __syncthreads();          // the only workgroup barrier: weights are staged
+  __syncthreads();          // the only workgroup barrier of the edge half: weights are staged
   STAMP3(1);
-  if (va >= vb) return;     // wave-uniform
+  if (va < vb) {            // wave-uniform
 
   float* act = sm.act[wave];
   float acc_h = 0.0f, acc_x = 0.0f;
@@ -344,9 +255,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
-      if constexpr (X3 == 2) mm16_rows_x3(acc, act, sm.w.w2h, sm.w.w2l, lane);
-      else if constexpr (X3 == 3) mm16_rows_x6(acc, act, sm.w.w2h, sm.w.w2m, sm.w.w2l, lane);
-      else mm16_rows<4, H>(acc, act, sm.w.w2, lane);
+      mm16_rows<4, H>(acc, act, sm.w.w2, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -363,9 +272,7 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     if constexpr (COORD) {
       f32x4 acc[4];
       zero_acc4(acc);
-      if constexpr (X3 == 2) mm16_rows_x3(acc, act, sm.w.wc1h, sm.w.wc1l, lane);
-      else if constexpr (X3 == 3) mm16_rows_x6(acc, act, sm.w.wc1h, sm.w.wc1m, sm.w.wc1l, lane);
-      else mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
+      mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float part = 0.0f;
@@ -425,6 +332,111 @@ __global__ __launch_bounds__(256) void egnn_edge_fwd3_kernel(
     h_neigh[(size_t)u * ld_hn + lane] = 0.0f;
     if (COORD && lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
   }
+  }   // va < vb
+
+  // ================= node half: the workgroup's own nodes =================
+  using D = Node16Dims<DIN>;
+  constexpr int MT = 4, ROWS = 16 * MT;
+  static_assert(sizeof(float) * ROWS * (D::LD1 + LD) <= sizeof(Fwd3Weights) + sizeof(sm.act), "node tiles must fit the dead edge buffers");
+  const int c0 = blockIdx.x * W3;
+  const int n0 = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * c0]);
+  const int n1 = __builtin_amdgcn_readfirstlane(chunk_ptr[2 * min(c0 + W3, nchunks)]);
+  const bool has_next = psd_next != nullptr;
+  const int col = wave * 16 + r;                       // output column of the two node-MLP layers
+  f32x4 nb1[D::KQ1 / 4], nb2[4], nb3[2][4];
+  {
+    const f32x4* fp = reinterpret_cast<const f32x4*>(fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < D::KQ1 / 4; ++g) nb1[g] = fp[g * 64];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) nb2[g] = fp[(D::KQ1 / 4 + g) * 64];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nb3[nt][g] = has_next ? fp[(D::KQ1 / 4 + 4 + nt * 4 + g) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float bn1_c = bn1[col], bn2_c = bn2[col];
+  float b1n_c[2] = {0.f, 0.f};
+  if (has_next) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int cc = wave * 32 + nt * 16 + r;          // psd column: [0, 64) = Ps (bias b0n, may be null), [64, 128) = Pd (bias b1n)
+      b1n_c[nt] = cc >= 64 ? b1n[cc - 64] : (b0n != nullptr ? b0n[cc] : 0.0f);
+    }
+  }
+  __syncthreads();     // every wave's h_neigh rows are written (L2 / the CU's L1); weight tiles and act buffers are dead
+  float* xs = reinterpret_cast<float*>(&sm);           // [ROWS][LD1]   X = [h | h_neigh | 0]
+  float* a1s = xs + ROWS * D::LD1;                     // [ROWS][LD]    SiLU(zn1)
+  float* hps = xs;                                     // [ROWS][LD]    h' (over X, which is dead by then)
+  for (int row0 = n0; row0 < n1; row0 += ROWS) {
+    const int mt_used = min(MT, (n1 - row0 + 15) >> 4);     // 16-row tiles of this pass that hold nodes
+    {
+      constexpr int RPW = ROWS / W3;                   // rows staged per wave: all loads first, then the LDS stores
+      float hv[RPW], nv[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = min(row0 + wave * RPW + i, n1 - 1);
+        hv[i] = h[(size_t)row * ld_h + min(lane, DIN - 1)];
+        nv[i] = h_neigh[(size_t)row * ld_hn + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int lr = wave * RPW + i;
+        const bool valid = row0 + lr < n1;
+        if (lane < DIN) xs[lr * D::LD1 + lane] = valid ? hv[i] : 0.0f;
+        xs[lr * D::LD1 + DIN + lane] = valid ? nv[i] : 0.0f;
+        if (lane < D::KP - D::KV) xs[lr * D::LD1 + D::KV + lane] = 0.0f;
+      }
+    }
+    __syncthreads();
+    {     // zn1 = X Wn1^T + bn1 ; a1 = SiLU(zn1)
+      f32x4 acc[MT];
+      zero_acc4(acc);
+      mm16_regB_used<MT, D::KQ1, D::LD1>(acc, xs, nb1, lane, mt_used);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int lr = mt * 16 + tile16_row(t, q);
+          const float z = acc[mt][t] + bn1_c;
+          if (SAVE && row0 + lr < n1) zn1[(size_t)(row0 + lr) * H + col] = z;
+          a1s[lr * LD + col] = silu_f(z);
+        }
+    }
+    __syncthreads();
+    {     // h' = a1 Wn2^T + bn2
+      f32x4 acc[MT];
+      zero_acc4(acc);
+      mm16_regB_used<MT, 16, LD>(acc, a1s, nb2, lane, mt_used);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int lr = mt * 16 + tile16_row(t, q);
+          const float v = acc[mt][t] + bn2_c;
+          if (row0 + lr < n1) h_out[(size_t)(row0 + lr) * H + col] = v;
+          hps[lr * LD + col] = v;
+        }
+    }
+    __syncthreads();
+    if (has_next) {     // next pre-projection: wave w produces psd columns [32w, 32w + 32)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 acc[MT];
+        zero_acc4(acc);
+        mm16_regB_used<MT, 16, LD>(acc, hps, nb3[nt], lane, mt_used);
+        const int cc = wave * 32 + nt * 16 + r;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int lr = mt * 16 + tile16_row(t, q);
+            if (row0 + lr < n1) psd_next[(size_t)(row0 + lr) * 128 + cc] = acc[mt][t] + b1n_c[nt];
+          }
+      }
+    }
+    if (row0 + ROWS < n1) __syncthreads();     // the next pass restages X over h'
+  }
 }
 
 }  // namespace is
@@ -435,63 +447,41 @@ extern "C" int is_debug_stamps3(long long* out) {
 }
 #endif
 
-static int edge_fwd_v3_launch(int x3, const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                              const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                              const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                              const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                              const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                              float* z3s, int N, int E, int Fe, void* stream) {
-  if (N <= 0 || nchunks <= 0) return 0;
-  // x_out == nullptr: the coordinate branch is not evaluated (fp32 kernels only); z3s is then not written and may be null
+// One EGNNConv layer forward (edge pass + node MLP + next pre-projection).  h [N, ld_h] (din = 20 | 64 columns): the
+// layer's input node features; ps / pd [N, ld_p]: its pre-projections; chunk_ptr: nchunks + 1 rows (node, first edge);
+// fpack: the layer's forward operand pack (is_stack_prologue); x_out == NULL: the coordinate branch is not evaluated
+// (z3s unused); z2s == NULL: nothing is saved for a backward pass (z3s, zn1 unused); psd_next == NULL: no next
+// projection (b0n / b1n unused); b0n may be NULL.
+extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                                 const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                                 const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                                 const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                                 const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                                 float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
+                                 const float* bn2, const float* b0n, const float* b1n, const float* fpack,
+                                 float* zn1, float* h_out, float* psd_next, void* stream) {
+  if (N <= 0) return 0;
   const bool coord = x_out != nullptr;
-  if (Fe < 0 || Fe > 8 || (coord && (z2s == nullptr) != (z3s == nullptr)) || (!coord && x3 != 0)) return -22;
+  const bool save = z2s != nullptr;
+  if (nchunks <= 0 || (nchunks % is::W3) != 0 || Fe < 0 || Fe > 8 || (din != 20 && din != 64) || fpack == nullptr || h == nullptr ||
+      h_out == nullptr || (save && ((coord && z3s == nullptr) || zn1 == nullptr)) || (psd_next != nullptr && b1n == nullptr))
+    return -22;
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
   const long long lim = 0x7fffffffLL;
   if ((long long)N * ld_p * 4 > lim || (long long)N * ld_hn * 4 > lim || (long long)(E + 16) * 64 * 4 > lim) return -22;
   if (Fe == 0) ea = x;   // never used as a feature, but the clamped prefetch address must be valid
-  const dim3 grid((nchunks + is::W3 - 1) / is::W3), block(256);
+  const dim3 grid(nchunks / is::W3), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool save = z2s != nullptr;
-#define IS_LAUNCH_FWD3(FE, SV, XX, CO)                                                                                       \
-  hipLaunchKernelGGL((is::egnn_edge_fwd3_kernel<FE, SV, XX, CO>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
-                     chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe)
-  if (x3 == 2) {
-    if (Fe > 1) return -22;
-    if (save) IS_LAUNCH_FWD3(1, true, 2, true); else IS_LAUNCH_FWD3(1, false, 2, true);
-  } else if (x3 == 3) {
-    if (Fe > 1) return -22;
-    if (save) IS_LAUNCH_FWD3(1, true, 3, true); else IS_LAUNCH_FWD3(1, false, 3, true);
-  } else if (!coord) {
-    if (Fe <= 1) { if (save) IS_LAUNCH_FWD3(1, true, 0, false); else IS_LAUNCH_FWD3(1, false, 0, false); }
-    else { if (save) IS_LAUNCH_FWD3(8, true, 0, false); else IS_LAUNCH_FWD3(8, false, 0, false); }
-  } else if (Fe <= 1) {
-    if (save) IS_LAUNCH_FWD3(1, true, 0, true); else IS_LAUNCH_FWD3(1, false, 0, true);
-  } else {
-    if (save) IS_LAUNCH_FWD3(8, true, 0, true); else IS_LAUNCH_FWD3(8, false, 0, true);
-  }
-#undef IS_LAUNCH_FWD3
+#define IS_LAUNCH_LF(FE, SV, CO, DI)                                                                                           \
+  hipLaunchKernelGGL((is::egnn_layer_fwd_kernel<FE, SV, CO, DI>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
+                     chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe, h, ld_h, \
+                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next)
+#define IS_LAUNCH_LF_D(FE, SV, CO) do { if (din == 20) IS_LAUNCH_LF(FE, SV, CO, 20); else IS_LAUNCH_LF(FE, SV, CO, 64); } while (0)
+#define IS_LAUNCH_LF_C(FE, SV) do { if (coord) IS_LAUNCH_LF_D(FE, SV, true); else IS_LAUNCH_LF_D(FE, SV, false); } while (0)
+  if (Fe <= 1) { if (save) IS_LAUNCH_LF_C(1, true); else IS_LAUNCH_LF_C(1, false); }
+  else { if (save) IS_LAUNCH_LF_C(8, true); else IS_LAUNCH_LF_C(8, false); }
+#undef IS_LAUNCH_LF_C
+#undef IS_LAUNCH_LF_D
+#undef IS_LAUNCH_LF
   return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-
-extern "C" int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                                   const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                                   const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                                   const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                                   const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                                   float* z3s, int N, int E, int Fe, void* stream) {
-  return edge_fwd_v3_launch(0, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
-                            wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
-}
-
-// Same pass with the two 64 x 64 layers on split-bf16 MFMA (three v_mfma_f32_16x16x32_bf16 per product term, fp32
-// accumulation): opt-in, Fe <= 1, not bit-identical to the fp32 kernels (relative error of a product ~2^-16).
-extern "C" int is_egnn_edge_fwd_v3x(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                                    const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                                    const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                                    const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                                    const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                                    float* z3s, int N, int E, int Fe, void* stream) {
-  static const int pieces = (getenv("IMMUNOSTRUCT_SPLIT_PIECES") != nullptr && atoi(getenv("IMMUNOSTRUCT_SPLIT_PIECES")) == 3) ? 3 : 2;
-  return edge_fwd_v3_launch(pieces, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1,
-                            wc2, h_neigh, ld_hn, x_out, z2s, z3s, N, E, Fe, stream);
 }

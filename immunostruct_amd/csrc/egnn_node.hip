@@ -1,21 +1,14 @@
-// Node-level half of an EGNNConv layer as fused MFMA kernels (replaces the dense
-// torch/hipBLASLt ops around the edge pass: cat, node_mlp Linear-SiLU-Linear and
-// the node pre-projection of the next layer's edge_mlp.0 -- SURVEY.md K6):
+// Node pre-projection (VALU form, any Din <= 64), its backward, and the fixed-order reduction of per-workgroup
+// partial records:
 //
-//   is_node_proj_fwd    psd = [h W1s^T | h W1d^T + b1]            (any Din <= 64, VALU)
-//   is_egnn_node_fwd    zn1 = [h | h_neigh] Wn1^T + bn1 ; h' = SiLU(zn1) Wn2^T + bn2 ;
-//                       psd' = [h' W1s'^T | h' W1d'^T + b1']       (next layer, optional)
+//   is_node_proj_fwd    psd = [h W1s^T (+ b0) | h W1d^T + b1]
 //   is_node_proj_bwd    dh = g_h + g_psd W1sd (optional) ; dW1sd += g_psd^T h ; db1 += colsum
-//   is_egnn_node_bwd    backward of the two-layer node MLP: d[h | h_neigh], dWn1, dbn1, dWn2, dbn2
-//   is_reduce_partials  fixed-order sum of per-workgroup partial records, scattered
-//                       through an index map into the native parameter-gradient layout
+//   is_reduce_partials(_batched)  fixed-order sum of per-workgroup partial records, scattered through an index map
+//                       into the native parameter-gradient layout
 //
-// All kernels read the reference's NATIVE parameter tensors (edge_mlp.0.weight is
-// [64, 2*Din+1+Fe] with columns [h_src | h_dst | radial | edge feats]); no weight
-// re-layout happens on the host.  One wave owns a 32-row tile; the tile's activations
-// live in that wave's private LDS buffers, so no workgroup barriers are needed inside
-// the tile loop.  Weight-gradient accumulators persist in registers over a
-// persistent grid and leave the kernel as ONE partial record per workgroup.
+// The node MLP itself lives in egnn_node16.hip / the fused layer kernels.  All kernels read the reference's NATIVE
+// parameter tensors (edge_mlp.0.weight is [64, 2*Din+1+Fe] with columns [h_src | h_dst | radial | edge feats]).
+#include <algorithm>
 #include "common.h"
 
 namespace is {
@@ -52,119 +45,6 @@ __global__ __launch_bounds__(256) void node_proj_fwd_kernel(const float* __restr
     }
     psd[(size_t)n * 128 + lane] = as;
     psd[(size_t)n * 128 + 64 + lane] = ad;
-  }
-}
-
-// ---------------------------------------------------------------------------
-template <int DIN>
-struct NodeDims {
-  static constexpr int KH = (DIN <= 32) ? 32 : 64;  // padded width of the h part
-  static constexpr int K1 = KH + 64;
-  static constexpr int LD1 = K1 + 4;                 // 100 or 132: LD1/4 odd
-};
-
-template <int DIN>
-struct NodeFwdSmem {
-  float wn1[64 * NodeDims<DIN>::LD1];
-  float wn2[64 * LD];
-  float wsd[128 * LD];
-  float act[WAVES][32 * NodeDims<DIN>::LD1];
-};
-
-template <int DIN>
-__global__ __launch_bounds__(256, 1) void egnn_node_fwd_kernel(
-    const float* __restrict__ h, int ld_h, const float* __restrict__ h_neigh, int ld_hn,
-    const float* __restrict__ Wn1, const float* __restrict__ bn1, const float* __restrict__ Wn2,
-    const float* __restrict__ bn2, const float* __restrict__ W1n, int ldw_n, const float* __restrict__ b1n,
-    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, int N) {
-  using D = NodeDims<DIN>;
-  __shared__ NodeFwdSmem<DIN> sm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hf = lane >> 5;
-  const bool has_next = W1n != nullptr;
-
-  staged_copy<64 * D::K1, 256>(tid,
-      [&](int idx) {
-        const int o = idx / D::K1, k = idx % D::K1;
-        if (k < DIN) return Wn1[o * (DIN + 64) + k];
-        if (k >= D::KH) return Wn1[o * (DIN + 64) + DIN + (k - D::KH)];
-        return 0.0f;
-      },
-      [&](int idx, float v) { sm.wn1[(idx / D::K1) * D::LD1 + idx % D::K1] = v; });
-  load_matrix_lds(sm.wn2, Wn2, H, tid, 256);
-  if (has_next) {
-    staged_copy<128 * 64, 256>(tid,
-        [&](int idx) {
-          const int c = idx / 64, k = idx % 64;
-          return (c < 64) ? W1n[c * ldw_n + k] : W1n[(c - 64) * ldw_n + 64 + k];
-        },
-        [&](int idx, float v) { sm.wsd[(idx / 64) * LD + idx % 64] = v; });
-  }
-  float bn1_c[2], bn2_c[2], b1n_c[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    bn1_c[nt] = bn1[nt * 32 + r];
-    bn2_c[nt] = bn2[nt * 32 + r];
-    b1n_c[nt] = has_next ? b1n[nt * 32 + r] : 0.0f;
-  }
-  __syncthreads();
-
-  float* act = sm.act[wave];
-  const int num_tiles = (N + 31) / 32;
-  for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += gridDim.x * WAVES) {
-    const int row0 = tile * 32;
-    // ---- X = [h | h_neigh] rows -> LDS (lane = column) ----
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      const int row = row0 + i;
-      const bool valid = row < N;
-      if (lane < D::KH) act[i * D::LD1 + lane] = (valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
-      act[i * D::LD1 + D::KH + lane] = valid ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
-    }
-    // ---- zn1 = X Wn1^T + bn1 ; a1 = SiLU(zn1) (written over the same buffer, stride LD) ----
-    {
-      f32x16 acc[2];
-      zero_acc(acc);
-      mm_rows<2, D::K1, D::LD1, D::LD1>(acc, act, sm.wn1, lane);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = tile_row(t, hf);
-          const float z = acc[nt][t] + bn1_c[nt];
-          if (zn1 != nullptr && row0 + row < N) zn1[(size_t)(row0 + row) * H + nt * 32 + r] = z;
-          act[row * LD + nt * 32 + r] = silu_f(z);
-        }
-    }
-    // ---- h' = a1 Wn2^T + bn2 ----
-    {
-      f32x16 acc[2];
-      zero_acc(acc);
-      mm_rows<2, H>(acc, act, sm.wn2, lane);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = tile_row(t, hf);
-          const float v = acc[nt][t] + bn2_c[nt];
-          if (row0 + row < N) h_out[(size_t)(row0 + row) * H + nt * 32 + r] = v;
-          act[row * LD + nt * 32 + r] = v;
-        }
-    }
-    // ---- next layer's node pre-projection psd' = [h' W1s'^T | h' W1d'^T + b1'] ----
-    if (has_next) {
-      f32x16 acc[4];
-      zero_acc(acc);
-      mm_rows<4, H>(acc, act, sm.wsd, lane);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = tile_row(t, hf);
-          const float v = acc[nt][t] + (nt >= 2 ? b1n_c[nt - 2] : 0.0f);
-          if (row0 + row < N) psd_next[(size_t)(row0 + row) * 128 + nt * 32 + r] = v;
-        }
-    }
   }
 }
 
@@ -253,135 +133,6 @@ __global__ __launch_bounds__(256, 1) void node_proj_bwd_kernel(
     const int s = tid / H, c = tid % H;
     const float* v = vec + s * WAVES * H;
     part[128 * 64 + tid] = ((v[c] + v[H + c]) + v[2 * H + c]) + v[3 * H + c];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// backward of h' = SiLU([h | h_neigh] Wn1^T + bn1) Wn2^T + bn2
-// record: [dWn1 64 x 128 (h part padded to 64 columns | h_neigh part)][dWn2 64 x 64][dbn1 64][dbn2 64]
-constexpr int NODE_STRIDE = 64 * 128 + 64 * 64 + 128;
-
-struct NodeBwdSmem {
-  float wn2t[64 * LD];    // wn2t[i][o] = Wn2[o][i]
-  float wn1t[128 * LD];   // wn1t[k][o] = Wn1[o][k'] (k < 64: h column k, zero beyond DIN; k >= 64: h_neigh column k-64)
-  float bufA[WAVES][32 * LD];
-  float bufB[WAVES][32 * LD];
-};
-
-template <int DIN>
-__global__ __launch_bounds__(256, 1) void egnn_node_bwd_kernel(
-    const float* __restrict__ g_hout, const float* __restrict__ h, int ld_h, const float* __restrict__ h_neigh,
-    int ld_hn, const float* __restrict__ zn1, const float* __restrict__ Wn1, const float* __restrict__ Wn2,
-    float* __restrict__ d_h, float* __restrict__ d_hneigh, float* __restrict__ partials, int N) {
-  __shared__ NodeBwdSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hf = lane >> 5;
-  load_matrix_lds_t(sm.wn2t, Wn2, tid, 256);
-  staged_copy<64 * 128, 256>(tid,
-      [&](int idx) {
-        const int o = idx / 128, k = idx % 128;
-        if (k < 64) return (k < DIN) ? Wn1[o * (DIN + 64) + k] : 0.0f;
-        return Wn1[o * (DIN + 64) + DIN + (k - 64)];
-      },
-      [&](int idx, float v) { sm.wn1t[(idx % 128) * LD + idx / 128] = v; });
-  __syncthreads();
-
-  f32x16 dWn1h[2][2], dWn1n[2][2], dWn2[2][2];
-  zero_acc2(dWn1h); zero_acc2(dWn1n); zero_acc2(dWn2);
-  float dbn1_a[2] = {0.f, 0.f}, dbn2_a[2] = {0.f, 0.f};
-  float* bufA = sm.bufA[wave];
-  float* bufB = sm.bufB[wave];
-  const int num_tiles = (N + 31) / 32;
-  for (int tile = blockIdx.x * WAVES + wave; tile < num_tiles; tile += gridDim.x * WAVES) {
-    const int row0 = tile * 32;
-    // ---- dh' -> bufA, a1 = SiLU(zn1) -> bufB (tile layout) ----
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int row = tile_row(t, hf);
-        const bool rv = row0 + row < N;
-        const size_t off = (size_t)(row0 + row) * H + nt * 32 + r;
-        const float g = rv ? g_hout[off] : 0.0f;
-        const float z = rv ? zn1[off] : 0.0f;
-        const float a1 = silu_f(z);
-        dbn2_a[nt] += g;
-        bufA[row * LD + nt * 32 + r] = g;
-        bufB[row * LD + nt * 32 + r] = rv ? a1 : 0.0f;
-      }
-    mm_outer<2, 2>(dWn2, bufA, bufB, lane);
-    // ---- da1 = dh' Wn2 ; dzn1 = da1 * SiLU'(zn1) -> bufA ----
-    {
-      f32x16 acc[2];
-      zero_acc(acc);
-      mm_rows<2, H>(acc, bufA, sm.wn2t, lane);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = tile_row(t, hf);
-          const bool rv = row0 + row < N;
-          float y, dy;
-          silu_fg(rv ? zn1[(size_t)(row0 + row) * H + nt * 32 + r] : 0.0f, y, dy);  // re-read: L2 hit
-          const float dz = rv ? acc[nt][t] * dy : 0.0f;
-          dbn1_a[nt] += dz;
-          bufA[row * LD + nt * 32 + r] = dz;
-        }
-    }
-    // ---- dWn1 (h part): X_h -> bufB ----
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      const int row = row0 + i;
-      bufB[i * LD + lane] = (row < N && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
-    }
-    mm_outer<2, 2>(dWn1h, bufA, bufB, lane);
-    // ---- dWn1 (h_neigh part): X_n -> bufB ----
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      const int row = row0 + i;
-      bufB[i * LD + lane] = (row < N) ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
-    }
-    mm_outer<2, 2>(dWn1n, bufA, bufB, lane);
-    // ---- dX = dzn1 Wn1 : columns [0,64) -> d_h, [64,128) -> d_hneigh ----
-    {
-      f32x16 acc[4];
-      zero_acc(acc);
-      mm_rows<4, H>(acc, bufA, sm.wn1t, lane);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int row = row0 + tile_row(t, hf);
-          if (row < N) {
-            if (nt < 2) { if (d_h != nullptr) d_h[(size_t)row * H + nt * 32 + r] = acc[nt][t]; }
-            else d_hneigh[(size_t)row * H + (nt - 2) * 32 + r] = acc[nt][t];
-          }
-        }
-    }
-  }
-  // ---- workgroup partial record ----
-  __syncthreads();
-  float* part = partials + (size_t)blockIdx.x * NODE_STRIDE;
-  float* scratch = reinterpret_cast<float*>(&sm);   // 16384 floats of the (now idle) LDS image
-  wg_sum_store_64x64(dWn1h, scratch, part, 128, tid, wave, lane);
-  wg_sum_store_64x64(dWn1n, scratch, part + 64, 128, tid, wave, lane);
-  wg_sum_store_64x64(dWn2, scratch, part + 64 * 128, 64, tid, wave, lane);
-  float* vec = &sm.bufA[0][0];  // [wave][2][64]
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const float v1 = dbn1_a[nt] + __shfl_xor(dbn1_a[nt], 32, 64);
-    const float v2 = dbn2_a[nt] + __shfl_xor(dbn2_a[nt], 32, 64);
-    if (hf == 0) {
-      vec[(wave * 2 + 0) * H + nt * 32 + r] = v1;
-      vec[(wave * 2 + 1) * H + nt * 32 + r] = v2;
-    }
-  }
-  __syncthreads();
-  if (tid < 2 * H) {
-    const int s = tid / H, c = tid % H;
-    float v = 0.0f;
-    for (int w = 0; w < WAVES; ++w) v += vec[(w * 2 + s) * H + c];
-    part[64 * 128 + 64 * 64 + s * H + c] = v;
   }
 }
 
@@ -485,36 +236,11 @@ extern "C" int is_node_proj_fwd(const float* h, int ld_h, int din, const float* 
   IS_RET();
 }
 
-extern "C" int is_egnn_node_fwd(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
-                                const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
-                                const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream) {
-  if (N <= 0) return 0;
-  const dim3 grid((N + 127) / 128), block(256);
-  if (din == 20) hipLaunchKernelGGL(is::egnn_node_fwd_kernel<20>, grid, block, 0, IS_STREAM(stream), h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
-  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_fwd_kernel<64>, grid, block, 0, IS_STREAM(stream), h, ld_h, h_neigh, ld_hn, Wn1, bn1, Wn2, bn2, W1n, ldw_n, b1n, zn1, h_out, psd_next, N);
-  else return -22;
-  IS_RET();
-}
-
-extern "C" int is_node_proj_bwd_floats(int grid) { return grid * is::PROJ_STRIDE; }
-
 extern "C" int is_node_proj_bwd(const float* g_h, const float* g_psd, const float* h, int ld_h, int din,
                                 const float* W1, int ldw, float* dh_total, float* partials, int grid, int N,
                                 void* stream) {
   if (N <= 0 || grid <= 0 || din <= 0 || din > 64) return -22;
   hipLaunchKernelGGL(is::node_proj_bwd_kernel, dim3(grid), dim3(256), 0, IS_STREAM(stream), g_h, g_psd, h, ld_h, din, W1, ldw, dh_total, partials, N);
-  IS_RET();
-}
-
-extern "C" int is_egnn_node_bwd_floats(int grid) { return grid * is::NODE_STRIDE; }
-
-extern "C" int is_egnn_node_bwd(const float* g_hout, const float* h, int ld_h, int din, const float* h_neigh, int ld_hn,
-                                const float* zn1, const float* Wn1, const float* Wn2, float* d_h, float* d_hneigh,
-                                float* partials, int grid, int N, void* stream) {
-  if (N <= 0 || grid <= 0) return -22;
-  if (din == 20) hipLaunchKernelGGL(is::egnn_node_bwd_kernel<20>, dim3(grid), dim3(256), 0, IS_STREAM(stream), g_hout, h, ld_h, h_neigh, ld_hn, zn1, Wn1, Wn2, d_h, d_hneigh, partials, N);
-  else if (din == 64) hipLaunchKernelGGL(is::egnn_node_bwd_kernel<64>, dim3(grid), dim3(256), 0, IS_STREAM(stream), g_hout, h, ld_h, h_neigh, ld_hn, zn1, Wn1, Wn2, d_h, d_hneigh, partials, N);
-  else return -22;
   IS_RET();
 }
 

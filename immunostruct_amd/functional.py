@@ -16,36 +16,26 @@ import os
 
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
-_NODES_PER_TILE = 32
-# edge-kernel mapping: "v2" = 16-edge tiles / 16x16x4 MFMA (default), "v1" = 32-edge tiles / 32x32x2 MFMA
-EDGE_KERNELS = os.environ.get("IMMUNOSTRUCT_EDGE_KERNELS", "v2")
-EDGE_FWD = os.environ.get("IMMUNOSTRUCT_EDGE_FWD", "v3")          # v3: wave-autonomous pipelined forward
-NODE_PACKS = os.environ.get("IMMUNOSTRUCT_NODE_PACKS", "1") != "0"     # lane-ordered operand packs for the node kernels
-WGRAD_ROWS = int(os.environ.get("IMMUNOSTRUCT_WGRAD_ROWS", "96"))     # rows per workgroup of a single-layer weight-gradient launch
-WGRAD_GRID = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID", "64"))     # workgroups per layer of the batched launch (x up to 8 layers)
-BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "auto")   # greedy 64-edge node tiles for the v2 backward: 1 | 0 | auto
+WGRAD_GRID = 64      # workgroups per layer of the batched node weight-gradient launch (x up to 8 layers)
+FWD_CHUNKS_MAX = 2048
+FWD_CHUNK_EDGES = 32
 
 
-def use_bwd_tiles(num_nodes, num_edges, slots):
+def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     """The backward edge kernel runs ceil(tiles / slots) rounds of persistent workgroups.  Greedy tiles (~62 edges)
     fill the 64-edge windows but only pay when they save a whole round; on the B = 128 benchmark batch both cuts need
     3 rounds and the fuller windows are slower per round (measured 82 vs 78 us), at B = 512 they save 2 of 12."""
-    if BWD_TILES in ("0", "1"):
-        return BWD_TILES == "1"
+    if fe > 1:
+        return False          # the listed-tile instantiation exists for Fe <= 1 only (LDS)
     rounds = lambda tiles: (tiles + slots - 1) // slots
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
-FWD_CHUNKS_MAX = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNKS", "2048"))
-FWD_CHUNK_EDGES = int(os.environ.get("IMMUNOSTRUCT_FWD_CHUNK_EDGES", "32"))
 
 
 def fwd_chunk_count(num_edges):
-    """number of wave-chunks of the v3 forward: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves"""
+    """number of wave-chunks of the forward layer kernel: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves,
+    a multiple of the 4 waves of a workgroup"""
     k = max(4, min(FWD_CHUNKS_MAX, (num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES))
     return (k + 3) // 4 * 4
-# node-kernel mapping: "v2" = one workgroup per 32-row tile, weights from L2, separate weight-gradient kernel
-NODE_KERNELS = os.environ.get("IMMUNOSTRUCT_NODE_KERNELS", "v2")
-# weight gradients of all layers in one launch + all partial reductions in one launch pair, after the data path
-BATCH_WGRAD = os.environ.get("IMMUNOSTRUCT_BATCH_WGRAD", "1") != "0"
 
 
 class StackBoundary:
@@ -163,21 +153,6 @@ _EDGE_STRIDE = 8448 + 64 * 8
 _NODE_STRIDE = 64 * 128 + 64 * 64 + 128
 _PROJ_STRIDE = 128 * 64 + 128
 _plan_cache = {}
-# weight-gradient work (streaming outer products + partial reductions) does not feed the backward data path and CAN
-# be enqueued on a side stream that joins at the end of the stack's backward.  Measured on MI355X (B = 128) this is
-# a loss (2.23 vs 2.05 ms/step: the side kernels take CUs/LDS away from the latency-critical edge kernels), so it
-# is off by default; IMMUNOSTRUCT_OVERLAP_WGRAD=1 turns it on.
-OVERLAP_WGRAD = os.environ.get("IMMUNOSTRUCT_OVERLAP_WGRAD", "0") == "1"
-_wgrad_streams = {}
-
-
-def _wgrad_stream(device):
-    key = (device.type, device.index)
-    if key not in _wgrad_streams:
-        _wgrad_streams[key] = torch.cuda.Stream(device=device)
-    return _wgrad_streams[key]
-
-
 class _LayerPlan:
     """Offsets of one layer's native gradient tensors in a flat buffer + the scatter maps that send the
     kernels' partial-record layouts there (built once per (Din, Fe, device))."""
@@ -244,27 +219,30 @@ def _grid_for(n_rows, rows_per_wg):
 
 
 class EGNNStackFn(torch.autograd.Function):
-    """L chained EGNNConv layers as fused HIP kernels (2 launches per layer forward, 4 + reductions backward).
+    """L chained EGNNConv layers on the fused layer kernels: one launch per layer forward (``csrc/egnn_layer_fwd.hip``),
+    node data path + edge pass + source gather per layer backward, one batched weight-gradient launch and one batched
+    reduction for the whole stack.
 
-    forward(h0 (N, Din0) [row stride may exceed Din0], x0 (N,3), ea_csr (E,Fe) | None, csr, n_layers, *params)
-      -> (h_L (N,64), x_L (N,3)).  Layer 0 has Din0 in {20, 64}; later layers 64.
+    forward(h0 (N, Din0) [row stride may exceed Din0], x0 (N,3), ea_csr (E,Fe) | None, csr, n_layers, final_coords, *params)
+      -> (h_L (N,64), x_L (N,3) | None[, head projection (N,128)]).  Layer 0 has Din0 in {20, 64}; later layers 64.
     """
 
     @staticmethod
     def forward(ctx, h0, x0, ea, csr, n_layers, final_coords, *params):
         """params = 11 tensors per layer [+ (Wa, ba, Wb, bb) of an optional 128-wide projection head of the final h:
-        the node attention's query / key projection, emitted by the last layer's node kernel].
+        the node attention's query / key projection, emitted by the last layer's node half].
         ``final_coords=False``: the caller does not use the last layer's coordinates (the reference's models never do:
         ``hybrid_models.py:323-324`` keeps only h) -- that layer's coordinate MLP is then not evaluated, forward or
         backward, and None is returned in place of x."""
         lib = _lib.load()
         _lib.require_device(h0, x0, ea, csr.rowptr_dst, *params)
         ctx.set_materialize_grads(False)      # an unused output (the final coordinates) reaches backward as None, not as zeros
-        has_head = len(params) == PARAMS_PER_LAYER * n_layers + 4
-        if not has_head and len(params) != PARAMS_PER_LAYER * n_layers:
+        P = PARAMS_PER_LAYER
+        has_head = len(params) == P * n_layers + 4
+        if not has_head and len(params) != P * n_layers:
             raise ValueError("expected 11 parameter tensors per layer (+ 4 for the projection head)")
-        if has_head and not (NODE_KERNELS == "v2" and BATCH_WGRAD and n_layers <= 6):
-            raise ValueError("the fused projection head needs the v2 node kernels with batched weight gradients")
+        if not 1 <= n_layers <= 7:
+            raise ValueError("the fused stack holds 1 to 7 layers")
         n, e = csr.num_nodes, csr.num_edges
         dev = x0.device
         din0 = int(h0.shape[1])
@@ -290,83 +268,53 @@ class EGNNStackFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
         layers = []
-        P = PARAMS_PER_LAYER
         w1_0, b1_0 = params[0], params[1]
         psd = torch.empty(n, 2 * HIDDEN, **f32)
-        fused_prologue = NODE_KERNELS == "v2" and NODE_PACKS and STACK_PROLOGUE
-        if not fused_prologue:
-            with KernelTimer.span("node_proj_fwd"):
-                _lib.check(lib.is_node_proj_fwd(_lib.ptr(h0), ld_h0, din0, _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0),
-                                                _lib.ptr(psd), n, st), "is_node_proj_fwd")
+        # layer-0 pre-projection and the lane-ordered operand packs of every layer's node half (forward + backward
+        # order): independent, ONE launch
+        packs = torch.empty(n_layers, 2, lib.is_node_pack_floats(), **f32)
+        jobs = []
+        for i in range(n_layers):
+            lp = params[i * P:(i + 1) * P]
+            w1n = (head[0] if head is not None else None) if i == n_layers - 1 else params[(i + 1) * P]
+            jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), w1n.data_ptr() if w1n is not None else None,
+                                         packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN,
+                                         int(w1n.shape[1]) if w1n is not None else 0, 0, 0))
+        jarr = (_lib.NodePackJob * len(jobs))(*jobs)
+        with KernelTimer.span("stack_prologue"):
+            _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
+                                             _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd), n, st),
+                       "is_stack_prologue")
+        kf = fwd_chunk_count(e)
+        chunks = csr.chunks(kf)
         h_in, ld_h, din = h0, ld_h0, din0
-        packs = None
-        if NODE_KERNELS == "v2" and NODE_PACKS:
-            # operand packs of the node kernels for every layer, forward + backward order: ONE launch
-            pf = lib.is_node_pack_floats()
-            packs = torch.empty(n_layers, 2, pf, **f32)
-            jobs = []
-            for i in range(n_layers):
-                lp = params[i * P:(i + 1) * P]
-                last_i = i == n_layers - 1
-                w1n = (head[0] if head is not None else None) if last_i else params[(i + 1) * P]
-                jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), w1n.data_ptr() if w1n is not None else None,
-                                             packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN,
-                                             int(w1n.shape[1]) if w1n is not None else 0, 0, 0))
-            jarr = (_lib.NodePackJob * len(jobs))(*jobs)
-            if fused_prologue:
-                # layer-0 pre-projection and the operand packs of every layer: independent, one launch
-                with KernelTimer.span("stack_prologue"):
-                    _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
-                                                     _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd), n, st),
-                               "is_stack_prologue")
-            else:
-                _lib.check(lib.is_node_pack_weights(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_node_pack_weights")
         for i in range(n_layers):
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
             ldw = int(W1.shape[1])
             if ldw != 2 * din + 1 + fe:
                 raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
-            h_neigh = torch.empty(n, HIDDEN, **f32)
-            # (kernels that can skip the coordinate branch: fp32 v3 forward, v2-family backward)
-            no_coords = (not final_coords) and i == n_layers - 1 and EDGE_FWD == "v3" and EDGE_KERNELS == "v2" and fe <= 1
-            x_out = torch.empty(n, 3, **f32) if not no_coords else None
-            z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # v3 stores full 16-row tiles
-            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
-            with KernelTimer.span("egnn_edge_fwd_nocoord" if no_coords else "egnn_edge_fwd"):
-                if EDGE_FWD in ("v3", "v3x") and EDGE_KERNELS == "v2":
-                    # wave-autonomous, software-pipelined mapping (v3x: its opt-in split-bf16 variant)
-                    kf = fwd_chunk_count(e)
-                    fwd3 = lib.is_egnn_edge_fwd_v3x if (EDGE_FWD == "v3x" and fe <= 1) else lib.is_egnn_edge_fwd_v3
-                    _lib.check(fwd3(
-                        _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
-                        _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted),
-                        _lib.ptr(csr.chunks(kf)), kf, _lib.ptr(W1), ldw, din,
-                        _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-                        _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe, st),
-                        "is_egnn_edge_fwd_v3")
-                else:
-                    edge_fwd = lib.is_egnn_edge_fwd_v2 if EDGE_KERNELS == "v2" else lib.is_egnn_edge_fwd
-                    _lib.check(edge_fwd(
-                        _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
-                        _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
-                        _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-                        _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, fe, st), "is_egnn_edge_fwd")
             last = i == n_layers - 1
+            no_coords = (not final_coords) and last
+            h_neigh = torch.empty(n, HIDDEN, **f32)
+            x_out = torch.empty(n, 3, **f32) if not no_coords else None
+            z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # full 16-row tiles are stored
+            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
             zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
             h_out = torch.empty(n, HIDDEN, **f32)
             emit = (not last) or head is not None
             psd_next = torch.empty(n, 2 * HIDDEN, **f32) if emit else None
             if last:
-                W1n, b0n, b1n = head if head is not None else (None, None, None)
+                b0n, b1n = (head[1], head[2]) if head is not None else (None, None)
             else:
-                W1n, b0n, b1n = params[(i + 1) * P], None, params[(i + 1) * P + 1]
-            node_fwd = lib.is_egnn_node_fwd_v2 if NODE_KERNELS == "v2" else lib.is_egnn_node_fwd
-            with KernelTimer.span("egnn_node_fwd"):
-                _lib.check(node_fwd(
-                    _lib.ptr(h_in), ld_h, din, _lib.ptr(h_neigh), HIDDEN, _lib.ptr(Wn1), _lib.ptr(bn1), _lib.ptr(Wn2),
-                    _lib.ptr(bn2), _lib.ptr(W1n), int(W1n.shape[1]) if emit else 0, *((_lib.ptr(b0n),) if NODE_KERNELS == "v2" else ()),
-                    _lib.ptr(b1n), _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), n,
-                    *((_lib.ptr(packs[i, 0]) if packs is not None else None,) if NODE_KERNELS == "v2" else ()), st), "is_egnn_node_fwd")
+                b0n, b1n = None, params[(i + 1) * P + 1]
+            with KernelTimer.span("egnn_layer_fwd_nocoord" if no_coords else "egnn_layer_fwd"):
+                _lib.check(lib.is_egnn_layer_fwd(
+                    _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
+                    _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(chunks), kf,
+                    _lib.ptr(W1), ldw, din, _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+                    _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe,
+                    _lib.ptr(h_in), ld_h, _lib.ptr(bn1), _lib.ptr(bn2), _lib.ptr(b0n), _lib.ptr(b1n), _lib.ptr(packs[i, 0]),
+                    _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), st), "is_egnn_layer_fwd")
             layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
                                h_out=h_out))
             psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
@@ -390,46 +338,19 @@ class EGNNStackFn(torch.autograd.Function):
         g_hd = _lib.f32c(g_h) if g_h is not None else torch.zeros(n, HIDDEN, **f32)
         plans = [layer_plan(layers[i]["din"], fe, dev) for i in range(L)]
         gflat = [torch.empty(pl.total, **f32) for pl in plans]
-        use_v2 = EDGE_KERNELS == "v2" and fe <= 1   # (the Fe = 8 instantiation of the v2 backward spills)
         # no gradient at the final coordinates (unused, or never produced): the last layer's backward skips its
         # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
-        if g_x is not None:
-            g_xc = _lib.f32c(g_x)
-        else:
-            g_xc = None if use_v2 else torch.zeros(n, 3, **f32)
-        edge_bwd = lib.is_egnn_edge_bwd_v2 if use_v2 else lib.is_egnn_edge_bwd
+        g_xc = _lib.f32c(g_x) if g_x is not None else None
         # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
-        tiles = csr.tiles(64, 24) if (use_v2 and use_bwd_tiles(n, e, 2 * _MAX_BWD_GRID)) else None
+        tiles = csr.tiles(64, 24) if use_bwd_tiles(n, e, 2 * _MAX_BWD_GRID, fe) else None
         if tiles is not None:
             grid_e = max(1, min(2 * _MAX_BWD_GRID, tiles.numel() - 2))
         else:
-            grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16)) if use_v2 else _grid_for(n, _NODES_PER_TILE)
-        grid_n = _grid_for(n, 128)
-        part_n = torch.empty(grid_n * _NODE_STRIDE, **f32)
-        part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
-        scratch = torch.empty(lib.is_reduce_partials_scratch_floats(_NODE_STRIDE), **f32)
-        main = torch.cuda.current_stream()
-        side = _wgrad_stream(dev) if (OVERLAP_WGRAD and NODE_KERNELS == "v2") else main
-        keep = []          # tensors the side stream still reads: released only after the final join
-
-        def on_side():
-            side.wait_stream(main)
-            return torch.cuda.stream(side)
-
-        def reduce(part, nparts, stride, mp, dst, count=None):
-            # every reduction runs on the side stream (single user of `scratch`)
-            with on_side():
-                _lib.check(lib.is_reduce_partials(_lib.ptr(part), nparts, stride, stride if count is None else count, _lib.ptr(mp),
-                                                  _lib.ptr(dst), _lib.ptr(scratch), _lib.stream_ptr()), "is_reduce_partials")
-
-        node_v2 = NODE_KERNELS == "v2"
-        batched = node_v2 and BATCH_WGRAD and L <= 7
-        wjobs, rjobs = [], []     # deferred weight-gradient layers / reduction jobs (batched mode)
-        if node_v2:
-            wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
-            grid_w = _grid_for(n, WGRAD_ROWS) if not batched else max(1, min(WGRAD_GRID, (n + 15) // 16))
-            part_w = None if batched else torch.empty(grid_w * wg_stride, **f32)
-
+            grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16))
+        wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
+        grid_w = max(1, min(WGRAD_GRID, (n + 15) // 16))
+        wjobs, rjobs = [], []     # weight-gradient layers / reduction jobs of the two batched launches at the end
+        keep = []
         head = ctx.head
         g_psd_next = None
         head_flat = None
@@ -437,6 +358,7 @@ class EGNNStackFn(torch.autograd.Function):
             # the head's projection is "the next layer's pre-projection" of the last layer
             g_psd_next = _lib.f32c(g_head) if g_head is not None else torch.zeros(n, 2 * HIDDEN, **f32)
             head_flat = torch.empty(_PROJ_STRIDE, **f32)       # [dWa ; dWb] (128 x 64) | db_b | db_a
+        above = None      # (dZ1, dD, dx) of the layer above: gathered by source inside the next launch
         for i in reversed(range(L)):
             lay = layers[i]
             W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
@@ -444,91 +366,55 @@ class EGNNStackFn(torch.autograd.Function):
             need_dh = i > 0 or ctx.h0_needs_grad
             d_h = torch.empty(n, HIDDEN, **f32) if need_dh else None
             d_hn = torch.empty(n, HIDDEN, **f32)
-            if node_v2:
-                # (1+2) data path: dh = g_h + g_psd W1sd(next), node-MLP backward; then the streaming weight gradients
-                has_psd = g_psd_next is not None
-                is_head = has_psd and i == L - 1
-                W1n = (head[0] if is_head else params[(i + 1) * P]) if has_psd else None
-                dh_total = torch.empty(n, HIDDEN, **f32) if has_psd else g_hd
-                dzn1 = torch.empty(n, HIDDEN, **f32)
-                with KernelTimer.span("egnn_node_bwd"):
-                    _lib.check(lib.is_egnn_node_bwd_data(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(W1n),
-                                                         int(W1n.shape[1]) if has_psd else 0, _lib.ptr(lay["zn1"]), din,
-                                                         _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(dh_total) if has_psd else None,
-                                                         _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), n,
-                                                         _lib.ptr(ctx.packs[i, 1]) if ctx.packs is not None else None, st),
-                           "is_egnn_node_bwd_data")
-                keep.extend([dh_total, dzn1, g_psd_next, g_hd])
-                if batched:
-                    pw = torch.empty(grid_w * wg_stride, **f32)
-                    keep.append(pw)
-                    wjobs.append(_lib.WgradLayer(_lib.ptr(g_psd_next).value if has_psd else None, lay["h_out"].data_ptr(),
-                                                 dh_total.data_ptr(), lay["zn1"].data_ptr(), dzn1.data_ptr(), lay["h_in"].data_ptr(),
-                                                 lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, HIDDEN, HIDDEN, 0))
-                    if is_head:
-                        rjobs.append((pw, grid_w, wg_stride, wg_proj, None, head_flat))
-                    elif has_psd:
-                        rjobs.append((pw, grid_w, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
-                    rjobs.append((pw[wg_proj:], grid_w, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
-                else:
-                    with on_side():
-                        with KernelTimer.span("egnn_node_wgrad"):
-                            _lib.check(lib.is_egnn_node_wgrad(_lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), _lib.ptr(dh_total), _lib.ptr(lay["zn1"]),
-                                                              _lib.ptr(dzn1), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
-                                                              HIDDEN, _lib.ptr(part_w), grid_w, n, _lib.stream_ptr()), "is_egnn_node_wgrad")
-                        if has_psd:
-                            reduce(part_w, grid_w, wg_stride, plans[i + 1].proj_map, gflat[i + 1], count=wg_proj)
-                        reduce(part_w[wg_proj:], grid_w, wg_stride, plans[i].node_map, gflat[i], count=_NODE_STRIDE)
-            else:
-                # (1) total gradient w.r.t. this layer's output h: direct + through the next layer's pre-projection
-                if g_psd_next is not None:
-                    W1n = params[(i + 1) * P]
-                    dh_total = torch.empty(n, HIDDEN, **f32)
-                    with KernelTimer.span("node_proj_bwd"):
-                        _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["h_out"]), HIDDEN, HIDDEN,
-                                                        _lib.ptr(W1n), int(W1n.shape[1]), _lib.ptr(dh_total), _lib.ptr(part_p),
-                                                        grid_n, n, st), "is_node_proj_bwd")
-                    reduce(part_p, grid_n, _PROJ_STRIDE, plans[i + 1].proj_map, gflat[i + 1])
-                else:
-                    dh_total = g_hd
-                # (2) node MLP backward
-                with KernelTimer.span("egnn_node_bwd"):
-                    _lib.check(lib.is_egnn_node_bwd(_lib.ptr(dh_total), _lib.ptr(lay["h_in"]), lay["ld_h"], din, _lib.ptr(lay["h_neigh"]),
-                                                    HIDDEN, _lib.ptr(lay["zn1"]), _lib.ptr(Wn1), _lib.ptr(Wn2), _lib.ptr(d_h),
-                                                    _lib.ptr(d_hn), _lib.ptr(part_n), grid_n, n, st), "is_egnn_node_bwd")
-                reduce(part_n, grid_n, _NODE_STRIDE, plans[i].node_map, gflat[i])
-            # (3) fused edge backward + source-side gather
-            part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)   # per layer: its reduction runs on the side stream
+            has_psd = g_psd_next is not None
+            is_head = has_psd and i == L - 1
+            dh_total = torch.empty(n, HIDDEN, **f32) if has_psd else g_hd
+            dzn1 = torch.empty(n, HIDDEN, **f32)
+            part_e = torch.empty(grid_e * _EDGE_STRIDE, **f32)
             dZ1 = torch.empty(max(e, 1), HIDDEN, **f32)
             dD = torch.empty(max(e, 1), 3, **f32)
             dpsd = torch.empty(n, 2 * HIDDEN, **f32)
             dx = torch.empty(n, 3, **f32)
             psd = lay["psd"]
-            extra = (_lib.ptr(tiles),) if use_v2 else ()
-            with KernelTimer.span("egnn_edge_bwd_nocoord" if g_xc is None else "egnn_edge_bwd"):
-                _lib.check(edge_bwd(
+            dZ1n, dDn, dxn = above if above is not None else (None, None, None)
+            gxtot = torch.empty(n, 3, **f32) if above is not None else None      # scratch: dL/dx_out completed by the gather
+            # ONE launch: source gather of the layer above (completes g_psd_next[:, :64] and the coordinate gradient) ->
+            # node data path (dh = g_h + g_psd W1sd(next), node-MLP backward) -> fused edge pass backward
+            with KernelTimer.span("egnn_layer_bwd_nocoord" if (g_xc is None and above is None) else "egnn_layer_bwd"):
+                _lib.check(lib.is_egnn_layer_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
-                    _lib.ptr(d_hn), HIDDEN, _lib.ptr(g_xc), _lib.ptr(dZ1), _lib.ptr(dD),
-                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), *extra, grid_e, n, fe, st),
-                    "is_egnn_edge_bwd")
-            keep.append(part_e)
-            if batched:
-                rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
-            else:
-                reduce(part_e, grid_e, _EDGE_STRIDE, plans[i].edge_map, gflat[i])
-            with KernelTimer.span("gather_segment_sum"):
-                _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
-                                                     _lib.ptr(dpsd), 2 * HIDDEN, _lib.ptr(dx), n, st), "is_gather_segment_sum")
+                    _lib.ptr(g_xc) if above is None else None, _lib.ptr(dZ1), _lib.ptr(dD),
+                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), _lib.ptr(tiles), grid_e, n, fe,
+                    _lib.ptr(dZ1n), _lib.ptr(dDn), _lib.ptr(dxn), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
+                    _lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["zn1"]), _lib.ptr(ctx.packs[i, 1]),
+                    _lib.ptr(dh_total) if has_psd else None, _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), _lib.ptr(gxtot), st),
+                    "is_egnn_layer_bwd")
+            pw = torch.empty(grid_w * wg_stride, **f32)
+            keep.extend([dh_total, dzn1, g_psd_next, g_hd, pw, part_e, d_hn, above, gxtot])
+            wjobs.append(_lib.WgradLayer(_lib.ptr(g_psd_next).value if has_psd else None, lay["h_out"].data_ptr(),
+                                         dh_total.data_ptr(), lay["zn1"].data_ptr(), dzn1.data_ptr(), lay["h_in"].data_ptr(),
+                                         lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, HIDDEN, HIDDEN, 0))
+            if is_head:
+                rjobs.append((pw, grid_w, wg_stride, wg_proj, None, head_flat))
+            elif has_psd:
+                rjobs.append((pw, grid_w, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
+            rjobs.append((pw[wg_proj:], grid_w, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
+            rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
+            above = (dZ1, dD, dx)
             g_hd, g_psd_next, g_xc = d_h, dpsd, dx
+        # the gather of layer 0's per-edge gradients completes dL/dpsd_0 (and dL/dx_0): its own launch (no layer below)
+        dZ1, dD, dx = above
+        with KernelTimer.span("gather_segment_sum"):
+            _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
+                                                 _lib.ptr(g_psd_next), 2 * HIDDEN, _lib.ptr(dx), n, st), "is_gather_segment_sum")
         # (4) layer-0 pre-projection: weight gradient (+ input-feature gradient when requested)
         lay0 = layers[0]
         W1_0 = params[0]
         dh0 = torch.empty(n, HIDDEN, **f32) if ctx.h0_needs_grad else None
         keep.extend([g_hd, g_psd_next])
-        proj0_in_batch = batched and not ctx.h0_needs_grad and len(wjobs) < 8
-        if proj0_in_batch:
+        if not ctx.h0_needs_grad:
             # weight gradient of the layer-0 pre-projection as one more (projection-only) job of the batched launch
             pw0 = torch.empty(grid_w * wg_stride, **f32)
             keep.append(pw0)
@@ -536,31 +422,28 @@ class EGNNStackFn(torch.autograd.Function):
                                          pw0.data_ptr(), HIDDEN, HIDDEN, HIDDEN, lay0["ld_h"], lay0["din"], 0))
             rjobs.append((pw0, grid_w, wg_stride, wg_proj, plans[0].proj_map, gflat[0]))
         else:
+            grid_n = max(1, min(_MAX_BWD_GRID, (n + 127) // 128))
+            part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
+            keep.append(part_p)
             with KernelTimer.span("node_proj_bwd"):
                 _lib.check(lib.is_node_proj_bwd(_lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay0["h_in"]), lay0["ld_h"], lay0["din"],
                                                 _lib.ptr(W1_0), int(W1_0.shape[1]), _lib.ptr(dh0), _lib.ptr(part_p), grid_n, n, st),
                            "is_node_proj_bwd")
-        if batched:
-            if not proj0_in_batch:
-                rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
-            arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
-            with KernelTimer.span("egnn_node_wgrad_batched"):
-                _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
-                           "is_egnn_node_wgrad_batched")
-            split = lib.is_reduce_partials_scratch_floats(1)
-            big = torch.empty(sum(split * c for (_, _, _, c, _, _) in rjobs), **f32)
-            jobs, off = [], 0
-            for (pt, nparts, stride, count, mp, dst) in rjobs:
-                jobs.append(_lib.ReduceJob(pt.data_ptr(), mp.data_ptr() if mp is not None else None, dst.data_ptr(),
-                                           big[off:].data_ptr(), nparts, stride, count, 0))
-                off += split * count
-            jarr = (_lib.ReduceJob * len(jobs))(*jobs)
-            with KernelTimer.span("reduce_partials_batched"):
-                _lib.check(lib.is_reduce_partials_batched(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_reduce_partials_batched")
-        else:
-            reduce(part_p, grid_n, _PROJ_STRIDE, plans[0].proj_map, gflat[0])
-        if side is not main:
-            main.wait_stream(side)     # every weight gradient is complete before autograd hands them on
+            rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
+        arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
+        with KernelTimer.span("egnn_node_wgrad_batched"):
+            _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
+                       "is_egnn_node_wgrad_batched")
+        split = lib.is_reduce_partials_scratch_floats(1)
+        big = torch.empty(sum(split * c for (_, _, _, c, _, _) in rjobs), **f32)
+        jobs, off = [], 0
+        for (pt, nparts, stride, count, mp, dst) in rjobs:
+            jobs.append(_lib.ReduceJob(pt.data_ptr(), mp.data_ptr() if mp is not None else None, dst.data_ptr(),
+                                       big[off:].data_ptr(), nparts, stride, count, 0))
+            off += split * count
+        jarr = (_lib.ReduceJob * len(jobs))(*jobs)
+        with KernelTimer.span("reduce_partials_batched"):
+            _lib.check(lib.is_reduce_partials_batched(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), st), "is_reduce_partials_batched")
         keep.clear()
         grads = []
         for i in range(L):
@@ -784,8 +667,9 @@ def combined_attention_mean(x, mha):
 
 
 def fused_head_available(n_layers):
-    """the (Wa, ba, Wb, bb) projection head of the final h can ride on the last layer's node kernels"""
-    return NODE_KERNELS == "v2" and BATCH_WGRAD and n_layers <= 6
+    """the (Wa, ba, Wb, bb) projection head of the final h rides on the last layer's node half (the batched weight-gradient
+    launch holds 8 jobs: the layers, the layer-0 pre-projection and the head)"""
+    return n_layers <= 7
 
 
 def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None, final_coords=True):
@@ -856,9 +740,6 @@ def mlp2(x, w1, b1, w2, b2, mask=None, act1=0, act2=0, hgroup=0):
     return Mlp2Fn.apply(x, w1, b1, w2, b2, mask, int(act1), int(act2), int(hgroup))
 
 
-MLP_HEADS = os.environ.get("IMMUNOSTRUCT_MLP_HEADS", "1") != "0"
-ATTN_TAIL = os.environ.get("IMMUNOSTRUCT_ATTN_TAIL", "1") != "0"      # single-head pooled tail inside the attention forward launch
-STACK_PROLOGUE = os.environ.get("IMMUNOSTRUCT_STACK_PROLOGUE", "1") != "0"      # layer-0 projection + operand packs as one launch
 _ones_cache = {}
 
 
@@ -875,7 +756,7 @@ def sequential_mlp2(seq, x):
     and property embedding) through :func:`mlp2`; returns None when the module does not have that form or the sizes
     exceed the kernel's limits (the caller then uses the module itself)."""
     mods = [m for m in seq if not isinstance(m, torch.nn.Flatten)]
-    if not MLP_HEADS or len(mods) not in (4, 5) or not x.is_cuda or x.dim() != 2:
+    if len(mods) not in (4, 5) or not x.is_cuda or x.dim() != 2:
         return None
     l1, r1, dr, l2 = mods[:4]
     ok = (isinstance(l1, torch.nn.Linear) and isinstance(r1, torch.nn.ReLU) and isinstance(dr, torch.nn.Dropout)
@@ -980,12 +861,9 @@ class LinearSmallBatchFn(torch.autograd.Function):
 
 def linear_small_batch(x, weight, bias):
     """nn.Linear forward for (batch, features) inputs on a GPU; plain F.linear otherwise"""
-    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and DENSE_WGRAD:
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
         return LinearSmallBatchFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
-
-
-DENSE_WGRAD = os.environ.get("IMMUNOSTRUCT_DENSE_WGRAD", "1") != "0"
 
 
 class SegmentPoolFn(torch.autograd.Function):

@@ -43,7 +43,7 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=
     x2 = x.reshape(b * n, dm)
     if qk is None:     # else: already produced by the EGNN stack's last node kernel (functional.egnn_stack head)
         qk = HF.pair_linear(x2, wq, bq, wk, bk)
-    if (heads == 1 and n <= 256 and dm == 64 and out_proj is not None and HF.MLP_HEADS and HF.ATTN_TAIL and x.is_cuda
+    if (heads == 1 and n <= 256 and dm == 64 and out_proj is not None and x.is_cuda
             and not need_weights):
         # scores -> softmax -> column mean -> ctx -> value projection -> w_concat: ONE forward launch
         return HF.attn_pooled_tail(qk, x2, wv, bv, out_proj.weight, out_proj.bias, b, n), None
@@ -60,7 +60,7 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=
         q, k = q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2)
         w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
         ctx = torch.matmul(w.mean(dim=2), x)
-    if out_proj is not None and HF.MLP_HEADS and x.is_cuda and dm == 64 and ctx.is_contiguous():
+    if out_proj is not None and x.is_cuda and dm == 64 and ctx.is_contiguous():
         # per-head value projection and the output projection (w_concat) of the pooled vector in one HIP launch
         u = HF.mlp2(ctx.reshape(b, heads * dm), wv, bv, out_proj.weight, out_proj.bias, hgroup=dh)
         return u, w

@@ -15,9 +15,9 @@ unchanged.  How the layer is evaluated differs from DGL by design:
   edge_mlp.0 is split as W1 = [W1s | W1d | w_r | W_a]; the node-level
   projections Ps = h W1s^T and Pd = h W1d^T + b1 are computed once per node so
   the per-edge work is a 256-byte row gather + two 64x64 MFMA layers; gather,
-  messages, coordinate messages and the sum/mean reductions run in ONE fused
-  kernel (``csrc/egnn_edge_fwd.hip``); the node MLP and the NEXT layer's
-  projections run in a second fused kernel (``csrc/egnn_node.hip``).
+  messages, coordinate messages, the sum/mean reductions, the node MLP and the
+  NEXT layer's projections run in ONE fused kernel per layer
+  (``csrc/egnn_layer_fwd.hip``).
 """
 from __future__ import annotations
 

@@ -5,12 +5,13 @@
  * Each entry point below replaces the native kernels reached by one of those
  * call sites (paths relative to /root/reference/immunostruct):
  *
- *   is_egnn_edge_fwd / _bwd   dgl.nn.EGNNConv.forward + its autograd
+ *   is_egnn_layer_fwd / _bwd  dgl.nn.EGNNConv.forward + its autograd, one launch per layer
  *                             (models/hybrid_models.py:323-324; SDDMM u_sub_v,
- *                             edges.src/dst gathers, edge/coord MLP, SpMM
- *                             copy_e sum/mean -- SURVEY.md section 2, K1-K5, K7)
+ *                             edges.src/dst gathers, edge/coord/node MLP, SpMM
+ *                             copy_e sum/mean -- SURVEY.md section 2, K1-K7)
  *   is_gather_segment_sum     the scatter-add to SOURCE rows in that backward,
- *                             expressed as a CSR-by-source gather (K7)
+ *                             expressed as a CSR-by-source gather (K7): its own launch
+ *                             for the lowest layer, inside is_egnn_layer_bwd otherwise
  *   is_segment_pool_fwd/_bwd  torch_geometric.nn.global_mean_pool /
  *                             global_max_pool (models/hybrid_models.py:331,
  *                             models/ablation_models.py:296-297; K9)
@@ -40,115 +41,81 @@ int is_version(void);
 int is_mfma_selftest(const float* A, const float* W, float* out, void* stream);
 int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* stream);
 
-/* Fused EGNN edge pass, forward, for one EGNNConv layer.
- *   ps, pd   [N, ld_p]  node pre-projections of edge_mlp.0:  Ps = h W1s^T,
- *                       Pd = h W1d^T + b1  (64 columns each are read)
- *   x        [N, 3]     coordinates            ea [E, Fe] edge features, CSR slot order
- *   rowptr   [N+1], srcs [E]   CSR by destination (in-edges of node v are the
- *                       slots rowptr[v] .. rowptr[v+1])
- *   W1 [64, ldw]        the NATIVE edge_mlp.0.weight, ldw = 2*din + 1 + Fe, columns
- *                       [h_src (din) | h_dst (din) | radial | edge feats]; only the radial
- *                       and edge-feature columns are read here
- *   W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
- *   h_neigh  [N, ld_hn] out: sum of messages     x_out [N, 3] out: x + mean coord message
- *   z2s, z3s [E, 64]    out (may be NULL): pre-activations saved for the backward
- *   Fe in [0, 8].                                                              */
-int is_egnn_edge_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                     const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                     const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                     const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                     float* z3s, int N, int Fe, void* stream);
+/* ---------------------------------------------------------------------------------------------------------
+ * One EGNNConv layer per launch (dgl.nn.EGNNConv.forward and its autograd; models/hybrid_models.py:261-263,
+ * 323-324).  Algebra: edge_mlp.0 applied to [h_src | h_dst | radial | a] = Ps[src] + Pd[dst] + radial w_r + a W_a
+ * with the node-level pre-projections Ps = h W1s^T, Pd = h W1d^T + b1 ("psd" [N,128] = [Ps | Pd]).
+ *
+ * is_stack_prologue   psd of layer 0 from the raw node features (h [N, ld_h] with din = 20 | 64 feature columns,
+ *                     W1 = edge_mlp.0.weight [64, ldw], b0 may be NULL, b1 = edge_mlp.0.bias) NEXT TO the lane-ordered
+ *                     operand packs of every layer's node half (forward + backward order; is_node_pack_floats()
+ *                     floats per layer and direction), one launch.  jobs: host array of njobs (<= 8) records
+ *                       { const float *Wn1, *Wn2, *W1n; float *fpack, *bpack; int din, ldw_n, pad0, pad1; }
+ *                     (Wn1 / Wn2 = node_mlp.0 / .2 weights, W1n = the NEXT layer's edge_mlp.0.weight or the [Wq | Wk]
+ *                     column blocks of a projection head, or NULL).
+ *
+ * is_egnn_layer_fwd   edge pass (gather Ps[src] + Pd[dst], geometry, SiLU, edge_mlp.2, coord_mlp, running segment
+ *                     sum / mean by destination -> h_neigh [N, ld_hn], x_out [N,3]) followed in the same workgroup by
+ *                     the node MLP of its own nodes (zn1 = [h | h_neigh] Wn1^T + bn1, h_out = SiLU(zn1) Wn2^T + bn2)
+ *                     and the next pre-projection psd_next = [h_out W1s'^T + b0n | h_out W1d'^T + b1n].
+ *     ps, pd [N, ld_p]   this layer's pre-projections (64 columns each)     x [N,3]   ea [E,Fe] (CSR slot order)
+ *     rowptr [N+1], srcs [E], dsts [E]   CSR by destination
+ *     chunk_ptr [nchunks+1][2]   rows (b_j, rowptr[b_j]) of the node-aligned, edge-balanced cut of the destination nodes
+ *                        (b_0 = 0, b_nchunks = N, non-decreasing; nchunks a multiple of 4): one wave walks one chunk
+ *     W1 [64, ldw]       NATIVE edge_mlp.0.weight, ldw = 2*din + 1 + Fe; only the radial / edge-feature columns are read
+ *     W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
+ *     h [N, ld_h]        the layer's input node features (din = 20 | 64 columns); fpack = its forward operand pack
+ *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward (z2s == NULL: none saved)
+ *     x_out == NULL      the coordinate branch is not evaluated (last layer of a stack whose coordinates are unused,
+ *                        hybrid_models.py:323-324); z3s is then unused.   psd_next == NULL: no next projection.
+ *
+ * is_egnn_layer_bwd   per tile of destination nodes: (optional) source-side gather of the layer ABOVE -> node data path
+ *                     -> edge pass backward.
+ *     edge half: forward arguments + z2s / z3s; out: dZ1 [E,64], dD [E,3] (per-edge gradients of the first edge-MLP
+ *       pre-activation and of x_src - x_dst, CSR slot order: gathered by source by the NEXT call or by
+ *       is_gather_segment_sum), dPd [N, ld_dpd] and dx [N,3] (destination-side parts, identity path included), ONE
+ *       partial weight-gradient record per workgroup (`grid` persistent workgroups, 8960 floats):
+ *         dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
+ *       tiles: NULL (16 consecutive nodes per tile) or the greedy tile list [count, b_0 ... b_count] (<= 64 in-edges and
+ *       <= 24 nodes per tile, graph.py greedy_node_tiles; Fe <= 1).
+ *     node half: g_h [N,64] direct gradient of the layer's output h (may be NULL); g_psd [N,128] gradient of the next
+ *       pre-projection of h (NULL: none, then dh = g_h); zn1; bpack; out: dh_total (with g_psd), dzn1, d_h (first din
+ *       columns, may be NULL), d_hn [N,64] (scratch: dL/dh_neigh, read back by the edge half).
+ *     dZ1n != NULL: dZ1n / dDn / dxn = dZ1 / dD / dx of the layer above, rowptr_src / pos_by_src = CSR by source; the call
+ *       completes g_psd[:, :64] = gather(dZ1n) (WRITTEN: the weight-gradient launch reads it) and uses dxn + gather(dDn)
+ *       (gxtot [N,3], scratch) as the coordinate gradient; g_xout must be NULL.  Otherwise g_xout [N,3] or NULL (no
+ *       coordinate gradient: the coordinate-MLP half is skipped, z3s / Wc1 / wc2 are not read).                       */
+int is_node_pack_floats(void);
+int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
+                      const float* b0, const float* b1, float* psd, int N, void* stream);
+int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                      const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
+                      const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
+                      const float* W2, const float* b2, const float* Wc1, const float* bc1,
+                      const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
+                      float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
+                      const float* bn2, const float* b0n, const float* b1n, const float* fpack,
+                      float* zn1, float* h_out, float* psd_next, void* stream);
+int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                      const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
+                      const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                      const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
+                      float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                      const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
+                      const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
+                      const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
+                      void* stream);
 
-/* number of floats of the `partials` scratch buffer is_egnn_edge_bwd needs for `grid` workgroups */
-int is_egnn_edge_bwd_partials_floats(int grid);
-
-/* Fused EGNN edge pass, backward.  Inputs as in the forward plus
- *   g_hn [N, ld_ghn] = dL/dh_neigh, g_xout [N,3] = dL/dx_out.
- * Outputs: dZ1 [E,64] and dD [E,3] (per-edge gradients of the first edge-MLP
- * pre-activation and of x_src - x_dst, CSR slot order, consumed by
- * is_gather_segment_sum), dPd [N, ld_dpd], dx [N,3] (destination-side part,
- * incl. the identity path), and ONE partial weight-gradient record per workgroup
- * (`grid` persistent workgroups, <= number of 32-node tiles) laid out as
- *   dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
- * to be summed by is_reduce_partials.                                             */
-int is_egnn_edge_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                     const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                     const float* W2, const float* Wc1, const float* wc2, const float* z2s,
-                     const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                     float* dD, float* dPd, int ld_dpd, float* dx, float* partials, int grid, int N,
-                     int Fe, void* stream);
-
-/* Second mapping of the same two edge passes (identical arguments, results and partial-record
- * layout): 16-edge tiles on v_mfma_f32_16x16x4_f32, 2-4 waves per SIMD; the default for Fe <= 1.
- * is_egnn_edge_bwd_v2 takes grid <= number of tiles; `tiles` is NULL (tiles of 16 consecutive
- * nodes) or the greedy tile list [count, b_0, ..., b_count, ...] (int32, <= 64 in-edges and <= 24
- * nodes per tile, immunostruct_amd/graph.py greedy_node_tiles) that fills the 64-edge windows.
- * is_egnn_edge_bwd_v2 with g_xout == NULL: no gradient arrives at the layer's coordinate output; the coordinate-MLP half of the pass is
- * skipped (z3s / Wc1 / wc2 are not read, their entries of the partial record are zero).                          */
-int is_egnn_edge_fwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                        const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                        const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                        const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                        float* z3s, int N, int Fe, void* stream);
-int is_egnn_edge_bwd_v2(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                        const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                        const float* W2, const float* Wc1, const float* wc2, const float* z2s,
-                        const float* z3s, const float* g_hn, int ld_ghn, const float* g_xout, float* dZ1,
-                        float* dD, float* dPd, int ld_dpd, float* dx, float* partials,
-                        const int32_t* tiles, int grid, int N,
-                        int Fe, void* stream);
-
-/* Third mapping of the forward edge pass (results bit-identical to v2): wave-autonomous and software-
- * pipelined.  `dsts` [E] = destination of every CSR slot; `chunk_ptr` [nchunks+1][2] = rows (b_j, rowptr[b_j]) of the
- * node-aligned, edge-balanced cut of the destination nodes (b_0 = 0, b_nchunks = N, non-decreasing): one wave walks
- * one chunk in full 16-edge tiles, prefetching the next tile's rows while the current one is on the
- * matrix cores.  E = number of CSR slots (rowptr[N] <= E); z2s / z3s (when not NULL) need at least
- * max(E, 16) rows: tiles are always stored at full width.
- * x_out == NULL: the layer's coordinate output is not wanted (the last layer of a stack whose final coordinates are
- * unused, reference hybrid_models.py:323-324): the coordinate MLP is not evaluated, z3s is not written (may be NULL). */
-int is_egnn_edge_fwd_v3(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                        const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                        const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                        const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                        const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                        float* z3s, int N, int E, int Fe, void* stream);
-/* is_egnn_edge_fwd_v3 with the two 64 x 64 layers on split-bf16 MFMA (x = hi + lo in bf16, three
- * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; with IMMUNOSTRUCT_SPLIT_PIECES=3 in the environment
- * x = hi + mid + lo and six MFMAs per product: fp32-class accuracy).  Opt-in (IMMUNOSTRUCT_EDGE_FWD=v3x), Fe <= 1;
- * not bit-identical to the fp32 kernels (two pieces: ~2^-16 relative error per product).               */
-int is_egnn_edge_fwd_v3x(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
-                         const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
-                         const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
-                         const float* W2, const float* b2, const float* Wc1, const float* bc1,
-                         const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
-                         float* z3s, int N, int E, int Fe, void* stream);
-
-/* Node-level kernels of an EGNNConv layer (replace the torch/hipBLASLt Linear, cat and SiLU
- * launches around the edge pass; node_mlp of dgl.nn.EGNNConv).
- *   is_node_proj_fwd : psd [N,128] = [h W1s^T + b0 | h W1d^T + b1], h [N, ld_h] with din in {20, 64};
- *                      b0 may be NULL (EGNN); with W1 = [Wq | Wk] it is also the fused query/key
- *                      projection of the node attention (models/layers.py:13-16,68)
- *   is_egnn_node_fwd : zn1 [N,64] = [h | h_neigh] Wn1^T + bn1 (saved, may be NULL);
- *                      h_out = SiLU(zn1) Wn2^T + bn2; if W1n != NULL also the NEXT layer's
- *                      psd_next [N,128] from h_out (W1n [64, ldw_n] = next edge_mlp.0.weight, b1n its bias)
- *   is_node_proj_bwd : dh_total [N,64] = g_h + g_psd W1sd (either may be NULL: g_h treated as 0,
- *                      dh_total skipped); partial record dW1sd [128,64] | db1 [64] | db0 [64]
- *   is_egnn_node_bwd : d_h [N,64] (may be NULL) and d_hneigh [N,64] from g_hout; partial record
- *                      dWn1 [64,128] (h part padded to 64 columns | h_neigh part) | dWn2 [64,64] | dbn1 | dbn2
- * The *_floats functions give the size of the `partials` buffer for `grid` workgroups.          */
+/* Node pre-projection on its own (any caller of a 128-wide two-bias projection of 64-wide rows: with W1 = [Wq | Wk]
+ * it is the fused query/key projection of the node attention, models/layers.py:13-16,68) and its backward:
+ *   is_node_proj_fwd : psd [N,128] = [h W1s^T + b0 | h W1d^T + b1], h [N, ld_h] with din in {20, 64}; b0 may be NULL
+ *   is_node_proj_bwd : dh_total [N,64] = g_h + g_psd W1sd (either may be NULL: g_h treated as 0, dh_total skipped);
+ *                      partial record per workgroup dW1sd [128,64] | db1 [64] | db0 [64]  (8320 floats)            */
 int is_node_proj_fwd(const float* h, int ld_h, int din, const float* W1, int ldw, const float* b0,
                      const float* b1, float* psd, int N, void* stream);
-int is_egnn_node_fwd(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
-                     const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
-                     const float* b1n, float* zn1, float* h_out, float* psd_next, int N, void* stream);
-int is_node_proj_bwd_floats(int grid);
 int is_node_proj_bwd(const float* g_h, const float* g_psd, const float* h, int ld_h, int din,
                      const float* W1, int ldw, float* dh_total, float* partials, int grid, int N,
                      void* stream);
-int is_egnn_node_bwd_floats(int grid);
-int is_egnn_node_bwd(const float* g_hout, const float* h, int ld_h, int din, const float* h_neigh, int ld_hn,
-                     const float* zn1, const float* Wn1, const float* Wn2, float* d_h, float* d_hneigh,
-                     float* partials, int grid, int N, void* stream);
 
 /* dst[map[i]] = sum_p partials[p*stride + i] for i < count, fixed summation order (deterministic);
  * map may be NULL (identity), entries < 0 are skipped.  scratch: is_reduce_partials_scratch_floats(count). */
@@ -156,56 +123,21 @@ int is_reduce_partials_scratch_floats(int stride);
 int is_reduce_partials(const float* partials, int nparts, int stride, int count, const int32_t* map,
                        float* dst, float* scratch, void* stream);
 
-/* Second mapping of the node block (default): one workgroup per 32-row tile, weights fetched by the
- * lanes straight from the native parameter tensors (L2), no LDS weight staging.
- *   is_egnn_node_fwd_v2   : arguments / results of is_egnn_node_fwd plus b0n (NULL or [64]): bias of the FIRST
- *                           half of the pre-projection -- the last layer of a stack can so emit another
- *                           128-wide projection of h' (the fused query / key projection of the node
- *                           attention: W1n = [Wq | Wk] column blocks, ldw_n = 128, b0n = bq, b1n = bk)
- *   is_egnn_node_bwd_data : dh_total = g_h + g_psd W1sd (when g_psd != NULL; else dh := g_h and dh_total
- *                           is not written), dzn1 [N,64] = (dh Wn2) * SiLU'(zn1), d_h [N,64] (first
- *                           din columns valid; may be NULL), d_hneigh [N,64].  No weight gradients.
- *   is_egnn_node_wgrad    : the layer's weight gradients as streaming outer products over the rows:
- *                           partial record per workgroup = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out,
- *                           present when g_psd != NULL; is_egnn_node_wgrad_proj_floats floats) followed by
- *                           [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride is_egnn_node_wgrad_stride. */
-/* Operand packs of the node kernels: one launch per step rewrites the node-MLP / pre-projection weights of every layer
- * in the order the lanes of is_egnn_node_fwd_v2 (fpack) and is_egnn_node_bwd_data (bpack) consume them, so each of
- * their register operand loads is one coalesced 1 KB access (NULL pack: the kernels read the native tensors).
- * jobs: host array of njobs (<= 8) records
- *   { const float *Wn1, *Wn2, *W1n; float *fpack, *bpack; int din, ldw_n, pad0, pad1; }      (W1n may be NULL)
- * with fpack / bpack of is_node_pack_floats() floats each.                                                  */
-int is_node_pack_floats(void);
-int is_node_pack_weights(const void* jobs, int njobs, void* stream);
-
-/* The EGNN stack's prologue as one launch: is_node_proj_fwd for layer 0 (h [N, ld_h] with din = 20 | 64 feature columns,
- * W1 = edge_mlp.0.weight [64, ldw], b0 may be NULL, b1 = edge_mlp.0.bias -> psd [N, 128]) next to is_node_pack_weights
- * (same jobs array): the packs depend on the weights only, the two run side by side.                               */
-int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
-                      const float* b0, const float* b1, float* psd, int N, void* stream);
-int is_egnn_node_fwd_v2(const float* h, int ld_h, int din, const float* h_neigh, int ld_hn, const float* Wn1,
-                        const float* bn1, const float* Wn2, const float* bn2, const float* W1n, int ldw_n,
-                        const float* b0n, const float* b1n, float* zn1, float* h_out, float* psd_next, int N,
-                        const float* fpack, void* stream);
-int is_egnn_node_bwd_data(const float* g_h, const float* g_psd, const float* W1n, int ldw_n, const float* zn1,
-                          int din, const float* Wn1, const float* Wn2, float* dh_total, float* dzn1,
-                          float* d_h, float* d_hneigh, int N, const float* bpack, void* stream);
-int is_egnn_node_wgrad_stride(void);
-int is_egnn_node_wgrad_proj_floats(void);
-int is_egnn_node_wgrad(const float* g_psd, const float* h_out, const float* dh, const float* zn1,
-                       const float* dzn1, const float* h, int ld_h, int din, const float* h_neigh,
-                       int ld_hn, float* partials, int grid, int N, void* stream);
-
 /* Batched forms (one launch for all layers of a stack / for all pending reductions).
- *   is_egnn_node_wgrad_batched: `layers` = host array of nlayers (<= 8) records
+ *   is_egnn_node_wgrad_batched: the weight gradients of the node blocks as streaming outer products over the rows;
+ *     `layers` = host array of nlayers (<= 8) records
  *       { const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh; float* partials;
  *         int ld_h, din, ld_hn, ld_ho, dho, pad; }
- *     each processed like is_egnn_node_wgrad with `grid` workgroups; h_out has row stride ld_ho and dho (<= 64)
- *     valid columns; dzn1 == NULL marks a projection-only job (only the dW1sd part, e.g. the layer-0
- *     pre-projection of the raw node features), g_psd == NULL a job without projection part.
+ *     each processed by `grid` workgroups; partial record per workgroup = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out,
+ *     is_egnn_node_wgrad_proj_floats floats) followed by [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride
+ *     is_egnn_node_wgrad_stride.  h_out has row stride ld_ho and dho (<= 64) valid columns; dzn1 == NULL marks a
+ *     projection-only job (only the dW1sd part, e.g. the layer-0 pre-projection of the raw node features), g_psd ==
+ *     NULL a job without projection part.
  *   is_reduce_partials_batched: `jobs` = host array of njobs (<= 24) records
  *       { const float* partials; const int32_t* map; float* dst; float* scratch; int nparts, stride, count, pad; }
  *     each processed exactly like is_reduce_partials (scratch: is_reduce_partials_scratch_floats(count) floats). */
+int is_egnn_node_wgrad_stride(void);
+int is_egnn_node_wgrad_proj_floats(void);
 int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream);
 int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 

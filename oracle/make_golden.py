@@ -204,6 +204,25 @@ def golden_losses(Losses, PCL, out):
     out["contrastive/value"] = np.float32(val.item())
     out["contrastive/grad_cancer"] = ec.grad.numpy().copy()
     out["contrastive/grad_wt"] = ew.grad.numpy().copy()
+    # self-supervised variants (utils/loss.py:33-61): + cross-entropy of the masked residue's predicted type; an EMPTY
+    # prediction tensor drops the term (the validation passes of procedures/train_SSL.py)
+    pred_aa = torch.from_numpy(rng.normal(size=(b, 20)).astype(np.float32)).requires_grad_(True)
+    aa = torch.from_numpy(rng.randint(0, 20, size=(b,)).astype(np.int64))
+    for seq_flag in (True, False):
+        losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=seq_flag)
+        for kind, fn, y in (("regression", losses.regression_loss_SSL, y_reg), ("bce", losses.BCE_loss_SSL, y_bin)):
+            for t in (recon, mu, lv, logit, pred_aa):
+                t.grad = None
+            val = fn(recon, x, mu, lv, logit, y, pred_aa, aa)
+            val.backward()
+            tag = f"loss_ssl/{kind}/seq{int(seq_flag)}"
+            out[f"{tag}/value"] = np.float32(val.item())
+            out[f"{tag}/grad_logit"] = logit.grad.numpy().copy()
+            out[f"{tag}/grad_pred_aa"] = pred_aa.grad.numpy().copy()
+            if seq_flag:
+                out[f"{tag}/grad_mu"] = mu.grad.numpy().copy()
+            empty = fn(recon, x, mu, lv, logit, y, torch.zeros(0, 20), torch.zeros(0, dtype=torch.int64))
+            out[f"{tag}/value_no_residue"] = np.float32(empty.item())
 
 
 def golden_egnn(out):

@@ -57,14 +57,38 @@ def egnn_shapes(dins, fe, prefix="GCN_layers."):
 
 
 def rel_err(a, b):
-    """max |a-b| / max(|b|, tiny): error relative to the tensor's scale."""
+    """max |a-b| / max(|b|, tiny): error relative to the tensor's scale (reported, not the pass criterion)."""
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     scale = max(float(b.abs().max()), 1e-30)
     return float((a - b).abs().max()) / scale
 
 
+ATOL_FRACTION = 0.5
+
+
+def worst_ratio(a, b, tol):
+    """max over the entries of |a - b| / (atol + rtol |b|) -- the quantity :func:`assert_close` bounds by 1"""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    scale = max(float(b.abs().max()), 1e-30)
+    bound = ATOL_FRACTION * tol * scale + tol * b.abs()
+    return float(((a - b).abs() / bound).max()) if a.numel() else 0.0
+
+
 def assert_close(a, b, tol, what=""):
-    err = rel_err(a, b)
-    assert err <= tol, f"{what}: scaled max error {err:.3e} > {tol:.1e}"
-    return err
+    """ELEMENT-WISE |a - b| <= atol + rtol * |b| with rtol = ``tol`` and atol = 0.5 * tol * max|b| (an absolute floor tied to
+    the tensor's scale: entries that are small against the largest one carry cancellation error of that size).  Every
+    entry is checked on its own: a kernel that is wrong in the small entries only does not hide behind the large ones.
+    Returns the scaled max error (max|a-b| / max|b|) for reporting."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = max(float(b.abs().max()), 1e-30)
+    diff = (a - b).abs()
+    bound = ATOL_FRACTION * tol * scale + tol * b.abs()
+    worst = float((diff / bound).max()) if diff.numel() else 0.0
+    assert worst <= 1.0, (f"{what}: element-wise error is {worst:.2f} x the bound (rtol {tol:.1e}, atol {ATOL_FRACTION * tol * scale:.2e}); "
+                          f"scaled max error {float(diff.max()) / scale:.3e}")
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    return float(diff.max()) / scale

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_scratch_sizes():
     lib = _lib.load()
     assert lib.is_version() >= 100
-    assert lib.is_egnn_edge_bwd_partials_floats(2) == 2 * lib.is_egnn_edge_bwd_partials_floats(1)
+    assert lib.is_reduce_partials_scratch_floats(2) == 2 * lib.is_reduce_partials_scratch_floats(1)
     assert lib.is_loss_partials_floats() >= 1024
 
 

@@ -32,7 +32,7 @@ def test_mfma_layout_selftests(cuda_device):
     out = torch.zeros(32, 64, device=cuda_device)
     a_d, w_d = a.to(cuda_device), w.to(cuda_device)
     assert lib.is_mfma_selftest(_lib.ptr(a_d), _lib.ptr(w_d), _lib.ptr(out), _lib.stream_ptr()) == 0
-    H.assert_close(out, a.double() @ w.double().T, 1e-6, "mm_rows")
+    H.assert_close(out, a.double() @ w.double().T, 1e-5, "mm_rows")
     # identity check catches row/col swaps
     eye = torch.eye(64)[:32].contiguous().to(cuda_device)
     assert lib.is_mfma_selftest(_lib.ptr(eye), _lib.ptr(w_d), _lib.ptr(out), _lib.stream_ptr()) == 0
@@ -42,7 +42,7 @@ def test_mfma_layout_selftests(cuda_device):
     out2 = torch.zeros(64, 64, device=cuda_device)
     g_d, m_d = g.to(cuda_device), m.to(cuda_device)
     assert lib.is_mfma_outer_selftest(_lib.ptr(g_d), _lib.ptr(m_d), _lib.ptr(out2), _lib.stream_ptr()) == 0
-    H.assert_close(out2, g.double().T @ m.double(), 1e-6, "mm_outer")
+    H.assert_close(out2, g.double().T @ m.double(), 1e-5, "mm_outer")
 
 
 def _raw_cases():
@@ -233,6 +233,31 @@ def test_fused_loss_matches_golden_and_oracle(cuda_device, kind, seq_flag):
         H.assert_close(t[2].grad.cpu(), gold[f"{tag}/grad_logvar"], 2e-6, "grad logvar")
 
 
+@pytest.mark.parametrize("seq_flag", [True, False])
+@pytest.mark.parametrize("kind", ["regression", "bce"])
+def test_ssl_losses_match_golden(cuda_device, kind, seq_flag):
+    """the ``*_SSL`` losses (utils/loss.py:33-61) on the device vs values / gradients of the reference's own functions"""
+    from immunostruct_amd.utils import Losses
+    from tests.test_oracle_golden import _loss_inputs
+    gold = H.golden("losses.npz")
+    recon, x, mu, lv, logit, y_reg, y_bin, pred_aa, aa = _loss_inputs(ssl=True)
+    dev = cuda_device
+    t = [v.detach().to(dev).requires_grad_(True) for v in (recon, mu, lv, logit, pred_aa)]
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=seq_flag)
+    y = (y_reg if kind == "regression" else y_bin).to(dev)
+    fn = losses.regression_loss_SSL if kind == "regression" else losses.BCE_loss_SSL
+    val = fn(t[0], x.to(dev), t[1], t[2], t[3], y, t[4], aa.to(dev))
+    val.backward()
+    tag = f"loss_ssl/{kind}/seq{int(seq_flag)}"
+    assert abs(float(val.detach()) - float(gold[f"{tag}/value"])) <= 2e-6 * abs(float(gold[f"{tag}/value"]))
+    H.assert_close(t[3].grad.cpu(), gold[f"{tag}/grad_logit"], 2e-6, "grad logit")
+    H.assert_close(t[4].grad.cpu(), gold[f"{tag}/grad_pred_aa"], 2e-6, "grad residue logits")
+    if seq_flag:
+        H.assert_close(t[1].grad.cpu(), gold[f"{tag}/grad_mu"], 2e-6, "grad mu")
+    empty = fn(t[0], x.to(dev), t[1], t[2], t[3], y, torch.zeros(0, 20, device=dev), torch.zeros(0, dtype=torch.int64, device=dev))
+    assert abs(float(empty.detach()) - float(gold[f"{tag}/value_no_residue"])) <= 2e-6 * abs(float(gold[f"{tag}/value_no_residue"]))
+
+
 def test_contrastive_loss_matches_golden(cuda_device):
     from immunostruct_amd.utils import PairedContrastiveLoss
     from tests.test_oracle_golden import _loss_inputs
@@ -337,27 +362,27 @@ def test_multi_copy_matches_copy(cuda_device):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["padded190_deg3", "dense_fe8", "hub", "no_edges", "ragged_nodes"])
-@pytest.mark.parametrize("chunk_edges", [4, 32, 1000])
-def test_edge_forward_v3_is_bit_identical_to_v2(cuda_device, monkeypatch, case, chunk_edges):
-    """The wave-chunked forward keeps the per-node summation order of the node-tiled kernel: same bits, for chunks
-    much shorter than a tile, about a tile, and one chunk holding everything (multi-tile pipeline)."""
+def test_layer_forward_does_not_depend_on_the_chunking(cuda_device, monkeypatch, case):
+    """The wave-chunked forward keeps every node's summation order whatever the cut of the edges into chunks (and of
+    the nodes into the workgroups' node-MLP ranges): same bits for chunks much shorter than a tile, about a tile, and
+    one chunk holding everything (multi-tile pipeline, many node passes in one workgroup)."""
     from immunostruct_amd import functional as HF
     raw = {"hub": _hub_graph, "no_edges": _no_edge_graph}[case]() if case in ("hub", "no_edges") else _raw_cases()[case]
     fe = raw.edge_attr.shape[1]
     out = {}
-    for mode in ("v2", "v3"):
-        monkeypatch.setattr(HF, "EDGE_FWD", mode)
+    for chunk_edges in (4, 32, 1000):
         monkeypatch.setattr(HF, "FWD_CHUNK_EDGES", chunk_edges)
         torch.manual_seed(3)
         layers = [EGNNConv(20 if i == 0 else 64, 64, 64, fe).to(cuda_device) for i in range(2)]
         g = H.product_graph(raw, cuda_device)
         with torch.no_grad():
             h, x = egnn_stack_forward(layers, g, g.ndata["x"][:, :20], g.ndata["x"][:, 20:], g.edata["edge_attr"] if fe else None)
-        out[mode] = (h.cpu(), x.cpu())
-    assert torch.isfinite(out["v3"][0]).all()
-    dh = float((out["v2"][0] - out["v3"][0]).abs().max())
-    dx = float((out["v2"][1] - out["v3"][1]).abs().max())
-    assert dh == 0.0 and dx == 0.0, f"v3 differs from v2: max |dh| {dh:.3e}, max |dx| {dx:.3e}"
+        out[chunk_edges] = (h.cpu(), x.cpu())
+    assert torch.isfinite(out[32][0]).all()
+    for k in (4, 1000):
+        dh = float((out[k][0] - out[32][0]).abs().max())
+        dx = float((out[k][1] - out[32][1]).abs().max())
+        assert dh == 0.0 and dx == 0.0, f"chunks of {k} edges differ from chunks of 32: max |dh| {dh:.3e}, max |dx| {dx:.3e}"
 
 
 @pytest.mark.gpu
@@ -491,29 +516,6 @@ def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
     assert abs(float(val) - float(ref)) <= 1e-4 * abs(float(ref)), (float(val), float(ref))
     H.assert_close(ecd.grad.cpu(), ec64.grad, 1e-4, "d emb cancer")
     H.assert_close(ewd.grad.cpu(), ew64.grad, 1e-4, "d emb wt")
-
-
-@pytest.mark.gpu
-def test_edge_forward_split_bf16_option_error_budget(cuda_device, monkeypatch):
-    """The opt-in split-bf16 forward (IMMUNOSTRUCT_EDGE_FWD=v3x: x = hi + lo in bf16, three bf16 MFMAs per product) stays
-    inside the forward tolerance of the fp32 kernels over a 6-layer stack; it is NOT the default because it is an order of
-    magnitude less accurate than fp32 arithmetic (measured ~1e-5 vs ~6e-7 against fp64)."""
-    if HF.EDGE_KERNELS != "v2":
-        pytest.skip("the v3 / v3x forward is only selected with the v2 edge-kernel family")
-    raw = synthetic.make_batch(4, seed=8)
-    out = {}
-    for mode in ("v3", "v3x"):
-        monkeypatch.setattr(HF, "EDGE_FWD", mode)
-        torch.manual_seed(4)
-        layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(cuda_device) for i in range(6)]
-        g = H.product_graph(raw, cuda_device)
-        with torch.no_grad():
-            h, x = egnn_stack_forward(layers, g, g.ndata["x"][:, :20], g.ndata["x"][:, 20:], g.edata["edge_attr"])
-        out[mode] = (h.cpu(), x.cpu())
-    eh = H.assert_close(out["v3x"][0], out["v3"][0], FWD_TOL, "split-bf16 h")
-    ex = H.assert_close(out["v3x"][1], out["v3"][1], FWD_TOL, "split-bf16 x")
-    assert eh > 0.0      # it really is a different arithmetic
-    print(f"split-bf16 vs fp32 after 6 layers: h {eh:.1e}, x {ex:.1e}")
 
 
 @pytest.mark.gpu

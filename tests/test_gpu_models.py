@@ -13,7 +13,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 BATCH = 16
-OUT_TOL, GRAD_TOL = 5e-5, 2e-4
+OUT_TOL, GRAD_TOL = 1e-5, 1e-4      # element-wise (tests/helpers.py): SURVEY 8c / BASELINE.md: 1e-5 rel on outputs, 1e-4 on gradients
 
 
 def _with_eps(fn, eps_list, device):
@@ -106,9 +106,10 @@ def test_comparative_train_step_matches_reference_golden(cuda_device, name, wt):
     print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
 
 
-@pytest.mark.parametrize("n_pad,b", [(190, 8), (40, 5), (100, 3), (150, 4), (250, 2)])
+@pytest.mark.parametrize("n_pad,b", [(190, 8), (40, 5), (100, 3), (150, 4), (250, 2), (190, 128)])
 def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
-    """HybridModelv2: loss and every parameter gradient vs oracle autograd -- at the reference's padded node count (190) and
+    """HybridModelv2: loss and every parameter gradient vs oracle autograd -- at BASELINE config 2's full size (B = 128 x 190
+    nodes: what bench.py times), at the reference's padded node count (190) and
     at other dataset-wide node counts (the node-attention kernels have one instantiation per 64 nodes, the edge / node
     kernels tile by 16 / 32 rows: 40, 100, 150 and 250 nodes hit every variant and ragged last tiles)."""
     dev = cuda_device
@@ -124,6 +125,14 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
     it = FR.forward("HybridModelv2", sd_o, go, seq, prop, eps=eps)
     lo = FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, H.VAE_IN)
     lo.backward()
+    sd_64 = None
+    if b >= 64:
+        # full size: sums over ~150 k edges in fp32 differ between two correct implementations by more than the small-batch
+        # tolerance (dw_r sums products with squared distances up to 1e4); the yardstick is then the fp64 oracle -- the HIP
+        # gradient must meet the element-wise bound against it, or be within 4x of the fp32 oracle's own distance from it
+        sd_64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+        it64 = FR.forward("HybridModelv2", sd_64, H.oracle_graph(raw, torch.float64), seq.double(), prop.double(), eps=eps.double())
+        FR.regression_loss(it64["recon_x"], seq.double(), it64["mu"], it64["logvar"], it64["final_output"], y.double(), H.VAE_IN).backward()
     # HIP
     model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
     model.load_state_dict(sd)
@@ -145,7 +154,14 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
             # analytically zero gradient (softmax is invariant to the key bias): both sides are pure round-off
             assert float(p.grad.abs().max()) < 1e-5 * gmax, f"{name} should be ~0"
             continue
-        err = H.assert_close(p.grad.cpu(), ref_grad, GRAD_TOL, f"grad {name}")
+        if sd_64 is not None:
+            r_hip = H.worst_ratio(p.grad.cpu(), sd_64[name].grad, GRAD_TOL)
+            r_ref = H.worst_ratio(ref_grad, sd_64[name].grad, GRAD_TOL)
+            assert r_hip <= max(1.0, 4.0 * r_ref), (f"grad {name}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
+                                                    f"gradient, the fp32 oracle {r_ref:.2f} x")
+            err = H.rel_err(p.grad.cpu(), sd_64[name].grad)
+        else:
+            err = H.assert_close(p.grad.cpu(), ref_grad, GRAD_TOL, f"grad {name}")
         if err > worst[1]:
             worst = (name, err)
     print("worst parameter-gradient error", worst)
@@ -353,17 +369,18 @@ def test_merged_pair_encoding_equals_two_passes(cuda_device, monkeypatch):
         H.assert_close(res[True][1][k], g, GRAD_TOL, f"grad {k}")
 
 
-def test_training_trajectory_matches_oracle(cuda_device):
-    """Ten Adam steps at the reference's learning rate (1e-3, train_IEDB_wFT.py:19) on fresh batches: the HIP path's loss
+@pytest.mark.parametrize("nb,steps", [(12, 10), (128, 20)])
+def test_training_trajectory_matches_oracle(cuda_device, nb, steps):
+    """Adam steps at the reference's learning rate (1e-3, train_IEDB_wFT.py:19) on fresh batches: the HIP path's loss
     follows the CPU oracle's step by step (same initial weights, same reparameterisation noise) -- the whole chain
-    forward / loss / backward / optimizer, compounded.  (B = 128, 20 steps: 5e-6, tests/tools/trajectory_check.py.  The
-    un-normalised EGNN is unstable at this learning rate on synthetic data: a few steps later BOTH implementations
-    blow up at the same step -- loss 6160 vs 6127 at step 13 of this very sequence -- which is where a trajectory
-    comparison stops being meaningful.)"""
+    forward / loss / backward / optimizer, compounded; 10 steps of B = 12 and 20 steps at BASELINE config 2's B = 128.
+    (The un-normalised EGNN is unstable at this learning rate on synthetic data: a few steps after the B = 12 sequence
+    ends BOTH implementations blow up at the same step -- loss 6160 vs 6127 at its step 13 -- which is where a
+    trajectory comparison stops being meaningful.)"""
     from immunostruct_amd import optim
     from oracle import graph_ref
     dev = cuda_device
-    nb = 12
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     torch.manual_seed(0)
     model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
     model.eval()
@@ -371,7 +388,7 @@ def test_training_trajectory_matches_oracle(cuda_device):
     opt_h, opt_o = optim.Adam(model.parameters(), lr=1e-3), torch.optim.Adam(list(sd.values()), lr=1e-3)
     losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
     worst = 0.0
-    for s in range(10):
+    for s in range(steps):
         raw = synthetic.make_batch(nb, seed=500 + s, deg_extra=2)
         eps = H.make_eps(900 + s, nb)
         seq, prop, y = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop), torch.from_numpy(raw.y_reg)
@@ -392,7 +409,7 @@ def test_training_trajectory_matches_oracle(cuda_device):
         rel = abs(float(lh.detach()) - float(lo.detach())) / abs(float(lo.detach()))
         worst = max(worst, rel)
         assert rel <= 1e-4, f"step {s}: hip {float(lh.detach())} oracle {float(lo.detach())}"
-    print("worst relative loss difference over 10 steps", worst)
+    print(f"worst relative loss difference over {steps} steps of B = {nb}: {worst:.2e}")
 
 
 def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):

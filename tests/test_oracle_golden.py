@@ -100,7 +100,7 @@ def test_contrastive_early_outs_match_reference():
     assert FR.paired_contrastive_loss(psd, e, e, torch.linspace(-1, 1, 8)) == 0
 
 
-def _loss_inputs():
+def _loss_inputs(ssl=False):
     rng = np.random.RandomState(77)
     b = BATCH
     recon = torch.from_numpy(rng.normal(size=(b, H.VAE_IN)).astype(np.float32) * 0.3).requires_grad_(True)
@@ -112,6 +112,10 @@ def _loss_inputs():
     y_bin = torch.from_numpy((rng.uniform(size=(b,)) < 0.3).astype(np.float32))
     ec = torch.from_numpy(rng.normal(size=(b, 104)).astype(np.float32)).requires_grad_(True)
     ew = torch.from_numpy(rng.normal(size=(b, 104)).astype(np.float32)).requires_grad_(True)
+    if ssl:
+        pred_aa = torch.from_numpy(rng.normal(size=(b, 20)).astype(np.float32)).requires_grad_(True)
+        aa = torch.from_numpy(rng.randint(0, 20, size=(b,)).astype(np.int64))
+        return recon, x, mu, lv, logit, y_reg, y_bin, pred_aa, aa
     return recon, x, mu, lv, logit, y_reg, y_bin, ec, ew
 
 
@@ -132,6 +136,32 @@ def test_losses_match_reference_golden(kind, seq_flag):
         H.assert_close(recon.grad[:, H.RECON_COLS], gold[f"{tag}/grad_recon_cols"], 1e-6, "grad recon")
         H.assert_close(mu.grad, gold[f"{tag}/grad_mu"], 1e-6, "grad mu")
         H.assert_close(lv.grad, gold[f"{tag}/grad_logvar"], 1e-6, "grad logvar")
+
+
+@pytest.mark.parametrize("seq_flag", [True, False])
+@pytest.mark.parametrize("kind", ["regression", "bce"])
+def test_ssl_losses_match_reference_golden(kind, seq_flag):
+    """``Losses.regression_loss_SSL`` / ``BCE_loss_SSL`` (utils/loss.py:33-61): the oracle's loss + amino cross-entropy equals
+    the reference's value and gradients, with and without a masked residue"""
+    gold = H.golden("losses.npz")
+    recon, x, mu, lv, logit, y_reg, y_bin, pred_aa, aa = _loss_inputs(ssl=True)
+
+    def total(pa, a):
+        if kind == "regression":
+            base = FR.regression_loss(recon, x, mu, lv, logit, y_reg, H.VAE_IN, sequence=seq_flag)
+        else:
+            base = FR.bce_loss(recon, x, mu, lv, logit, y_bin, H.VAE_IN, 81.0 / 19.0, sequence=seq_flag)
+        return base + FR.amino_cross_entropy(pa, a)
+    val = total(pred_aa, aa)
+    val.backward()
+    tag = f"loss_ssl/{kind}/seq{int(seq_flag)}"
+    assert abs(float(val) - float(gold[f"{tag}/value"])) <= 1e-6 * abs(float(val))
+    H.assert_close(logit.grad, gold[f"{tag}/grad_logit"], 1e-6, "grad logit")
+    H.assert_close(pred_aa.grad, gold[f"{tag}/grad_pred_aa"], 1e-6, "grad residue logits")
+    if seq_flag:
+        H.assert_close(mu.grad, gold[f"{tag}/grad_mu"], 1e-6, "grad mu")
+    empty = total(torch.zeros(0, 20), torch.zeros(0, dtype=torch.int64))
+    assert abs(float(empty) - float(gold[f"{tag}/value_no_residue"])) <= 1e-6 * abs(float(empty))
 
 
 def test_contrastive_matches_reference_golden():
