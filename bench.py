@@ -244,6 +244,55 @@ class IedbWorkload(TrainStepWorkload):
         return timed_cpu(step, a.batch, budget_s, f"B={a.batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam)")
 
 
+    def e2e(self, num_graphs=27000):
+        """One epoch over a device-resident dataset of ``num_graphs`` synthetic graphs (the IEDB set's size, README.md:59) with
+        the on-GPU batcher INSIDE the timed region: per step one gather launch from a shuffled id tensor into the captured
+        step's static buffers + the replay (``procedures.train_model_device``'s inner loop)."""
+        from immunostruct_amd.data import DeviceResidentDataset
+        from immunostruct_amd.data.packed import PackedDataset
+        from immunostruct_amd.engine import CapturedTrainStep
+        a = self.args
+        dev = next(self.model.parameters()).device
+        t_build = time.perf_counter()
+        raw = synthetic.make_batch(num_graphs, seed=77, deg_extra=a.deg_extra)
+        n = int(raw.batch_num_nodes[0])
+        counts = np.bincount(raw.dst // n, minlength=num_graphs)
+        bounds = np.concatenate([[0], np.cumsum(counts)])
+        order = np.argsort(raw.dst // n, kind="stable")
+        src, dst, ea = raw.src[order], raw.dst[order], raw.edge_attr[order]
+        graphs = [(raw.x[i * n:(i + 1) * n], torch.from_numpy(src[bounds[i]:bounds[i + 1]] - i * n),
+                   torch.from_numpy(dst[bounds[i]:bounds[i + 1]] - i * n), torch.from_numpy(ea[bounds[i]:bounds[i + 1]]))
+                  for i in range(num_graphs)]
+        packed = PackedDataset.from_graphs(graphs, names=[str(i) for i in range(num_graphs)], pad_to=n)
+        packed.seq, packed.prop = torch.from_numpy(raw.seq_tokens), torch.from_numpy(raw.prop)
+        packed.y_reg, packed.y_bin = torch.from_numpy(raw.y_reg), torch.from_numpy(raw.y_bin)
+        dds = DeviceResidentDataset.from_packed(packed, dev, binary=False)
+        t_build = time.perf_counter() - t_build
+        buf = dds.new_batch(a.batch)
+        perm = torch.randperm(num_graphs, generator=torch.Generator().manual_seed(5)).to(dev)
+        dds.gather_into(perm[:a.batch], *buf)
+        eng = CapturedTrainStep(self.model, self.opt, D.FlatGradReducer(self.model.parameters(), world=1), self.forward_loss, buf,
+                                edge_capacity=a.batch * dds.max_edges, warmup=1)
+        steps = num_graphs // a.batch
+
+        def epoch():
+            for k in range(steps):
+                dds.gather_into(perm[k * a.batch:(k + 1) * a.batch], eng.sgraph, eng.seq, eng.prop, eng.y)
+                eng.replay()
+        for k in range(5):
+            dds.gather_into(perm[k * a.batch:(k + 1) * a.batch], eng.sgraph, eng.seq, eng.prop, eng.y)
+            eng.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dict(value=round(steps * a.batch / dt, 1), unit="graphs/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps,
+                    dataset_graphs=num_graphs, dataset_build_s=round(t_build, 1),
+                    what="one epoch of full batches over a DeviceResidentDataset: shuffled ids -> on-GPU batcher (one gather launch "
+                         "+ partition refresh) -> captured step replay, all inside the timed region (single GPU)")
+
+
 class PairedWorkload(TrainStepWorkload):
     name = "paired"
 
@@ -521,6 +570,8 @@ def main():
     ap.add_argument("--deg-extra", type=int, default=2, help="iedb / paired: random contact edges per residue (E/N - 1)")
     ap.add_argument("--model", default="HybridModelv2", help="iedb: the model class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="iedb, one GPU: skip the batcher-inclusive epoch over 27 000 resident graphs")
+    ap.add_argument("--e2e-graphs", type=int, default=27000)
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--force-pack", action="store_true", help="exercise the multi-rank gradient-bucket path on one GPU")
     ap.add_argument("--eager", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
@@ -637,7 +688,9 @@ def main():
         roof = wl.roofline(timers)
         if roof is not None:
             roof["measured"] = timers_mode
-        cpu = None
+        cpu = e2e = None
+        if world == 1 and not args.no_e2e and not args.eager and hasattr(wl, "e2e"):
+            e2e = wl.e2e(args.e2e_graphs)
         if world == 1 and not args.no_cpu_baseline:
             cpu = wl.cpu_baseline()
         ddp = torch.distributed.is_initialized()
@@ -654,7 +707,7 @@ def main():
                                  settle_blocks_ms=settle,
                                  note="device time per step from HIP events between the steps (rank 0); settle_blocks_ms = the "
                                       "untimed 5-step blocks replayed after the warm-up until two agreed within 2 %"),
-                    roofline=roof, cpu_baseline=cpu,
+                    roofline=roof, cpu_baseline=cpu, e2e=e2e,
                     kernel_timers_us={k: [v[0], round(v[1] * 1e3, 2)] for k, v in timers.items()})
         flush_c_stdio()
         print(json.dumps(line), flush=True)

@@ -116,7 +116,7 @@ __device__ __forceinline__ void load_fwd_rows(FwdRows& rw, const EdgeIds<FE_MAX>
 // COORD = false: the layer's coordinate output is not wanted (last layer of a stack whose final coordinates are unused):
 // the coordinate MLP (z3 = mh Wc1^T + bc1, s = SiLU(z3) . wc2), the z3s store and the x_out update are skipped.
 template <int FE_MAX, bool SAVE, bool COORD, int DIN>
-__global__ __launch_bounds__(256) void egnn_layer_fwd_kernel(
+__global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs, const int* __restrict__ dsts,

@@ -27,7 +27,7 @@ from ..graph import PackedGraphBatch
 from .utils import AMINO_ACIDS, RandomRotation, collate
 
 __all__ = ["SplitDataset", "ExtendedDataset", "collate_amino_acid", "mask_single_structure", "mask_single_structure_pair",
-           "mask_structure", "mask_sequence", "augment_batch_on_device", "mask_sequence_on_device"]
+           "mask_structure", "mask_sequence", "augment_batch_on_device", "augment_pair_on_device", "mask_sequence_on_device"]
 
 N_AA = len(AMINO_ACIDS)
 PAD_INDEX = N_AA            # 'J', the last symbol of the 21-letter alphabet
@@ -193,6 +193,48 @@ def augment_batch_on_device(x, batch_size, generator=None, rotate=True, mask_sin
         nodes = torch.rand(b, n, device=x.device, generator=generator).topk(structure_pad_count, dim=1).indices
         r = rows[:, None].expand_as(nodes)
         keep = (onehot[r, nodes].sum(-1, keepdim=True) > 1).to(x.dtype)      # the self-supervision node stays
+        onehot[r, nodes] = onehot[r, nodes] * keep
+    return amino
+
+
+def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=True, structure_pad_count=0):
+    """In place on the node-feature buffer ``x2`` ((2 * pairs * n) x (20 + 3)) of a merged (cancer; wild-type) batch: an
+    independent random orthogonal transform per graph, ONE masked residue per pair member chosen as the reference does
+    (``data/immmunopred_dataloader.py:253-271``: a uniformly random real residue of the cancer graph among those whose type
+    also occurs in the wild-type graph, and a uniformly random wild-type residue of that type), ``structure_pad_count``
+    blanked residues per graph.  Returns the masked type per pair (int64; 0 for a pair without a common type, left unmasked)."""
+    b = int(pairs)
+    feats = x2.view(2 * b, x2.shape[0] // (2 * b), x2.shape[1])
+    n = feats.shape[1]
+    dev = x2.device
+    if rotate:
+        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], _random_orthogonal(2 * b, dev, generator))
+    onehot = feats[:, :, :-3]
+    oc, ow = onehot[:b], onehot[b:]                                  # views: writes go to the buffer
+    rows = torch.arange(b, device=dev)
+    amino = torch.zeros(b, dtype=torch.int64, device=dev)
+    if mask_single:
+        real_c = oc.sum(-1) == 1                                       # real, not yet masked / blanked
+        type_c = oc.argmax(-1)                                         # (b, n)
+        present_w = (ow.sum(1) > 0) & True                             # (b, 20): types that occur in the wild-type graph
+        ok = real_c & torch.gather(present_w, 1, type_c)               # cancer nodes with a partner
+        score = torch.rand(b, n, device=dev, generator=generator).masked_fill(~ok, -1.0)
+        node_c = score.argmax(1)
+        found = ok.any(1)
+        t = type_c[rows, node_c]
+        same = (ow[rows, :, t] > 0) & (ow.sum(-1) == 1)                # wild-type nodes of that type
+        score_w = torch.rand(b, n, device=dev, generator=generator).masked_fill(~same, -1.0)
+        node_w = score_w.argmax(1)
+        found = found & same.any(1)
+        amino = torch.where(found, t, amino)
+        pc, pw = oc[rows, node_c], ow[rows, node_w]
+        oc[rows, node_c] = torch.where(found[:, None], torch.ones_like(pc), pc)
+        ow[rows, node_w] = torch.where(found[:, None], torch.ones_like(pw), pw)
+    if structure_pad_count > 0:
+        rows2 = torch.arange(2 * b, device=dev)
+        nodes = torch.rand(2 * b, n, device=dev, generator=generator).topk(structure_pad_count, dim=1).indices
+        r = rows2[:, None].expand_as(nodes)
+        keep = (onehot[r, nodes].sum(-1, keepdim=True) > 1).to(x2.dtype)      # the self-supervision node stays
         onehot[r, nodes] = onehot[r, nodes] * keep
     return amino
 

@@ -25,8 +25,9 @@ The index arrays are exactly what ``graph.CSRIndex`` builds per graph (stable so
 with a handful of vectorised torch calls.  Joining graphs with the property / HLA tables (pandas, ``preprocess.py:45-145``)
 stays with the caller, who passes ``labels = {name: (full_sequence, mprop1, mprop2, immunogenicity, foreignness)}``.
 
-The pickles are read WITHOUT torch_geometric: a restricted unpickler maps every ``torch_geometric.*`` class to an inert
-attribute bag and the four fields are looked up in it (PyG 2.x keeps them in ``_store._mapping``, 1.x in ``__dict__``).
+The pickles are read WITHOUT torch_geometric: an allow-list unpickler maps every ``torch_geometric.*`` class to an inert
+attribute bag, loads tensors / storages / plain containers and refuses every other global; the four fields are looked up in
+the bag (PyG 2.x keeps them in ``_store._mapping``, 1.x in ``__dict__``).
 That layout follows the PyG sources; no real file was available to this build, so it is unverified against one
 (``tests/test_packed_format.py`` fabricates files with stand-in classes under the same module paths).
 """
@@ -41,7 +42,7 @@ import torch
 from ..graph import PackedGraphBatch
 from .utils import AMINO_ACIDS, PADDING_CHAR
 
-__all__ = ["PackedDataset", "convert_pyg_directory", "load_pyg_pickle"]
+__all__ = ["PackedDataset", "convert_pyg_directory", "load_pyg_pickle", "list_structure_names"]
 
 _TOKEN = {ch: i for i, ch in enumerate(AMINO_ACIDS + PADDING_CHAR)}
 _ARRAYS = ("x", "eoff", "rowptr_dst", "rowptr_src", "src", "dst", "pos", "ea")
@@ -179,11 +180,29 @@ class _Bag:
         self.__dict__.update(state if isinstance(state, dict) else {"_state": state})
 
 
+# globals a tensor-holding PyG ``Data`` pickle needs besides the torch_geometric classes themselves; anything else is refused
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "set"),
+    ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"),
+    ("builtins", "slice"), ("builtins", "range"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+}
+
+
 class _Unpickler(pickle.Unpickler):
+    """allow-list unpickler: torch_geometric classes become inert bags, tensors / storages / plain containers load, every other
+    global (``os.system``, ``builtins.eval``, ...) raises -- a crafted ``.pt`` file cannot run code through this reader"""
+
     def find_class(self, module, name):
         if module.split(".")[0] == "torch_geometric":
             return _Bag
-        return super().find_class(module, name)
+        if (module, name) in _ALLOWED_GLOBALS or (module == "torch" and name.endswith("Storage")) \
+                or (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage", "_load_from_bytes")):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"global {module}.{name} is not allowed in a graph file")
 
 
 class _PickleModule:
@@ -209,11 +228,29 @@ def load_pyg_pickle(path):
     return tuple(_field(obj, k) for k in ("x", "coords", "edge_index", "name"))
 
 
-def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=3, labels=None, drop_features=2):
+def list_structure_names(directory):
+    """the structure names (the part of ``graph.name`` after "Immuno") of a directory of the reference's ``*.pt`` files, with
+    the reference's filter (no ``X``), first occurrence per name, directory order -- the input of the table joins
+    (``data.tables.labels_from_tables``)"""
+    names, seen = [], set()
+    for fname in [f for f in os.listdir(directory) if f.endswith(".pt")]:
+        name = load_pyg_pickle(os.path.join(directory, fname))[3]
+        if "X" in name:
+            continue
+        key = name.split("Immuno")[1]
+        if key not in seen:
+            seen.add(key)
+            names.append(key)
+    return names
+
+
+def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=3, labels=None, drop_features=2, order=None):
     """The reference's ``preprocess_graphs`` + ``graph.x = cat(x, coords)`` + ``preprocess_graph`` for a directory of
     ``*.pt`` files, as a :class:`PackedDataset` (saved to ``out_path`` when given).  Rules kept: names containing ``X``
     are skipped, the first graph of every name (the part after ``Immuno``) wins, the last ``drop_features`` node
-    features (hydrogen bonding) are cut, every graph is padded to the largest node count."""
+    features (hydrogen bonding) are cut, every graph is padded to the largest node count.  ``order``: structure names in
+    the order the dataset should have (the reference's datasets follow the TABLE's row order, ``data.tables``); names
+    without a file are an error, files outside ``order`` are left out."""
     graphs, names, seen = [], [], set()
     for fname in [f for f in os.listdir(directory) if f.endswith(".pt")]:     # directory order, as the reference
         x, coords, edge_index, name = load_pyg_pickle(os.path.join(directory, fname))
@@ -228,6 +265,12 @@ def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=
             raise ValueError("`convert_pyg_directory`: graph.x shape mismatch.")
         graphs.append((x, edge_index[0], edge_index[1]))
         names.append(key)
+    if order is not None:
+        at = {k: i for i, k in enumerate(names)}
+        missing = [k for k in order if k not in at]
+        if missing:
+            raise KeyError(f"no graph file for {len(missing)} structure(s), e.g. {missing[0]}")
+        graphs, names = [graphs[at[k]] for k in order], list(order)
     packed = PackedDataset.from_graphs(graphs, names, labels=labels)
     if out_path is not None:
         packed.save(out_path)

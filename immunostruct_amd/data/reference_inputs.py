@@ -1,0 +1,102 @@
+"""From the reference's on-disk inputs (a directory of per-structure ``*.pt`` files + the property / HLA tables named by the
+entry scripts' path flags) to packed datasets -- what ``ImmunoPredDataset`` / ``ImmunoPredDatasetComparative`` do on every
+start (``data/immmunopred_dataloader.py:20-36,128-155``), done once here: ``data.tables`` joins the tables,
+``data.convert_pyg_directory`` reads the graphs in the table's row order and attaches the labels."""
+from __future__ import annotations
+
+import os
+
+from torch.utils.data import Dataset
+
+from . import tables
+from .packed import PackedDataset, convert_pyg_directory, list_structure_names
+
+__all__ = ["packed_from_reference_inputs", "paired_from_reference_inputs", "PairedDataset", "require_paths"]
+
+
+def require_paths(**paths):
+    missing = {k: v for k, v in paths.items() if not os.path.exists(v)}
+    if missing:
+        raise SystemExit("input(s) not found: " + ", ".join(f"--{k.replace('_', '-')} {v}" for k, v in missing.items()) +
+                         " (the reference never shipped its graph directories; pass --packed FILE or --synthetic N instead)")
+
+
+def packed_from_reference_inputs(graph_dir, property_path, hla_path, cancer=None, feature_size=23, coord_size=3, binary=False):
+    """single-graph dataset (``ImmunoPredDataset``): ``cancer`` defaults to the reference's rule ("Cancer" in the directory name)"""
+    cancer = ("Cancer" in graph_dir) if cancer is None else cancer
+    names = list_structure_names(graph_dir)
+    labels, keys = tables.labels_from_tables(property_path, hla_path, names, cancer=cancer)
+    mapper = tables.preprocess_hla(keys, hla_path)
+    order, seen = [], set()
+    for k in keys:                      # the dataset follows the table's row order (one item per key; keys may share a structure)
+        n = mapper[k][1]
+        if n not in seen:
+            seen.add(n)
+            order.append(n)
+    packed = convert_pyg_directory(graph_dir, feature_size=feature_size, coord_size=coord_size, labels=labels, order=order)
+    packed.binary = binary
+    return packed
+
+
+class PairedDataset(Dataset):
+    """items ``((graph_c, graph_w), (seq_c, seq_w), target, (prop_c, prop_w))`` over two single-graph datasets of equal
+    length (``.c`` / ``.w``: what ``procedures.train_model_comparative_device`` keeps on the device)"""
+
+    def __init__(self, cancer, wildtype):
+        if len(cancer) != len(wildtype):
+            raise ValueError("cancer / wild-type datasets differ in length")
+        self.c, self.w = cancer, wildtype
+        self.class_weights = cancer.class_weights
+
+    def __len__(self):
+        return len(self.c)
+
+    def __getitem__(self, i):
+        gc, sc, y, pc = self.c[i]
+        gw, sw, _, pw = self.w[i]
+        return (gc, gw), (sc, sw), y, (pc, pw)
+
+
+def paired_from_reference_inputs(graph_dir_cancer, graph_dir_wt, property_path_cancer, property_path_wt, hla_path,
+                                 feature_size=23, coord_size=3, binary=True):
+    """(cancer, wild-type) pair dataset (``ImmunoPredDatasetComparative``) in the joined table's row order; both members are
+    padded to the same node count (the larger of the two directories' maxima, ``data/immmunopred_dataloader.py:146-147``
+    pads each side on its own; one common count lets a pair share a batch layout)"""
+    names_c, names_w = list_structure_names(graph_dir_cancer), list_structure_names(graph_dir_wt)
+    lab_c, lab_w, pairs = tables.paired_labels_from_tables(property_path_cancer, property_path_wt, hla_path, names_c, names_w)
+    pc = convert_pyg_directory(graph_dir_cancer, feature_size=feature_size, coord_size=coord_size, labels=lab_c,
+                               order=_unique([p[0] for p in pairs]))
+    pw = convert_pyg_directory(graph_dir_wt, feature_size=feature_size, coord_size=coord_size, labels=lab_w,
+                               order=_unique([p[1] for p in pairs]))
+    pc.binary = pw.binary = binary
+    at_c = {n: i for i, n in enumerate(pc.names)}
+    at_w = {n: i for i, n in enumerate(pw.names)}
+    return PairedDataset(_View(pc, [at_c[p[0]] for p in pairs]), _View(pw, [at_w[p[1]] for p in pairs]))
+
+
+def _unique(seq):
+    seen, out = set(), []
+    for s in seq:
+        if s not in seen:
+            seen.add(s)
+            out.append(s)
+    return out
+
+
+class _View(Dataset):
+    """rows of a packed dataset by index (several pairs may share a wild-type structure)"""
+
+    def __init__(self, packed, index):
+        self.packed, self.index = packed, list(index)
+
+    @property
+    def class_weights(self):
+        from collections import Counter
+        counts = Counter(float(self.packed.y_bin[i]) for i in self.index)
+        return {0: float(counts.get(0.0, 1)), 1: float(max(counts.get(1.0, 1), 1))}
+
+    def __len__(self):
+        return len(self.index)
+
+    def __getitem__(self, i):
+        return self.packed[self.index[i]]

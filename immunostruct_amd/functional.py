@@ -866,6 +866,68 @@ def linear_small_batch(x, weight, bias):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class VaeLatentFn(torch.autograd.Function):
+    """The sequence VAE's latent block (``csrc/vae_latent.hip``): from a1 = vae_fc1(x) (pre-activation) to
+    (mu, logvar, [z | p], h3 = relu(vae_fc3([z | p]))) in one launch; backward = two launches (data path, weight gradients).
+    ``eps`` is the caller's ``torch.randn_like`` draw (reference ``hybrid_models.py:301-304``); ``p`` may be None."""
+
+    @staticmethod
+    def forward(ctx, a1, w21, b21, w22, b22, eps, p, w3, b3):
+        lib = _lib.load()
+        _lib.require_device(a1, w21, b21, w22, b22, eps, p, w3, b3)
+        a1, w21, b21, w22, b22, eps, w3, b3 = (_lib.f32c(t) for t in (a1, w21, b21, w22, b22, eps, w3, b3))
+        p = _lib.f32c(p) if p is not None else None
+        b, hd = int(a1.shape[0]), int(a1.shape[1])
+        lat = int(w21.shape[0])
+        pw = int(p.shape[1]) if p is not None else 0
+        if tuple(w21.shape) != (lat, hd) or tuple(w22.shape) != (lat, hd) or tuple(w3.shape) != (hd, lat + pw) or tuple(eps.shape) != (b, lat):
+            raise ValueError("VaeLatentFn: inconsistent shapes")
+        f32 = dict(dtype=torch.float32, device=a1.device)
+        mu, logvar = torch.empty(b, lat, **f32), torch.empty(b, lat, **f32)
+        zp, h3 = torch.empty(b, lat + pw, **f32), torch.empty(b, hd, **f32)
+        with KernelTimer.span("vae_latent_fwd"):
+            _lib.check(lib.is_vae_latent_fwd(_lib.ptr(a1), _lib.ptr(w21), _lib.ptr(b21), _lib.ptr(w22), _lib.ptr(b22), _lib.ptr(eps),
+                                             _lib.ptr(p), pw, _lib.ptr(w3), _lib.ptr(b3), _lib.ptr(mu), _lib.ptr(logvar), _lib.ptr(zp),
+                                             _lib.ptr(h3), b, hd, lat, _lib.stream_ptr()), "is_vae_latent_fwd")
+        ctx.dims = (b, hd, lat, pw)
+        ctx.has_p = p is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a1, w21, w22, eps, w3, logvar, zp, h3)
+        return mu, logvar, zp, h3
+
+    @staticmethod
+    def backward(ctx, g_mu, g_lv, g_zp, g_h3):
+        lib = _lib.load()
+        a1, w21, w22, eps, w3, logvar, zp, h3 = ctx.saved_tensors
+        b, hd, lat, pw = ctx.dims
+        f32 = dict(dtype=torch.float32, device=a1.device)
+        g_mu, g_lv, g_zp, g_h3 = (None if g is None else _lib.f32c(g) for g in (g_mu, g_lv, g_zp, g_h3))
+        d_a3, d_a1 = torch.empty(b, hd, **f32), torch.empty(b, hd, **f32)
+        dmu, dlv = torch.empty(b, lat, **f32), torch.empty(b, lat, **f32)
+        d_p = torch.empty(b, pw, **f32) if pw else None
+        wg = torch.empty(lib.is_vae_latent_grad_floats(hd, pw), **f32)
+        with KernelTimer.span("vae_latent_bwd"):
+            _lib.check(lib.is_vae_latent_bwd(_lib.ptr(g_h3), _lib.ptr(h3), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_zp), _lib.ptr(eps),
+                                             _lib.ptr(logvar), _lib.ptr(a1), _lib.ptr(zp), _lib.ptr(w21), _lib.ptr(w22), pw, _lib.ptr(w3),
+                                             _lib.ptr(d_a3), _lib.ptr(dmu), _lib.ptr(dlv), _lib.ptr(d_p), _lib.ptr(d_a1), _lib.ptr(wg),
+                                             b, hd, lat, _lib.stream_ptr()), "is_vae_latent_bwd")
+        n2 = lat * hd
+        o = 2 * n2 + 2 * lat
+        n3 = hd * (lat + pw)
+        return (d_a1, wg[:n2].view(lat, hd), wg[2 * n2:2 * n2 + lat], wg[n2:2 * n2].view(lat, hd), wg[2 * n2 + lat:o], None,
+                d_p if ctx.has_p else None, wg[o:o + n3].view(hd, lat + pw), wg[o + n3:])
+
+
+def vae_latent_supported(a1, latent, p):
+    return (a1.is_cuda and a1.dim() == 2 and a1.dtype == torch.float32 and latent == 32 and a1.shape[1] % 16 == 0
+            and 16 <= a1.shape[1] <= 2048 and (p is None or (p.dim() == 2 and p.shape[1] <= 16)))
+
+
+def vae_latent(a1, w21, b21, w22, b22, eps, p, w3, b3):
+    """-> (mu, logvar, [z | p], relu(vae_fc3([z | p])))"""
+    return VaeLatentFn.apply(a1, w21, b21, w22, b22, eps, p, w3, b3)
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """Per-segment mean and/or max over rows (``csrc/segment_ops.hip``).
 

@@ -195,11 +195,28 @@ class MultimodalNet(nn.Module):
         elif sp.prop == "raw":
             p = prop
         if sp.vae:
-            mu, logvar = self.encode_vae(seq.reshape(-1, self.vae_input_dim))
-            z = self.reparameterize(mu, logvar)
-            if p is not None:
-                z = torch.cat([z, p], dim=1)
-            o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=self.decode_vae(z))
+            x = seq.reshape(-1, self.vae_input_dim)
+            a1 = HF.linear_small_batch(x, self.vae_fc1.weight, self.vae_fc1.bias)
+            if HF.vae_latent_supported(a1, self.vae_latent_dim, p) and self.vae_fc21.bias is not None:
+                # fc21 | fc22, reparameterisation, cat(p), fc3 and the two ReLUs as ONE launch (csrc/vae_latent.hip); the noise
+                # is drawn exactly as the reference does (torch.randn_like of a (B, latent) tensor; two draws for a merged pair)
+                like = a1.new_empty(a1.shape[0], self.vae_latent_dim)
+                if self._pair_rows:
+                    b = self._pair_rows
+                    eps = torch.cat([torch.randn_like(like[:b]), torch.randn_like(like[b:])], dim=0)
+                else:
+                    eps = torch.randn_like(like)
+                mu, logvar, z, h3 = HF.vae_latent(a1, self.vae_fc21.weight, self.vae_fc21.bias, self.vae_fc22.weight,
+                                                  self.vae_fc22.bias, eps, p, self.vae_fc3.weight, self.vae_fc3.bias)
+                recon = HF.linear_small_batch(h3, self.vae_fc4.weight, self.vae_fc4.bias)
+            else:
+                h1 = F.relu(a1)
+                mu, logvar = self.vae_fc21(h1), self.vae_fc22(h1)
+                z = self.reparameterize(mu, logvar)
+                if p is not None:
+                    z = torch.cat([z, p], dim=1)
+                recon = self.decode_vae(z)
+            o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=recon)
         return o
 
     def _encode(self, g, seq, prop, need_attention=False):

@@ -111,25 +111,24 @@ def train_model_comparative(config, device, model, train_loader, val_loader, opt
                 lambda batch: _paired_loss(model, loss_function, batch, device, contrastive, coeff))
 
 
-def train_model_device(config, device, model, dataset, train_index, val_index, optimizer, loss_function, scheduler=None,
-                       stage="pretrain", seed=0):
-    """``train_model`` on a :class:`~immunostruct_amd.data.DeviceResidentDataset` (SURVEY.md section 8 f-1): same epoch
-    loop, loss, best-validation checkpoint and printed / returned values as :func:`train_model` with a shuffling
-    ``DataLoader(batch_size=config.batch_size)``, but batches are assembled on the GPU from graph ids
-    (``dataset.gather_into``) and every full batch runs as one replay of the captured HIP graph
-    (``engine.CapturedTrainStep``); a trailing partial batch is run eagerly.  ``train_index`` / ``val_index``: graph
-    ids (any integer sequence).
+def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index, new_batch, assemble,
+                forward_loss, edge_capacity):
+    """The epoch loop shared by the four device-resident training loops.
+
+    ``new_batch(b)`` -> static buffers ``(graph, seq, prop, y)`` for b items; ``assemble(idx, buf, train)`` fills them with the
+    items ``idx`` (device int64 ids) -- gather, and for the self-supervised loops the train-time augmentation -- and returns
+    the tuple ``forward_loss(model, *tuple)`` consumes.  Every full batch is one replay of the captured HIP graph
+    (``engine.CapturedTrainStep``); a trailing partial batch runs eagerly.
 
     Data parallel (SURVEY.md section 8 e): when ``torch.distributed`` is initialised (one process per GPU, every rank
     holding the dataset) rank r trains on ``perm[r::world]`` of each epoch's permutation (the same seeded permutation on
-    all ranks, cut to a multiple of the world size), ``config.batch_size`` graphs per rank and step; the gradients are
-    all-reduced through ``distributed.FlatGradReducer`` (inside the captured step: overlapped with the backward when that
-    measures faster), rank 0's initial weights are broadcast, every rank validates on the full validation set and only
-    rank 0 writes the checkpoint."""
+    all ranks, cut to a multiple of the world size), ``config.batch_size`` items per rank and step; gradients are all-reduced
+    through ``distributed.FlatGradReducer`` (inside the captured step: overlapped with the backward when that measures
+    faster), rank 0's initial weights are broadcast, the device random streams (reparameterisation noise, dropout,
+    augmentation) are offset per rank, every rank validates on the full validation set and rank 0 writes the checkpoint."""
     import torch.distributed as dist
     from ..distributed import FlatGradReducer, broadcast_parameters
     from ..engine import CapturedTrainStep
-    device = dataset.device
     bsz = int(config.batch_size)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -138,27 +137,25 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
     if world > 1:
         broadcast_parameters(model)
-
-    def forward_loss(m, g, seq, prop, y):
-        recon, mu, logvar, final = m(g, seq, prop)
-        return loss_function(recon, seq, mu, logvar, final, y)
+        # identical seeds on every rank would make the ranks draw the same noise / dropout masks for their (different) samples
+        torch.cuda.manual_seed(int(seed) + 7919 * (rank + 1))
 
     captured = None
     reducer = FlatGradReducer(model.parameters(), world=world)
     if train_index.numel() // world >= bsz:
-        buf = dataset.new_batch(bsz)
-        dataset.gather_into(train_index[rank:rank + bsz * world:world][:bsz], *buf)
+        buf = new_batch(bsz)
         model.train()
+        first = assemble(train_index[rank:rank + bsz * world:world][:bsz], buf, True)
         # the engine's construction runs one eager warm-up step on this batch and then restores model + optimizer
-        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=bsz * dataset.max_edges,
+        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, first, edge_capacity=edge_capacity(bsz),
                                      warmup=1, preserve_state=True)
     tails = {}
 
-    def eager_batch(idx):
+    def eager_batch(idx, train):
         b = int(idx.numel())
         if b not in tails:
-            tails[b] = dataset.new_batch(b)
-        return dataset.gather_into(idx, *tails[b])
+            tails[b] = new_batch(b)
+        return assemble(idx, tails[b], train)
 
     train_losses, val_losses = [], []
     best = float("inf")
@@ -171,13 +168,13 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
         for at in range(0, perm.numel(), bsz):
             idx = perm[at:at + bsz]
             if idx.numel() == bsz and captured is not None:
-                dataset.gather_into(idx, captured.sgraph, captured.seq, captured.prop, captured.y)
+                assemble(idx, (captured.sgraph, captured.seq, captured.prop, captured.y), True)
                 loss = captured.replay().clone()
             else:
-                g, seq, prop, y = eager_batch(idx)
+                args = eager_batch(idx, True)
                 with reducer.live_gradients():      # not the captured graph's (stale) gradient buffers
                     reducer.zero()
-                    loss = forward_loss(model, g, seq, prop, y)
+                    loss = forward_loss(model, *args)
                     loss.backward()
                     reducer.all_reduce_mean()
                     optimizer.step()
@@ -192,8 +189,7 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
         running, vsteps = None, 0
         with torch.no_grad():
             for at in range(0, val_index.numel(), bsz):
-                g, seq, prop, y = eager_batch(val_index[at:at + bsz])
-                loss = forward_loss(model, g, seq, prop, y).detach()
+                loss = forward_loss(model, *eager_batch(val_index[at:at + bsz], False)).detach()
                 running = loss if running is None else running + loss
                 vsteps += 1
         val_total = float(running) if running is not None else 0.0
@@ -210,6 +206,22 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
     return train_losses, val_losses
 
 
+def train_model_device(config, device, model, dataset, train_index, val_index, optimizer, loss_function, scheduler=None,
+                       stage="pretrain", seed=0):
+    """``train_model`` on a :class:`~immunostruct_amd.data.DeviceResidentDataset` (SURVEY.md section 8 f-1): same epoch
+    loop, loss, best-validation checkpoint and printed / returned values as :func:`train_model` with a shuffling
+    ``DataLoader(batch_size=config.batch_size)``, but batches are assembled on the GPU from graph ids
+    (``dataset.gather_into``) and every full batch runs as one replay of the captured HIP graph; data parallel under an
+    initialised process group (:func:`_device_fit`).  ``train_index`` / ``val_index``: graph ids (any integer sequence)."""
+    def forward_loss(m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return loss_function(recon, seq, mu, logvar, final, y)
+
+    return _device_fit(config, model, optimizer, scheduler, stage, seed, dataset.device, train_index, val_index,
+                       dataset.new_batch, lambda idx, buf, train: dataset.gather_into(idx, *buf), forward_loss,
+                       lambda b: b * dataset.max_edges)
+
+
 def train_model_comparative_device(config, device, model, dataset_cancer, dataset_wt, train_index, val_index, optimizer,
                                    loss_function, scheduler=None, stage="pretrain", seed=0):
     """``train_model_comparative`` with both members of every (cancer, wild-type) pair in device-resident datasets
@@ -218,86 +230,21 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
     single pass (``MultimodalNet._encode_pair``); the loss is the reference's (``procedures/train.py:97-114``: shared
     prediction term, averaged reconstruction terms, ``coeff_contrastive`` x paired contrastive loss).  Every full batch is
     one replay of the captured HIP graph of that step; the contrastive loss' class-count early-out
-    (``utils/contrastive.py:38-43``) is evaluated on the device there (``PairedContrastiveLoss.capturable``).
-    ``IMMUNOSTRUCT_CAPTURE_PAIRED=0`` runs every step eagerly."""
+    (``utils/contrastive.py:38-43``) is evaluated on the device there (``PairedContrastiveLoss.capturable``).  Data parallel
+    under an initialised process group (:func:`_device_fit`; the contrastive loss is computed per rank on its local pairs)."""
     from ..data import DeviceResidentDataset
-    from ..distributed import FlatGradReducer
-    from ..engine import CapturedTrainStep
     device = dataset_cancer.device
-    bsz = int(config.batch_size)
     coeff = float(getattr(config, "coeff_contrastive", 0) or 0)
     contrastive = PairedContrastiveLoss(device=device, embedding_dim=104) if coeff > 0 else None
-    train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
-    val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
-    gen = torch.Generator(device="cpu").manual_seed(int(seed))
+    if contrastive is not None:
+        contrastive.capturable = True
     both = DeviceResidentDataset.concat(dataset_cancer, dataset_wt)
     shift = len(dataset_cancer)
-    bufs = {}
-
-    def gather(idx, buf):
-        return both.gather_into(torch.cat([idx, idx + shift]), *buf)
-
-    def batch(idx):
-        b = int(idx.numel())
-        if b not in bufs:
-            bufs[b] = both.new_batch(2 * b)
-        return gather(idx, bufs[b])
 
     def forward_loss(m, g2, seq2, prop2, y2):
         # y2 holds the targets of both members; the pair's label is the cancer member's
         return _paired_loss(m, loss_function, (g2, seq2, y2[:y2.numel() // 2], prop2), device, contrastive, coeff)
 
-    def step_loss(idx):
-        return forward_loss(model, *batch(idx))
-
-    captured = None
-    if train_index.numel() >= bsz and os.environ.get("IMMUNOSTRUCT_CAPTURE_PAIRED", "1") != "0":
-        buf = both.new_batch(2 * bsz)
-        gather(train_index[:bsz], buf)
-        model.train()
-        if contrastive is not None:
-            contrastive.capturable = True
-        reducer = FlatGradReducer(model.parameters(), world=1)
-        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=2 * bsz * both.max_edges,
-                                     warmup=1, preserve_state=True)
-
-    train_losses, val_losses = [], []
-    best = float("inf")
-    for epoch in range(config.num_epochs):
-        model.train()
-        perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
-        running, steps = None, 0
-        for at in range(0, perm.numel(), bsz):
-            idx = perm[at:at + bsz]
-            if captured is not None and idx.numel() == bsz:
-                gather(idx, (captured.sgraph, captured.seq, captured.prop, captured.y))
-                loss = captured.replay().clone()
-            else:
-                optimizer.zero_grad(set_to_none=True)
-                loss = step_loss(idx)
-                loss.backward()
-                optimizer.step()
-                loss = loss.detach()
-            running = loss if running is None else running + loss
-            steps += 1
-        train_loss = float(running) / max(steps, 1)
-        train_losses.append(train_loss)
-        if scheduler is not None:
-            scheduler.step()
-        model.eval()
-        running, vsteps = None, 0
-        with torch.no_grad():
-            for at in range(0, val_index.numel(), bsz):
-                loss = step_loss(val_index[at:at + bsz]).detach()
-                running = loss if running is None else running + loss
-                vsteps += 1
-        val_total = float(running) if running is not None else 0.0
-        if val_total < best:
-            _save_best(config, model, stage)
-            best = val_total
-        val_loss = val_total / max(vsteps, 1)
-        val_losses.append(val_loss)
-        if wandb is not None and getattr(wandb, "run", None) is not None:
-            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
-        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
-    return train_losses, val_losses
+    return _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index,
+                       lambda b: both.new_batch(2 * b), lambda idx, buf, train: both.gather_into(torch.cat([idx, idx + shift]), *buf),
+                       forward_loss, lambda b: 2 * b * both.max_edges)

@@ -12,9 +12,9 @@ from __future__ import annotations
 import torch
 
 from ..utils import PairedContrastiveLoss
-from .train import _fit, _save_best, _to, wandb
+from .train import _device_fit, _fit, _to
 
-__all__ = ["train_model_SSL", "train_model_comparative_SSL", "train_model_SSL_device"]
+__all__ = ["train_model_SSL", "train_model_comparative_SSL", "train_model_SSL_device", "train_model_comparative_SSL_device"]
 
 
 def _ssl_targets(model, pred_amino_acid, amino_acid, device):
@@ -57,18 +57,13 @@ def train_model_comparative_SSL(config, device, model, train_loader, val_loader,
 def train_model_SSL_device(config, device, model, dataset, train_index, val_index, optimizer, loss_function, scheduler=None,
                            stage="pretrain", seed=0):
     """``train_model_SSL`` on a device-resident dataset: gather -> augment (rotation, masked residue, optional
-    ``config.structure_pad_count`` / ``config.sequence_pad_count``) -> captured step, all on the GPU."""
+    ``config.structure_pad_count`` / ``config.sequence_pad_count``) -> captured step, all on the GPU; data parallel under an
+    initialised process group (``procedures.train._device_fit``: every rank augments its own shard with its own stream)."""
     from ..data import augment_batch_on_device, mask_sequence_on_device
-    from ..distributed import FlatGradReducer
-    from ..engine import CapturedTrainStep
     device = dataset.device
-    bsz = int(config.batch_size)
     pad_structure = int(getattr(config, "structure_pad_count", 0) or 0)
     pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0)
-    train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
-    val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
-    gen = torch.Generator(device="cpu").manual_seed(int(seed))
-    dgen = torch.Generator(device=device).manual_seed(int(seed) + 1)
+    dgen = torch.Generator(device=device).manual_seed(int(seed) + 1 + 104729 * _rank())
     amino = {}
 
     def forward_loss(m, g, seq, prop, y):
@@ -87,61 +82,63 @@ def train_model_SSL_device(config, device, model, dataset, train_index, val_inde
             mask_sequence_on_device(seq, pad_sequence, generator=dgen)
         return g, seq, prop, y
 
-    captured = None
-    if train_index.numel() >= bsz:
-        buf = dataset.new_batch(bsz)
-        model.train()
-        assemble(train_index[:bsz], buf, True)
-        reducer = FlatGradReducer(model.parameters(), world=1)
-        captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, buf, edge_capacity=bsz * dataset.max_edges,
-                                     warmup=1, preserve_state=True)
-    tails = {}
+    return _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index, dataset.new_batch,
+                       assemble, forward_loss, lambda b: b * dataset.max_edges)
 
-    def eager_batch(idx, train):
-        b = int(idx.numel())
-        if b not in tails:
-            tails[b] = dataset.new_batch(b)
-        return assemble(idx, tails[b], train)
 
-    train_losses, val_losses = [], []
-    best = float("inf")
-    for epoch in range(config.num_epochs):
-        model.train()
-        perm = train_index[torch.randperm(train_index.numel(), generator=gen).to(device)]
-        running, steps = None, 0
-        for at in range(0, perm.numel(), bsz):
-            idx = perm[at:at + bsz]
-            if idx.numel() == bsz and captured is not None:
-                assemble(idx, (captured.sgraph, captured.seq, captured.prop, captured.y), True)
-                loss = captured.replay().clone()
-            else:
-                g, seq, prop, y = eager_batch(idx, True)
-                optimizer.zero_grad(set_to_none=True)
-                loss = forward_loss(model, g, seq, prop, y)
-                loss.backward()
-                optimizer.step()
-                loss = loss.detach()
-            running = loss if running is None else running + loss
-            steps += 1
-        train_loss = float(running) / max(steps, 1)
-        train_losses.append(train_loss)
-        if scheduler is not None:
-            scheduler.step()
-        model.eval()
-        running, vsteps = None, 0
-        with torch.no_grad():
-            for at in range(0, val_index.numel(), bsz):
-                g, seq, prop, y = eager_batch(val_index[at:at + bsz], False)
-                loss = forward_loss(model, g, seq, prop, y).detach()
-                running = loss if running is None else running + loss
-                vsteps += 1
-        val_total = float(running) if running is not None else 0.0
-        if val_total < best:
-            _save_best(config, model, stage)
-            best = val_total
-        val_loss = val_total / max(vsteps, 1)
-        val_losses.append(val_loss)
-        if wandb is not None and getattr(wandb, "run", None) is not None:
-            wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
-        print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
-    return train_losses, val_losses
+def train_model_comparative_SSL_device(config, device, model, dataset_cancer, dataset_wt, train_index, val_index, optimizer,
+                                       loss_function, scheduler=None, stage="pretrain", seed=0):
+    """``train_model_comparative_SSL`` (``procedures/train_SSL.py:71-180``) on device-resident (cancer, wild-type) datasets:
+    a batch of B pairs is gathered as ONE merged batch of 2B graphs, augmented on the GPU (independent rotations, one masked
+    residue of the SAME type in both members of a pair -- ``data.augment_pair_on_device`` -- optional structure / sequence
+    padding) and run as one replay of the captured step; the loss is 0.5 * (L(cancer) + L(wild-type)) with a shared
+    prediction term plus the residue cross-entropy (counted once, as the two halves add up to) plus
+    ``coeff_contrastive`` x the paired contrastive loss.  Data parallel under an initialised process group."""
+    from ..data import DeviceResidentDataset, augment_pair_on_device, mask_sequence_on_device
+    device = dataset_cancer.device
+    coeff = float(getattr(config, "coeff_contrastive", 0) or 0)
+    contrastive = PairedContrastiveLoss(device=device, embedding_dim=104) if coeff > 0 else None
+    if contrastive is not None:
+        contrastive.capturable = True
+    pad_structure = int(getattr(config, "structure_pad_count", 0) or 0)
+    pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0)
+    dgen = torch.Generator(device=device).manual_seed(int(seed) + 1 + 104729 * _rank())
+    both = DeviceResidentDataset.concat(dataset_cancer, dataset_wt)
+    shift = len(dataset_cancer)
+    amino = {}
+
+    def forward_loss(m, g2, seq2, prop2, y2):
+        b = int(y2.numel()) // 2
+        target = y2[:b]
+        emb, recon, mu, logvar, final, pred = m.forward_comparative(g2, seq2, prop2)
+        if m.training:
+            pa, aa = pred, amino[b]
+        else:
+            pa, aa = torch.tensor([]), torch.tensor([])
+        merged = [getattr(t, "merged", None) for t in (recon, mu, logvar)]
+        if all(t is not None for t in merged):
+            loss = loss_function(merged[0], seq2, merged[1], merged[2], final, target, pa, aa)
+        else:
+            loss = 0.5 * (loss_function(recon[0], seq2[:b], mu[0], logvar[0], final, target, pa, aa)
+                          + loss_function(recon[1], seq2[b:], mu[1], logvar[1], final, target, pa, aa))
+        if coeff > 0:
+            loss = loss + coeff * contrastive(emb[0], emb[1], target)
+        return loss
+
+    def assemble(idx, buf, train):
+        g2, seq2, prop2, y2 = both.gather_into(torch.cat([idx, idx + shift]), *buf)
+        if train:
+            b = int(idx.numel())
+            if b not in amino:
+                amino[b] = torch.zeros(b, dtype=torch.int64, device=device)
+            amino[b].copy_(augment_pair_on_device(g2.ndata["x"], b, dgen, structure_pad_count=pad_structure))
+            mask_sequence_on_device(seq2, pad_sequence, generator=dgen)
+        return g2, seq2, prop2, y2
+
+    return _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index,
+                       lambda b: both.new_batch(2 * b), assemble, forward_loss, lambda b: 2 * b * both.max_edges)
+
+
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_initialized() else 0

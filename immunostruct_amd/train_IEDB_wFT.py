@@ -2,8 +2,10 @@
 
 Same stages, flags and checkpoint naming as the reference's ``train_IEDB_wFT.py:15-163``, running the
 HIP-backed ``immunostruct_amd.models``.  The reference's on-disk inputs (pickled PyG graphs + tables) were
-never shipped; ``--synthetic N`` draws N synthetic peptide-MHC graphs of the same shape instead, and ``--packed FILE``
-trains on a packed dataset (``data.convert_pyg_directory`` converts the reference's graph directory once).
+never shipped: with the reference's path flags (``--graph-dir-IEDB``, ``--property-path-IEDB``, ``--hla-path``) the graph
+directory is read and joined with the tables (``data.reference_inputs``); ``--packed FILE`` trains on a packed dataset
+written once by ``data.convert_pyg_directory``; ``--synthetic N`` draws N synthetic peptide-MHC graphs of
+the same shape instead.
 
     python -m immunostruct_amd.train_IEDB_wFT --model HybridModelv2 --full-sequence --sequence-loss --synthetic 512
 """
@@ -16,11 +18,12 @@ import torch
 from torch.utils.data import DataLoader, random_split
 
 from . import optim
-from .data import DeviceResidentDataset, PackedDataset, SplitDataset, SyntheticImmunoDataset, collate, collate_amino_acid
+from .data import (DeviceResidentDataset, PackedDataset, SplitDataset, SyntheticImmunoDataset, collate, collate_amino_acid,
+                   packed_from_reference_inputs, require_paths)
 from .models.mapping import model_map
 from .procedures import (inference, inference_SSL, train_model, train_model_device, train_model_SSL,
                          train_model_SSL_device)
-from .utils import Losses, seed_everything
+from .utils import Losses, seed_everything, update_paths
 
 
 def parse_args(argv=None):
@@ -35,7 +38,11 @@ def parse_args(argv=None):
     p.add_argument("--sequence-loss", action="store_true")
     p.add_argument("--feature-size", default=23, type=int)
     p.add_argument("--coord-size", default=3, type=int)
-    p.add_argument("--model-save-dir", default="./checkpoints/IEDB/", type=str)
+    p.add_argument("--model-save-dir", default="$ROOT/results/PropIEDB_ImmunoIEDB/", type=str)
+    p.add_argument("--graph-dir-IEDB", default="$ROOT/data/graph_pyg_IEDB/", type=str)
+    p.add_argument("--property-path-IEDB", default="$ROOT/data/complete_score_Mprops_1_2_smoothed_sasa_v2.txt", type=str)
+    p.add_argument("--hla-path", default="$ROOT/data/HLA_27_seqs_csv.csv", type=str)
+    p.add_argument("--wandb-username", default=None, type=str)
     p.add_argument("--seed", default=1, type=int)
     p.add_argument("--sequence-pad-count", default=0, type=int)
     p.add_argument("--structure-pad-count", default=0, type=int)
@@ -51,11 +58,19 @@ def parse_args(argv=None):
 
 def main(argv=None):
     config = parse_args(argv)
+    update_paths(config)
     if not config.full_sequence:
-        raise SystemExit("only --full-sequence inputs (283 x 21) are generated by the synthetic dataset")
-    if config.synthetic <= 0 and not config.packed:
-        raise SystemExit("pass --packed FILE (see data.convert_pyg_directory for the one-time conversion of the reference's "
-                         "graph directory) or --synthetic N")
+        raise SystemExit("only --full-sequence inputs (283 x 21) are supported")
+    from_reference = config.synthetic <= 0 and not config.packed
+    if from_reference:
+        # the reference's own inputs (train_IEDB_wFT.py:55-57): graph directory + property table + HLA table
+        require_paths(graph_dir_IEDB=config.graph_dir_IEDB, property_path_IEDB=config.property_path_IEDB, hla_path=config.hla_path)
+    if config.wandb_username is not None:
+        try:
+            import wandb
+            wandb.init(project="ImmunoStruct", entity=config.wandb_username, name=config.model, config=vars(config))
+        except ImportError:
+            print("wandb is not installed: --wandb-username ignored")
     tag = (f"{config.model}-lr_pt_{config.learning_rate_pretrain}-lr_ft_{config.learning_rate_finetune}"
            f"-ep_{config.num_epochs}-bs_{config.batch_size}-fseq_{config.full_sequence}-seql_{config.sequence_loss}"
            f"-fs_{config.feature_size}-cs_{config.coord_size}-seed_{config.seed}")
@@ -69,8 +84,11 @@ def main(argv=None):
     rank, local_rank, world = init_from_env()
     if world > 1 and not config.device_dataset:
         raise SystemExit("data-parallel runs need --device-dataset (the host-loader loop is single-process, as the reference)")
-    if world > 1 and config.self_supervision:
-        raise SystemExit("data-parallel runs of the self-supervised loop are not implemented")
+    if config.device_dataset and not config.self_supervision and (config.sequence_pad_count or config.structure_pad_count):
+        # the reference's SplitDataset masks the sequence / pads the structure at train time also WITHOUT self-supervision
+        # (data/util_dataloader.py:60-86); the on-device loop applies those transforms in its self-supervised form only
+        raise SystemExit("--sequence-pad-count / --structure-pad-count with --device-dataset need --self-supervision "
+                         "(the plain on-device loop applies no train-time masking); drop --device-dataset or the pad counts")
     if world > 1:
         local_rank = int(os.environ.get("IMMUNOSTRUCT_FORCE_DEVICE", local_rank))      # debugging aid: ranks sharing a GPU (gloo)
         torch.cuda.set_device(local_rank)
@@ -82,8 +100,17 @@ def main(argv=None):
     ssl = config.self_supervision
     pads = dict(structure_pad_count=config.structure_pad_count, sequence_pad_count=config.sequence_pad_count)
 
+    reference_packed = {}
+
     def loaders(binary):
-        if config.packed:
+        if from_reference:
+            if not reference_packed:         # read the graph files and join the tables once for both stages
+                reference_packed["ds"] = packed_from_reference_inputs(config.graph_dir_IEDB, config.property_path_IEDB, config.hla_path,
+                                                                      feature_size=config.feature_size, coord_size=config.coord_size)
+                reference_packed["ds"].normalize()
+            ds = reference_packed["ds"]
+            ds.binary = binary
+        elif config.packed:
             ds = PackedDataset.load(config.packed, binary=binary)
             ds.normalize()                   # foreignness -> [-1, 1] (reference data/immmunopred_dataloader.py:67-70)
         else:
@@ -99,7 +126,7 @@ def main(argv=None):
         if config.device_dataset:
             # same split, same batch size; batches are assembled (and, with --self-supervision, augmented) on the device
             full = splits[0].dataset
-            dds = DeviceResidentDataset.from_packed(full, device) if config.packed else DeviceResidentDataset(full, device)
+            dds = DeviceResidentDataset.from_packed(full, device) if isinstance(full, PackedDataset) else DeviceResidentDataset(full, device)
             run = train_model_SSL_device if ssl else train_model_device
             return run(config, device, model, dds, splits[0].indices, splits[1].indices, opt, loss_fn, stage=stage, seed=config.seed)
         return (train_model_SSL if ssl else train_model)(config, device, model, tr, va, opt, loss_fn, stage=stage)

@@ -18,11 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import os
-
 __all__ = ["PairedContrastiveLoss"]
-
-USE_HIP_KERNEL = os.environ.get("IMMUNOSTRUCT_CONTRASTIVE_KERNEL", "1") != "0"
 
 
 def _weighted_sq(m, ideal_diag, off_weight):
@@ -71,7 +67,7 @@ class PairedContrastiveLoss(nn.Module):
         if embedding_cancer.shape != embedding_wt.shape:
             raise AssertionError("cancer / wild-type embeddings must have equal shapes")
         if (embedding_cancer.is_cuda and self.z_dim == 128 and 2 <= embedding_cancer.shape[0] <= 256
-                and embedding_cancer.dim() == 2 and embedding_cancer.shape[1] <= 256 and USE_HIP_KERNEL):
+                and embedding_cancer.dim() == 2 and embedding_cancer.shape[1] <= 256):
             # fused HIP path (csrc/contrastive.hip): the projector is frozen in the reference, so only the embedding
             # gradients are produced; BatchNorm running statistics are not maintained (never read: train mode only)
             from .. import functional as HF

@@ -141,6 +141,21 @@ int is_egnn_node_wgrad_proj_floats(void);
 int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream);
 int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 
+/* Latent block of the sequence VAE (models/hybrid_models.py:297-308,334-340): a1 [B,Hd] = vae_fc1(x) (pre-activation) ->
+ *   mu = W21 relu(a1) + b21, logvar = W22 relu(a1) + b22 [B,32]; z = mu + eps * exp(0.5 logvar) (eps [B,32] from the caller);
+ *   zp [B, 32 + P] = [z | p] (p [B,P] the property embedding, P <= 16, NULL when P == 0); h3 [B,Hd] = relu(W3 zp + b3).
+ * L must be 32, Hd a multiple of 16 <= 2048.  Backward: upstream g_h3 / g_mu / g_lv / g_zp (each may be NULL) -> d_a1 [B,Hd],
+ * d_p [B,P], wgrad = [dW21 (32 x Hd) | dW22 | db21 | db22 | dW3 (Hd x (32 + P)) | db3] (is_vae_latent_grad_floats floats,
+ * contraction over the batch in a fixed order); d_a3 [B,Hd], dmu, dlv [B,32] are scratch.                              */
+int is_vae_latent_fwd(const float* a1, const float* W21, const float* b21, const float* W22, const float* b22,
+                      const float* eps, const float* p, int P, const float* W3, const float* b3, float* mu,
+                      float* logvar, float* zp, float* h3, int B, int Hd, int L, void* stream);
+int is_vae_latent_grad_floats(int Hd, int P);
+int is_vae_latent_bwd(const float* g_h3, const float* h3, const float* g_mu, const float* g_lv, const float* g_zp,
+                      const float* eps, const float* logvar, const float* a1, const float* zp, const float* W21,
+                      const float* W22, int P, const float* W3, float* d_a3, float* dmu, float* dlv, float* d_p,
+                      float* d_a1, float* wgrad, int B, int Hd, int L, void* stream);
+
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
  * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,

@@ -121,3 +121,38 @@ def test_augment_batch_on_device_form():
     changed = (s != seq).any(2)
     assert int(changed[:, -11:].sum()) == 0 and bool((changed.sum(1) <= 5).all())
     assert bool((s[changed].argmax(1) == A.PAD_INDEX).all())
+
+
+def test_augment_pair_on_device_rules():
+    """merged (cancer; wild-type) batch: one masked residue per member, the SAME type in both, taken among the types the two
+    graphs share; a pair without a common type stays unmasked (type 0 reported, the reference's fallback); rotations are
+    isometries and differ between the members"""
+    pairs = 6
+    ca, wt = dataset(pairs, seed=5), dataset(pairs, seed=6)
+    n = ca[0][0].num_nodes()
+    x0 = torch.cat([ca[i][0].ndata["x"] for i in range(pairs)] + [wt[i][0].ndata["x"] for i in range(pairs)]).clone()
+    f0 = x0.view(2 * pairs, n, -1)
+    f0[2, :, :-3] = 0
+    f0[2, :, 3] = 1                      # pair 2: the cancer graph holds only type 3 ...
+    f0[pairs + 2, :, :-3] = 0
+    f0[pairs + 2, :, 7] = 1              # ... the wild-type graph only type 7: nothing in common
+    x = x0.clone()
+    gen = torch.Generator().manual_seed(13)
+    amino = A.augment_pair_on_device(x, pairs, gen, structure_pad_count=2)
+    f1 = x.view(2 * pairs, n, -1)
+    for b in range(pairs):
+        mc = (f1[b, :, :-3].sum(1) > 1).nonzero().flatten()
+        mw = (f1[pairs + b, :, :-3].sum(1) > 1).nonzero().flatten()
+        if b == 2:
+            assert mc.numel() == 0 and mw.numel() == 0 and int(amino[b]) == 0
+            continue
+        assert mc.numel() == 1 and mw.numel() == 1
+        tc, tw = int(f0[b, int(mc), :-3].argmax()), int(f0[pairs + b, int(mw), :-3].argmax())
+        assert tc == tw == int(amino[b])
+        assert float(f0[b, int(mc), :-3].sum()) == 1 and float(f0[pairs + b, int(mw), :-3].sum()) == 1
+        for g in (b, pairs + b):
+            rows = (f0[g, :, :-3].sum(1) > 0).nonzero().flatten()
+            d0 = torch.cdist(f0[g, rows, -3:], f0[g, rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
+            d1 = torch.cdist(f1[g, rows, -3:], f1[g, rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
+            assert torch.allclose(d0, d1, atol=2e-3)
+            assert int(((f0[g, :, :-3].sum(1) == 1) & (f1[g, :, :-3].sum(1) == 0)).sum()) <= 2

@@ -44,10 +44,25 @@ def test_entry_script_two_ranks(cuda_device, tmp_path):
     """train_IEDB_wFT under torch.distributed.run with --device-dataset: pretrain -> new head -> finetune -> inference on
     two ranks; rank 0 writes both checkpoints, every rank loads them after the barrier."""
     res = _run(["-m", "immunostruct_amd.train_IEDB_wFT", "--model", "HybridModelv2", "--full-sequence", "--sequence-loss",
-                "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160", "--device-dataset", "--seed", "3",
+                "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16", "--synthetic", "160", "--device-dataset", "--seed", "3",
                 "--model-save-dir", str(tmp_path)], 29553)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count("DONE FINE TUNING") == 2 and len(list(tmp_path.glob("*.pt"))) == 2
+
+
+@pytest.mark.gpu
+def test_entry_scripts_two_ranks_self_supervision_and_pairs(cuda_device, tmp_path):
+    """the data-parallel form of the remaining device loops: train_IEDB_wFT --self-supervision and
+    train_Cancer_wFT (paired, self-supervised) under torch.distributed.run on two ranks"""
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16", "--synthetic", "160", "--device-dataset",
+              "--seed", "3", "--self-supervision", "--model-save-dir", str(tmp_path)]
+    res = _run(["-m", "immunostruct_amd.train_IEDB_wFT", "--model", "HybridModelv2_SSL"] + common, 29556)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("DONE FINE TUNING") == 2
+    res = _run(["-m", "immunostruct_amd.train_Cancer_wFT", "--model", "HybridModelv2_Comparative_SSL", "--use-wt-for-downstream",
+                "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common, 29557)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert len(list(tmp_path.glob("*_finetune.pt"))) == 2
 
 
 @pytest.mark.gpu

@@ -550,3 +550,41 @@ def test_contrastive_targets_kernel(cuda_device):
         assert float(gate) == want_gate, (y, float(gate))
     with pytest.raises(NotImplementedError):
         HF.contrastive_targets(torch.zeros(2000, device=cuda_device))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,hd,pw", [(128, 512, 8), (5, 512, 2), (16, 64, 0), (37, 2048, 16)])
+def test_vae_latent_block_matches_torch(cuda_device, b, hd, pw):
+    """fc21 | fc22 -> reparameterise -> cat(p) -> fc3 -> ReLU (hybrid_models.py:297-308,334-340) as one HIP launch, and its
+    backward, against the un-fused torch formulation in fp64: every output, every input / parameter gradient"""
+    rng = np.random.RandomState(b + hd)
+    t = lambda *shape, s=1.0: torch.from_numpy((rng.normal(size=shape) * s).astype(np.float32))
+    a1, eps = t(b, hd), t(b, 32)
+    w21, b21, w22, b22 = t(32, hd, s=hd ** -0.5), t(32, s=0.1), t(32, hd, s=hd ** -0.5), t(32, s=0.1)
+    w3, b3 = t(hd, 32 + pw, s=0.2), t(hd, s=0.1)
+    p = t(b, pw).abs() if pw else None
+    ups = [t(b, 32), t(b, 32), t(b, 32 + pw), t(b, hd)]
+
+    def run(dtype, dev, fused):
+        leaves = [v.to(dev, dtype).requires_grad_(True) if v is not None else None for v in (a1, w21, b21, w22, b22, p, w3, b3)]
+        A1, W21, B21, W22, B22, P_, W3, B3 = leaves
+        e = eps.to(dev, dtype)
+        if fused:
+            mu, lv, zp, h3 = HF.vae_latent(A1, W21, B21, W22, B22, e, P_, W3, B3)
+        else:
+            h1 = torch.relu(A1)
+            mu, lv = h1 @ W21.T + B21, h1 @ W22.T + B22
+            z = mu + e * torch.exp(0.5 * lv)
+            zp = torch.cat([z, P_], dim=1) if P_ is not None else z
+            h3 = torch.relu(zp @ W3.T + B3)
+        outs = [mu, lv, zp, h3]
+        sum((o * u.to(dev, dtype)).sum() for o, u in zip(outs, ups)).backward()
+        return [o.detach().cpu() for o in outs], [l.grad.cpu() if l is not None else None for l in leaves]
+
+    outs_h, grads_h = run(torch.float32, cuda_device, True)
+    outs_r, grads_r = run(torch.float64, torch.device("cpu"), False)
+    for name, h, r in zip(("mu", "logvar", "z|p", "h3"), outs_h, outs_r):
+        H.assert_close(h, r, FWD_TOL, name)
+    for name, h, r in zip(("a1", "W21", "b21", "W22", "b22", "p", "W3", "b3"), grads_h, grads_r):
+        if r is not None:
+            H.assert_close(h, r, GRAD_TOL, "grad " + name)

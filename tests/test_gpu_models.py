@@ -415,7 +415,7 @@ def test_training_trajectory_matches_oracle(cuda_device, nb, steps):
 def test_entry_scripts_run_end_to_end(cuda_device, tmp_path):
     """both entry points: pretrain -> new head -> finetune -> inference on a small synthetic set (1 epoch)."""
     from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
-    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160",
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16", "--synthetic", "160",
               "--model-save-dir", str(tmp_path)]
     train_IEDB_wFT.main(["--model", "HybridModelv2"] + common)
     train_IEDB_wFT.main(["--model", "HybridModelv2", "--device-dataset", "--seed", "3"] + common)      # on-GPU batcher + captured step
@@ -429,7 +429,7 @@ def test_entry_scripts_self_supervision(cuda_device, tmp_path):
     """--self-supervision: masked-residue augmentation -> 5-field batches -> *_SSL models and losses ->
     inference with the train-set Youden threshold; loader path, on-device (captured) path, and the paired script."""
     from immunostruct_amd import train_Cancer_wFT, train_IEDB_wFT
-    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16", "--synthetic", "160",
+    common = ["--full-sequence", "--sequence-loss", "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16", "--synthetic", "160",
               "--self-supervision", "--structure-pad-count", "2", "--sequence-pad-count", "3", "--model-save-dir", str(tmp_path)]
     keys = {"optimal_threshold", "accuracy", "accuracy_op", "f1", "f1_op", "precision", "precision_op", "recall", "recall_op",
             "roc_auc", "pr_auc", "ppvn", "ppvn_op", "ppv30", "ppv30_op"}
@@ -438,9 +438,10 @@ def test_entry_scripts_self_supervision(cuda_device, tmp_path):
         assert set(train_stats) == keys and set(test_stats) == keys
         assert test_stats["optimal_threshold"] == train_stats["optimal_threshold"]
         assert all(np.isfinite(float(v)) for v in train_stats.values())
-    train_stats, test_stats = train_Cancer_wFT.main(["--model", "HybridModelv2_Comparative_SSL", "--use-wt-for-downstream",
-                                                     "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common)
-    assert set(test_stats) == keys and 0.0 <= test_stats["roc_auc"] <= 1.0
+    for extra in ([], ["--device-dataset", "--seed", "3"]):      # host loaders; merged pair batches gathered + augmented on the GPU
+        train_stats, test_stats = train_Cancer_wFT.main(["--model", "HybridModelv2_Comparative_SSL", "--use-wt-for-downstream",
+                                                         "--coeff-contrastive", "0.01", "--min-finetuning-batches", "2"] + common + extra)
+        assert set(test_stats) == keys and 0.0 <= test_stats["roc_auc"] <= 1.0
 
 
 def test_entry_script_on_packed_file(cuda_device, tmp_path):
@@ -469,7 +470,7 @@ def test_entry_script_on_packed_file(cuda_device, tmp_path):
     hc = hg.csr()
     e = hc.num_edges
     assert torch.equal(g._csr.src_sorted[:e].cpu(), hc.src_sorted) and torch.equal(g._csr.rowptr_dst.cpu(), hc.rowptr_dst)
-    common = ["--model", "HybridModelv2", "--full-sequence", "--sequence-loss", "--num-epochs", "1", "--batch-size", "16",
+    common = ["--model", "HybridModelv2", "--full-sequence", "--sequence-loss", "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16",
               "--packed", path, "--model-save-dir", str(tmp_path)]
     for extra in ([], ["--device-dataset", "--seed", "3"]):
         train_stats, test_stats = train_IEDB_wFT.main(common + extra)

