@@ -55,27 +55,32 @@ H = 64
 TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
-def edge_pass_algorithmic(n_nodes, n_edges, din, fe):
-    """Algorithmic bytes / FLOP of one fused EGNN edge pass (DESIGN.md section "Roofline accounting").
+def layer_algorithmic(n_nodes, n_edges, din, fe):
+    """Algorithmic bytes / FLOP of one EGNN layer launch.
 
-    bytes follow SURVEY.md section 8(d); FLOP count only the per-edge dense layers the fused kernel actually needs after
-    hoisting the first edge-MLP layer to node level (2 x 64x64 + 64 forward; backward = 2 data-grad + 2 weight-grad
-    64x64 products).  The node halves fused into the same launches are not counted (they would only raise the figure).
+    bytes: SURVEY's per-layer figure (it already holds the node rows: self rows for the node MLP / coordinate update and
+    the writes).  FLOP: the dense work the launch performs -- edge half: the per-edge layers that remain after hoisting the
+    first edge-MLP layer to node level (forward 2 x 64x64 + 64; backward 2 data-gradient + 2 weight-gradient 64x64
+    products); node half (in the same launch since round 2): forward node MLP (Din+64 -> 64 -> 64) + the next 64 -> 128
+    pre-projection, backward their three data-gradient products.  Returns (bytes_fwd, bytes_bwd, flop_fwd, flop_bwd,
+    edge-only flop_fwd, edge-only flop_bwd).
     """
     bytes_fwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + (n_nodes + 1) * 4 + n_nodes * (din * 4 + 12) + n_nodes * (H * 4 + 12)
     bytes_bwd = n_edges * (2 * din * 4 + 24 + fe * 4 + 4) + n_nodes * H * 4 + 2 * n_nodes * (din + 3) * 4
-    flop_fwd = 2.0 * n_edges * (H * H + H * H + H)
-    flop_bwd = 2.0 * n_edges * (4 * H * H + 2 * H)
-    return bytes_fwd, bytes_bwd, flop_fwd, flop_bwd
+    edge_fwd = 2.0 * n_edges * (H * H + H * H + H)
+    edge_bwd = 2.0 * n_edges * (4 * H * H + 2 * H)
+    node = 2.0 * n_nodes * ((din + H) * H + H * H + H * 2 * H)
+    return bytes_fwd, bytes_bwd, edge_fwd + node, edge_bwd + node, edge_fwd, edge_bwd
 
 
 def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key):
     """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included)"""
     if "egnn_layer_bwd" not in timers or "egnn_layer_fwd" not in timers:
         return None
-    per = [edge_pass_algorithmic(n_nodes, n_edges, din, fe) for din in dins]
+    per = [layer_algorithmic(n_nodes, n_edges, din, fe) for din in dins]
     b_fwd, b_bwd = np.mean([p[0] for p in per]), np.mean([p[1] for p in per])
     f_fwd, f_bwd = np.mean([p[2] for p in per]), np.mean([p[3] for p in per])
+    e_fwd, e_bwd = np.mean([p[4] for p in per]), np.mean([p[5] for p in per])
     n_b, ms_b = timers["egnn_layer_bwd"]
     n_f, ms_f = timers["egnn_layer_fwd"]
     tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
@@ -90,10 +95,15 @@ def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key):
     roof = dict(kernel="egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src, launches=n_b,
                 mean_launch_us=round(ms_b * 1e3, 2), algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
+                edge_half_only=dict(algorithmic_flop_per_launch=e_bwd, tflops=round(e_bwd / (ms_b * 1e-3) / 1e12, 2),
+                                    frac=round(e_bwd / (ms_b * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    note="FLOP of the per-edge products only over the whole launch's duration (round 1's accounting, "
+                                         "when the node data path and the source gather were their own launches)"),
                 hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                               frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
                 forward_kernel=dict(kernel="egnn_layer_fwd_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
                                     tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    edge_half_only_frac_mfma=round(e_fwd / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                     hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
                                     frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
     if "gather_segment_sum" in timers:

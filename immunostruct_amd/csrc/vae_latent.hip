@@ -93,10 +93,18 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_data_kernel(
   {
     // d zp[c] = sum_j W3[j][c] d a3[j]: lane = column c (rows of W3 are contiguous), wave = quarter of the j range
     const int q = Hd / 4;
-    float acc = 0.0f;
-    if (lane < W)
-      for (int j = wave * q; j < (wave + 1) * q; ++j) acc = __builtin_fmaf(W3[(size_t)j * W + lane], da3s[j], acc);
-    part[wave][lane] = acc;
+    // four independent chains (j, j+1, j+2, j+3): the loads of a row group are in flight together; fixed summation order
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    if (lane < W) {
+#pragma unroll 4
+      for (int j = wave * q; j < (wave + 1) * q; j += 4) {
+        c0 = __builtin_fmaf(W3[(size_t)j * W + lane], da3s[j], c0);
+        c1 = __builtin_fmaf(W3[(size_t)(j + 1) * W + lane], da3s[j + 1], c1);
+        c2 = __builtin_fmaf(W3[(size_t)(j + 2) * W + lane], da3s[j + 2], c2);
+        c3 = __builtin_fmaf(W3[(size_t)(j + 3) * W + lane], da3s[j + 3], c3);
+      }
+    }
+    part[wave][lane] = (c0 + c1) + (c2 + c3);
   }
   __syncthreads();
   if (tid < W) {
@@ -115,13 +123,13 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_data_kernel(
   }
   __syncthreads();
   for (int k = tid; k < Hd; k += 256) {
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int o = 0; o < VL; ++o) {
-      acc = __builtin_fmaf(W21[(size_t)o * Hd + k], dml[o], acc);
-      acc = __builtin_fmaf(W22[(size_t)o * Hd + k], dml[VL + o], acc);
+    float m = 0.0f, l = 0.0f;
+#pragma unroll
+    for (int o = 0; o < VL; ++o) {      // fully unrolled: the 64 (coalesced) loads of a thread are independent
+      m = __builtin_fmaf(W21[(size_t)o * Hd + k], dml[o], m);
+      l = __builtin_fmaf(W22[(size_t)o * Hd + k], dml[VL + o], l);
     }
-    d_a1[(size_t)b * Hd + k] = a1[(size_t)b * Hd + k] > 0.0f ? acc : 0.0f;
+    d_a1[(size_t)b * Hd + k] = a1[(size_t)b * Hd + k] > 0.0f ? (m + l) : 0.0f;
   }
 }
 
@@ -137,7 +145,13 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_wgrad_kernel(
   if (e < n_w2) {
     const int o = (int)(e / Hd), k = (int)(e % Hd);                 // o in [0, 64): mu rows then logvar rows
     const float* d = (o < VL) ? dmu + o : dlv + (o - VL);
-    for (int b = 0; b < B; ++b) acc = __builtin_fmaf(d[(size_t)b * VL], fmaxf(a1[(size_t)b * Hd + k], 0.0f), acc);
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 4 <= B; b += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = __builtin_fmaf(d[(size_t)(b + u) * VL], fmaxf(a1[(size_t)(b + u) * Hd + k], 0.0f), c[u]);
+    for (; b < B; ++b) c[0] = __builtin_fmaf(d[(size_t)b * VL], fmaxf(a1[(size_t)b * Hd + k], 0.0f), c[0]);
+    acc = (c[0] + c[1]) + (c[2] + c[3]);
   } else if (e < n_w2 + n_b2) {
     const int o = (int)(e - n_w2);
     const float* d = (o < VL) ? dmu + o : dlv + (o - VL);
@@ -145,7 +159,13 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_wgrad_kernel(
   } else if (e < n_w2 + n_b2 + n_w3) {
     const long long r = e - n_w2 - n_b2;
     const int j = (int)(r / W), c = (int)(r % W);
-    for (int b = 0; b < B; ++b) acc = __builtin_fmaf(d_a3[(size_t)b * Hd + j], zp[(size_t)b * W + c], acc);
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 4 <= B; b += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] = __builtin_fmaf(d_a3[(size_t)(b + u) * Hd + j], zp[(size_t)(b + u) * W + c], s4[u]);
+    for (; b < B; ++b) s4[0] = __builtin_fmaf(d_a3[(size_t)b * Hd + j], zp[(size_t)b * W + c], s4[0]);
+    acc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   } else {
     const int j = (int)(e - n_w2 - n_b2 - n_w3);
     for (int b = 0; b < B; ++b) acc += d_a3[(size_t)b * Hd + j];
