@@ -65,13 +65,13 @@ SIGNATURES = {
     "is_comb_attn_stats_floats": [_I, _I],
     "is_comb_attn_partials_floats": [_I],
     "is_comb_attn_grad_floats": [_I],
-    "is_comb_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "is_comb_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_comb_attn_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_comb_attn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_loss_partials_floats": [],
     "is_vae_latent_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_vae_latent_grad_floats": [_I, _I],
     "is_vae_latent_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P],
+    "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 
 
@@ -92,6 +92,11 @@ class ReduceJob(ctypes.Structure):
     """one job of is_reduce_partials_batched (mirrors `ReduceJob` in csrc/egnn_node.hip)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("partials", "map", "dst", "scratch")] + \
                [(n, ctypes.c_int) for n in ("nparts", "stride", "count", "pad")]
+
+
+class CaPart(ctypes.Structure):
+    """one piece of the combined attention's token row (mirrors `CaPart` in csrc/combined_attention.hip)"""
+    _fields_ = [("x", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("width", ctypes.c_int), ("ld", ctypes.c_int)]
 
 
 class CopyJob(ctypes.Structure):

@@ -30,6 +30,35 @@ constexpr int CA_TMAX = 256;
 constexpr int CA_NSTAT = 5;   // gamma, mx, 1/den, m, second moment
 constexpr int CA_PART = 3 * CA_HEADS + 1;
 
+// The T tokens of a graph may come from up to four row-major pieces laid side by side ([x_gat | z_vae], or the four pieces of a
+// (cancer, wild-type) pair): the kernels read them where they are -- no concatenation launch in front, no slice copies behind
+// (the backward writes each piece's gradient into its own contiguous tensor).
+constexpr int CA_MAX_PARTS = 4;
+struct CaPart { const float* x; float* dx; int width, ld; };
+struct CaParts { CaPart part[CA_MAX_PARTS]; int n; };
+
+__device__ __forceinline__ float ca_load(const CaParts& P, int b, int j) {
+  int off = 0;
+#pragma unroll
+  for (int p = 0; p < CA_MAX_PARTS; ++p) {
+    if (p < P.n) {
+      if (j < off + P.part[p].width) return P.part[p].x[(size_t)b * P.part[p].ld + (j - off)];
+      off += P.part[p].width;
+    }
+  }
+  return 0.0f;
+}
+__device__ __forceinline__ void ca_store_grad(const CaParts& P, int b, int j, float v) {
+  int off = 0;
+#pragma unroll
+  for (int p = 0; p < CA_MAX_PARTS; ++p) {
+    if (p < P.n) {
+      if (j < off + P.part[p].width) { P.part[p].dx[(size_t)b * P.part[p].ld + (j - off)] = v; return; }
+      off += P.part[p].width;
+    }
+  }
+}
+
 struct CaCoef {
   float A2[CA_HEADS], C2[CA_HEADS], alpha[CA_HEADS], beta;
 };
@@ -64,7 +93,7 @@ __device__ __forceinline__ void ca_coefficients(CaCoef& co, const float* wq, con
 
 template <int F>
 __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bq,
+    CaParts X, const float* __restrict__ wq, const float* __restrict__ bq,
     const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ bv,
     const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ z,
     float* __restrict__ stats, int T) {
@@ -76,7 +105,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   float lo = INFINITY, hi = -INFINITY;
   for (int j = tid; j < T; j += CA_THREADS) {
-    const float v = x[(size_t)b * T + j];
+    const float v = ca_load(X, b, j);
     c[j] = v;
     lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
@@ -119,10 +148,10 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
 
 template <int F>
 __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dz,
+    CaParts X, const float* __restrict__ stats, const float* __restrict__ dz,
     const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ Wc,
-    const float* __restrict__ bc, float* __restrict__ dx, float* __restrict__ partials, int T) {
+    const float* __restrict__ bc, float* __restrict__ partials, int T) {
   constexpr int D = F / CA_HEADS;
   __shared__ float c[CA_TMAX];
   __shared__ float dxi[CA_TMAX];
@@ -132,7 +161,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
   __shared__ float acc[4][CA_THREADS];
   const int tid = threadIdx.x, b = blockIdx.x;
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
-  for (int j = tid; j < T; j += CA_THREADS) c[j] = x[(size_t)b * T + j];
+  for (int j = tid; j < T; j += CA_THREADS) c[j] = ca_load(X, b, j);
   __syncthreads();
   const float rs = rsqrtf((float)D);
   const int items = CA_HEADS * T, hd = tid & 7;
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     if (tid < T) {
       float v = dxi[tid];
       for (int k = 0; k < split; ++k) v += (&acc[0][0])[k * CA_TMAX + tid];
-      dx[(size_t)b * T + tid] = v;
+      ca_store_grad(X, b, tid, v);
     }
   }
 }
@@ -256,28 +285,47 @@ extern "C" int is_comb_attn_stats_floats(int B, int T) { return B * is::CA_HEADS
 extern "C" int is_comb_attn_partials_floats(int B) { return B * is::CA_PART; }
 extern "C" int is_comb_attn_grad_floats(int F) { return 7 * F + F * F; }
 
-extern "C" int is_comb_attn_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* wv,
+static int ca_parts_from(is::CaParts& P, const void* parts, int nparts, int T, bool need_dx) {
+  if (nparts <= 0 || nparts > is::CA_MAX_PARTS) return -22;
+  const is::CaPart* src = static_cast<const is::CaPart*>(parts);
+  int total = 0;
+  for (int p = 0; p < nparts; ++p) {
+    P.part[p] = src[p];
+    if (src[p].x == nullptr || src[p].width <= 0 || src[p].ld < src[p].width || (need_dx && src[p].dx == nullptr)) return -22;
+    total += src[p].width;
+  }
+  P.n = nparts;
+  return total == T ? 0 : -22;
+}
+
+// parts: host array of nparts (<= 4) records { const float* x; float* dx; int width, ld; } -- the T = sum(width) scalar tokens of
+// graph b are the rows b of the pieces side by side (dx: the piece's gradient, written by the backward; unused in the forward)
+extern "C" int is_comb_attn_fwd(const void* parts, int nparts, const float* wq, const float* bq, const float* wk, const float* wv,
                                 const float* bv, const float* Wc, const float* bc, float* z, float* stats, int B,
                                 int T, int F, void* stream) {
   if (B <= 0) return 0;
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
+  is::CaParts P;
+  if (ca_parts_from(P, parts, nparts, T, false) != 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (F == 16) hipLaunchKernelGGL(is::comb_attn_fwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
-  else hipLaunchKernelGGL(is::comb_attn_fwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, x, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
+  if (F == 16) hipLaunchKernelGGL(is::comb_attn_fwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
+  else hipLaunchKernelGGL(is::comb_attn_fwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int is_comb_attn_bwd(const float* x, const float* stats, const float* dz, const float* wq, const float* bq,
+extern "C" int is_comb_attn_bwd(const void* parts, int nparts, const float* stats, const float* dz, const float* wq, const float* bq,
                                 const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
-                                float* dx, float* partials, float* grads, int B, int T, int F, void* stream) {
+                                float* partials, float* grads, int B, int T, int F, void* stream) {
   if (B <= 0) return 0;
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
+  is::CaParts P;
+  if (ca_parts_from(P, parts, nparts, T, true) != 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (F == 16) {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
+    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   } else {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, x, stats, dz, wq, bq, wk, wv, bv, Wc, bc, dx, partials, T);
+    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -164,15 +164,22 @@ constexpr int WG_PROJ = 128 * 64 + 128;
 constexpr int WG_NODE = 64 * 128 + 64 * 64 + 128;
 constexpr int WG_STRIDE = WG_PROJ + WG_NODE;
 
+// two sets of row tiles: chunk c+1 is staged into one set while the MFMAs of chunk c read the other -- ONE barrier per chunk
+struct WgradSmem {
+  static constexpr int LDP = 132;
+  float Ps2[2][16 * LDP], Xs2[2][16 * LDP];
+  float Hs2[2][16 * LD], Gs2[2][16 * LD], As2[2][16 * LD], Zs2[2][16 * LD];
+  float vec[4][4][64];
+};
+
 template <int DIN>
-__device__ __forceinline__ void egnn_node_wgrad16_body(
+__device__ __forceinline__ void egnn_node_wgrad16_body(WgradSmem& sm,
     const float* __restrict__ g_psd, const float* __restrict__ h_out, int ld_ho, int dho, const float* __restrict__ dh,
     const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
     const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
-  constexpr int LDP = 132;
-  __shared__ float Ps[16 * LDP], Xs[16 * LDP];
-  __shared__ float Hs[16 * LD], Gs[16 * LD], As[16 * LD], Zs[16 * LD];
-  __shared__ float vec[4][4][64];
+  constexpr int LDP = WgradSmem::LDP;
+  auto& Ps2 = sm.Ps2; auto& Xs2 = sm.Xs2; auto& Hs2 = sm.Hs2; auto& Gs2 = sm.Gs2; auto& As2 = sm.As2; auto& Zs2 = sm.Zs2;
+  auto& vec = sm.vec;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const bool has_psd = g_psd != nullptr;
@@ -204,10 +211,8 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
       rxn[i] = (has_node && valid) ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
     }
   };
-  if (r_begin < r_end) fetch(r_begin);
-  for (int c0 = r_begin; c0 < r_end; c0 += 16) {
-    __syncthreads();
-    // ---- stage 16 rows: wave w stages rows 4w .. 4w+3 (lane = column) ----
+  auto stage = [&](int c0, int buf) {      // registers -> LDS set `buf`: wave w stages rows 4w .. 4w+3 (lane = column)
+    float *Ps = Ps2[buf], *Xs = Xs2[buf], *Hs = Hs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int lr = wave * 4 + i;
@@ -225,8 +230,17 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
         Xs[lr * LDP + 64 + lane] = rxn[i];
       }
     }
-    __syncthreads();
-    if (c0 + 16 < r_end) fetch(c0 + 16);
+  };
+  if (r_begin < r_end) {
+    fetch(r_begin);
+    stage(r_begin, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = r_begin; c0 < r_end; c0 += 16, buf ^= 1) {
+    const bool more = c0 + 16 < r_end;
+    if (more) fetch(c0 + 16);        // in flight while this chunk's MFMAs run
+    const float *Ps = Ps2[buf], *Xs = Xs2[buf], *Hs = Hs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
     // ---- outer products: contraction over the 16 staged rows ----
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -255,6 +269,8 @@ __device__ __forceinline__ void egnn_node_wgrad16_body(
         }
       }
     }
+    if (more) stage(c0 + 16, buf ^ 1);
+    __syncthreads();      // the other set is complete, and every wave is done reading this one
   }
   // ---- partial record ----
   float* part = partials + (size_t)blockIdx.x * WG_STRIDE;
@@ -297,11 +313,12 @@ constexpr int WGRAD_MAX_LAYERS = 8;
 struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
 
 __global__ __launch_bounds__(256, 2) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
+  __shared__ WgradSmem sm;      // one copy for both instantiations of the body
   const WgradLayer& L = batch.layer[blockIdx.y];
   if (L.din == 20)
-    egnn_node_wgrad16_body<20>(L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+    egnn_node_wgrad16_body<20>(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
   else
-    egnn_node_wgrad16_body<64>(L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+    egnn_node_wgrad16_body<64>(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
 }
 
 }  // namespace is

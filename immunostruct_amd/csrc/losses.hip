@@ -49,7 +49,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
     const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ d_mu,
     float* __restrict__ d_logvar, int latent_total,
     const float* __restrict__ logit, const float* __restrict__ y, float* __restrict__ d_logit, int batch,
-    int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ out) {
+    int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ out, float* __restrict__ total) {
   __shared__ float red[3][LOSS_BLOCK / 64];
   const int tid = threadIdx.x;
   // the three per-thread partial sums first (their loads are independent: all in flight together), then ONE pass of
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
   const float pred = (((red[2][0] + red[2][1]) + red[2][2]) + red[2][3]) * invb;
   if (tid == 0) {
     out[0] = c_pred * pred + c_mse * mse + c_kld * kld;
+    if (total != nullptr) total[0] = out[0];
     out[1] = pred; out[2] = mse; out[3] = kld;
   }
 }
@@ -108,7 +109,7 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
                            const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total,
                            const float* logit, const float* y, float* d_logit, int batch, int mode,
                            float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out,
-                           void* stream) {
+                           float* total, void* stream) {
   if (batch <= 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int nparts = 0;
@@ -120,6 +121,6 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
   }
   hipLaunchKernelGGL(is::loss_finish_kernel, dim3(1), dim3(is::LOSS_BLOCK), 0, st, partials, nparts, recon_total, mu,
                      logvar, d_mu, d_logvar, latent_total, logit, y, d_logit, batch, mode, pos_weight, c_pred, c_mse,
-                     c_kld, out);
+                     c_kld, out, total);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

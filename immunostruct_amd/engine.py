@@ -291,7 +291,8 @@ class CapturedTrainStep:
         self.reducer.zero()
         loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         Stamps.mark("loss done")
-        loss.backward()
+        from .functional import unit_gradient
+        loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
         Stamps.mark("backward done (main stream)")
         return loss.detach()
 
@@ -335,10 +336,10 @@ class CapturedTrainStep:
         if self._late is None:
             self._classify(loss, bnd)      # first eager step
             if not self.two_stage:
-                loss.backward()
+                loss.backward(HF.unit_gradient(loss.device))
                 self._bnd = self._bnd_grads = None
                 return loss.detach()
-        outs = torch.autograd.grad(loss, bnd + self._early, allow_unused=True)
+        outs = torch.autograd.grad(loss, bnd + self._early, grad_outputs=HF.unit_gradient(loss.device), allow_unused=True)
         pairs = [(t, g) for t, g in zip(bnd, outs[:len(bnd)]) if g is not None]
         self._bnd, self._bnd_grads = [t for t, _ in pairs], [g for _, g in pairs]
         for p, g in zip(self._early, outs[len(bnd):]):

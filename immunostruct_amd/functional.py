@@ -614,56 +614,65 @@ def attn_pooled_tail(qk, x, wv, bv, wc, bc, b, n):
 
 
 class CombinedAttentionMeanFn(torch.autograd.Function):
-    """z (B,T) = mean over features of MultiHeadAttention(F, 8, input_dim=1) applied to the scalar tokens x (B,T)
-    (``csrc/combined_attention.hip``, closed form)."""
+    """z (B,T) = mean over features of MultiHeadAttention(F, 8, input_dim=1) applied to the scalar tokens of a row
+    (``csrc/combined_attention.hip``, closed form).  The row is given as 1-4 pieces (B, w_p) laid side by side -- the kernels
+    read them where they are (no ``torch.cat`` in front) and the backward returns one contiguous gradient per piece (no
+    slice copies behind)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wc, bc):
+    def forward(ctx, wq, bq, wk, bk, wv, bv, wc, bc, *pieces):
         lib = _lib.load()
-        _lib.require_device(x, wq, bq, wk, bk, wv, bv, wc, bc)
-        if x.dim() != 2:
-            raise ValueError("expected (batch, tokens)")
-        b, t = int(x.shape[0]), int(x.shape[1])
+        _lib.require_device(wq, bq, wk, bk, wv, bv, wc, bc, *pieces)
+        if not 1 <= len(pieces) <= 4 or any(p.dim() != 2 or p.shape[0] != pieces[0].shape[0] for p in pieces):
+            raise ValueError("expected 1 to 4 pieces of shape (batch, tokens_p)")
+        b, t = int(pieces[0].shape[0]), sum(int(p.shape[1]) for p in pieces)
         f = int(wc.shape[0])
         if f not in (16, 32) or t > 256:
             raise NotImplementedError("combined attention kernel supports feature_dim 16/32 and <= 256 tokens")
-        x = _lib.f32c(x)
+        rows = [(_lib.f32c(p), int(p.shape[1])) for p in pieces]      # dense pieces: one leading dimension serves x and dx
         wq, bq, wk, wv, bv, wc, bc = (_lib.f32c(v) for v in (wq, bq, wk, wv, bv, wc, bc))
-        dev = x.device
+        dev = pieces[0].device
         z = torch.empty(b, t, dtype=torch.float32, device=dev)
         need = any(ctx.needs_input_grad)
         stats = torch.empty(lib.is_comb_attn_stats_floats(b, t), dtype=torch.float32, device=dev) if need else None
+        parts = (_lib.CaPart * len(rows))(*[_lib.CaPart(x.data_ptr(), None, int(x.shape[1]), ld) for x, ld in rows])
         with KernelTimer.span("comb_attn_fwd"):
-            _lib.check(lib.is_comb_attn_fwd(_lib.ptr(x), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(bv),
-                                            _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), _lib.ptr(stats), b, t, f, _lib.stream_ptr()),
-                       "is_comb_attn_fwd")
+            _lib.check(lib.is_comb_attn_fwd(ctypes.cast(parts, ctypes.c_void_p), len(rows), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk),
+                                            _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), _lib.ptr(stats), b, t, f,
+                                            _lib.stream_ptr()), "is_comb_attn_fwd")
         ctx.dims = (b, t, f)
-        ctx.save_for_backward(x, stats, wq, bq, wk, wv, bv, wc, bc)
+        ctx.lds = [ld for _, ld in rows]
+        ctx.save_for_backward(stats, wq, bq, wk, wv, bv, wc, bc, *[x for x, _ in rows])
         return z
 
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.load()
-        x, stats, wq, bq, wk, wv, bv, wc, bc = ctx.saved_tensors
+        stats, wq, bq, wk, wv, bv, wc, bc = ctx.saved_tensors[:8]
+        xs = ctx.saved_tensors[8:]
         b, t, f = ctx.dims
-        dev = x.device
+        dev = dz.device
         dz = _lib.f32c(dz)
-        dx = torch.empty(b, t, dtype=torch.float32, device=dev)
+        dxs = [torch.empty(b, int(x.shape[1]), dtype=torch.float32, device=dev) for x in xs]
         part = torch.empty(lib.is_comb_attn_partials_floats(b), dtype=torch.float32, device=dev)
         g = torch.empty(lib.is_comb_attn_grad_floats(f), dtype=torch.float32, device=dev)
+        parts = (_lib.CaPart * len(xs))(*[_lib.CaPart(x.data_ptr(), d.data_ptr(), int(x.shape[1]), ld)
+                                          for x, d, ld in zip(xs, dxs, ctx.lds)])
         with KernelTimer.span("comb_attn_bwd"):
-            _lib.check(lib.is_comb_attn_bwd(_lib.ptr(x), _lib.ptr(stats), _lib.ptr(dz), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk),
-                                            _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(dx), _lib.ptr(part),
-                                            _lib.ptr(g), b, t, f, _lib.stream_ptr()), "is_comb_attn_bwd")
+            _lib.check(lib.is_comb_attn_bwd(ctypes.cast(parts, ctypes.c_void_p), len(xs), _lib.ptr(stats), _lib.ptr(dz), _lib.ptr(wq),
+                                            _lib.ptr(bq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc),
+                                            _lib.ptr(part), _lib.ptr(g), b, t, f, _lib.stream_ptr()), "is_comb_attn_bwd")
         col = lambda i: g[i * f:(i + 1) * f]
-        return (dx, col(0).view(f, 1), col(1), col(2).view(f, 1), col(3), col(4).view(f, 1), col(5),
-                g[6 * f:6 * f + f * f].view(f, f), g[6 * f + f * f:7 * f + f * f])
+        return (col(0).view(f, 1), col(1), col(2).view(f, 1), col(3), col(4).view(f, 1), col(5),
+                g[6 * f:6 * f + f * f].view(f, f), g[6 * f + f * f:7 * f + f * f]) + tuple(dxs)
 
 
 def combined_attention_mean(x, mha):
-    """``mha``: a models.layers.MultiHeadAttention built with input_dim=1 and 8 heads."""
-    return CombinedAttentionMeanFn.apply(x, mha.w_q.weight, mha.w_q.bias, mha.w_k.weight, mha.w_k.bias,
-                                         mha.w_v.weight, mha.w_v.bias, mha.w_concat.weight, mha.w_concat.bias)
+    """``mha``: a models.layers.MultiHeadAttention built with input_dim=1 and 8 heads; ``x``: (batch, tokens) or a list of 1-4
+    pieces (batch, tokens_p) that form the row side by side."""
+    pieces = list(x) if isinstance(x, (list, tuple)) else [x]
+    return CombinedAttentionMeanFn.apply(mha.w_q.weight, mha.w_q.bias, mha.w_k.weight, mha.w_k.bias,
+                                         mha.w_v.weight, mha.w_v.bias, mha.w_concat.weight, mha.w_concat.bias, *pieces)
 
 
 def fused_head_available(n_layers):
@@ -751,7 +760,17 @@ def dropout_mask(rows, cols, p, device):
     return torch.nn.functional.dropout(_ones_cache[key], p=p, training=True)
 
 
-def sequential_mlp2(seq, x):
+def sequential_dropout_mask(seq, rows, device):
+    """the scaled keep-mask :func:`sequential_mlp2` would draw for ``seq`` on ``rows`` samples (None in eval mode / p = 0) -- so that
+    a caller can draw it EARLY, off the critical path (the models draw the classifier's mask on the sequence branch's stream)"""
+    mods = [m for m in seq if not isinstance(m, torch.nn.Flatten)]
+    if len(mods) < 4 or not isinstance(mods[2], torch.nn.Dropout) or not isinstance(mods[0], torch.nn.Linear):
+        return None
+    dr = mods[2]
+    return dropout_mask(rows, mods[0].out_features, dr.p, device) if (seq.training and dr.p > 0) else None
+
+
+def sequential_mlp2(seq, x, mask="draw"):
     """Run an ``nn.Sequential`` of the form [Flatten,] Linear, ReLU, Dropout, Linear [, ReLU] (the reference's classifier
     and property embedding) through :func:`mlp2`; returns None when the module does not have that form or the sizes
     exceed the kernel's limits (the caller then uses the module itself)."""
@@ -763,7 +782,8 @@ def sequential_mlp2(seq, x):
           and isinstance(l2, torch.nn.Linear) and (len(mods) == 4 or isinstance(mods[4], torch.nn.ReLU)))
     if not ok or l1.in_features > 256 or l1.out_features > 64 or l2.out_features > 64 or l1.bias is None or l2.bias is None:
         return None
-    mask = dropout_mask(x.shape[0], l1.out_features, dr.p, x.device) if (seq.training and dr.p > 0) else None
+    if isinstance(mask, str):      # "draw": draw the keep-mask now; otherwise the caller's (possibly None) pre-drawn mask
+        mask = dropout_mask(x.shape[0], l1.out_features, dr.p, x.device) if (seq.training and dr.p > 0) else None
     return mlp2(x, l1.weight, l1.bias, l2.weight, l2.bias, mask=mask, act1=1, act2=1 if len(mods) == 5 else 0)
 
 
@@ -1014,16 +1034,16 @@ class VaeLossFn(torch.autograd.Function):
         d_logit = torch.empty(b, dtype=torch.float32, device=dev)
         partials = torch.empty(lib.is_loss_partials_floats(), dtype=torch.float32, device=dev)
         out = torch.empty(4, dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)      # its own buffer: no clone launch for the differentiable result
         code = lib.is_vae_loss(_lib.ptr(recon_c), _lib.ptr(x_c), _lib.ptr(d_recon), rt, _lib.ptr(mu_c), _lib.ptr(lv_c),
                                _lib.ptr(d_mu), _lib.ptr(d_lv), lt, _lib.ptr(logit_c), _lib.ptr(y_c), _lib.ptr(d_logit),
                                b, int(mode), float(pos_weight), float(c_pred), float(c_mse), float(c_kld),
-                               _lib.ptr(partials), _lib.ptr(out), _lib.stream_ptr())
+                               _lib.ptr(partials), _lib.ptr(out), _lib.ptr(total), _lib.stream_ptr())
         _lib.check(code, "is_vae_loss")
         ctx.seq = seq
         ctx.logit_shape = logit.shape
         ctx.set_materialize_grads(False)       # no zero-fill launch for the (non-differentiable) term vector's gradient
         ctx.save_for_backward(d_recon, d_mu, d_lv, d_logit)
-        total = out[0].clone()
         ctx.mark_non_differentiable(out)
         return total, out
 
@@ -1032,11 +1052,27 @@ class VaeLossFn(torch.autograd.Function):
         d_recon, d_mu, d_lv, d_logit = ctx.saved_tensors
         if g is None:
             return (None,) * 11
+        if g is _unit_gradients.get((g.device.type, g.device.index)):
+            # the engine seeds the backward with unit_gradient(): d loss / d loss = 1 exactly, no scaling launches
+            return d_recon, None, d_mu, d_lv, d_logit.reshape(ctx.logit_shape), None, None, None, None, None, None
         if ctx.seq:
             gr, gm, gl, gz = torch._foreach_mul([d_recon, d_mu, d_lv, d_logit], g)     # one multi-tensor launch
         else:
             gr, gm, gl, gz = None, None, None, d_logit * g
         return gr, None, gm, gl, gz.reshape(ctx.logit_shape), None, None, None, None, None, None
+
+
+_unit_gradients = {}
+
+
+def unit_gradient(device):
+    """THE ones scalar to seed ``loss.backward(unit_gradient(dev))`` with: ``VaeLossFn`` recognises it by identity and hands
+    its stored gradients on unscaled (no ones_like fill, no multi-tensor multiply of the 3 MB reconstruction gradient)"""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _unit_gradients:
+        _unit_gradients[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _unit_gradients[key]
 
 
 def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):

@@ -217,6 +217,10 @@ class MultimodalNet(nn.Module):
                     z = torch.cat([z, p], dim=1)
                 recon = self.decode_vae(z)
             o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=recon)
+        if not sp.ssl and prop.is_cuda:
+            # the classifier's dropout mask, drawn here -- on the sequence branch's stream, long before the head needs it
+            rows = prop.shape[0] // 2 if self._pair_rows else prop.shape[0]
+            o["_cls_mask"] = (HF.sequential_dropout_mask(self.classifier, rows, prop.device),)
         return o
 
     def _encode(self, g, seq, prop, need_attention=False):
@@ -243,20 +247,25 @@ class MultimodalNet(nn.Module):
         if overlap:
             main.wait_stream(side)
             for t in o.values():
-                if torch.is_tensor(t):
-                    t.record_stream(main)
+                for u in (t if isinstance(t, tuple) else (t,)):
+                    if torch.is_tensor(u):
+                        u.record_stream(main)
         else:
             o.update(self._encode_sequence(seq, prop))
         return o
 
-    def _head(self, fused):
+    def _head(self, pieces, cls_mask=None):
+        """``pieces``: the fused row as a list of (B, w) tensors laid side by side"""
         if self.SPEC.comb:
             ca = self.combined_attention
-            if ca.n_head == 8 and ca.w_q.in_features == 1 and fused.shape[1] <= 256:
-                fused = HF.combined_attention_mean(fused, ca)     # closed-form HIP kernel
+            if ca.n_head == 8 and ca.w_q.in_features == 1 and sum(p.shape[1] for p in pieces) <= 256 and len(pieces) <= 4:
+                # closed-form HIP kernel; reads the pieces where they are (no concatenation, no slice copies in backward)
+                fused = HF.combined_attention_mean(pieces, ca)
             else:
-                fused = ca(fused.unsqueeze(2))[0].mean(dim=2)
-        hid = HF.sequential_mlp2(self.classifier, fused.flatten(1)) if not self.SPEC.ssl else None
+                fused = ca(torch.cat(pieces, dim=1).unsqueeze(2))[0].mean(dim=2)
+        else:
+            fused = torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0]
+        hid = HF.sequential_mlp2(self.classifier, fused.flatten(1), mask=cls_mask[0] if cls_mask else "draw") if not self.SPEC.ssl else None
         if hid is None:
             hid = self.classifier(fused)
         if self.SPEC.ssl:
@@ -278,10 +287,9 @@ class MultimodalNet(nn.Module):
             parts = [o["x_gat_node"], o["z_vae"]]
             if sp.paired and self.use_wt_for_downstream:
                 parts = parts * 2   # single-sample pretraining of a paired model
-            fused = torch.cat(parts, dim=1)
         else:
-            fused = o["x_gat_node"] if sp.graph else o["z_vae"]
-        final, node_pred = self._head(fused)
+            parts = [o["x_gat_node"] if sp.graph else o["z_vae"]]
+        final, node_pred = self._head(parts, o.get("_cls_mask"))
         first = o.get("recon_x")
         if sp.graph and sp.vae:
             if return_embedding:
@@ -333,10 +341,12 @@ class MultimodalNet(nn.Module):
         if not self.SPEC.paired:
             raise AttributeError(f"{type(self).__name__} has no comparative forward")
         oc, ow = self._encode_pair(graph_data_pair, sequence_data_pair, peptide_property_pair, return_attention)
-        emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)
+        emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)      # returned to the caller (contrastive loss)
         emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)
-        fused = torch.cat([emb_c, emb_w], dim=1) if self.use_wt_for_downstream else emb_c
-        final, node_pred = self._head(fused)
+        pieces = [oc["x_gat_node"], oc["z_vae"]]
+        if self.use_wt_for_downstream:
+            pieces += [ow["x_gat_node"], ow["z_vae"]]
+        final, node_pred = self._head(pieces, oc.get("_cls_mask"))
         tail = (node_pred,) if self.SPEC.ssl else ()
         if return_embedding:
             return (oc["x_gat_node"], oc["mu"], oc["logvar"], final) + tail

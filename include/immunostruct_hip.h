@@ -278,23 +278,27 @@ int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, cons
 int is_comb_attn_stats_floats(int B, int T);
 int is_comb_attn_partials_floats(int B);
 int is_comb_attn_grad_floats(int F);
-int is_comb_attn_fwd(const float* x, const float* wq, const float* bq, const float* wk, const float* wv,
+/* parts: host array of nparts (<= 4) records { const float* x; float* dx; int width, ld; }: the T = sum(width) scalar tokens of
+ * graph b are the rows b of these pieces side by side ([x_gat | z_vae], or the four pieces of a pair) -- read where they are, and
+ * the backward writes each piece's gradient into its own tensor dx (no concatenation in front, no slice copies behind).   */
+int is_comb_attn_fwd(const void* parts, int nparts, const float* wq, const float* bq, const float* wk, const float* wv,
                      const float* bv, const float* Wc, const float* bc, float* z, float* stats, int B,
                      int T, int F, void* stream);
-int is_comb_attn_bwd(const float* x, const float* stats, const float* dz, const float* wq, const float* bq,
+int is_comb_attn_bwd(const void* parts, int nparts, const float* stats, const float* dz, const float* wq, const float* bq,
                      const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
-                     float* dx, float* partials, float* grads, int B, int T, int F, void* stream);
+                     float* partials, float* grads, int B, int T, int F, void* stream);
 
 /* floats of scratch is_vae_loss needs */
 int is_loss_partials_floats(void);
 /* mode 0: c_pred*MSE(logit,y), mode 1: c_pred*BCEWithLogits(logit,y,pos_weight);
  * + c_mse*MSE(recon,x) + c_kld*(-0.5*mean(1+logvar-mu^2-exp(logvar))).
  * recon/x/d_recon may be NULL with recon_total = 0, mu/logvar likewise with latent_total = 0.
- * out[4] = {total, prediction term, recon MSE, KLD}; d_* receive d total / d input.           */
+ * out[4] = {total, prediction term, recon MSE, KLD}; total (may be NULL) receives out[0] as well (its own buffer:
+ * the differentiable result); d_* receive d total / d input.                                                        */
 int is_vae_loss(const float* recon, const float* x, float* d_recon, long long recon_total,
                 const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total,
                 const float* logit, const float* y, float* d_logit, int batch, int mode,
-                float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out,
+                float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out, float* total,
                 void* stream);
 
 #ifdef __cplusplus

@@ -307,6 +307,15 @@ def test_combined_attention_closed_form(cuda_device, feat, tokens):
             assert float(p.grad.abs().max()) == 0.0, name      # key bias: exactly no influence
         else:
             H.assert_close(p.grad.cpu(), refg, 2e-5, f"combined attention d{name}")
+    # the same row handed over as pieces laid side by side (what the models do: [x_gat | z_vae], or the four pieces of a pair):
+    # same bits as the concatenated row, one contiguous gradient per piece
+    cuts = [0, 64, tokens] if tokens == 104 else [0, 64, 104, 168, tokens]
+    pieces = [torch.from_numpy(x[:, a:b_].copy()).to(cuda_device).requires_grad_(True) for a, b_ in zip(cuts, cuts[1:])]
+    zp = HF.combined_attention_mean(pieces, mha)
+    assert torch.equal(zp, z)
+    (zp * torch.from_numpy(gup).to(cuda_device)).sum().backward()
+    assert torch.equal(torch.cat([p.grad for p in pieces], dim=1), xd.grad)
+    assert all(p.grad.is_contiguous() for p in pieces)
 
 
 @pytest.mark.parametrize("heads,n", [(1, 190), (8, 190), (1, 45), (8, 9), (1, 256), (8, 70)])
