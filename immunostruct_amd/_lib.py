@@ -36,7 +36,7 @@ SIGNATURES = {
     "is_reduce_partials_scratch_floats": [_I],
     "is_reduce_partials": [_P, _I, _I, _I, _P, _P, _P, _P],
     "is_node_pack_floats": [],
-    "is_stack_prologue": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
+    "is_stack_prologue": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
@@ -61,6 +61,7 @@ SIGNATURES = {
     "is_attn_colmean_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_fwd_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_attn_colmean_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_attn_colmean_bwd_tail": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "is_attn_colmean_probs_floats": [_I, _I, _I],
     "is_comb_attn_stats_floats": [_I, _I],
     "is_comb_attn_partials_floats": [_I],
@@ -84,8 +85,8 @@ class WgradLayer(ctypes.Structure):
 
 class NodePackJob(ctypes.Structure):
     """one layer of is_node_pack_weights (mirrors `NodePackJob` in csrc/egnn_node16.hip)"""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("Wn1", "Wn2", "W1n", "fpack", "bpack")] + \
-               [(n, ctypes.c_int) for n in ("din", "ldw_n", "pad0", "pad1")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Wn1", "Wn2", "W1n", "W1nb", "fpack", "bpack")] + \
+               [(n, ctypes.c_int) for n in ("din", "ldw_n")]
 
 
 class ReduceJob(ctypes.Structure):

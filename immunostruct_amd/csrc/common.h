@@ -232,11 +232,24 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
 }
+// bounded view: accesses at byte offsets (voff + instruction offset) >= nbytes return 0 / are dropped by the hardware -- the
+// range check that replaces per-element predication (the scalar offset is NOT part of the check: put it into the base).
+__device__ __forceinline__ rsrc_t make_rsrc_n(const void* p, int nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000);
+}
+constexpr int BUF_OOB = 0x7ffff000;      // a voffset that is out of range for every bounded view
 __device__ __forceinline__ float buf_load(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 __device__ __forceinline__ int buf_load_i(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+// three consecutive floats (a node's coordinates): three dword loads off ONE offset register (the b96 builtin of this
+// toolchain loads a single dword)
+__device__ __forceinline__ void buf_load3(rsrc_t rs, int voff, int soff, float& a, float& b, float& c) {
+  a = buf_load(rs, voff, soff);
+  b = buf_load(rs, voff + 4, soff);
+  c = buf_load(rs, voff + 8, soff);
 }
 __device__ __forceinline__ void buf_store(float v, rsrc_t rs, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);

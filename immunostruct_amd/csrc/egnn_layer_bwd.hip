@@ -30,8 +30,10 @@ namespace is {
 #ifdef IS_STAGE_STAMPS
 __device__ long long g_stamps_b[24];
 #define STAMPB(k) do { if (blockIdx.x == 300 && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPP(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMPB(k) do { } while (0)
+#define STAMPP(k) do { } while (0)
 #endif
 
 constexpr int WB16 = 4;
@@ -46,7 +48,6 @@ struct Bwd16Smem {
   float bufB[WB16][TE16 * LD];
   float pdt[NVB * H];   // Pd rows of this tile's destination nodes
   int rp[NVB + 1];
-  int e_src[WB16][TE16];
   int e_dl[WB16][TE16];
   float e_ra[WB16][TE16 * (FE_MAX + 1)];   // per edge: [radial | edge features]: the B operand of the dw_r / dW_a outer product
   float wa[FE_MAX > 1 ? FE_MAX * H : 1];   // W_a columns, lane = channel (registers when FE_MAX == 1)
@@ -101,12 +102,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
   static_assert(sizeof(float) * PROWS * (LDP + 2 * LD) <= sizeof(float) * (2 * H * LD + 2 * WB16 * TE16 * LD),
                 "the node phase's tiles must fit the (not yet staged) weight tiles + window buffers");
   __shared__ Bwd16Smem<FE_MAX, NVB> sm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
   constexpr int RA_LD = FE_MAX + 1;
   const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
   const float* __restrict__ gxsrc = GATHER ? nb.gxtot : g_xout;
 
+  STAMPP(13);
   // ================= P1 + P2: source gather and node data path of ALL tiles of this workgroup =================
   // (before the persistent edge loop: its weight-gradient accumulators do not exist yet, so the 80 operand registers
   //  of the node phase cost nothing, they are fetched once per workgroup, and the gathers of several tiles overlap)
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
     float* ps_ = &sm.w2t[0];                  // [PROWS][LDP]  g_psd rows     (w2t | wc1t | bufA | bufB are contiguous)
     float* gs = ps_ + PROWS * LDP;            // [PROWS][LD]   dh
     float* zs = gs + PROWS * LD;              // [PROWS][LD]   dzn1
-    int* tv0 = &sm.e_src[0][0];               // [TPP] first node of the pass's tiles | [TPP] their node counts
+    int* tv0 = &sm.e_dl[0][0];                // [TPP] first node of the pass's tiles | [TPP] their node counts
     const bool has_psd = nb.g_psd != nullptr;
     const int col = wave * 16 + r;
     // transposed-weight operands of this wave's output columns (operand pack: coalesced 16-byte loads, L2)
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         }
       }
       __syncthreads();
+      STAMPP(14);
       if (has_psd) {      // dh = g_h + g_psd W1sd
         f32x4 acc[MT];
         zero_acc4(acc);
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           }
         __syncthreads();
       }
+      STAMPP(15);
       {     // da1 = dh Wn2 ; dzn1 = da1 * SiLU'(zn1)
         f32x4 acc[MT];
         zero_acc4(acc);
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           }
       }
       __syncthreads();
+      STAMPP(16);
       // [d_h | d_hneigh] = dzn1 Wn1: wave w produces columns [32w, 32w + 32) of the (DIN + 64)-wide row
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         }
       }
       __syncthreads();     // the pass's tiles are dead; d_hn / gxtot rows of these tiles are visible to the whole workgroup
+      STAMPP(17);
     }
   }
 
@@ -342,7 +349,13 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 
   float* bufA = sm.bufA[wave];
   float* bufB = sm.bufB[wave];
-  constexpr int NPW = NVB / WB16;
+  // raw-buffer views: scalar bases, one lane-constant byte offset per access pattern, range-checked where rows past a
+  // tile's end must read as zero / must not be written (no per-element predication, no 64-bit vector address math)
+  const int voff_tile = (4 * q * H + r) * 4;            // element (row 4q [+ t], column r [+ 16 nt]) of a [16][64] tile
+  const int ld_p_bytes = ld_p * 4;
+  const rsrc_t rs_ps = make_rsrc(ps), rs_pd = make_rsrc(pd), rs_x = make_rsrc(x), rs_srcs = make_rsrc(srcs);
+  const rsrc_t rs_ghn = make_rsrc_n(g_hn, N * H * 4);
+  const rsrc_t rs_gx = make_rsrc(gxsrc), rs_ea = make_rsrc(ea);
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     STAMPB(0);
@@ -353,17 +366,22 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NVB / WB16; ++i) {
       const int nl = wave * (NVB / WB16) + i;
-      sm.pdt[nl * H + lane] = (nl < nv) ? pd[(size_t)(v0 + nl) * ld_p + lane] : 0.0f;
+      sm.pdt[nl * H + lane] = (nl < nv) ? buf_load(rs_pd, lane * 4, (v0 + nl) * ld_p_bytes) : 0.0f;
     }
     __syncthreads();
-    const int e_begin = sm.rp[0], e_end = sm.rp[nv];
-    float acc_h[NPW], acc_x[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) { acc_h[i] = 0.0f; acc_x[i] = 0.0f; }
+    const int e_begin = __builtin_amdgcn_readfirstlane(sm.rp[0]), e_end = __builtin_amdgcn_readfirstlane(sm.rp[nv]);
+    // destination-side segment sums as MFMA products with the 0 / 1 incidence of the tile (exact products; fixed order):
+    //   seg_h[m][t]: node 16 m + 4 q + t, column 16 wave + r        seg_x (wave XW only): same node, coordinate r < 3
+    constexpr int MTN = (NVB + 15) / 16, XW = WB16 - 1;
+    f32x4 seg_h[MTN], seg_x[MTN];
+    zero_acc4(seg_h);
+    zero_acc4(seg_x);
 
     for (int win = e_begin; win < e_end; win += WB16 * TE16) {
       const int cb = win + wave * TE16;
-      const int nvalid = max(0, min(TE16, e_end - cb));
+      const int nvalid = __builtin_amdgcn_readfirstlane(max(0, min(TE16, e_end - cb)));
+      int vt = voff_tile;      // opaque per window: the constant parts of the 48 tile accesses then stay instruction offsets
+      asm volatile("" : "+v"(vt));      // (hoisted out of the loop they would be 16 more live registers)
       STAMPB(1);
       float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
       float up[4][4];   // dL/dh_neigh[dst] for this tile (prefetched)
@@ -371,17 +389,19 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
       // the saved pre-activation tiles only depend on the window position: issue their loads first so that
       // they are in flight during S0's dependent (src index -> coordinates) chain
       float z3v[4][4], z2v[4][4];
+      // bounded views of this wave's 16 rows: rows past the tile's last edge read as z = 0 (SiLU(0) = 0: such rows then
+      // contribute nothing below without any mask) and are not written
+      const rsrc_t rz2 = make_rsrc_n(z2s + (size_t)cb * H, nvalid * H * 4);
+      const rsrc_t rz3 = make_rsrc_n(GX ? z3s + (size_t)cb * H : z2s, GX ? nvalid * H * 4 : 0);
+      const rsrc_t rdz1 = make_rsrc_n(dZ1 + (size_t)cb * H, nvalid * H * 4);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          // unconditional (row clamped into the tile's edge range; rows past nvalid are masked where they are used):
-          // predicated loads cost the compiler its count of loads in flight, and every later wait becomes vmcnt(0)
-          const int row = tile16_row(t, q);
-          const size_t off = (size_t)min(cb + row, e_end - 1) * H + nt * 16 + r;
-          if constexpr (GX) z3v[t][nt] = z3s[off];
-          z2v[t][nt] = z2s[off];
+          if constexpr (GX) z3v[t][nt] = buf_load(rz3, vt + (t * H + nt * 16) * 4, 0);
+          z2v[t][nt] = buf_load(rz2, vt + (t * H + nt * 16) * 4, 0);
         }
+      int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
       if (nvalid > 0) {
         // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
         {
@@ -389,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           const int l16 = lane & (TE16 - 1);
           const bool valid = l16 < nvalid;
           const int e = min(cb + l16, e_end - 1);
-          const int s = srcs[e];
+          const int s = buf_load_i(rs_srcs, e * 4, 0);
+          src_lane = s;
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -397,13 +418,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           }
           const int dl = valid ? lo : 0;
           const int v = v0 + dl;
-          const float xs0 = x[s * 3 + 0], xs1 = x[s * 3 + 1], xs2 = x[s * 3 + 2];
-          const float xv0 = x[v * 3 + 0], xv1 = x[v * 3 + 1], xv2 = x[v * 3 + 2];
+          float xs0, xs1, xs2, xv0, xv1, xv2;
+          buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
+          buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
           float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
-          if constexpr (GX) { gx0 = gxsrc[v * 3 + 0]; gx1 = gxsrc[v * 3 + 1]; gx2 = gxsrc[v * 3 + 2]; }
+          if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
           float av[FE_MAX];
 #pragma unroll
-          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? ea[(size_t)e * Fe + f] : 0.0f;      // Fe is kernel-uniform
+          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
           float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
           float rad = radial3(d0, d1, d2);
           float rr = sqrtf(rad);
@@ -412,7 +434,6 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
           if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
           if (lane < TE16) {
-            sm.e_src[wave][lane] = valid ? s : v0;
             sm.e_dl[wave][lane] = dl;
             sm.e_ra[wave][lane * RA_LD] = rad;
             sm.e_r[wave][lane] = rr;
@@ -432,9 +453,10 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
-          const int v = v0 + sm.e_dl[wave][row];      // e_dl = 0 for rows past nvalid: a valid node
+          // rows past nvalid: out of range => zero => dz2 = 0 there
+          const int vo = (row < nvalid) ? ((v0 + sm.e_dl[wave][row]) * H + r) * 4 : BUF_OOB;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) up[t][nt] = g_hn[(size_t)v * H + nt * 16 + r];      // written by the node phase
+          for (int nt = 0; nt < 4; ++nt) up[t][nt] = buf_load(rs_ghn, vo + nt * 64, 0);      // written by the node phase
         }
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
@@ -442,7 +464,6 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int row = tile16_row(t, q);
-            const bool rv = row < nvalid;
             float tt[4], sp[4];
             float part = 0.0f;
 #pragma unroll
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
               part += tt[nt] * wc2_c[nt];
               float mh;
               silu_fg(z2v[t][nt], mh, dy[t][nt]);
-              bufB[row * LD + nt * 16 + r] = rv ? mh : 0.0f;
+              bufB[row * LD + nt * 16 + r] = mh;      // rows past nvalid: SiLU(0) = 0
             }
             part = sum_over_r16(part);
             if (r == 0) sm.e_s[wave][row] = part;
@@ -476,10 +497,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         }
         // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
 #pragma unroll
-        for (int i = 0; i < TE16; ++i) {
-          const int s = sm.e_src[wave][i];
-          gth[i] = ps[(size_t)s * ld_p + lane];      // raw: not consumed before SA
-        }
+        for (int i = 0; i < TE16; ++i)      // one v_readlane + s_mul + buffer_load per row; not consumed before SA
+          gth[i] = buf_load(rs_ps, lane * 4, __builtin_amdgcn_readlane(src_lane, i) * ld_p_bytes);
       }
       if constexpr (GX) {
         STAMPB(3);
@@ -499,11 +518,9 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         if constexpr (GX) mm16_rows<4, H>(acc, bufA, sm.wc1t, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int row = tile16_row(t, q);
-          const bool rv = row < nvalid;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const float dz2 = rv ? (acc[nt][t] + up[t][nt]) * dy[t][nt] : 0.0f;
+            const float dz2 = (acc[nt][t] + up[t][nt]) * dy[t][nt];      // rows past nvalid: (0 + 0) * SiLU'(0)
             db2_a[nt] += dz2;
             dy[t][nt] = dz2;   // parked in registers until every wave has finished reading bufA / bufB
           }
@@ -532,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
               for (int f = 0; f < FE_MAX; ++f) z1 += sm.e_ra[wave][i * RA_LD + 1 + f] * sm.wa[f * H + lane];
             }
-            bufB[i * LD + lane] = (i < nvalid) ? z1 : 0.0f;
+            bufB[i * LD + lane] = z1;      // rows past nvalid: some finite value; their dz2 / dz1 are zero
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
             const float z1 = bufB[row * LD + nt * 16 + r];
             float y;
             silu_fg(z1, y, dy[t][nt]);
-            bufB[row * LD + nt * 16 + r] = (row < nvalid) ? y : 0.0f;
+            bufB[row * LD + nt * 16 + r] = y;
           }
         }
       }
@@ -567,12 +584,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
-          const bool rv = row < nvalid;
           float part = 0.0f;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const float dz1 = rv ? acc[nt][t] * dy[t][nt] : 0.0f;
-            if (rv) dZ1[(size_t)(cb + row) * H + nt * 16 + r] = dz1;
+            const float dz1 = acc[nt][t] * dy[t][nt];      // rows past nvalid: 0 (dz2 = 0)
+            buf_store(dz1, rdz1, vt + (t * H + nt * 16) * 4, 0);      // (rows past nvalid: dropped)
             dy[t][nt] = dz1;
             part += dz1 * wr_t[nt];
           }
@@ -628,41 +644,47 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
             dWra = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.bufA[wt][e * LD + wave * 16 + r], r <= FE_MAX ? b : 0.0f, dWra, 0, 0, 0);
           }
         }
-      // ---- SEG: destination-side segment sums (deterministic, CSR order) ----
-      {
-        const int win_hi = min(win + WB16 * TE16, e_end);
+      // ---- SEG: dPd[v] += sum over the window's in-edges of v of dz1, dx[v] -= sum of dL/dd -- as [nodes x edges] x
+      //      [edges x columns] products with the incidence matrix built from e_dl (rows past a tile's end: dz1 = dL/dd = 0).
+      //      Wave w owns columns [16 w, 16 w + 16); the coordinate columns ride on the last wave (the one whose edge tile
+      //      is empty in most windows).  Replaces a per-node loop over LDS rows (dependent reads: 4 k cycles per window).
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-          const int nl = wave + WB16 * i;
-          if (nl < nv) {
-            const int lo = max(sm.rp[nl], win), hi = min(sm.rp[nl + 1], win_hi);
-            float ah = acc_h[i], ax = acc_x[i];
-            for (int e = lo; e < hi; ++e) {
-              const int rel = e - win;
-              const int w = rel >> 4, row = rel & 15;
-              ah += sm.bufA[w][row * LD + lane];
-              if (lane < 3) ax += sm.e_gx[w][lane][row];
+      for (int wt = 0; wt < WB16; ++wt)
+        if (win + wt * TE16 < e_end) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int e = 4 * q + s;
+            const int dl = sm.e_dl[wt][e];
+            const float bh = sm.bufA[wt][e * LD + wave * 16 + r];
+            float bx = 0.0f;
+            if (wave == XW) bx = sm.e_gx[wt][min(r, 2)][e];
+#pragma unroll
+            for (int m = 0; m < MTN; ++m) {
+              const float ind = (dl == 16 * m + r) ? 1.0f : 0.0f;
+              seg_h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ind, bh, seg_h[m], 0, 0, 0);
+              if (wave == XW) seg_x[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ind, r < 3 ? bx : 0.0f, seg_x[m], 0, 0, 0);
             }
-            acc_h[i] = ah; acc_x[i] = ax;
           }
         }
-      }
       __syncthreads();
     }
 
     STAMPB(12);
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int nl = wave + WB16 * i;
-      if (nl < nv) {
-        const int v = v0 + nl;
-        dPd[(size_t)v * ld_dpd + lane] = acc_h[i];
-        if (lane < 3) dx[v * 3 + lane] = (GX ? gxsrc[v * 3 + lane] : 0.0f) - acc_x[i];
+    for (int m = 0; m < MTN; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int nl = 16 * m + tile16_row(t, q);
+        if (nl < nv) {
+          const int v = v0 + nl;
+          dPd[(size_t)v * ld_dpd + wave * 16 + r] = seg_h[m][t];
+          if (wave == XW && r < 3) dx[v * 3 + r] = (GX ? gxsrc[v * 3 + r] : 0.0f) - seg_x[m][t];
+        }
       }
-    }
   }
 
   // ---- write the workgroup's partial record: each wave owns 16 rows of dW2 / dWc1 ----
+  STAMPP(18);
   __syncthreads();
   float* part = partials + (size_t)blockIdx.x * PART16_STRIDE;
 #pragma unroll
@@ -702,6 +724,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
       part[2 * H * H + sidx * H + c] = v;
     }
   }
+  STAMPP(19);
 }
 
 }  // namespace is

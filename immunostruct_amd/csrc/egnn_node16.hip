@@ -33,9 +33,12 @@ __device__ __forceinline__ int align_of(const float* base, int ld) {
 }
 
 struct NodePackJob {
-  const float *Wn1, *Wn2, *W1n;     // W1n may be NULL (last layer without a projection head)
+  const float *Wn1, *Wn2;
+  const float *W1n, *W1nb;          // next pre-projection: rows of its source half / destination half (row stride ldw_n); NULL:
+                                    // last layer without a projection head.  A layer's edge_mlp.0.weight: W1nb = W1n + 64; a
+                                    // [Wq | Wk] head: the two matrices where they are (no concatenation in front)
   float *fpack, *bpack;
-  int din, ldw_n, pad0, pad1;
+  int din, ldw_n;
 };
 constexpr int NODE_PACK_MAX = 8;
 struct NodePackBatch { NodePackJob job[NODE_PACK_MAX]; };
@@ -52,6 +55,7 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
   const float* __restrict__ Wn1 = J.Wn1;
   const float* __restrict__ Wn2 = J.Wn2;
   const float* __restrict__ W1n = J.W1n;
+  const float* __restrict__ W1nb = J.W1nb;
   const int ldw_n = J.ldw_n;
   f32x4 fv[NODE_FWD_SLOTS], bv[NODE_BWD_SLOTS];
 #pragma unroll
@@ -72,7 +76,7 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int c = wave * 32 + nt * 16 + r;
-      const float* row = (c < 64) ? W1n + (size_t)c * ldw_n : W1n + (size_t)(c - 64) * ldw_n + 64;
+      const float* row = (c < 64) ? W1n + (size_t)c * ldw_n : W1nb + (size_t)(c - 64) * ldw_n;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -86,7 +90,7 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = q * 32 + 4 * g + j;
-        bv[g][j] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1n[(size_t)(c - 64) * ldw_n + 64 + col];
+        bv[g][j] = (c < 64) ? W1n[(size_t)c * ldw_n + col] : W1nb[(size_t)(c - 64) * ldw_n + col];
       }
   }
 #pragma unroll
@@ -108,47 +112,87 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
   for (int i = 0; i < NODE_BWD_SLOTS; ++i) bp[i * 64] = bv[i];
 }
 
-// The stack's prologue in ONE launch: blocks [0, proj_blocks) compute the layer-0 pre-projection psd = [h W1s^T + b0 |
-// h W1d^T + b1] (the body of node_proj_fwd_kernel, csrc/egnn_node.hip: lane = channel, a wave walks nodes), the
-// remaining njobs blocks write the operand packs (wave = former blockIdx.x of node_pack_kernel).  The two are
+// The stack's prologue in ONE launch: njobs blocks write the operand packs, proj_blocks blocks compute the layer-0
+// pre-projection psd = [h W1s^T + b0 | h W1d^T + b1] (lane = channel, a wave walks nodes; bit-identical to
+// node_proj_fwd_kernel of csrc/egnn_node.hip: same k order) and the dense copy of the coordinates.  The two are
 // independent -- the packs depend on the weights only -- so they run side by side instead of back to back.
 template <int DIN>
 __device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int ld_h, const float* __restrict__ W1, int ldw,
                                                 const float* __restrict__ b0, const float* __restrict__ b1,
-                                                float* __restrict__ psd, int N, int block, int nblocks) {
-  const int lane = threadIdx.x & 63;
-  float ws[DIN], wd[DIN];
+                                                float* __restrict__ psd, const float* __restrict__ x_src, int ld_x,
+                                                float* __restrict__ x_dst, int N, int block, int nblocks, float* wl) {
+  // the [W1s | W1d] column blocks go through LDS once per workgroup (near-coalesced row segments; a lane reading its own row
+  // straight from global memory touches 64 cache lines per load), row stride odd => conflict-free column reads
+  constexpr int LDWL = 2 * DIN + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    constexpr int CNT = 64 * 2 * DIN, PER = (CNT + 255) / 256;
+    float v[PER];
 #pragma unroll
-  for (int k = 0; k < DIN; ++k) {
-    ws[k] = W1[lane * ldw + k];
-    wd[k] = W1[lane * ldw + DIN + k];
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * 256;
+      v[j] = (i < CNT) ? W1[(i / (2 * DIN)) * ldw + i % (2 * DIN)] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * 256;
+      if (i < CNT) wl[(i / (2 * DIN)) * LDWL + i % (2 * DIN)] = v[j];
+    }
   }
   const float bias = b1[lane];
   const float bias0 = b0 != nullptr ? b0[lane] : 0.0f;
-  for (int n = block * 4 + (threadIdx.x >> 6); n < N; n += nblocks * 4) {
-    const float hv = (lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
-    float as = bias0, ad = bias;
+  __syncthreads();
+  float ws[DIN], wd[DIN];
 #pragma unroll
-    for (int k = 0; k < DIN; ++k) {
-      const float hk = __shfl(hv, k, 64);
-      as += hk * ws[k];
-      ad += hk * wd[k];
+  for (int k = 0; k < DIN; ++k) {
+    ws[k] = wl[lane * LDWL + k];
+    wd[k] = wl[lane * LDWL + DIN + k];
+  }
+  // a wave walks nodes n = (block * 4 + wave) + i * stride in groups of G: the group's feature rows are in flight together
+  constexpr int G = 6;
+  const int stride = nblocks * 4;
+  for (int n0 = block * 4 + wave; n0 < N; n0 += G * stride) {
+    float hv[G], xv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int n = n0 + g * stride;
+      hv[g] = (n < N && lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
+      xv[g] = (x_dst != nullptr && n < N && lane < 3) ? x_src[(size_t)n * ld_x + lane] : 0.0f;
     }
-    psd[(size_t)n * 128 + lane] = as;
-    psd[(size_t)n * 128 + 64 + lane] = ad;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int n = n0 + g * stride;
+      if (n < N) {      // wave-uniform
+        float as = bias0, ad = bias;
+#pragma unroll
+        for (int k = 0; k < DIN; ++k) {
+          const float hk = __shfl(hv[g], k, 64);
+          as += hk * ws[k];
+          ad += hk * wd[k];
+        }
+        psd[(size_t)n * 128 + lane] = as;
+        psd[(size_t)n * 128 + 64 + lane] = ad;
+        if (x_dst != nullptr && lane < 3) x_dst[n * 3 + lane] = xv[g];      // dense copy of strided coordinates
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void stack_prologue_kernel(NodePackBatch batch, int proj_blocks, const float* __restrict__ h,
+// blocks [0, njobs) write the operand packs (first: their 160 scattered loads per lane are the longest chain of the launch),
+// the remaining proj_blocks compute the layer-0 pre-projection
+__global__ __launch_bounds__(256) void stack_prologue_kernel(NodePackBatch batch, int njobs, int proj_blocks, const float* __restrict__ h,
                                                              int ld_h, int din, const float* __restrict__ W1, int ldw,
                                                              const float* __restrict__ b0, const float* __restrict__ b1,
-                                                             float* __restrict__ psd, int N) {
-  if ((int)blockIdx.x < proj_blocks) {
-    if (din == 20) stack_proj_body<20>(h, ld_h, W1, ldw, b0, b1, psd, N, blockIdx.x, proj_blocks);
-    else stack_proj_body<64>(h, ld_h, W1, ldw, b0, b1, psd, N, blockIdx.x, proj_blocks);
+                                                             float* __restrict__ psd, const float* __restrict__ x_src, int ld_x,
+                                                             float* __restrict__ x_dst, int N) {
+  __shared__ float wl[64 * 129];
+  if ((int)blockIdx.x >= njobs) {
+    const int blk = blockIdx.x - njobs;
+    if (din == 20) stack_proj_body<20>(h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N, blk, proj_blocks, wl);
+    else stack_proj_body<64>(h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N, blk, proj_blocks, wl);
     return;
   }
-  const NodePackJob& J = batch.job[blockIdx.x - proj_blocks];
+  const NodePackJob& J = batch.job[blockIdx.x];
   if (J.din == 20) node_pack_body<20>(J, threadIdx.x >> 6, threadIdx.x & 63);
   else node_pack_body<64>(J, threadIdx.x >> 6, threadIdx.x & 63);
 }
@@ -332,19 +376,22 @@ extern "C" int is_debug_stamps_node(long long* out) {
 extern "C" int is_node_pack_floats(void) { return is::NODE_PACK_FLOATS; }
 
 // is_node_proj_fwd (layer-0 pre-projection: h [N, ld_h] (din = 20 | 64 columns), W1 [64, ldw], b0 (may be NULL), b1 -> psd
-// [N, 128]) and is_node_pack_weights (jobs as there) as ONE launch.
+// [N, 128]) and is_node_pack_weights (jobs as there) as ONE launch; x_dst != NULL: also the dense [N,3] copy of the
+// coordinates x_src [N, ld_x] (the reference keeps them as the last three columns of ndata['x']).
 extern "C" int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
-                                 const float* b0, const float* b1, float* psd, int N, void* stream) {
+                                 const float* b0, const float* b1, float* psd, const float* x_src, int ld_x, float* x_dst,
+                                 int N, void* stream) {
   if (njobs <= 0 || njobs > is::NODE_PACK_MAX || N <= 0 || (din != 20 && din != 64)) return -22;
+  if (x_dst != nullptr && (x_src == nullptr || ld_x < 3)) return -22;
   is::NodePackBatch batch;
   const is::NodePackJob* src = static_cast<const is::NodePackJob*>(jobs);
   for (int i = 0; i < njobs; ++i) {
     batch.job[i] = src[i];
-    if (src[i].din != 20 && src[i].din != 64) return -22;
+    if ((src[i].din != 20 && src[i].din != 64) || ((src[i].W1n == nullptr) != (src[i].W1nb == nullptr))) return -22;
   }
-  const int proj_blocks = std::min((N + 3) / 4, 2048);
+  const int proj_blocks = std::min((N + 23) / 24, 1024);
   hipLaunchKernelGGL(is::stack_prologue_kernel, dim3(proj_blocks + njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
-                     proj_blocks, h, ld_h, din, W1, ldw, b0, b1, psd, N);
+                     njobs, proj_blocks, h, ld_h, din, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -224,17 +224,132 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
   }
 }
 
+// Backward of the pooled tail y = W_c (W_v ctx + b_v) + b_c (single head; models/layers.py:74-77 on the mean-pooled vector)
+// inside the attention backward launch: every graph's workgroup derives its g_ctx = W_v^T W_c^T gy on the fly (each wave
+// on its own: lane = component, the other operand broadcast by v_readlane -- no barrier), and ONE extra workgroup
+// (blockIdx.x == B) contracts the B samples into the parameter gradients in ascending sample order (deterministic):
+//   gtail = dW_v [64][64] | db_v [64] | dW_c [64][64] | db_c [64]      (the record layout of is_mlp2_bwd)
+struct AttnTailBwd {
+  const float *gy, *wv, *wc, *pooled, *a1;
+  float* gtail;
+  int B;
+};
+
+__device__ __forceinline__ float attn_tail_matvec_t(const float* __restrict__ w, float v, int lane) {
+  // out[lane] = sum_o w[o][lane] * v[o]   (v[o] lives in lane o)
+  float acc = 0.0f;
+#pragma unroll
+  for (int o0 = 0; o0 < 64; o0 += 16) {
+    float wr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wr[u] = w[(o0 + u) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += wr[u] * __shfl(v, o0 + u, 64);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float attn_tail_gctx(const AttnTailBwd& t, int b, int lane) {
+  const float gyv = t.gy[(size_t)b * 64 + lane];
+  const float ghid = attn_tail_matvec_t(t.wc, gyv, lane);      // d hid = W_c^T gy
+  return attn_tail_matvec_t(t.wv, ghid, lane);                 // d ctx = W_v^T d hid
+}
+
+template <int NTHREADS>
+__device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t, int tid) {
+  constexpr int S = 16;                        // samples per chunk: 4 x [S][64] floats of LDS
+  constexpr int TPT = (256 + NTHREADS - 1) / NTHREADS;      // 4x4 output tiles per thread and matrix
+  float* gys = lds;
+  float* a1s = gys + S * 64;
+  float* pls = a1s + S * 64;
+  float* ghs = pls + S * 64;
+  float accC[TPT][16], accV[TPT][16];
+#pragma unroll
+  for (int k = 0; k < TPT; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accC[k][i] = 0.0f; accV[k][i] = 0.0f; }
+  float bsum = 0.0f;                           // tid < 64: db_c[tid]; 64 <= tid < 128: db_v[tid - 64]
+  for (int s0 = 0; s0 < t.B; s0 += S) {
+    __syncthreads();
+    for (int i = tid; i < S * 64; i += NTHREADS) {
+      const int s = s0 + i / 64;
+      const bool ok = s < t.B;
+      const size_t off = (size_t)(ok ? s : 0) * 64 + (i & 63);
+      gys[i] = ok ? t.gy[off] : 0.0f;
+      a1s[i] = ok ? t.a1[off] : 0.0f;
+      pls[i] = ok ? t.pooled[off] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < S * 64; i += NTHREADS) {
+      const int s = i / 64, h = i & 63;
+      float acc = 0.0f;
+#pragma unroll 16
+      for (int o = 0; o < 64; ++o) acc += t.wc[o * 64 + h] * gys[s * 64 + o];
+      ghs[i] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int tile = tid + k * NTHREADS;
+      if (tile < 256) {
+        const int r4 = (tile >> 4) * 4, c4 = (tile & 15) * 4;
+        for (int s = 0; s < S; ++s) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(gys + s * 64 + r4);
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(a1s + s * 64 + c4);
+          const f32x4 h4 = *reinterpret_cast<const f32x4*>(ghs + s * 64 + r4);
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(pls + s * 64 + c4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              accC[k][i * 4 + j] += g4[i] * a4[j];
+              accV[k][i * 4 + j] += h4[i] * p4[j];
+            }
+        }
+      }
+    }
+    if (tid < 128) {
+      const float* src = tid < 64 ? gys + tid : ghs + (tid - 64);
+      for (int s = 0; s < S; ++s) bsum += src[s * 64];
+    }
+  }
+  float* dWv = t.gtail;
+  float* dbv = dWv + 64 * 64;
+  float* dWc = dbv + 64;
+  float* dbc = dWc + 64 * 64;
+#pragma unroll
+  for (int k = 0; k < TPT; ++k) {
+    const int tile = tid + k * NTHREADS;
+    if (tile < 256) {
+      const int r4 = (tile >> 4) * 4, c4 = (tile & 15) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(dWc + (r4 + i) * 64 + c4) = f32x4{accC[k][i * 4], accC[k][i * 4 + 1], accC[k][i * 4 + 2], accC[k][i * 4 + 3]};
+        *reinterpret_cast<f32x4*>(dWv + (r4 + i) * 64 + c4) = f32x4{accV[k][i * 4], accV[k][i * 4 + 1], accV[k][i * 4 + 2], accV[k][i * 4 + 3]};
+      }
+    }
+  }
+  if (tid < 64) dbc[tid] = bsum;
+  else if (tid < 128) dbv[tid - 64] = bsum;
+}
+
 constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop
 
 template <int NT, int D>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
     const float* __restrict__ probs, const float* __restrict__ g_ctx, float* __restrict__ dqk,
-    float* __restrict__ dx, int n, int heads) {
+    float* __restrict__ dx, int n, int heads, AttnTailBwd tail) {
   constexpr int LDQ = AttnBwdSmem<NT, D>::LDQ;
   constexpr int CT = (D + 31) / 32;
   __shared__ AttnBwdSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  if constexpr (D == 64) {
+    if (tail.gy != nullptr && b == tail.B) {      // the extra workgroup: parameter gradients of the pooled tail
+      attn_tail_wgrad<64 * NT>(sm.kq, tail, tid);
+      return;
+    }
+  }
   const int r = lane & 31, hf = lane >> 5;
   const float scale = rsqrtf((float)D);
   const float coef = scale / (float)n;
@@ -242,16 +357,21 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
   // and accumulates over the heads in global memory (same thread, same address: no race)
 
   STAMPA(0);
+  float g_tail = 0.0f;
+  if constexpr (D == 64) {
+    if (tail.gy != nullptr) g_tail = attn_tail_gctx(tail, b, lane);
+    __builtin_amdgcn_sched_barrier(0);      // keep the two mat-vecs' loads out of the register-heavy passes below
+  }
   for (int hd = 0; hd < heads; ++hd) {
     __syncthreads();
     attn_stage_half<NT, D>(sm.kq, qk, 1, b, n, hd, tid, 64 * NT);       // K rows
     STAMPA(1);
-    const float* gc = g_ctx + (size_t)(b * heads + hd) * 64;
+    const float* gc = g_ctx != nullptr ? g_ctx + (size_t)(b * heads + hd) * 64 : nullptr;
     const float* pbase = probs + (size_t)(b * heads + hd) * NT * NT * 1024;
     // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NT, ... with
     // lane = channel (one coalesced 256-byte row per load, 8 rows in flight)
     {
-      const float g = gc[lane];
+      const float g = (gc != nullptr) ? gc[lane] : g_tail;
       for (int j0 = wave; j0 < NT * 32; j0 += DAB_ROWS * NT) {
         float xv[DAB_ROWS], ab[DAB_ROWS];
 #pragma unroll
@@ -454,6 +574,24 @@ extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float*
                                    const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream) {
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
-  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads);
+  const is::AttnTailBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, none);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// Single head with the pooled tail of is_attn_colmean_fwd_tail behind it: gy [B,64] is the gradient of the tail's output y;
+// the launch derives g_ctx per graph, runs the attention backward, and one extra workgroup writes the tail's parameter
+// gradients gtail = dW_v [64,64] | db_v [64] | dW_c [64,64] | db_c [64] from pooled (= ctx) [B,64] and a1 (= hid) [B,64].
+extern "C" int is_attn_colmean_bwd_tail(const float* qk, const float* x, const float* abar, const float* probs,
+                                        const float* gy, const float* wv, const float* wc, const float* pooled,
+                                        const float* a1, float* dqk, float* dx, float* gtail, int B_, int n, void* stream) {
+  if (B_ <= 0) return 0;
+  if (n <= 0 || n > 256 || gy == nullptr || wv == nullptr || wc == nullptr || pooled == nullptr || a1 == nullptr || gtail == nullptr)
+    return -22;
+  const int heads = 1;
+  const float* g_ctx = nullptr;
+  const is::AttnTailBwd tail{gy, wv, wc, pooled, a1, gtail, B_};
+  const int B = B_ + 1;      // grid: the graphs + the parameter-gradient workgroup
+  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -254,7 +254,15 @@ class EGNNStackFn(torch.autograd.Function):
         if fe > 8:
             raise ValueError("edge_feat_size > 8 is not supported by the HIP kernel")
         h0, ld_h0 = _lib.rows_ld(h0)
-        x = _lib.f32c(x0)
+        # coordinates: the kernels read a dense [N,3] array; the reference keeps them as the last columns of ndata['x'] -- the
+        # prologue launch writes the dense copy (no copy launch in front of the stack)
+        if x0.dtype != torch.float32:
+            raise ValueError(f"expected float32 coordinates, got {x0.dtype}")
+        if x0.is_contiguous():
+            x, x_src, ld_x0 = x0, None, 0
+        else:
+            x_src, ld_x0 = _lib.rows_ld(x0)
+            x = torch.empty(n, 3, dtype=torch.float32, device=dev)
         ea = _lib.f32c(ea) if fe else None
         params = [_lib.f32c(p) for p in params]
         head = None
@@ -263,7 +271,7 @@ class EGNNStackFn(torch.autograd.Function):
             params = params[:-4]
             if wa.shape != (HIDDEN, HIDDEN) or wb.shape != (HIDDEN, HIDDEN):
                 raise ValueError("projection head weights must be (64, 64)")
-            head = (torch.cat([wa, wb], dim=1), ba, bb)      # [64][128]: column blocks [Wa | Wb], the edge_mlp.0 layout
+            head = ((wa, wb), ba, bb)
         need_grad = any(ctx.needs_input_grad)
         st = _lib.stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -276,14 +284,20 @@ class EGNNStackFn(torch.autograd.Function):
         jobs = []
         for i in range(n_layers):
             lp = params[i * P:(i + 1) * P]
-            w1n = (head[0] if head is not None else None) if i == n_layers - 1 else params[(i + 1) * P]
-            jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), w1n.data_ptr() if w1n is not None else None,
-                                         packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN,
-                                         int(w1n.shape[1]) if w1n is not None else 0, 0, 0))
+            if i < n_layers - 1:
+                w1n = params[(i + 1) * P]          # next layer's edge_mlp.0.weight: [W1s | W1d | w_r | W_a] column blocks
+                wa_p, wb_p, ldn = w1n.data_ptr(), w1n.data_ptr() + 4 * HIDDEN, int(w1n.shape[1])
+            elif head is not None:
+                wa_p, wb_p, ldn = head[0][0].data_ptr(), head[0][1].data_ptr(), HIDDEN      # [Wq | Wk] where they are
+            else:
+                wa_p, wb_p, ldn = None, None, 0
+            jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), wa_p, wb_p,
+                                         packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN, ldn))
         jarr = (_lib.NodePackJob * len(jobs))(*jobs)
         with KernelTimer.span("stack_prologue"):
             _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
-                                             _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd), n, st),
+                                             _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd),
+                                             _lib.ptr(x_src), ld_x0, _lib.ptr(x) if x_src is not None else None, n, st),
                        "is_stack_prologue")
         kf = fwd_chunk_count(e)
         chunks = csr.chunks(kf)
@@ -592,19 +606,14 @@ class AttnPooledTailFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         gy = _lib.f32c(gy)
         hid = HIDDEN
-        nrec, rec = lib.is_mlp2_bwd_records(b), lib.is_mlp2_bwd_record_floats(hid, hid, hid)
-        part = torch.empty(nrec * rec, **f32)
-        g_ctx = torch.empty(b, hid, **f32)
-        with KernelTimer.span("mlp2_bwd"):
-            _lib.check(lib.is_mlp2_bwd(_lib.ptr(pooled), hid, _lib.ptr(wv), _lib.ptr(wc), None, _lib.ptr(a1), _lib.ptr(y),
-                                       _lib.ptr(gy), _lib.ptr(g_ctx), _lib.ptr(part), b, hid, hid, hid, hid, 0, 0, st), "is_mlp2_bwd")
-            flat = torch.empty(rec, **f32)
-            scratch = torch.empty(lib.is_reduce_partials_scratch_floats(rec), **f32)
-            _lib.check(lib.is_reduce_partials(_lib.ptr(part), nrec, rec, rec, None, _lib.ptr(flat), _lib.ptr(scratch), st), "is_reduce_partials")
+        # ONE launch: every graph's workgroup derives g_ctx = W_v^T W_c^T gy itself, an extra workgroup contracts the samples
+        # into the tail's parameter gradients (no per-workgroup records, no reduction launch)
+        flat = torch.empty(2 * hid * hid + 2 * hid, **f32)
         dqk, dx = torch.empty_like(qk), torch.empty_like(x)
         with KernelTimer.span("attn_colmean_bwd"):
-            _lib.check(lib.is_attn_colmean_bwd(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(probs), _lib.ptr(g_ctx),
-                                               _lib.ptr(dqk), _lib.ptr(dx), b, n, 1, st), "is_attn_colmean_bwd")
+            _lib.check(lib.is_attn_colmean_bwd_tail(_lib.ptr(qk), _lib.ptr(x), _lib.ptr(abar), _lib.ptr(probs), _lib.ptr(gy),
+                                                    _lib.ptr(wv), _lib.ptr(wc), _lib.ptr(pooled), _lib.ptr(a1), _lib.ptr(dqk),
+                                                    _lib.ptr(dx), _lib.ptr(flat), b, n, st), "is_attn_colmean_bwd_tail")
         o1, o2, o3 = hid * hid, hid * hid + hid, 2 * hid * hid + hid
         return dqk, dx, flat[:o1].view(hid, hid), flat[o1:o2], flat[o2:o3].view(hid, hid), flat[o3:], None, None
 

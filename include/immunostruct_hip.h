@@ -50,9 +50,11 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *                     W1 = edge_mlp.0.weight [64, ldw], b0 may be NULL, b1 = edge_mlp.0.bias) NEXT TO the lane-ordered
  *                     operand packs of every layer's node half (forward + backward order; is_node_pack_floats()
  *                     floats per layer and direction), one launch.  jobs: host array of njobs (<= 8) records
- *                       { const float *Wn1, *Wn2, *W1n; float *fpack, *bpack; int din, ldw_n, pad0, pad1; }
- *                     (Wn1 / Wn2 = node_mlp.0 / .2 weights, W1n = the NEXT layer's edge_mlp.0.weight or the [Wq | Wk]
- *                     column blocks of a projection head, or NULL).
+ *                       { const float *Wn1, *Wn2, *W1n, *W1nb; float *fpack, *bpack; int din, ldw_n; }
+ *                     (Wn1 / Wn2 = node_mlp.0 / .2 weights; W1n / W1nb = first row of the source / destination half of the
+ *                     NEXT pre-projection, row stride ldw_n: edge_mlp.0.weight and edge_mlp.0.weight + 64 of the next layer,
+ *                     or the Wq / Wk matrices of a projection head where they are; both NULL: none).  x_dst != NULL: the
+ *                     launch also writes the dense [N,3] copy of the coordinates x_src [N, ld_x].
  *
  * is_egnn_layer_fwd   edge pass (gather Ps[src] + Pd[dst], geometry, SiLU, edge_mlp.2, coord_mlp, running segment
  *                     sum / mean by destination -> h_neigh [N, ld_hn], x_out [N,3]) followed in the same workgroup by
@@ -87,7 +89,8 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *       coordinate gradient: the coordinate-MLP half is skipped, z3s / Wc1 / wc2 are not read).                       */
 int is_node_pack_floats(void);
 int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
-                      const float* b0, const float* b1, float* psd, int N, void* stream);
+                      const float* b0, const float* b1, float* psd, const float* x_src, int ld_x, float* x_dst, int N,
+                      void* stream);
 int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                       const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                       const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
@@ -267,6 +270,12 @@ int is_attn_colmean_fwd_tail(const float* qk, const float* x, float* ctx, float*
                              void* stream);
 int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* probs,
                         const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream);
+/* Backward of is_attn_colmean_fwd_tail as ONE launch: gy [B,64] = gradient of y; every graph's workgroup derives
+ * g_ctx = W_v^T W_c^T gy itself and runs the attention backward; one extra workgroup contracts the B samples (ascending
+ * order) into gtail = dW_v [64,64] | db_v [64] | dW_c [64,64] | db_c [64] from pooled (= ctx) [B,64] and a1 (= hid) [B,64]. */
+int is_attn_colmean_bwd_tail(const float* qk, const float* x, const float* abar, const float* probs, const float* gy,
+                             const float* wv, const float* wc, const float* pooled, const float* a1, float* dqk, float* dx,
+                             float* gtail, int B, int n, void* stream);
 
 /* "Combined attention" of the fusion head in closed form (models/hybrid_models.py:344-347 with
  * MultiHeadAttention(F, 8 heads, input_dim = 1), models/layers.py:51-106): x [B,T] scalar tokens ->
