@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     const float* __restrict__ b0n, const float* __restrict__ b1n, const float* __restrict__ fpack,
     float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next) {
   __shared__ Fwd3Smem<FE_MAX> sm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
   STAMP3(0);
   int stamp_k = 2;

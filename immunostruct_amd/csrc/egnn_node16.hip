@@ -208,146 +208,187 @@ constexpr int WG_PROJ = 128 * 64 + 128;
 constexpr int WG_NODE = 64 * 128 + 64 * 64 + 128;
 constexpr int WG_STRIDE = WG_PROJ + WG_NODE;
 
-// two sets of row tiles: chunk c+1 is staged into one set while the MFMAs of chunk c read the other -- ONE barrier per chunk
+// Two kinds of workgroups per layer (blockIdx.y = 2 * layer + kind), so that each kind is small enough for THREE
+// workgroups per CU (45 KB LDS, <= 168 registers; one combined workgroup needed 73 KB / two per CU and ran the MFMA pipe
+// at 39 %: measured, profiles/r02 SQ counters):
+//   kind 0 (NODE):  dWn2 (64 x 64) and dWn1 (64 x 128) + dbn2 / dbn1     -- 12 MFMAs per 4-row step
+//   kind 1 (PROJ):  dW1sd (128 x 64) + db0 / db1                          --  8 MFMAs per 4-row step
+// Two sets of row tiles: chunk c+1 is staged into one set while the MFMAs of chunk c read the other -- ONE barrier per
+// chunk.  Rows come in through bounded raw-buffer views (rows past N read as zero; no 64-bit address math).
 struct WgradSmem {
   static constexpr int LDP = 132;
-  float Ps2[2][16 * LDP], Xs2[2][16 * LDP];
-  float Hs2[2][16 * LD], Gs2[2][16 * LD], As2[2][16 * LD], Zs2[2][16 * LD];
-  float vec[4][4][64];
+  union {
+    struct { float Xs2[2][16 * LDP], Gs2[2][16 * LD], Zs2[2][16 * LD], As2[2][16 * LD]; } node;
+    struct { float Ps2[2][16 * LDP], Hs2[2][16 * LD]; } proj;
+  };
+  float vec[4][2][64];
 };
 
 template <int DIN>
-__device__ __forceinline__ void egnn_node_wgrad16_body(WgradSmem& sm,
-    const float* __restrict__ g_psd, const float* __restrict__ h_out, int ld_ho, int dho, const float* __restrict__ dh,
-    const float* __restrict__ zn1, const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
-    const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ partials, int N, int rows_per_wg) {
+__device__ __forceinline__ void egnn_node_wgrad16_node(WgradSmem& sm, const float* __restrict__ dh, const float* __restrict__ zn1,
+                                                       const float* __restrict__ dzn1, const float* __restrict__ h, int ld_h,
+                                                       const float* __restrict__ h_neigh, int ld_hn, float* __restrict__ part,
+                                                       int N, int rows_per_wg) {
   constexpr int LDP = WgradSmem::LDP;
-  auto& Ps2 = sm.Ps2; auto& Xs2 = sm.Xs2; auto& Hs2 = sm.Hs2; auto& Gs2 = sm.Gs2; auto& As2 = sm.As2; auto& Zs2 = sm.Zs2;
-  auto& vec = sm.vec;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto& Xs2 = sm.node.Xs2; auto& Gs2 = sm.node.Gs2; auto& Zs2 = sm.node.Zs2; auto& As2 = sm.node.As2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const bool has_psd = g_psd != nullptr;
-  const bool has_node = dzn1 != nullptr;     // false: a projection-only job (layer-0 pre-projection): NODE part left untouched
   const int r_begin = blockIdx.x * rows_per_wg, r_end = min(N, r_begin + rows_per_wg);
-
-  f32x4 dW1[2][4], dW2[4], dWn[8];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) zero_acc4(dW1[a]);
+  const rsrc_t rs_g = make_rsrc_n(dh, N * H * 4), rs_z = make_rsrc_n(dzn1, N * H * 4), rs_zn = make_rsrc_n(zn1, N * H * 4);
+  const rsrc_t rs_h = make_rsrc_n(h, N * ld_h * 4), rs_hn = make_rsrc_n(h_neigh, N * ld_hn * 4);
+  f32x4 dW2[4], dWn[8];
   zero_acc4(dW2);
   zero_acc4(dWn);
-  float s_p0 = 0.f, s_p1 = 0.f, s_g = 0.f, s_z = 0.f;   // lane = column partial sums
-
-  // rows are fetched one chunk ahead into registers so that the loads of chunk c+1 are in flight
-  // while the MFMAs of chunk c run
-  float rp0[4], rp1[4], rho[4], rg[4], rz[4], rzn[4], rxh[4], rxn[4];
+  float s_g = 0.f, s_z = 0.f;   // lane = column partial sums
+  float rg[4], rz[4], rzn[4], rxh[4], rxn[4];
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = c0 + wave * 4 + i;
-      const bool valid = row < r_end;
-      rp0[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + lane] : 0.0f;
-      rp1[i] = (has_psd && valid) ? g_psd[(size_t)row * 128 + 64 + lane] : 0.0f;
-      rho[i] = (has_psd && valid && lane < dho) ? h_out[(size_t)row * ld_ho + lane] : 0.0f;
-      rg[i] = (has_node && valid) ? dh[(size_t)row * H + lane] : 0.0f;
-      rz[i] = (has_node && valid) ? dzn1[(size_t)row * H + lane] : 0.0f;
-      rzn[i] = (has_node && valid) ? zn1[(size_t)row * H + lane] : 0.0f;
-      rxh[i] = (has_node && valid && lane < DIN) ? h[(size_t)row * ld_h + lane] : 0.0f;
-      rxn[i] = (has_node && valid) ? h_neigh[(size_t)row * ld_hn + lane] : 0.0f;
+      const int row = c0 + wave * 4 + i;      // wave-uniform
+      rg[i] = buf_load(rs_g, lane * 4 + row * (H * 4), 0);
+      rz[i] = buf_load(rs_z, lane * 4 + row * (H * 4), 0);
+      rzn[i] = buf_load(rs_zn, lane * 4 + row * (H * 4), 0);
+      rxh[i] = (lane < DIN) ? buf_load(rs_h, lane * 4 + row * (ld_h * 4), 0) : 0.0f;
+      rxn[i] = buf_load(rs_hn, lane * 4 + row * (ld_hn * 4), 0);
     }
   };
-  auto stage = [&](int c0, int buf) {      // registers -> LDS set `buf`: wave w stages rows 4w .. 4w+3 (lane = column)
-    float *Ps = Ps2[buf], *Xs = Xs2[buf], *Hs = Hs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
+  auto stage = [&](int buf) {      // registers -> LDS set `buf`: wave w stages rows 4w .. 4w+3 (lane = column)
+    float *Xs = Xs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int lr = wave * 4 + i;
-      const bool valid = c0 + lr < r_end;
-      if (has_psd) {
-        Ps[lr * LDP + lane] = rp0[i]; Ps[lr * LDP + 64 + lane] = rp1[i];
-        s_p0 += rp0[i]; s_p1 += rp1[i];
-        Hs[lr * LD + lane] = rho[i];
-      }
-      if (has_node) {
-        Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
-        s_g += rg[i]; s_z += rz[i];
-        As[lr * LD + lane] = valid ? silu_f(rzn[i]) : 0.0f;
-        Xs[lr * LDP + lane] = rxh[i];
-        Xs[lr * LDP + 64 + lane] = rxn[i];
-      }
+      Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
+      s_g += rg[i]; s_z += rz[i];
+      As[lr * LD + lane] = silu_f(rzn[i]);      // rows past N: SiLU(0) = 0
+      Xs[lr * LDP + lane] = rxh[i];
+      Xs[lr * LDP + 64 + lane] = rxn[i];
     }
   };
   if (r_begin < r_end) {
     fetch(r_begin);
-    stage(r_begin, 0);
+    stage(0);
   }
   __syncthreads();
   int buf = 0;
   for (int c0 = r_begin; c0 < r_end; c0 += 16, buf ^= 1) {
     const bool more = c0 + 16 < r_end;
     if (more) fetch(c0 + 16);        // in flight while this chunk's MFMAs run
-    const float *Ps = Ps2[buf], *Xs = Xs2[buf], *Hs = Hs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
-    // ---- outer products: contraction over the 16 staged rows ----
+    const float *Xs = Xs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int e = 4 * q + s;
-      float bh[4];
-      if (has_node) {
-        const float ag = Gs[e * LD + wave * 16 + r], az = Zs[e * LD + wave * 16 + r];
-        float ba1[4], bxv[8];
+      const float ag = Gs[e * LD + wave * 16 + r], az = Zs[e * LD + wave * 16 + r];
+      float ba1[4], bxv[8];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) ba1[nt] = As[e * LD + nt * 16 + r];
+      for (int nt = 0; nt < 4; ++nt) ba1[nt] = As[e * LD + nt * 16 + r];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) bxv[nt] = Xs[e * LDP + nt * 16 + r];
+      for (int nt = 0; nt < 8; ++nt) bxv[nt] = Xs[e * LDP + nt * 16 + r];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) dW2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, ba1[nt], dW2[nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; ++nt) dW2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, ba1[nt], dW2[nt], 0, 0, 0);
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
-      }
-      if (has_psd) {
-        const float ap0 = Ps[e * LDP + (2 * wave) * 16 + r], ap1 = Ps[e * LDP + (2 * wave + 1) * 16 + r];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bh[nt] = Hs[e * LD + nt * 16 + r];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          dW1[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap0, bh[nt], dW1[0][nt], 0, 0, 0);
-          dW1[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, bh[nt], dW1[1][nt], 0, 0, 0);
-        }
-      }
+      for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
     }
-    if (more) stage(c0 + 16, buf ^ 1);
+    if (more) stage(buf ^ 1);
     __syncthreads();      // the other set is complete, and every wave is done reading this one
   }
-  // ---- partial record ----
-  float* part = partials + (size_t)blockIdx.x * WG_STRIDE;
   float* pn = part + WG_PROJ;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int lr = tile16_row(t, q);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      if (has_psd) {
-        part[((2 * wave) * 16 + lr) * H + nt * 16 + r] = dW1[0][nt][t];
-        part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
-      }
-      if (has_node) pn[64 * 128 + (wave * 16 + lr) * H + nt * 16 + r] = dW2[nt][t];
-    }
-    if (has_node) {
+    for (int nt = 0; nt < 4; ++nt) pn[64 * 128 + (wave * 16 + lr) * H + nt * 16 + r] = dW2[nt][t];
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
-    }
+    for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
   }
-  vec[wave][0][lane] = s_p1; vec[wave][1][lane] = s_p0; vec[wave][2][lane] = s_z; vec[wave][3][lane] = s_g;
+  sm.vec[wave][0][lane] = s_z; sm.vec[wave][1][lane] = s_g;
   __syncthreads();
-  {
-    const int which = tid >> 6;   // 0: db1, 1: db0, 2: dbn1, 3: dbn2
-    const float v = ((vec[0][which][lane] + vec[1][which][lane]) + vec[2][which][lane]) + vec[3][which][lane];
-    if (which < 2) { if (has_psd) part[128 * 64 + which * 64 + lane] = v; }
-    else if (has_node) pn[64 * 128 + 64 * 64 + (which - 2) * 64 + lane] = v;
+  if (tid < 128) {
+    const int which = tid >> 6;   // 0: dbn1, 1: dbn2
+    pn[64 * 128 + 64 * 64 + which * 64 + lane] =
+        ((sm.vec[0][which][lane] + sm.vec[1][which][lane]) + sm.vec[2][which][lane]) + sm.vec[3][which][lane];
   }
 }
 
+__device__ __forceinline__ void egnn_node_wgrad16_proj(WgradSmem& sm, const float* __restrict__ g_psd, const float* __restrict__ h_out,
+                                                       int ld_ho, int dho, float* __restrict__ part, int N, int rows_per_wg) {
+  constexpr int LDP = WgradSmem::LDP;
+  auto& Ps2 = sm.proj.Ps2; auto& Hs2 = sm.proj.Hs2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int r_begin = blockIdx.x * rows_per_wg, r_end = min(N, r_begin + rows_per_wg);
+  const rsrc_t rs_p = make_rsrc_n(g_psd, N * 128 * 4), rs_ho = make_rsrc_n(h_out, N * ld_ho * 4);
+  f32x4 dW1[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) zero_acc4(dW1[a]);
+  float s_p0 = 0.f, s_p1 = 0.f;
+  float rp0[4], rp1[4], rho[4];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c0 + wave * 4 + i;
+      rp0[i] = buf_load(rs_p, lane * 4 + row * 512, 0);
+      rp1[i] = buf_load(rs_p, lane * 4 + 256 + row * 512, 0);
+      rho[i] = (lane < dho) ? buf_load(rs_ho, lane * 4 + row * (ld_ho * 4), 0) : 0.0f;
+    }
+  };
+  auto stage = [&](int buf) {
+    float *Ps = Ps2[buf], *Hs = Hs2[buf];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = wave * 4 + i;
+      Ps[lr * LDP + lane] = rp0[i]; Ps[lr * LDP + 64 + lane] = rp1[i];
+      s_p0 += rp0[i]; s_p1 += rp1[i];
+      Hs[lr * LD + lane] = rho[i];
+    }
+  };
+  if (r_begin < r_end) {
+    fetch(r_begin);
+    stage(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = r_begin; c0 < r_end; c0 += 16, buf ^= 1) {
+    const bool more = c0 + 16 < r_end;
+    if (more) fetch(c0 + 16);
+    const float *Ps = Ps2[buf], *Hs = Hs2[buf];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = 4 * q + s;
+      const float ap0 = Ps[e * LDP + (2 * wave) * 16 + r], ap1 = Ps[e * LDP + (2 * wave + 1) * 16 + r];
+      float bh[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bh[nt] = Hs[e * LD + nt * 16 + r];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        dW1[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap0, bh[nt], dW1[0][nt], 0, 0, 0);
+        dW1[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, bh[nt], dW1[1][nt], 0, 0, 0);
+      }
+    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int lr = tile16_row(t, q);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      part[((2 * wave) * 16 + lr) * H + nt * 16 + r] = dW1[0][nt][t];
+      part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
+    }
+  }
+  sm.vec[wave][0][lane] = s_p1; sm.vec[wave][1][lane] = s_p0;
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6;   // 0: db1, 1: db0
+    part[128 * 64 + which * 64 + lane] =
+        ((sm.vec[0][which][lane] + sm.vec[1][which][lane]) + sm.vec[2][which][lane]) + sm.vec[3][which][lane];
+  }
+}
 
-// All layers of a stack in ONE launch (blockIdx.y = layer): 6 x 254 workgroups instead of six launches of 254
-// single-wave-per-SIMD workgroups -- the co-resident workgroups of different layers hide each other's latency.
+// All layers of a stack in ONE launch (blockIdx.y = 2 * layer + kind): the co-resident workgroups of different layers and
+// kinds hide each other's latency.
 struct WgradLayer {
   const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh;
   float* partials;
@@ -356,13 +397,18 @@ struct WgradLayer {
 constexpr int WGRAD_MAX_LAYERS = 8;
 struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
 
-__global__ __launch_bounds__(256, 2) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
-  __shared__ WgradSmem sm;      // one copy for both instantiations of the body
-  const WgradLayer& L = batch.layer[blockIdx.y];
-  if (L.din == 20)
-    egnn_node_wgrad16_body<20>(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
-  else
-    egnn_node_wgrad16_body<64>(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, L.partials, N, rows_per_wg);
+__global__ __launch_bounds__(256, 3) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
+  __shared__ WgradSmem sm;
+  const WgradLayer& L = batch.layer[blockIdx.y >> 1];
+  float* part = L.partials + (size_t)blockIdx.x * WG_STRIDE;
+  if ((blockIdx.y & 1) == 0) {
+    if (L.dzn1 == nullptr) return;      // a projection-only job (layer-0 pre-projection): NODE part left untouched
+    if (L.din == 20) egnn_node_wgrad16_node<20>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_per_wg);
+    else egnn_node_wgrad16_node<64>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_per_wg);
+  } else {
+    if (L.g_psd == nullptr) return;     // no next pre-projection: PROJ part left untouched
+    egnn_node_wgrad16_proj(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, part, N, rows_per_wg);
+  }
 }
 
 }  // namespace is
@@ -412,6 +458,6 @@ extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int g
     if (src[i].g_psd == nullptr && src[i].dzn1 == nullptr) return -22;
   }
   const int rows = (((N + grid - 1) / grid) + 15) / 16 * 16;
-  hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(grid, nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), batch, N, rows);
+  hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(grid, 2 * nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), batch, N, rows);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
 
 // Backward of the pooled tail y = W_c (W_v ctx + b_v) + b_c (single head; models/layers.py:74-77 on the mean-pooled vector)
 // inside the attention backward launch: every graph's workgroup derives its g_ctx = W_v^T W_c^T gy on the fly (each wave
-// on its own: lane = component, the other operand broadcast by v_readlane -- no barrier), and ONE extra workgroup
-// (blockIdx.x == B) contracts the B samples into the parameter gradients in ascending sample order (deterministic):
+// on its own: lane = component, the other operand broadcast by v_readlane -- no barrier), and TAIL_SLABS extra workgroups
+// (blockIdx.x >= B; each owns 8 rows of both matrices) contract the B samples into the parameter gradients in ascending
+// sample order (deterministic):
 //   gtail = dW_v [64][64] | db_v [64] | dW_c [64][64] | db_c [64]      (the record layout of is_mlp2_bwd)
 struct AttnTailBwd {
   const float *gy, *wv, *wc, *pooled, *a1;
@@ -255,20 +256,23 @@ __device__ __forceinline__ float attn_tail_gctx(const AttnTailBwd& t, int b, int
   return attn_tail_matvec_t(t.wv, ghid, lane);                 // d ctx = W_v^T d hid
 }
 
+constexpr int TAIL_SLABS = 8;      // extra workgroups: each owns TAIL_ROWS rows of dW_c and of dW_v
+constexpr int TAIL_ROWS = 64 / TAIL_SLABS;
+
 template <int NTHREADS>
-__device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t, int tid) {
-  constexpr int S = 16;                        // samples per chunk: 4 x [S][64] floats of LDS
-  constexpr int TPT = (256 + NTHREADS - 1) / NTHREADS;      // 4x4 output tiles per thread and matrix
-  float* gys = lds;
-  float* a1s = gys + S * 64;
-  float* pls = a1s + S * 64;
-  float* ghs = pls + S * 64;
-  float accC[TPT][16], accV[TPT][16];
+__device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t, int slab, int tid) {
+  constexpr int S = 16;                                      // samples per chunk
+  constexpr int OUT = 2 * TAIL_ROWS * 64;                    // outputs of this workgroup (both matrices)
+  constexpr int PER = (OUT + NTHREADS - 1) / NTHREADS;
+  float* gys = lds;                    // [S][64]  gy
+  float* a1s = gys + S * 64;           // [S][64]  hid
+  float* pls = a1s + S * 64;           // [S][64]  pooled ctx
+  float* ghs = pls + S * 64;           // [S][TAIL_ROWS]  d hid, this slab's components
+  const int r0 = slab * TAIL_ROWS;
+  float acc[PER];
 #pragma unroll
-  for (int k = 0; k < TPT; ++k)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { accC[k][i] = 0.0f; accV[k][i] = 0.0f; }
-  float bsum = 0.0f;                           // tid < 64: db_c[tid]; 64 <= tid < 128: db_v[tid - 64]
+  for (int k = 0; k < PER; ++k) acc[k] = 0.0f;
+  float bsum = 0.0f;                   // tid < TAIL_ROWS: db_c[r0 + tid]; TAIL_ROWS <= tid < 2 TAIL_ROWS: db_v[r0 + tid - TAIL_ROWS]
   for (int s0 = 0; s0 < t.B; s0 += S) {
     __syncthreads();
     for (int i = tid; i < S * 64; i += NTHREADS) {
@@ -280,37 +284,33 @@ __device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t
       pls[i] = ok ? t.pooled[off] : 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < S * 64; i += NTHREADS) {
-      const int s = i / 64, h = i & 63;
-      float acc = 0.0f;
+    for (int i = tid; i < S * TAIL_ROWS; i += NTHREADS) {      // d hid[s][h] = sum_o W_c[o][h] gy[s][o], h in the slab
+      const int s = i / TAIL_ROWS, h = r0 + i % TAIL_ROWS;
+      float v = 0.0f;
 #pragma unroll 16
-      for (int o = 0; o < 64; ++o) acc += t.wc[o * 64 + h] * gys[s * 64 + o];
-      ghs[i] = acc;
+      for (int o = 0; o < 64; ++o) v += t.wc[o * 64 + h] * gys[s * 64 + o];
+      ghs[i] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-      const int tile = tid + k * NTHREADS;
-      if (tile < 256) {
-        const int r4 = (tile >> 4) * 4, c4 = (tile & 15) * 4;
-        for (int s = 0; s < S; ++s) {
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(gys + s * 64 + r4);
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(a1s + s * 64 + c4);
-          const f32x4 h4 = *reinterpret_cast<const f32x4*>(ghs + s * 64 + r4);
-          const f32x4 p4 = *reinterpret_cast<const f32x4*>(pls + s * 64 + c4);
+    for (int k = 0; k < PER; ++k) {
+      const int idx = tid + k * NTHREADS;
+      if (idx < OUT) {
+        const int mat = idx / (TAIL_ROWS * 64), rr = (idx / 64) % TAIL_ROWS, j = idx & 63;
+        const float* av = mat == 0 ? gys + r0 + rr : ghs + rr;      // dW_c rows: gy components; dW_v rows: d hid components
+        const int as = mat == 0 ? 64 : TAIL_ROWS;
+        const float* bv = mat == 0 ? a1s + j : pls + j;
+        float v = acc[k];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              accC[k][i * 4 + j] += g4[i] * a4[j];
-              accV[k][i * 4 + j] += h4[i] * p4[j];
-            }
-        }
+        for (int s = 0; s < S; ++s) v += av[s * as] * bv[s * 64];
+        acc[k] = v;
       }
     }
-    if (tid < 128) {
-      const float* src = tid < 64 ? gys + tid : ghs + (tid - 64);
-      for (int s = 0; s < S; ++s) bsum += src[s * 64];
+    if (tid < 2 * TAIL_ROWS) {
+      const bool c = tid < TAIL_ROWS;
+      const float* src = c ? gys + r0 + tid : ghs + (tid - TAIL_ROWS);
+      const int st = c ? 64 : TAIL_ROWS;
+      for (int s = 0; s < S; ++s) bsum += src[s * st];
     }
   }
   float* dWv = t.gtail;
@@ -318,19 +318,15 @@ __device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t
   float* dWc = dbv + 64;
   float* dbc = dWc + 64 * 64;
 #pragma unroll
-  for (int k = 0; k < TPT; ++k) {
-    const int tile = tid + k * NTHREADS;
-    if (tile < 256) {
-      const int r4 = (tile >> 4) * 4, c4 = (tile & 15) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(dWc + (r4 + i) * 64 + c4) = f32x4{accC[k][i * 4], accC[k][i * 4 + 1], accC[k][i * 4 + 2], accC[k][i * 4 + 3]};
-        *reinterpret_cast<f32x4*>(dWv + (r4 + i) * 64 + c4) = f32x4{accV[k][i * 4], accV[k][i * 4 + 1], accV[k][i * 4 + 2], accV[k][i * 4 + 3]};
-      }
+  for (int k = 0; k < PER; ++k) {
+    const int idx = tid + k * NTHREADS;
+    if (idx < OUT) {
+      const int mat = idx / (TAIL_ROWS * 64), rr = (idx / 64) % TAIL_ROWS, j = idx & 63;
+      (mat == 0 ? dWc : dWv)[(r0 + rr) * 64 + j] = acc[k];
     }
   }
-  if (tid < 64) dbc[tid] = bsum;
-  else if (tid < 128) dbv[tid - 64] = bsum;
+  if (tid < TAIL_ROWS) dbc[r0 + tid] = bsum;
+  else if (tid < 2 * TAIL_ROWS) dbv[r0 + tid - TAIL_ROWS] = bsum;
 }
 
 constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop
@@ -345,8 +341,8 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
   __shared__ AttnBwdSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   if constexpr (D == 64) {
-    if (tail.gy != nullptr && b == tail.B) {      // the extra workgroup: parameter gradients of the pooled tail
-      attn_tail_wgrad<64 * NT>(sm.kq, tail, tid);
+    if (tail.gy != nullptr && b >= tail.B) {      // the extra workgroups: parameter gradients of the pooled tail
+      attn_tail_wgrad<64 * NT>(sm.kq, tail, b - tail.B, tid);
       return;
     }
   }
@@ -591,7 +587,7 @@ extern "C" int is_attn_colmean_bwd_tail(const float* qk, const float* x, const f
   const int heads = 1;
   const float* g_ctx = nullptr;
   const is::AttnTailBwd tail{gy, wv, wc, pooled, a1, gtail, B_};
-  const int B = B_ + 1;      // grid: the graphs + the parameter-gradient workgroup
+  const int B = B_ + is::TAIL_SLABS;      // grid: the graphs + the parameter-gradient workgroups
   ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

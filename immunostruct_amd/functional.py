@@ -16,7 +16,7 @@ import os
 
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
-WGRAD_GRID = 64      # workgroups per layer of the batched node weight-gradient launch (x up to 8 layers)
+WGRAD_GRID = 56      # workgroups per layer and kind of the batched node weight-gradient launch: 13 x 56 = 728 <= 3 x 256 resident
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
 
