@@ -68,6 +68,9 @@ SIGNATURES = {
     "is_comb_attn_grad_floats": [_I],
     "is_comb_attn_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_comb_attn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_comb_attn_cls_fwd": [_P, _I] + [_P] * 16 + [_I] * 6 + [_P],
+    "is_comb_attn_cls_grad_floats": [_I, _I, _I],
+    "is_comb_attn_cls_bwd": [_P, _I] + [_P] * 18 + [_I] * 6 + [_P],
     "is_loss_partials_floats": [],
     "is_vae_latent_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_vae_latent_grad_floats": [_I, _I],

@@ -91,17 +91,41 @@ __device__ __forceinline__ void ca_coefficients(CaCoef& co, const float* wq, con
   }
 }
 
-template <int F>
+// The classifier behind the combined attention (models/hybrid_models.py:288-295: Flatten, Linear(T, hid), ReLU, Dropout,
+// Linear(hid, out)) rides on the same launches: y = act2(W2 (mask * ReLU(W1 z + b1)) + b2) per sample, the arithmetic of
+// csrc/mlp_head.hip (k ascending from the bias).  hid <= 32, out <= 64.
+constexpr int CA_CLS_HID = 32;
+struct CaCls {
+  const float *W1, *b1, *W2, *b2, *mask;      // W1 [hid, T], W2 [out, hid]; mask [B, hid] (scaled keep-mask) or NULL
+  float *a1, *y;                              // forward outputs: ReLU(W1 z + b1) [B, hid] (may be NULL), y [B, out]
+  const float *a1_in, *y_in, *gy, *z_in;      // backward inputs: the saved a1 / y / z, gy [B, out]
+  float* gcls;                                // backward output: dW1 [hid * T] | db1 [hid] | dW2 [out * hid] | db2 [out]
+  int hid, out, act2, B;
+};
+
+template <int F, bool CLS>
 __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     CaParts X, const float* __restrict__ wq, const float* __restrict__ bq,
     const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ bv,
     const float* __restrict__ Wc, const float* __restrict__ bc, float* __restrict__ z,
-    float* __restrict__ stats, int T) {
+    float* __restrict__ stats, int T, CaCls cls) {
   constexpr int D = F / CA_HEADS;
   __shared__ float c[CA_TMAX];
   __shared__ CaCoef co;
   __shared__ float red[2][CA_THREADS / 64];
+  __shared__ float w1t[CLS ? CA_TMAX * (CA_CLS_HID + 1) : 1];      // W1 transposed [T][hid + 1]
+  __shared__ float zs[CLS ? CA_TMAX : 1], hs[CLS ? CA_CLS_HID : 1];
   const int tid = threadIdx.x, b = blockIdx.x;
+  if constexpr (CLS) {      // in flight while the attention rows are evaluated
+    const int ldw = cls.hid + 1;
+    for (int i0 = tid; i0 < cls.hid * T; i0 += 4 * CA_THREADS) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CA_THREADS; v[u] = (i < cls.hid * T) ? cls.W1[i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CA_THREADS; if (i < cls.hid * T) w1t[(i % T) * ldw + i / T] = v[u]; }
+    }
+  }
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   float lo = INFINITY, hi = -INFINITY;
   for (int j = tid; j < T; j += CA_THREADS) {
@@ -137,29 +161,181 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     contrib += __shfl_xor(contrib, 2, 64);
     contrib += __shfl_xor(contrib, 4, 64);
     if (on) {
-      if (hd == 0) z[(size_t)b * T + i] = co.beta + contrib;
+      if (hd == 0) {
+        z[(size_t)b * T + i] = co.beta + contrib;
+        if constexpr (CLS) zs[i] = co.beta + contrib;
+      }
       if (stats != nullptr) {
         float* st = stats + ((size_t)b * items + w) * CA_NSTAT;
         st[0] = gamma; st[1] = mx; st[2] = inv; st[3] = m; st[4] = sq * inv;
       }
     }
   }
+  if constexpr (CLS) {
+    __syncthreads();
+    const int ldw = cls.hid + 1;
+    if (tid < cls.hid) {
+      float acc = cls.b1[tid];
+      for (int k = 0; k < T; ++k) acc += w1t[k * ldw + tid] * zs[k];
+      acc = fmaxf(acc, 0.0f);
+      if (cls.a1 != nullptr) cls.a1[(size_t)b * cls.hid + tid] = acc;
+      if (cls.mask != nullptr) acc *= cls.mask[(size_t)b * cls.hid + tid];
+      hs[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < cls.out) {
+      float acc = cls.b2[tid];
+      for (int h = 0; h < cls.hid; ++h) acc += cls.W2[tid * cls.hid + h] * hs[h];
+      if (cls.act2 == 1) acc = fmaxf(acc, 0.0f);
+      cls.y[(size_t)b * cls.out + tid] = acc;
+    }
+  }
 }
 
-template <int F>
+// parameter gradients of the classifier, one workgroup: samples in ascending order (deterministic)
+__device__ __forceinline__ void ca_cls_wgrad(float* lds, const CaCls& cls, int T, int tid) {
+  constexpr int S = 8;                                   // samples per chunk
+  float* zc = lds;                                       // [S][T]
+  float* ghc = zc + S * CA_TMAX;                         // [S][hid]   d loss / d pre-activation 1
+  float* hc = ghc + S * CA_CLS_HID;                      // [S][hid]   hid = a1 * mask
+  float* g2c = hc + S * CA_CLS_HID;                      // [S][out]
+  const int hid = cls.hid, out = cls.out;
+  const int n1 = hid * T, n2 = out * hid;
+  constexpr int PER1 = (CA_CLS_HID * CA_TMAX + CA_THREADS - 1) / CA_THREADS;                    // dW1 entries per thread
+  constexpr int PER2 = (CA_CLS_HID + 64 * CA_CLS_HID + 64 + CA_THREADS - 1) / CA_THREADS;       // db1 | dW2 | db2 entries
+  float acc1[PER1], acc2[PER2];
+#pragma unroll
+  for (int k = 0; k < PER1; ++k) acc1[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < PER2; ++k) acc2[k] = 0.0f;
+  for (int s0 = 0; s0 < cls.B; s0 += S) {
+    __syncthreads();
+    for (int i = tid; i < S * T; i += CA_THREADS) {
+      const int s = s0 + i / T;
+      zc[(i / T) * CA_TMAX + i % T] = (s < cls.B) ? cls.z_in[(size_t)s * T + i % T] : 0.0f;
+    }
+    for (int i = tid; i < S * out; i += CA_THREADS) {
+      const int s = s0 + i / out, o = i % out;
+      float g = 0.0f;
+      if (s < cls.B) {
+        g = cls.gy[(size_t)s * out + o];
+        if (cls.act2 == 1 && !(cls.y_in[(size_t)s * out + o] > 0.0f)) g = 0.0f;
+      }
+      g2c[i] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < S * hid; i += CA_THREADS) {
+      const int sl = i / hid, h = i % hid, s = s0 + sl;
+      float a = 0.0f, m = 1.0f, g = 0.0f;
+      if (s < cls.B) {
+        a = cls.a1_in[(size_t)s * hid + h];
+        if (cls.mask != nullptr) m = cls.mask[(size_t)s * hid + h];
+        for (int o = 0; o < out; ++o) g += g2c[sl * out + o] * cls.W2[o * hid + h];
+        g *= m;
+        if (!(a > 0.0f)) g = 0.0f;
+      }
+      ghc[i] = g;
+      hc[i] = a * m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER1; ++k) {
+      const int idx = tid + k * CA_THREADS;
+      if (idx < n1) {
+        const int h = idx / T, kk = idx % T;
+        float v = acc1[k];
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) v += ghc[sl * hid + h] * zc[sl * CA_TMAX + kk];
+        acc1[k] = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PER2; ++k) {
+      const int idx = tid + k * CA_THREADS;      // db1 [hid] | dW2 [out * hid] | db2 [out]
+      if (idx < hid + n2 + out) {
+        // one form for the three blocks: sum over the chunk of A[sl] * Bv[sl] with Bv = 1 for the bias sums
+        const bool is_b1 = idx < hid, is_w2 = !is_b1 && idx < hid + n2;
+        const int o = is_w2 ? (idx - hid) / hid : (is_b1 ? 0 : idx - hid - n2);
+        const int h = is_b1 ? idx : (is_w2 ? (idx - hid) % hid : 0);
+        float v = acc2[k];
+        for (int sl = 0; sl < S; ++sl) {
+          const float a = is_b1 ? ghc[sl * hid + h] : g2c[sl * out + o];
+          const float bvv = is_w2 ? hc[sl * hid + h] : 1.0f;
+          v += a * bvv;
+        }
+        acc2[k] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PER1; ++k) {
+    const int idx = tid + k * CA_THREADS;
+    if (idx < n1) cls.gcls[idx] = acc1[k];
+  }
+#pragma unroll
+  for (int k = 0; k < PER2; ++k) {
+    const int idx = tid + k * CA_THREADS;
+    if (idx < hid + n2 + out) cls.gcls[n1 + idx] = acc2[k];
+  }
+}
+
+template <int F, bool CLS>
 __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     CaParts X, const float* __restrict__ stats, const float* __restrict__ dz,
     const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wk,
     const float* __restrict__ wv, const float* __restrict__ bv, const float* __restrict__ Wc,
-    const float* __restrict__ bc, float* __restrict__ partials, int T) {
+    const float* __restrict__ bc, float* __restrict__ partials, int T, CaCls cls) {
   constexpr int D = F / CA_HEADS;
   __shared__ float c[CA_TMAX];
   __shared__ float dxi[CA_TMAX];
-  __shared__ float s_gamma[CA_HEADS * CA_TMAX], s_mx[CA_HEADS * CA_TMAX], s_inv[CA_HEADS * CA_TMAX],
-      s_m[CA_HEADS * CA_TMAX], s_dm[CA_HEADS * CA_TMAX];
+  // s_gamma | s_mx | s_inv | s_m | s_dm  (5 x [heads * T]) followed by acc [4][threads]: one block, so that the classifier's
+  // prologue (W1 rows) and the parameter-gradient workgroup (sample chunks) can use it before / instead of the phases below
+  __shared__ float big[5 * CA_HEADS * CA_TMAX + 4 * CA_THREADS];
+  float* s_gamma = big;
+  float* s_mx = s_gamma + CA_HEADS * CA_TMAX;
+  float* s_inv = s_mx + CA_HEADS * CA_TMAX;
+  float* s_m = s_inv + CA_HEADS * CA_TMAX;
+  float* s_dm = s_m + CA_HEADS * CA_TMAX;
+  float (*acc)[CA_THREADS] = reinterpret_cast<float (*)[CA_THREADS]>(s_dm + CA_HEADS * CA_TMAX);
+  __shared__ float dzs[CLS ? CA_TMAX : 1], ghs[CLS ? CA_CLS_HID : 1];
   __shared__ CaCoef co;
-  __shared__ float acc[4][CA_THREADS];
   const int tid = threadIdx.x, b = blockIdx.x;
+  if constexpr (CLS) {
+    if (b == cls.B) {      // the extra workgroup: the classifier's parameter gradients
+      ca_cls_wgrad(big, cls, T, tid);
+      return;
+    }
+    // d z = W1^T (mask * ReLU' * (W2^T g2)): the gradient the classifier hands to the attention block, never in HBM
+    const int ldw = T + 1;
+    float* w1s = big;                                   // [hid][T + 1]
+    for (int i0 = tid; i0 < cls.hid * T; i0 += 4 * CA_THREADS) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CA_THREADS; v[u] = (i < cls.hid * T) ? cls.W1[i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CA_THREADS; if (i < cls.hid * T) w1s[(i / T) * ldw + i % T] = v[u]; }
+    }
+    if (tid < cls.hid) {
+      const float a = cls.a1_in[(size_t)b * cls.hid + tid];
+      const float m = cls.mask != nullptr ? cls.mask[(size_t)b * cls.hid + tid] : 1.0f;
+      float g = 0.0f;
+      for (int o = 0; o < cls.out; ++o) {
+        float g2 = cls.gy[(size_t)b * cls.out + o];
+        if (cls.act2 == 1 && !(cls.y_in[(size_t)b * cls.out + o] > 0.0f)) g2 = 0.0f;
+        g += g2 * cls.W2[o * cls.hid + tid];
+      }
+      g *= m;
+      if (!(a > 0.0f)) g = 0.0f;
+      ghs[tid] = g;
+    }
+    __syncthreads();
+    for (int j = tid; j < T; j += CA_THREADS) {
+      float v = 0.0f;
+      for (int h = 0; h < cls.hid; ++h) v += ghs[h] * w1s[h * ldw + j];
+      dzs[j] = v;
+    }
+    __syncthreads();      // w1s is dead: the phases below reuse the block
+  }
   ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   for (int j = tid; j < T; j += CA_THREADS) c[j] = ca_load(X, b, j);
   __syncthreads();
@@ -175,7 +351,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     if (on) {
       const float* st = stats + ((size_t)b * items + w) * CA_NSTAT;
       const float gamma = st[0], m = st[3], var = st[4] - st[3] * st[3];
-      const float g = dz[(size_t)b * T + i];
+      const float g = CLS ? dzs[i] : dz[(size_t)b * T + i];
       const float dm = g * co.alpha[hd];
       const float dgamma = dm * var;
       dA2 += dgamma * c[i] * rs;
@@ -308,8 +484,9 @@ extern "C" int is_comb_attn_fwd(const void* parts, int nparts, const float* wq, 
   is::CaParts P;
   if (ca_parts_from(P, parts, nparts, T, false) != 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (F == 16) hipLaunchKernelGGL(is::comb_attn_fwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
-  else hipLaunchKernelGGL(is::comb_attn_fwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T);
+  const is::CaCls none{};
+  if (F == 16) hipLaunchKernelGGL((is::comb_attn_fwd_kernel<16, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, none);
+  else hipLaunchKernelGGL((is::comb_attn_fwd_kernel<32, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, none);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -321,11 +498,65 @@ extern "C" int is_comb_attn_bwd(const void* parts, int nparts, const float* stat
   is::CaParts P;
   if (ca_parts_from(P, parts, nparts, T, true) != 0) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const is::CaCls none{};
   if (F == 16) {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<16>, dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T);
+    hipLaunchKernelGGL((is::comb_attn_bwd_kernel<16, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, none);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   } else {
-    hipLaunchKernelGGL(is::comb_attn_bwd_kernel<32>, dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T);
+    hipLaunchKernelGGL((is::comb_attn_bwd_kernel<32, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, none);
+    hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+static bool ca_cls_ok(int hid, int out, int act2) { return hid > 0 && hid <= is::CA_CLS_HID && out > 0 && out <= 64 && (act2 == 0 || act2 == 1); }
+
+// The combined attention with the classifier y = act2(W2 (mask * ReLU(W1 z + b1)) + b2) behind it (models/hybrid_models.py:
+// 288-295, 344-350) as ONE launch: W1 [hid, T], b1, W2 [out, hid], b2, mask [B, hid] (scaled dropout keep-mask) or NULL;
+// outputs z [B, T] (saved for the backward), a1 [B, hid] (ReLU output, saved), y [B, out].  hid <= 32, out <= 64.
+extern "C" int is_comb_attn_cls_fwd(const void* parts, int nparts, const float* wq, const float* bq, const float* wk,
+                                    const float* wv, const float* bv, const float* Wc, const float* bc, const float* W1,
+                                    const float* b1, const float* W2, const float* b2, const float* mask, float* z,
+                                    float* stats, float* a1, float* y, int B, int T, int F, int hid, int out, int act2,
+                                    void* stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32) || !ca_cls_ok(hid, out, act2) || W1 == nullptr || b1 == nullptr ||
+      W2 == nullptr || b2 == nullptr || z == nullptr || y == nullptr)
+    return -22;
+  is::CaParts P;
+  if (ca_parts_from(P, parts, nparts, T, false) != 0) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const is::CaCls cls{W1, b1, W2, b2, mask, a1, y, nullptr, nullptr, nullptr, nullptr, nullptr, hid, out, act2, B};
+  if (F == 16) hipLaunchKernelGGL((is::comb_attn_fwd_kernel<16, true>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, cls);
+  else hipLaunchKernelGGL((is::comb_attn_fwd_kernel<32, true>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, cls);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int is_comb_attn_cls_grad_floats(int T, int hid, int out) { return hid * T + hid + out * hid + out; }
+
+// Backward of is_comb_attn_cls_fwd: gy [B, out] -> the pieces' gradients (parts[].dx), the attention block's parameter
+// gradients `grads` (layout of is_comb_attn_bwd) and the classifier's gcls = dW1 [hid * T] | db1 | dW2 [out * hid] | db2
+// (is_comb_attn_cls_grad_floats): every sample's workgroup derives d z itself, one extra workgroup contracts the samples
+// (ascending order) into gcls; then the finish launch of is_comb_attn_bwd.
+extern "C" int is_comb_attn_cls_bwd(const void* parts, int nparts, const float* stats, const float* gy, const float* wq,
+                                    const float* bq, const float* wk, const float* wv, const float* bv, const float* Wc,
+                                    const float* bc, const float* W1, const float* W2, const float* mask, const float* z,
+                                    const float* a1, const float* y, float* partials, float* grads, float* gcls, int B,
+                                    int T, int F, int hid, int out, int act2, void* stream) {
+  if (B <= 0) return 0;
+  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32) || !ca_cls_ok(hid, out, act2) || W1 == nullptr || W2 == nullptr ||
+      z == nullptr || a1 == nullptr || gy == nullptr || gcls == nullptr || (act2 == 1 && y == nullptr))
+    return -22;
+  is::CaParts P;
+  if (ca_parts_from(P, parts, nparts, T, true) != 0) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const is::CaCls cls{W1, nullptr, W2, nullptr, mask, nullptr, nullptr, a1, y, gy, z, gcls, hid, out, act2, B};
+  const float* dz = nullptr;
+  if (F == 16) {
+    hipLaunchKernelGGL((is::comb_attn_bwd_kernel<16, true>), dim3(B + 1), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, cls);
+    hipLaunchKernelGGL(is::comb_attn_finish_kernel<16>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
+  } else {
+    hipLaunchKernelGGL((is::comb_attn_bwd_kernel<32, true>), dim3(B + 1), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, cls);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
   return hipGetLastError() == hipSuccess ? 0 : -5;

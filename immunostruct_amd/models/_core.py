@@ -256,6 +256,12 @@ class MultimodalNet(nn.Module):
 
     def _head(self, pieces, cls_mask=None):
         """``pieces``: the fused row as a list of (B, w) tensors laid side by side"""
+        if self.SPEC.comb and not self.SPEC.ssl and pieces[0].is_cuda:
+            # combined attention + classifier as ONE launch in each direction (csrc/combined_attention.hip)
+            hid = HF.combined_attention_classifier(pieces, self.combined_attention, self.classifier,
+                                                   mask=cls_mask[0] if cls_mask else "draw")
+            if hid is not None:
+                return hid, None
         if self.SPEC.comb:
             ca = self.combined_attention
             if ca.n_head == 8 and ca.w_q.in_features == 1 and sum(p.shape[1] for p in pieces) <= 256 and len(pieces) <= 4:

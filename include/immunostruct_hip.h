@@ -297,6 +297,23 @@ int is_comb_attn_bwd(const void* parts, int nparts, const float* stats, const fl
                      const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
                      float* partials, float* grads, int B, int T, int F, void* stream);
 
+/* The combined attention with the classifier y = act2(W2 (mask * ReLU(W1 z + b1)) + b2) behind it (models/hybrid_models.py:
+ * 288-295, 344-350: Flatten, Linear(T, hid), ReLU, Dropout, Linear(hid, out)) as ONE launch forward and ONE (+ the finish
+ * launch) backward.  W1 [hid, T], W2 [out, hid]; mask [B, hid] = scaled dropout keep-mask or NULL; hid <= 32, out <= 64.
+ * Forward outputs: z [B, T], stats (as is_comb_attn_fwd), a1 [B, hid] (ReLU output), y [B, out].
+ * Backward: gy [B, out] -> parts[].dx, grads (layout of is_comb_attn_bwd), gcls = dW1 [hid*T] | db1 | dW2 [out*hid] | db2
+ * (is_comb_attn_cls_grad_floats); samples are contracted in ascending order by one extra workgroup.                      */
+int is_comb_attn_cls_fwd(const void* parts, int nparts, const float* wq, const float* bq, const float* wk, const float* wv,
+                         const float* bv, const float* Wc, const float* bc, const float* W1, const float* b1,
+                         const float* W2, const float* b2, const float* mask, float* z, float* stats, float* a1, float* y,
+                         int B, int T, int F, int hid, int out, int act2, void* stream);
+int is_comb_attn_cls_grad_floats(int T, int hid, int out);
+int is_comb_attn_cls_bwd(const void* parts, int nparts, const float* stats, const float* gy, const float* wq, const float* bq,
+                         const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
+                         const float* W1, const float* W2, const float* mask, const float* z, const float* a1,
+                         const float* y, float* partials, float* grads, float* gcls, int B, int T, int F, int hid, int out,
+                         int act2, void* stream);
+
 /* floats of scratch is_vae_loss needs */
 int is_loss_partials_floats(void);
 /* mode 0: c_pred*MSE(logit,y), mode 1: c_pred*BCEWithLogits(logit,y,pos_weight);

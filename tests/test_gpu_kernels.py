@@ -318,6 +318,53 @@ def test_combined_attention_closed_form(cuda_device, feat, tokens):
     assert all(p.grad.is_contiguous() for p in pieces)
 
 
+@pytest.mark.parametrize("feat,tokens,b,out", [(16, 104, 5, 1), (32, 208, 37, 1), (32, 104, 128, 3)])
+def test_combined_attention_with_classifier_is_the_chain(cuda_device, feat, tokens, b, out):
+    """``combined_attention_classifier`` (one launch per direction) == ``combined_attention_mean`` followed by ``mlp2`` on the same
+    dropout mask: the forward to the bit (same arithmetic order), every gradient to fp32 round-off (the samples are contracted
+    in one pass instead of per-workgroup records + reduction)."""
+    from immunostruct_amd.models.layers import MultiHeadAttention
+    rng = np.random.RandomState(feat * 7 + tokens + b)
+    torch.manual_seed(5)
+    mha = MultiHeadAttention(feat, 8, input_dim=1).to(cuda_device)
+    cls = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(tokens, 32), torch.nn.ReLU(True), torch.nn.Dropout(0.1),
+                              torch.nn.Linear(32, out)).to(cuda_device)
+    cls.train()
+    cuts = [0, 64, tokens] if tokens == 104 else [0, 64, 104, 168, tokens]
+    x = rng.normal(size=(b, tokens)).astype(np.float32) * 1.5
+    gup = torch.from_numpy(rng.normal(size=(b, out)).astype(np.float32)).to(cuda_device)
+    mask = HF.dropout_mask(b, 32, 0.1, cuda_device)
+    res = {}
+    for which in ("chain", "fused"):
+        for m in (mha, cls):
+            m.zero_grad()
+        pieces = [torch.from_numpy(x[:, a:b_].copy()).to(cuda_device).requires_grad_(True) for a, b_ in zip(cuts, cuts[1:])]
+        if which == "chain":
+            z = HF.combined_attention_mean(pieces, mha)
+            y = HF.sequential_mlp2(cls, z, mask=mask)
+        else:
+            y = HF.combined_attention_classifier(pieces, mha, cls, mask=mask)
+        assert y is not None and y.shape == (b, out)
+        (y * gup).sum().backward()
+        res[which] = dict(y=y.detach().clone(), dx=[p.grad.clone() for p in pieces],
+                          g={n: p.grad.clone() for n, p in list(mha.named_parameters()) + list(cls.named_parameters())})
+    assert torch.equal(res["fused"]["y"], res["chain"]["y"])
+    for a, c in zip(res["fused"]["dx"], res["chain"]["dx"]):
+        assert a.is_contiguous()
+        H.assert_close(a.cpu(), c.cpu(), 2e-6, "piece gradient")
+    for n in res["chain"]["g"]:
+        c = res["chain"]["g"][n]
+        if float(c.abs().max()) == 0.0:
+            assert float(res["fused"]["g"][n].abs().max()) == 0.0, n
+        else:
+            H.assert_close(res["fused"]["g"][n].cpu(), c.cpu(), 5e-6, f"d {n}")
+    # eval mode / no mask
+    cls.eval()
+    pieces = [torch.from_numpy(x[:, a:b_].copy()).to(cuda_device) for a, b_ in zip(cuts, cuts[1:])]
+    with torch.no_grad():
+        assert torch.equal(HF.combined_attention_classifier(pieces, mha, cls), HF.sequential_mlp2(cls, HF.combined_attention_mean(pieces, mha)))
+
+
 @pytest.mark.parametrize("heads,n", [(1, 190), (8, 190), (1, 45), (8, 9), (1, 256), (8, 70)])
 def test_node_attention_pooled_mean(cuda_device, heads, n):
     """fused Q/K projection + scores/softmax/column-mean kernel == mean over nodes of the reference attention block."""
