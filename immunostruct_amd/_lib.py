@@ -42,7 +42,8 @@ SIGNATURES = {
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
-    "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P],
+    "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P, _I, _P],
+    "is_chunk_partition": [_P, _I, _I, _P, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_contrastive_scratch_floats": [_I],
@@ -90,6 +91,11 @@ class NodePackJob(ctypes.Structure):
     """one layer of is_node_pack_weights (mirrors `NodePackJob` in csrc/egnn_node16.hip)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("Wn1", "Wn2", "W1n", "W1nb", "fpack", "bpack")] + \
                [(n, ctypes.c_int) for n in ("din", "ldw_n")]
+
+
+class RowGather(ctypes.Structure):
+    """one per-sample row gather of is_batch_gather (mirrors `RowGather` in csrc/segment_ops.hip)"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("floats", ctypes.c_int), ("pad", ctypes.c_int)]
 
 
 class ReduceJob(ctypes.Structure):

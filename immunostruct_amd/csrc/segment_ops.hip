@@ -207,9 +207,13 @@ struct BatchSrc {     // dataset, all graphs padded to n nodes
 struct BatchDst {
   float* x; int* rowptr_dst; int* rowptr_src; int* src; int* dst; int* pos; float* ea;
 };
+// per-sample rows that ride along (sequence one-hots, property vectors, targets): dst[i][:] = src[idx[i]][:]
+constexpr int BATCH_ROWS_MAX = 4;
+struct RowGather { const float* src; float* dst; int floats, pad; };
+struct RowGathers { RowGather job[BATCH_ROWS_MAX]; int n; };
 
 __global__ __launch_bounds__(256) void batch_gather_kernel(const long long* __restrict__ idx, int B, int n, int F, int Fe,
-                                                           BatchSrc S, BatchDst D) {
+                                                           BatchSrc S, BatchDst D, RowGathers R) {
   __shared__ int red[256];
   const int i = blockIdx.x, tid = threadIdx.x;
   int part = 0;
@@ -241,6 +245,31 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const long long* __re
     D.pos[off + e] = S.pos[e0 + e] + off;
   }
   for (int k = tid; k < cnt * Fe; k += 256) D.ea[(size_t)off * Fe + k] = S.ea[(size_t)e0 * Fe + k];
+  for (int j = 0; j < R.n; ++j) {
+    const RowGather& J = R.job[j];
+    const float* src = J.src + (size_t)g * J.floats;
+    float* dst = J.dst + (size_t)i * J.floats;
+    for (int k = tid; k < J.floats; k += 256) dst[k] = src[k];
+  }
+}
+
+// chunk_ptr [k + 1][2] = (b_j, rowptr[b_j]) with b_0 = 0, b_k = N, b_j = first node whose first in-edge index is >= j * E / k:
+// the node-aligned, edge-balanced partition of graph.py `balanced_node_chunks`, straight from the rowptr in device memory
+__global__ __launch_bounds__(256) void chunk_partition_kernel(const int* __restrict__ rowptr, int N, int k, int* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > k) return;
+  const long long E = rowptr[N];
+  const long long target = ((long long)j * E) / k;
+  int lo = 0, hi = N + 1;      // first index i in [0, N] with rowptr[i] >= target (N + 1: none)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  int b = min(lo, N);
+  if (j == 0) b = 0;
+  if (j == k) b = N;
+  out[2 * j] = b;
+  out[2 * j + 1] = rowptr[b];
 }
 }  // namespace is
 
@@ -250,11 +279,25 @@ extern "C" int is_batch_gather(const long long* idx, int B, int n, int F, int Fe
                                const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all, const int32_t* src_all,
                                const int32_t* dst_all, const int32_t* pos_all, const float* ea_all, float* x,
                                int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* src_sorted, int32_t* dst_sorted,
-                               int32_t* pos_by_src, float* ea, void* stream) {
+                               int32_t* pos_by_src, float* ea, const void* rows, int nrows, void* stream) {
   if (B <= 0) return 0;
-  if (n <= 0 || F <= 0 || Fe < 0) return -22;
+  if (n <= 0 || F <= 0 || Fe < 0 || nrows < 0 || nrows > is::BATCH_ROWS_MAX || (nrows > 0 && rows == nullptr)) return -22;
   is::BatchSrc S{x_all, eoff, rowptr_dst_all, rowptr_src_all, src_all, dst_all, pos_all, ea_all};
   is::BatchDst D{x, rowptr_dst, rowptr_src, src_sorted, dst_sorted, pos_by_src, ea};
-  hipLaunchKernelGGL(is::batch_gather_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), idx, B, n, F, Fe, S, D);
+  is::RowGathers R{};
+  R.n = nrows;
+  for (int j = 0; j < nrows; ++j) {
+    R.job[j] = static_cast<const is::RowGather*>(rows)[j];
+    if (R.job[j].src == nullptr || R.job[j].dst == nullptr || R.job[j].floats <= 0) return -22;
+  }
+  hipLaunchKernelGGL(is::batch_gather_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), idx, B, n, F, Fe, S, D, R);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// rowptr [N + 1] (device) -> chunk_ptr [k + 1][2] int32: the edge-balanced node partition the layer kernels walk (graph.py
+// `balanced_node_chunks`), recomputed on the device after the batcher wrote a new rowptr -- one launch, no host sync.
+extern "C" int is_chunk_partition(const int32_t* rowptr, int N, int k, int32_t* chunk_ptr, void* stream) {
+  if (N < 0 || k <= 0 || rowptr == nullptr || chunk_ptr == nullptr) return -22;
+  hipLaunchKernelGGL(is::chunk_partition_kernel, dim3((k + 256) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, N, k, chunk_ptr);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -11,6 +11,8 @@ index construction on the same graphs (``tests/test_gpu_models.py::test_device_b
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -121,21 +123,26 @@ class DeviceResidentDataset:
 
     def gather_into(self, idx, sgraph, seq, prop, y):
         """Assemble the batch of the graphs ``idx`` (int64 tensor on the device, len == the buffers' batch size) in place:
-        one HIP launch for the graph, three row gathers for sequence / property / target, then the work partitions of
-        the edge kernels are refreshed from the new rowptr (device-side, no sync)."""
+        ONE HIP launch for the graph and the sequence / property / target rows, then the work partitions of the layer
+        kernels are refreshed from the new rowptr (one more launch; device-side, no sync)."""
         b = int(idx.numel())
         if b != sgraph.batch_size or idx.device != self.device or idx.dtype != torch.int64:
             raise ValueError("idx must be an int64 device tensor with one entry per graph slot of the batch buffers")
         csr = sgraph._csr
         lib = _lib.load()
+        jobs = []
+        for src, dst in ((self.seq, seq), (self.prop, prop), (self.y, y)):
+            if (src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous()
+                    or dst.shape[0] != b or dst.shape[1:] != src.shape[1:] or dst.device != self.device):
+                raise ValueError("batch buffers must be contiguous float32 device tensors shaped like the dataset's rows")
+            jobs.append(_lib.RowGather(src.data_ptr(), dst.data_ptr(), int(src[0].numel()) if src.dim() > 1 else 1, 0))
+        rows = (_lib.RowGather * len(jobs))(*jobs)
         _lib.check(lib.is_batch_gather(
             _lib.ptr(idx), b, self.nodes_per_graph, self.node_feats, self.edge_feats, _lib.ptr(self.x), _lib.ptr(self.eoff),
             _lib.ptr(self.rowptr_dst), _lib.ptr(self.rowptr_src), _lib.ptr(self.src), _lib.ptr(self.dst), _lib.ptr(self.pos),
             _lib.ptr(self.ea) if self.edge_feats else None, _lib.ptr(sgraph.ndata["x"]), _lib.ptr(csr.rowptr_dst),
             _lib.ptr(csr.rowptr_src), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(csr.pos_by_src),
-            _lib.ptr(sgraph._ea_csr) if self.edge_feats else None, _lib.stream_ptr()), "is_batch_gather")
-        torch.index_select(self.seq, 0, idx, out=seq)
-        torch.index_select(self.prop, 0, idx, out=prop)
-        torch.index_select(self.y, 0, idx, out=y)
+            _lib.ptr(sgraph._ea_csr) if self.edge_feats else None, ctypes.cast(rows, ctypes.c_void_p), len(jobs),
+            _lib.stream_ptr()), "is_batch_gather")
         sgraph.refresh_partitions()
         return sgraph, seq, prop, y

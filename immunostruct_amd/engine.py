@@ -86,9 +86,12 @@ class StaticGraphBatch(PackedGraphBatch):
     def refresh_partitions(self):
         """Recompute the edge kernels' work partitions from the rowptr currently in the buffers (after the on-device
         batcher wrote a new batch): vectorised torch ops on the device, no host sync, capturable."""
-        from .graph import balanced_node_chunks, greedy_node_tiles
-        for k, dst in self._csr._chunks.items():
-            dst.copy_(balanced_node_chunks(self._csr.rowptr_dst, k))
+        from . import _lib
+        from .graph import greedy_node_tiles
+        lib = _lib.load()
+        for k, dst in self._csr._chunks.items():      # == graph.balanced_node_chunks, one launch each
+            _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), _lib.ptr(dst),
+                                              _lib.stream_ptr()), "is_chunk_partition")
         for key, dst in self._csr._tiles.items():
             t = greedy_node_tiles(self._csr.rowptr_dst, self.edge_capacity, *key)
             dst[:t.numel()].copy_(t)

@@ -233,12 +233,18 @@ int is_multi_copy(const void* jobs, int njobs, void* stream);
  * nodes: x_all [G][n][F]; eoff [G+1] edge offsets; rowptr_dst_all / rowptr_src_all [G][n+1] (0-based per graph);
  * src_all / dst_all [Etot] local node ids in destination order; pos_all [Etot] local slot ids in source order;
  * ea_all [Etot][Fe].  Writes the batch arrays (node ids + slot*n, edge slots + running edge offset); the destination
- * edge arrays must hold the selected graphs' edges (B * max edges per graph is always enough).                   */
+ * edge arrays must hold the selected graphs' edges (B * max edges per graph is always enough).
+ * rows: host array of nrows (<= 4) records { const float* src; float* dst; int floats, pad; }: per-sample rows that ride
+ * along in the same launch, dst[i][:] = src[idx[i]][:] (sequence one-hots, property vectors, targets).            */
 int is_batch_gather(const long long* idx, int B, int n, int F, int Fe, const float* x_all, const int32_t* eoff,
                     const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all, const int32_t* src_all,
                     const int32_t* dst_all, const int32_t* pos_all, const float* ea_all, float* x,
                     int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* src_sorted, int32_t* dst_sorted,
-                    int32_t* pos_by_src, float* ea, void* stream);
+                    int32_t* pos_by_src, float* ea, const void* rows, int nrows, void* stream);
+/* rowptr [N+1] (device) -> chunk_ptr [k+1][2] int32 = (b_j, rowptr[b_j]), b_0 = 0, b_k = N, b_j = first node whose first
+ * in-edge index is >= j * E / k: the edge-balanced node partition the layer kernels walk, recomputed on the device after
+ * the batcher wrote a new rowptr (one launch, no host sync).                                                        */
+int is_chunk_partition(const int32_t* rowptr, int N, int k, int32_t* chunk_ptr, void* stream);
 
 /* Per-segment mean and/or max over rows seg_ptr[s] .. seg_ptr[s+1] of x [rows, ld_x] (C channels).
  * out_mean / out_max [num_segments, C] may each be NULL.  Empty segment: mean 0, max 0.            */
