@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/round_profiles.sh TAG   -- the evidence set of a round, written to gpurun_out/TAG/:
+#   bench_{iedb,paired,stress}.json  the JSON lines of python bench.py [--workload W]
+#   kernel_stats.txt / timeline.txt  rocprofv3 --kernel-trace of a short default bench (per-kernel table, last step's timeline)
+#   pmc_{iedb,paired,stress}.json    HBM traffic per launch (two PMC passes per workload, tools/pmc_traffic.sh)
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+for wl in iedb paired stress; do
+  python bench.py --workload $wl --steps 30 --warmup 5 > $out/bench_$wl.json 2> $out/bench_$wl.err
+  cut -c1-230 $out/bench_$wl.json
+done
+export TMPDIR=/tmp
+rm -rf /tmp/prof_$tag
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o rr -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-e2e > $out/prof.log 2> $out/prof.err
+db=$(find /tmp/prof_$tag -name "*.db" | head -1)
+python tools/rocpd_stats.py $db > $out/kernel_stats.txt 2>> $out/prof.err
+python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
+for wl in iedb paired stress; do
+  bash tools/pmc_traffic.sh $wl $out/pmc_$wl.json
+done
+ls -la $out
