@@ -218,6 +218,83 @@ def _grid_for(n_rows, rows_per_wg):
     return max(1, min(_MAX_BWD_GRID, (n_rows + rows_per_wg - 1) // rows_per_wg))
 
 
+class StackPrologue:
+    """Outputs of the stack's prologue launch (``is_stack_prologue``): layer-0 pre-projection ``psd`` [N,128], the operand
+    packs of every layer's node half, and the dense coordinates ``x`` [N,3].  A caller may launch it EARLY
+    (:func:`launch_stack_prologue`) -- the models do so before they fork the sequence branch onto its side stream, so that
+    the graph branch's first kernel is not the one that pays the fork -- and hand the object to :func:`egnn_stack`."""
+
+    __slots__ = ("psd", "packs", "x", "key")
+
+    def __init__(self, psd, packs, x, key):
+        self.psd, self.packs, self.x, self.key = psd, packs, x, key
+
+
+def _prologue_key(h0, x0, params):
+    return (h0.data_ptr(), tuple(h0.shape), x0.data_ptr(), tuple(x0.stride()), tuple(p.data_ptr() for p in params))
+
+
+def _launch_prologue(h0, ld_h0, din0, x0, params, head, n_layers, n, dev):
+    """params: the flat list of contiguous fp32 layer parameters (11 per layer); head: ((Wa, Wb), ba, bb) or None"""
+    lib = _lib.load()
+    P = PARAMS_PER_LAYER
+    f32 = dict(dtype=torch.float32, device=dev)
+    # coordinates: the kernels read a dense [N,3] array; the reference keeps them as the last columns of ndata['x'] -- the
+    # prologue launch writes the dense copy (no copy launch in front of the stack)
+    if x0.dtype != torch.float32:
+        raise ValueError(f"expected float32 coordinates, got {x0.dtype}")
+    if x0.is_contiguous():
+        x, x_src, ld_x0 = x0, None, 0
+    else:
+        x_src, ld_x0 = _lib.rows_ld(x0)
+        x = torch.empty(n, 3, **f32)
+    w1_0, b1_0 = params[0], params[1]
+    psd = torch.empty(n, 2 * HIDDEN, **f32)
+    # layer-0 pre-projection and the lane-ordered operand packs of every layer's node half (forward + backward
+    # order): independent, ONE launch
+    packs = torch.empty(n_layers, 2, lib.is_node_pack_floats(), **f32)
+    jobs = []
+    for i in range(n_layers):
+        lp = params[i * P:(i + 1) * P]
+        if i < n_layers - 1:
+            w1n = params[(i + 1) * P]          # next layer's edge_mlp.0.weight: [W1s | W1d | w_r | W_a] column blocks
+            wa_p, wb_p, ldn = w1n.data_ptr(), w1n.data_ptr() + 4 * HIDDEN, int(w1n.shape[1])
+        elif head is not None:
+            wa_p, wb_p, ldn = head[0][0].data_ptr(), head[0][1].data_ptr(), HIDDEN      # [Wq | Wk] where they are
+        else:
+            wa_p, wb_p, ldn = None, None, 0
+        jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), wa_p, wb_p,
+                                     packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN, ldn))
+    jarr = (_lib.NodePackJob * len(jobs))(*jobs)
+    with KernelTimer.span("stack_prologue"):
+        _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
+                                         _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd),
+                                         _lib.ptr(x_src), ld_x0, _lib.ptr(x) if x_src is not None else None, n, _lib.stream_ptr()),
+                   "is_stack_prologue")
+    return psd, packs, x
+
+
+def launch_stack_prologue(h0, x0, layer_params, head=None):
+    """Launch the prologue of :func:`egnn_stack` now, on the current stream; returns the :class:`StackPrologue` to pass on.
+    The arguments must be the very tensors the later ``egnn_stack`` call receives (checked there; a mismatch relaunches)."""
+    flat = [p for lp in layer_params for p in lp] + (list(head) if head is not None else [])
+    _lib.require_device(h0, x0, *flat)
+    din0, n = int(h0.shape[1]), int(h0.shape[0])
+    if din0 not in (20, HIDDEN) or x0.shape != (n, 3) or not 1 <= len(layer_params) <= 7:
+        raise ValueError("launch_stack_prologue: node features must be 20 or 64 wide, coordinates (N, 3), 1-7 layers")
+    key = _prologue_key(h0, x0, flat)
+    h0c, ld_h0 = _lib.rows_ld(h0)
+    params = [_lib.f32c(p) for p in flat]
+    hd = None
+    if head is not None:
+        wa, ba, wb, bb = params[-4:]
+        params = params[:-4]
+        hd = ((wa, wb), ba, bb)
+    with torch.no_grad():
+        psd, packs, x = _launch_prologue(h0c, ld_h0, din0, x0, params, hd, len(layer_params), n, h0.device)
+    return StackPrologue(psd, packs, x, key)
+
+
 class EGNNStackFn(torch.autograd.Function):
     """L chained EGNNConv layers on the fused layer kernels: one launch per layer forward (``csrc/egnn_layer_fwd.hip``),
     node data path + edge pass + source gather per layer backward, one batched weight-gradient launch and one batched
@@ -228,7 +305,7 @@ class EGNNStackFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h0, x0, ea, csr, n_layers, final_coords, *params):
+    def forward(ctx, h0, x0, ea, csr, n_layers, final_coords, prologue, *params):
         """params = 11 tensors per layer [+ (Wa, ba, Wb, bb) of an optional 128-wide projection head of the final h:
         the node attention's query / key projection, emitted by the last layer's node half].
         ``final_coords=False``: the caller does not use the last layer's coordinates (the reference's models never do:
@@ -253,16 +330,8 @@ class EGNNStackFn(torch.autograd.Function):
         fe = int(ea.shape[1]) if ea is not None else 0
         if fe > 8:
             raise ValueError("edge_feat_size > 8 is not supported by the HIP kernel")
+        early = prologue if (prologue is not None and prologue.key == _prologue_key(h0, x0, params)) else None
         h0, ld_h0 = _lib.rows_ld(h0)
-        # coordinates: the kernels read a dense [N,3] array; the reference keeps them as the last columns of ndata['x'] -- the
-        # prologue launch writes the dense copy (no copy launch in front of the stack)
-        if x0.dtype != torch.float32:
-            raise ValueError(f"expected float32 coordinates, got {x0.dtype}")
-        if x0.is_contiguous():
-            x, x_src, ld_x0 = x0, None, 0
-        else:
-            x_src, ld_x0 = _lib.rows_ld(x0)
-            x = torch.empty(n, 3, dtype=torch.float32, device=dev)
         ea = _lib.f32c(ea) if fe else None
         params = [_lib.f32c(p) for p in params]
         head = None
@@ -276,29 +345,10 @@ class EGNNStackFn(torch.autograd.Function):
         st = _lib.stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
         layers = []
-        w1_0, b1_0 = params[0], params[1]
-        psd = torch.empty(n, 2 * HIDDEN, **f32)
-        # layer-0 pre-projection and the lane-ordered operand packs of every layer's node half (forward + backward
-        # order): independent, ONE launch
-        packs = torch.empty(n_layers, 2, lib.is_node_pack_floats(), **f32)
-        jobs = []
-        for i in range(n_layers):
-            lp = params[i * P:(i + 1) * P]
-            if i < n_layers - 1:
-                w1n = params[(i + 1) * P]          # next layer's edge_mlp.0.weight: [W1s | W1d | w_r | W_a] column blocks
-                wa_p, wb_p, ldn = w1n.data_ptr(), w1n.data_ptr() + 4 * HIDDEN, int(w1n.shape[1])
-            elif head is not None:
-                wa_p, wb_p, ldn = head[0][0].data_ptr(), head[0][1].data_ptr(), HIDDEN      # [Wq | Wk] where they are
-            else:
-                wa_p, wb_p, ldn = None, None, 0
-            jobs.append(_lib.NodePackJob(lp[4].data_ptr(), lp[6].data_ptr(), wa_p, wb_p,
-                                         packs[i, 0].data_ptr(), packs[i, 1].data_ptr(), din0 if i == 0 else HIDDEN, ldn))
-        jarr = (_lib.NodePackJob * len(jobs))(*jobs)
-        with KernelTimer.span("stack_prologue"):
-            _lib.check(lib.is_stack_prologue(ctypes.cast(jarr, ctypes.c_void_p), len(jobs), _lib.ptr(h0), ld_h0, din0,
-                                             _lib.ptr(w1_0), int(w1_0.shape[1]), None, _lib.ptr(b1_0), _lib.ptr(psd),
-                                             _lib.ptr(x_src), ld_x0, _lib.ptr(x) if x_src is not None else None, n, st),
-                       "is_stack_prologue")
+        if early is not None:
+            psd, packs, x = early.psd, early.packs, early.x      # launched by the caller (before its stream fork)
+        else:
+            psd, packs, x = _launch_prologue(h0, ld_h0, din0, x0, params, head, n_layers, n, dev)
         kf = fwd_chunk_count(e)
         chunks = csr.chunks(kf)
         h_in, ld_h, din = h0, ld_h0, din0
@@ -468,7 +518,7 @@ class EGNNStackFn(torch.autograd.Function):
             hh = HIDDEN * HIDDEN
             grads.extend([head_flat[0:hh].view(HIDDEN, HIDDEN), head_flat[2 * hh + HIDDEN:2 * hh + 2 * HIDDEN],
                           head_flat[hh:2 * hh].view(HIDDEN, HIDDEN), head_flat[2 * hh:2 * hh + HIDDEN]])
-        return (g_h0, g_x0, None, None, None, None) + tuple(grads)
+        return (g_h0, g_x0, None, None, None, None, None) + tuple(grads)
 
 
 class PairLinearFn(torch.autograd.Function):
@@ -778,14 +828,14 @@ def fused_head_available(n_layers):
     return n_layers <= 7
 
 
-def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None, final_coords=True):
+def egnn_stack(h0, x0, ea_csr, csr, layer_params, head=None, final_coords=True, prologue=None):
     """layer_params: list (one entry per layer) of the 11 native parameter tensors; ``head`` = optional
     (Wa, ba, Wb, bb), 64x64 each: the call then also returns [h Wa^T + ba | h Wb^T + bb] (N, 128) of the final h.
     ``final_coords=False``: the last layer's coordinates are not needed; None may be returned in their place."""
     flat = [p for lp in layer_params for p in lp]
     if head is not None:
         flat = flat + list(head)
-    return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), bool(final_coords), *flat)
+    return EGNNStackFn.apply(h0, x0, ea_csr, csr, len(layer_params), bool(final_coords), prologue, *flat)
 
 
 class Mlp2Fn(torch.autograd.Function):

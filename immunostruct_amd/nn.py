@@ -61,7 +61,13 @@ class EGNNConv(nn.Module):
         return h, x
 
 
-def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True):
+def egnn_stack_prologue(layers, node_feat, coord_feat, head=None):
+    """Launch the first kernel of :func:`egnn_stack_forward` (layer-0 pre-projection, operand packs, dense coordinates) now and
+    return the handle to pass as ``prologue=`` -- for callers that fork other work onto a side stream before the stack."""
+    return HF.launch_stack_prologue(node_feat, coord_feat, [layer.native_parameters() for layer in layers], head=head)
+
+
+def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True, prologue=None):
     """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``).
 
     ``head`` = optional (Wa, ba, Wb, bb): also return the 128-wide projection [h Wa^T + ba | h Wb^T + bb] of the
@@ -80,7 +86,7 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, hea
         raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
     ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
     return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head,
-                         final_coords=final_coords)
+                         final_coords=final_coords, prologue=prologue)
 
 
 def _seg_ptr_from_batch(batch_index, size=None):
