@@ -758,6 +758,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
                                  void* stream) {
   if (N <= 0) return 0;
+  if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
   const bool gather = dZ1n != nullptr;
   const bool gx = gather || g_xout != nullptr;
   if (Fe < 0 || Fe > 8 || grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||

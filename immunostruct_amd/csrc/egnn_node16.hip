@@ -450,6 +450,7 @@ extern "C" int is_egnn_node_wgrad_proj_floats(void) { return is::WG_PROJ; }
 // columns of h_out, row stride ld_ho); a record with g_psd == NULL leaves the PROJ part untouched.
 extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream) {
   if (N <= 0 || grid <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
+  if ((long long)N * 128 * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer row loads (4.1 M nodes)
   is::WgradBatch batch;
   const is::WgradLayer* src = static_cast<const is::WgradLayer*>(layers);
   for (int i = 0; i < nlayers; ++i) {
