@@ -48,8 +48,8 @@ SIGNATURES = {
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_contrastive_scratch_floats": [_I],
     "is_contrastive_work_floats": [_I],
-    "is_contrastive_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _I, _P],
-    "is_contrastive_bwd": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_contrastive_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, ctypes.c_float, _I, _P],
+    "is_contrastive_bwd": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_float, _P, _P, _I, _I, _I, _P],
     "is_contrastive_targets": [_P, _P, _P, _I, _P],
     "is_mlp2_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "is_mlp2_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

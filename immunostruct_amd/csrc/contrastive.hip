@@ -245,12 +245,14 @@ __global__ __launch_bounds__(256) void contr_pair_fwd_kernel(
   }
 }
 
+// loss = scale * gate * (pair / correlation terms + hinge): `scale` is the caller's loss coefficient, `gate` (device, may be NULL)
+// the reference's early-out as a 0 / 1 factor -- both folded in here instead of two multiply launches behind the loss
 __global__ void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ hinge,
-                                    float* __restrict__ loss) {
+                                    float* __restrict__ loss, const float* __restrict__ gate, float scale) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.0f;
     for (int i = 0; i < nparts; ++i) s += partials[i];
-    loss[0] = s + 0.5f * (hinge[0] + hinge[1]);
+    loss[0] = (s + 0.5f * (hinge[0] + hinge[1])) * (gate != nullptr ? gate[0] * scale : scale);
   }
 }
 
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void contr_pair_bwd_kernel(
 __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
     const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ W2,
     const float* __restrict__ scratch, float* __restrict__ DZ, float* __restrict__ work, const float* __restrict__ g_loss,
-    float* __restrict__ demb_c, float* __restrict__ demb_w, int ld_d, int E, int B) {
+    const float* __restrict__ gate, float scale, float* __restrict__ demb_c, float* __restrict__ demb_w, int ld_d, int E, int B) {
   const int side = blockIdx.x;
   const float* S = scratch + (size_t)side * side_floats(B);
   const float* XH = S; const float* A1 = XH + (size_t)B * CZ; const float* Zc = A1 + (size_t)B * CZ;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
   __shared__ float part[C_GROUPS][CZ], part2[C_GROUPS][CZ];
   const int tid = threadIdx.x;
   const int col = tid & (CZ - 1), grp = tid / CZ;
-  const float g = g_loss[0];
+  const float g = g_loss[0] * (gate != nullptr ? gate[0] * scale : scale);
   // ---- hinge gradient + centring backward (per column) ----
   {
     const float sd = st[3 * CZ + col];
@@ -409,10 +411,10 @@ extern "C" long long is_contrastive_scratch_floats(int B) {
 extern "C" long long is_contrastive_work_floats(int B) { return 4LL * B * is::CZ; }
 
 // emb_c, emb_w [B, ld_e] (E valid columns), pos [B] (1.0 = immunogenic), W1 [128, E], gamma, beta [128], W2 [128, 128];
-// loss [1].  2 <= B <= 256, E <= 256.
+// loss [1] = scale * gate * L (gate [1] on the device or NULL: 1).  2 <= B <= 256, E <= 256.
 extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld_e, int E, const float* pos, const float* W1,
                                   const float* gamma, const float* beta, const float* W2, float lambda, float* scratch,
-                                  float* loss, int B, void* stream) {
+                                  float* loss, const float* gate, float scale, int B, void* stream) {
   if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_e < E) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long sides = 2 * is::side_floats(B);
@@ -424,7 +426,7 @@ extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld
   hipLaunchKernelGGL(is::contr_side_fwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, emb_c, emb_w, ld_e, E, W1, gamma, beta, W2,
                      scratch, hinge, B);
   hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
-  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, hinge, loss);
+  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, hinge, loss, gate, scale);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -437,10 +439,11 @@ extern "C" int is_contrastive_targets(const float* target, float* pos, float* ga
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// g_loss [1] = upstream gradient of the scalar loss; demb_c, demb_w [B, ld_d] (E columns written).
+// g_loss [1] = upstream gradient of the scalar loss (multiplied by scale * gate as in the forward); demb_c, demb_w [B, ld_d]
+// (E columns written).
 extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, const float* W2, float lambda,
-                                  const float* scratch, float* work, const float* g_loss, float* demb_c, float* demb_w,
-                                  int ld_d, int E, int B, void* stream) {
+                                  const float* scratch, float* work, const float* g_loss, const float* gate, float scale,
+                                  float* demb_c, float* demb_w, int ld_d, int E, int B, void* stream) {
   if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_d < E) return -22;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long sides = 2 * is::side_floats(B);
@@ -451,6 +454,6 @@ extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float
   const int rt = (B + 31) / 32, ntiles = 2 * rt * 4;
   hipLaunchKernelGGL(is::contr_pair_bwd_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, DZ, B);
   hipLaunchKernelGGL(is::contr_side_bwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, W1, gamma, W2, scratch, DZ, wk, g_loss,
-                     demb_c, demb_w, ld_d, E, B);
+                     gate, scale, demb_c, demb_w, ld_d, E, B);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

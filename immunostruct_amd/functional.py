@@ -959,9 +959,11 @@ class PairedContrastiveFn(torch.autograd.Function):
     (w1, gamma, beta, w2) is frozen in the reference (never handed to the optimizer): no parameter gradients."""
 
     @staticmethod
-    def forward(ctx, emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
+    def forward(ctx, emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate=None, scale=1.0):
+        """``gate`` (device tensor with one element, or None) and ``scale``: the result is scale * gate * loss, applied inside the
+        launches (the reference's early-out as a 0 / 1 factor and the caller's loss coefficient: no multiply launches behind)"""
         lib = _lib.load()
-        _lib.require_device(emb_c, emb_w, pos, w1, gamma, beta, w2)
+        _lib.require_device(emb_c, emb_w, pos, w1, gamma, beta, w2, gate)
         if emb_c.shape != emb_w.shape or emb_c.dim() != 2:
             raise AssertionError("cancer / wild-type embeddings must have equal (batch, features) shapes")
         b, e = int(emb_c.shape[0]), int(emb_c.shape[1])
@@ -970,20 +972,23 @@ class PairedContrastiveFn(torch.autograd.Function):
         emb_c, emb_w, pos, w1, gamma, beta, w2 = (_lib.f32c(t) for t in (emb_c, emb_w, pos, w1, gamma, beta, w2))
         dev = emb_c.device
         scratch = torch.empty(lib.is_contrastive_scratch_floats(b), dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)      # its own buffer: no clone launch for the result
+        gate = _lib.f32c(gate.reshape(1)) if gate is not None else None
         with KernelTimer.span("contrastive_fwd"):
             _lib.check(lib.is_contrastive_fwd(_lib.ptr(emb_c), _lib.ptr(emb_w), e, e, _lib.ptr(pos), _lib.ptr(w1), _lib.ptr(gamma),
-                                              _lib.ptr(beta), _lib.ptr(w2), float(lam), _lib.ptr(scratch), _lib.ptr(loss), b,
-                                              _lib.stream_ptr()), "is_contrastive_fwd")
-        ctx.cfg = (b, e, float(lam))
-        ctx.save_for_backward(pos, w1, gamma, w2, scratch)
-        return loss[0].clone()
+                                              _lib.ptr(beta), _lib.ptr(w2), float(lam), _lib.ptr(scratch), _lib.ptr(loss),
+                                              _lib.ptr(gate), float(scale), b, _lib.stream_ptr()), "is_contrastive_fwd")
+        ctx.cfg = (b, e, float(lam), float(scale))
+        ctx.has_gate = gate is not None
+        ctx.save_for_backward(pos, w1, gamma, w2, scratch, *([gate] if gate is not None else []))
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        pos, w1, gamma, w2, scratch = ctx.saved_tensors
-        b, e, lam = ctx.cfg
+        pos, w1, gamma, w2, scratch = ctx.saved_tensors[:5]
+        gate = ctx.saved_tensors[5] if ctx.has_gate else None
+        b, e, lam, scale = ctx.cfg
         dev = scratch.device
         work = torch.empty(lib.is_contrastive_work_floats(b), dtype=torch.float32, device=dev)
         dc = torch.empty(b, e, dtype=torch.float32, device=dev)
@@ -991,9 +996,9 @@ class PairedContrastiveFn(torch.autograd.Function):
         gl = _lib.f32c(g.reshape(1))
         with KernelTimer.span("contrastive_bwd"):
             _lib.check(lib.is_contrastive_bwd(_lib.ptr(pos), _lib.ptr(w1), _lib.ptr(gamma), _lib.ptr(w2), lam, _lib.ptr(scratch),
-                                              _lib.ptr(work), _lib.ptr(gl), _lib.ptr(dc), _lib.ptr(dw), e, e, b, _lib.stream_ptr()),
-                       "is_contrastive_bwd")
-        return dc, dw, None, None, None, None, None, None
+                                              _lib.ptr(work), _lib.ptr(gl), _lib.ptr(gate), scale, _lib.ptr(dc), _lib.ptr(dw), e, e, b,
+                                              _lib.stream_ptr()), "is_contrastive_bwd")
+        return dc, dw, None, None, None, None, None, None, None, None
 
 
 def contrastive_targets(target):
@@ -1010,8 +1015,8 @@ def contrastive_targets(target):
     return pos, gate[0]
 
 
-def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam):
-    return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam)
+def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate=None, scale=1.0):
+    return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate, scale)
 
 
 class LinearSmallBatchFn(torch.autograd.Function):

@@ -58,7 +58,10 @@ def _paired_loss(model, loss_function, batch, device, contrastive, coeff):
         loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
                       + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
     if coeff > 0:
-        loss = loss + coeff * contrastive(emb[0], emb[1], target)
+        if isinstance(contrastive, PairedContrastiveLoss):      # the coefficient rides inside the loss launches
+            loss = loss + contrastive(emb[0], emb[1], target, scale=coeff)
+        else:
+            loss = loss + coeff * contrastive(emb[0], emb[1], target)
     return loss
 
 

@@ -45,7 +45,9 @@ class PairedContrastiveLoss(nn.Module):
         self.projector.to(device)
         self.capturable = False      # True: no host-side early-out (engine.CapturedTrainStep on paired batches)
 
-    def forward(self, embedding_cancer, embedding_wt, is_immunogenic):
+    def forward(self, embedding_cancer, embedding_wt, is_immunogenic, scale=1.0):
+        """the reference's signature plus ``scale``: returns scale * loss with the factor applied inside the HIP launches (the
+        train loops pass their ``coeff_contrastive`` here instead of multiplying the result)"""
         from .. import _lib
         _lib.require_device(embedding_cancer, embedding_wt)      # no CPU path, as everywhere in this package
         gate = pos = None
@@ -58,10 +60,9 @@ class PairedContrastiveLoss(nn.Module):
             pos, gate = HF.contrastive_targets(is_immunogenic)
         elif is_immunogenic.unique().numel() != 2:
             return 0  # nothing to contrast (continuous target, or a single-class batch)
-        loss = self._loss(embedding_cancer, embedding_wt, is_immunogenic, pos)
-        return loss if gate is None else loss * gate
+        return self._loss(embedding_cancer, embedding_wt, is_immunogenic, pos, gate=gate, scale=scale)
 
-    def _loss(self, embedding_cancer, embedding_wt, is_immunogenic, pos=None):
+    def _loss(self, embedding_cancer, embedding_wt, is_immunogenic, pos=None, gate=None, scale=1.0):
         if pos is None:
             pos = (is_immunogenic > is_immunogenic.mean()).to(embedding_cancer.dtype)
         if embedding_cancer.shape != embedding_wt.shape:
@@ -74,7 +75,7 @@ class PairedContrastiveLoss(nn.Module):
             bn = self.projector[1]
             return HF.paired_contrastive(embedding_cancer, embedding_wt, pos, self.projector[0].weight.detach(),
                                          bn.weight.detach(), bn.bias.detach(), self.projector[3].weight.detach(),
-                                         self.lambda_off_diag)
+                                         self.lambda_off_diag, gate=gate, scale=scale)
         zc = self.projector(embedding_cancer)
         zw = self.projector(embedding_wt)
         b = zc.shape[0]
@@ -85,5 +86,8 @@ class PairedContrastiveLoss(nn.Module):
         pair = zc @ zw.T / self.z_dim
         corr = zc.T @ zw / b
         ones = torch.ones(self.z_dim, dtype=zc.dtype, device=zc.device)
-        return (_weighted_sq(pair, pos, self.lambda_off_diag)
+        loss = (_weighted_sq(pair, pos, self.lambda_off_diag)
                 + _weighted_sq(corr, ones, self.lambda_off_diag) + hinge)
+        if gate is not None:
+            loss = loss * gate
+        return loss if scale == 1.0 else loss * scale

@@ -173,12 +173,14 @@ int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* p
  * 2 <= B <= 256, E <= 256.                                                                                     */
 long long is_contrastive_scratch_floats(int B);
 long long is_contrastive_work_floats(int B);
+/* gate [1] (device; NULL: 1) and scale: loss = scale * gate * L and the backward multiplies g_loss alike -- the caller's loss
+ * coefficient and the early-out factor of is_contrastive_targets folded into the launches.                          */
 int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld_e, int E, const float* pos, const float* W1,
                        const float* gamma, const float* beta, const float* W2, float lambda, float* scratch,
-                       float* loss, int B, void* stream);
+                       float* loss, const float* gate, float scale, int B, void* stream);
 int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, const float* W2, float lambda,
-                       const float* scratch, float* work, const float* g_loss, float* demb_c, float* demb_w,
-                       int ld_d, int E, int B, void* stream);
+                       const float* scratch, float* work, const float* g_loss, const float* gate, float scale,
+                       float* demb_c, float* demb_w, int ld_d, int E, int B, void* stream);
 
 /* target [B] -> pos [B] = (target > mean(target)) as 1.0 / 0.0 (reference utils/contrastive.py:45) and gate [1] = 1.0 when
  * the target holds exactly two distinct values, else 0.0: the reference's host-side early-out (utils/contrastive.py:38-43)
