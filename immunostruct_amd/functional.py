@@ -761,10 +761,17 @@ class CombinedAttentionClassifierFn(torch.autograd.Function):
     workgroup (no partial records, no reduction launch).  ``mask``: the scaled dropout keep-mask (B, hid) or None."""
 
     @staticmethod
-    def forward(ctx, wq, bq, wk, bk, wv, bv, wc, bc, w1, b1, w2, b2, mask, *pieces):
+    def forward(ctx, wq, bq, wk, bk, wv, bv, wc, bc, w1, b1, w2, b2, mask, pair_rows, *pieces):
+        """``pair_rows`` = B > 0: every tensor of ``pieces`` holds the rows of a (cancer; wild-type) pair stacked, [2B, w]; sample
+        i's token row is then [cancer pieces of row i | wild-type pieces of row B + i] (``comparative_models.py:478-480``) -- read
+        where the rows are, and the gradients come back as ONE [2B, w] tensor per input (no slice / accumulate launches)."""
         lib = _lib.load()
         _lib.require_device(wq, bq, wk, bk, wv, bv, wc, bc, w1, b1, w2, b2, mask, *pieces)
-        b, t = int(pieces[0].shape[0]), sum(int(p.shape[1]) for p in pieces)
+        pr = int(pair_rows)
+        if pr and any(int(p.shape[0]) != 2 * pr for p in pieces):
+            raise ValueError("pair_rows: every piece must hold 2 * pair_rows rows")
+        b = pr if pr else int(pieces[0].shape[0])
+        t = sum(int(p.shape[1]) for p in pieces) * (2 if pr else 1)
         f = int(wc.shape[0])
         hid, out = int(w1.shape[0]), int(w2.shape[0])
         rows = [(_lib.f32c(p), int(p.shape[1])) for p in pieces]
@@ -777,13 +784,16 @@ class CombinedAttentionClassifierFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         stats = torch.empty(lib.is_comb_attn_stats_floats(b, t), **f32) if need else None
         a1 = torch.empty(b, hid, **f32) if need else None
-        parts = (_lib.CaPart * len(rows))(*[_lib.CaPart(x.data_ptr(), None, int(x.shape[1]), ld) for x, ld in rows])
+        recs = [_lib.CaPart(x.data_ptr(), None, int(x.shape[1]), ld) for x, ld in rows]
+        if pr:
+            recs += [_lib.CaPart(x.data_ptr() + 4 * pr * ld, None, int(x.shape[1]), ld) for x, ld in rows]
+        parts = (_lib.CaPart * len(recs))(*recs)
         with KernelTimer.span("comb_attn_cls_fwd"):
-            _lib.check(lib.is_comb_attn_cls_fwd(ctypes.cast(parts, ctypes.c_void_p), len(rows), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk),
+            _lib.check(lib.is_comb_attn_cls_fwd(ctypes.cast(parts, ctypes.c_void_p), len(recs), _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(wk),
                                                 _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(w1), _lib.ptr(b1),
                                                 _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(mask), _lib.ptr(z), _lib.ptr(stats), _lib.ptr(a1),
                                                 _lib.ptr(y), b, t, f, hid, out, 0, _lib.stream_ptr()), "is_comb_attn_cls_fwd")
-        ctx.dims = (b, t, f, hid, out)
+        ctx.dims = (b, t, f, hid, out, pr)
         ctx.lds = [ld for _, ld in rows]
         ctx.has_mask = mask is not None
         ctx.save_for_backward(stats, wq, bq, wk, wv, bv, wc, bc, w1, w2, z, a1, y, *([mask] if mask is not None else []), *[x for x, _ in rows])
@@ -796,18 +806,21 @@ class CombinedAttentionClassifierFn(torch.autograd.Function):
         stats, wq, bq, wk, wv, bv, wc, bc, w1, w2, z, a1, y = saved[:13]
         mask = saved[13] if ctx.has_mask else None
         xs = saved[14 if ctx.has_mask else 13:]
-        b, t, f, hid, out = ctx.dims
+        b, t, f, hid, out, pr = ctx.dims
         dev = gy.device
         f32 = dict(dtype=torch.float32, device=dev)
         gy = _lib.f32c(gy)
-        dxs = [torch.empty(b, int(x.shape[1]), **f32) for x in xs]
+        dxs = [torch.empty(int(x.shape[0]), int(x.shape[1]), **f32) for x in xs]      # (2B rows for a stacked pair)
         part = torch.empty(lib.is_comb_attn_partials_floats(b), **f32)
         g = torch.empty(lib.is_comb_attn_grad_floats(f), **f32)
         gc = torch.empty(lib.is_comb_attn_cls_grad_floats(t, hid, out), **f32)
-        parts = (_lib.CaPart * len(xs))(*[_lib.CaPart(x.data_ptr(), d.data_ptr(), int(x.shape[1]), ld)
-                                          for x, d, ld in zip(xs, dxs, ctx.lds)])
+        recs = [_lib.CaPart(x.data_ptr(), d.data_ptr(), int(x.shape[1]), ld) for x, d, ld in zip(xs, dxs, ctx.lds)]
+        if pr:
+            recs += [_lib.CaPart(x.data_ptr() + 4 * pr * ld, d.data_ptr() + 4 * pr * int(x.shape[1]), int(x.shape[1]), ld)
+                     for x, d, ld in zip(xs, dxs, ctx.lds)]
+        parts = (_lib.CaPart * len(recs))(*recs)
         with KernelTimer.span("comb_attn_cls_bwd"):
-            _lib.check(lib.is_comb_attn_cls_bwd(ctypes.cast(parts, ctypes.c_void_p), len(xs), _lib.ptr(stats), _lib.ptr(gy), _lib.ptr(wq),
+            _lib.check(lib.is_comb_attn_cls_bwd(ctypes.cast(parts, ctypes.c_void_p), len(recs), _lib.ptr(stats), _lib.ptr(gy), _lib.ptr(wq),
                                                 _lib.ptr(bq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(bv), _lib.ptr(wc), _lib.ptr(bc),
                                                 _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(mask), _lib.ptr(z), _lib.ptr(a1), _lib.ptr(y),
                                                 _lib.ptr(part), _lib.ptr(g), _lib.ptr(gc), b, t, f, hid, out, 0, _lib.stream_ptr()),
@@ -816,10 +829,10 @@ class CombinedAttentionClassifierFn(torch.autograd.Function):
         o1, o2, o3 = hid * t, hid * t + hid, hid * t + hid + out * hid
         return (col(0).view(f, 1), col(1), col(2).view(f, 1), col(3), col(4).view(f, 1), col(5),
                 g[6 * f:6 * f + f * f].view(f, f), g[6 * f + f * f:7 * f + f * f],
-                gc[:o1].view(hid, t), gc[o1:o2], gc[o2:o3].view(out, hid), gc[o3:], None) + tuple(dxs)
+                gc[:o1].view(hid, t), gc[o1:o2], gc[o2:o3].view(out, hid), gc[o3:], None, None) + tuple(dxs)
 
 
-def combined_attention_classifier(pieces, mha, classifier, mask="draw"):
+def combined_attention_classifier(pieces, mha, classifier, mask="draw", pair_rows=0):
     """The fusion head as one launch: combined attention (``mha``: MultiHeadAttention(F, 8, input_dim=1)) over the row given as
     1-4 pieces, then ``classifier`` = nn.Sequential(Flatten, Linear, ReLU, Dropout, Linear).  Returns None when the modules do
     not have that form / exceed the kernel's limits (the caller then chains the two separate functions)."""
@@ -828,18 +841,46 @@ def combined_attention_classifier(pieces, mha, classifier, mask="draw"):
     if len(mods) != 4 or not all(p.is_cuda and p.dim() == 2 for p in pieces):
         return None
     l1, r1, dr, l2 = mods
-    t = sum(int(p.shape[1]) for p in pieces)
+    t = sum(int(p.shape[1]) for p in pieces) * (2 if pair_rows else 1)
+    nparts = len(pieces) * (2 if pair_rows else 1)
     ok = (isinstance(l1, torch.nn.Linear) and isinstance(r1, torch.nn.ReLU) and isinstance(dr, torch.nn.Dropout)
           and isinstance(l2, torch.nn.Linear) and l1.bias is not None and l2.bias is not None and l1.in_features == t
-          and l1.out_features <= 32 and l2.out_features <= 64 and t <= 256 and 1 <= len(pieces) <= 4
+          and l1.out_features <= 32 and l2.out_features <= 64 and t <= 256 and 1 <= nparts <= 4
           and mha.n_head == 8 and mha.w_q.in_features == 1 and int(mha.w_concat.weight.shape[0]) in (16, 32))
     if not ok:
         return None
     if isinstance(mask, str):
-        mask = dropout_mask(pieces[0].shape[0], l1.out_features, dr.p, pieces[0].device) if (classifier.training and dr.p > 0) else None
+        rows_ = pair_rows if pair_rows else pieces[0].shape[0]
+        mask = dropout_mask(rows_, l1.out_features, dr.p, pieces[0].device) if (classifier.training and dr.p > 0) else None
     return CombinedAttentionClassifierFn.apply(mha.w_q.weight, mha.w_q.bias, mha.w_k.weight, mha.w_k.bias, mha.w_v.weight, mha.w_v.bias,
                                                mha.w_concat.weight, mha.w_concat.bias, l1.weight, l1.bias, l2.weight, l2.bias, mask,
-                                               *pieces)
+                                               int(pair_rows), *pieces)
+
+
+class PairEmbeddingsFn(torch.autograd.Function):
+    """(cancer, wild-type) embeddings [x_gat | z_vae] of a stacked pair (inputs [2B, w] each: cancer rows first), as the paired
+    models hand them to the contrastive loss (``comparative_models.py:474-476``).  The backward writes ONE gradient per stacked
+    input (two concatenations) -- slicing the stacked tensors instead costs a zero-fill + copy per slice and an add per pair."""
+
+    @staticmethod
+    def forward(ctx, xg, zv, b):
+        ctx.b, ctx.wx = int(b), int(xg.shape[1])
+        ctx.set_materialize_grads(False)
+        return torch.cat([xg[:b], zv[:b]], dim=1), torch.cat([xg[b:], zv[b:]], dim=1)
+
+    @staticmethod
+    def backward(ctx, gc, gw):
+        if gc is None and gw is None:
+            return None, None, None
+        ref = gc if gc is not None else gw
+        gc = torch.zeros_like(ref) if gc is None else gc
+        gw = torch.zeros_like(ref) if gw is None else gw
+        wx = ctx.wx
+        return torch.cat([gc[:, :wx], gw[:, :wx]], dim=0), torch.cat([gc[:, wx:], gw[:, wx:]], dim=0), None
+
+
+def pair_embeddings(xg, zv, b):
+    return PairEmbeddingsFn.apply(xg, zv, b)
 
 
 def fused_head_available(n_layers):

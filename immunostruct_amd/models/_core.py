@@ -356,12 +356,26 @@ class MultimodalNet(nn.Module):
         if not self.SPEC.paired:
             raise AttributeError(f"{type(self).__name__} has no comparative forward")
         oc, ow = self._encode_pair(graph_data_pair, sequence_data_pair, peptide_property_pair, return_attention)
-        emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)      # returned to the caller (contrastive loss)
-        emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)
-        pieces = [oc["x_gat_node"], oc["z_vae"]]
-        if self.use_wt_for_downstream:
-            pieces += [ow["x_gat_node"], ow["z_vae"]]
-        final, node_pred = self._head(pieces, oc.get("_cls_mask"))
+        final = None
+        m = oc.get("_merged")
+        if (m is not None and self.use_wt_for_downstream and self.SPEC.comb and not self.SPEC.ssl and m["x_gat_node"].is_cuda):
+            # one encoder pass produced the stacked pair: the embeddings and the fusion head read the stacked tensors where the
+            # rows are, and their backward returns ONE gradient per stacked tensor (no slice-backward / accumulate launches)
+            xg, zv = m["x_gat_node"], m["z_vae"]
+            b = xg.shape[0] // 2
+            cls_mask = oc.get("_cls_mask")
+            final = HF.combined_attention_classifier([xg, zv], self.combined_attention, self.classifier,
+                                                     mask=cls_mask[0] if cls_mask else "draw", pair_rows=b)
+            if final is not None:
+                emb_c, emb_w = HF.pair_embeddings(xg, zv, b)
+                node_pred = None
+        if final is None:
+            emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)      # returned to the caller (contrastive loss)
+            emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)
+            pieces = [oc["x_gat_node"], oc["z_vae"]]
+            if self.use_wt_for_downstream:
+                pieces += [ow["x_gat_node"], ow["z_vae"]]
+            final, node_pred = self._head(pieces, oc.get("_cls_mask"))
         tail = (node_pred,) if self.SPEC.ssl else ()
         if return_embedding:
             return (oc["x_gat_node"], oc["mu"], oc["logvar"], final) + tail
