@@ -364,11 +364,16 @@ class MultimodalNet(nn.Module):
             xg, zv = m["x_gat_node"], m["z_vae"]
             b = xg.shape[0] // 2
             cls_mask = oc.get("_cls_mask")
+            # (the embeddings FIRST: autograd runs later-created nodes earlier, so the head's backward is enqueued on the main
+            #  stream in front of the embeddings' backward, which has to wait for the contrastive loss' backward on the side stream)
+            emb_c, emb_w = HF.pair_embeddings(xg, zv, b)
+            # marks the point of the stream at which the embeddings exist: a consumer on another stream (the contrastive loss,
+            # procedures.train._contrastive_beside) waits for THIS, not for the head that is enqueued behind it
+            emb_c._ready_event = torch.cuda.Event()
+            emb_c._ready_event.record()
             final = HF.combined_attention_classifier([xg, zv], self.combined_attention, self.classifier,
                                                      mask=cls_mask[0] if cls_mask else "draw", pair_rows=b)
-            if final is not None:
-                emb_c, emb_w = HF.pair_embeddings(xg, zv, b)
-                node_pred = None
+            node_pred = None
         if final is None:
             emb_c = torch.cat([oc["x_gat_node"], oc["z_vae"]], dim=1)      # returned to the caller (contrastive loss)
             emb_w = torch.cat([ow["x_gat_node"], ow["z_vae"]], dim=1)

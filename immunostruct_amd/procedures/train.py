@@ -57,12 +57,43 @@ def _paired_loss(model, loss_function, batch, device, contrastive, coeff):
         # the prediction term is shared, the reconstruction terms are averaged (reference :107-114)
         loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target)
                       + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target))
+    return _add_contrastive(loss, contrastive, emb, target, coeff)
+
+
+def _add_contrastive(loss, contrastive, emb, target, coeff):
+    """loss + coeff * contrastive(cancer embedding, wild-type embedding, target) (reference ``procedures/train.py:116-117``)"""
     if coeff > 0:
         if isinstance(contrastive, PairedContrastiveLoss):      # the coefficient rides inside the loss launches
-            loss = loss + contrastive(emb[0], emb[1], target, scale=coeff)
+            loss = loss + _contrastive_beside(contrastive, emb, target, coeff, loss)
         else:
             loss = loss + coeff * contrastive(emb[0], emb[1], target)
     return loss
+
+
+def _contrastive_beside(contrastive, emb, target, coeff, loss):
+    """The paired contrastive loss depends on the two embeddings only -- not on the fusion head or the other loss terms -- so it is
+    evaluated on the models' side stream (idle between the sequence branch's forward and backward): its ~ 100 us forward and,
+    through autograd's stream bookkeeping, its ~ 95 us backward then run BESIDE the head's forward / loss / backward instead of
+    between them (also inside a captured step: fork / join).  ``target`` must be ready on the side stream: the loops' targets
+    are step inputs, complete before the forward starts."""
+    from ..models import _core
+    if not (_core.OVERLAP_BRANCHES and torch.is_tensor(loss) and loss.is_cuda and emb[0].is_cuda):
+        return contrastive(emb[0], emb[1], target, scale=coeff)
+    main = torch.cuda.current_stream()
+    side = _core._side_stream(loss.device)
+    ready = getattr(emb[0], "_ready_event", None)      # recorded by the model right behind the embeddings
+    if ready is not None:
+        side.wait_event(ready)       # not the fusion head / the other loss terms enqueued since: they run beside this loss
+    else:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        c = contrastive(emb[0], emb[1], target, scale=coeff)
+    main.wait_stream(side)
+    if torch.is_tensor(c):
+        c.record_stream(main)
+        for e in emb:
+            e.record_stream(side)
+    return c
 
 
 def _fit(config, model, train_loader, val_loader, optimizer, scheduler, stage, step_loss):

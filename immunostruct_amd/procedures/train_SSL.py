@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from ..utils import PairedContrastiveLoss
-from .train import _device_fit, _fit, _to
+from .train import _add_contrastive, _device_fit, _fit, _to
 
 __all__ = ["train_model_SSL", "train_model_comparative_SSL", "train_model_SSL_device", "train_model_comparative_SSL_device"]
 
@@ -36,9 +36,7 @@ def _paired_loss_ssl(model, loss_function, batch, device, contrastive, coeff):
     pred, amino = _ssl_targets(model, pred, batch[4], device)
     loss = 0.5 * (loss_function(recon[0], seqs[0], mu[0], logvar[0], final, target, pred, amino)
                   + loss_function(recon[1], seqs[1], mu[1], logvar[1], final, target, pred, amino))
-    if coeff > 0:
-        loss = loss + coeff * contrastive(emb[0], emb[1], target)
-    return loss
+    return _add_contrastive(loss, contrastive, emb, target, coeff)
 
 
 def train_model_SSL(config, device, model, train_loader, val_loader, optimizer, loss_function, scheduler=None, stage="pretrain"):
@@ -121,9 +119,7 @@ def train_model_comparative_SSL_device(config, device, model, dataset_cancer, da
         else:
             loss = 0.5 * (loss_function(recon[0], seq2[:b], mu[0], logvar[0], final, target, pa, aa)
                           + loss_function(recon[1], seq2[b:], mu[1], logvar[1], final, target, pa, aa))
-        if coeff > 0:
-            loss = loss + coeff * contrastive(emb[0], emb[1], target)
-        return loss
+        return _add_contrastive(loss, contrastive, emb, target, coeff)
 
     def assemble(idx, buf, train):
         g2, seq2, prop2, y2 = both.gather_into(torch.cat([idx, idx + shift]), *buf)
