@@ -169,6 +169,61 @@ def test_egnn_vs_fp64_error_budget(cuda_device):
     H.assert_close(x.cpu(), outs[torch.float32][1], 5e-5, "6-layer x vs fp32 oracle")
 
 
+def test_egnn_stack_gradients_at_the_stress_shape(cuda_device):
+    """BASELINE config 5's shape through the fused stack: 6 layers (64 -> 64 channels), Fe = 8, graphs of ~N(200, 15) nodes padded
+    to 245, average in-degree 8 (chain + 7 contacts) -- outputs and EVERY gradient against the oracle's ``egnn_conv`` chain
+    (the reference call shape, models/hybrid_models.py:261-263, 323-324).  Yardstick as at full size: the fp64 oracle; the HIP
+    result must meet the element-wise bound against it or be within 4x of the fp32 oracle's own distance."""
+    from bench import stress_batch
+    raw = stress_batch(6, seed=77)
+    n, fe, L = raw.num_nodes, 8, 6
+    assert raw.edge_attr.shape[1] == fe and raw.num_edges > 6 * n      # in-degree 8 over the ~200 real nodes of each 245-row graph
+    sd = H.det_sd(H.egnn_shapes([64] * L, fe), seed=93)
+    rng = np.random.RandomState(5)
+    h0 = (0.5 * rng.normal(size=(n, 64))).astype(np.float32)
+    x0 = raw.x[:, 20:].copy()
+    gh = (rng.normal(size=(n, 64)) / n).astype(np.float32)
+    gx = (rng.normal(size=(n, 3)) / n).astype(np.float32)
+    src, dst = torch.from_numpy(raw.src), torch.from_numpy(raw.dst)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        sdd = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+        h = torch.from_numpy(h0).to(dt).requires_grad_(True)
+        x = torch.from_numpy(x0).to(dt).requires_grad_(True)
+        a = torch.from_numpy(raw.edge_attr).to(dt)
+        hh, xx = h, x
+        for i in range(L):
+            hh, xx = graph_ref.egnn_conv(sdd, f"GCN_layers.{i}.", src, dst, n, hh, xx, a)
+        ((hh * torch.from_numpy(gh).to(dt)).sum() + (xx * torch.from_numpy(gx).to(dt)).sum()).backward()
+        ref[dt] = dict(h=hh.detach(), x=xx.detach(), dh0=h.grad, dx0=x.grad, **{"d" + k: v.grad for k, v in sdd.items()})
+    g = H.product_graph(raw, cuda_device)
+    layers = [EGNNConv(64, 64, 64, fe).to(cuda_device) for _ in range(L)]
+    for i, layer in enumerate(layers):
+        layer.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"GCN_layers.{i}.")})
+    hd = torch.from_numpy(h0).to(cuda_device).requires_grad_(True)
+    xd = torch.from_numpy(x0).to(cuda_device).requires_grad_(True)
+    from immunostruct_amd.nn import egnn_stack_forward
+    hh, xx = egnn_stack_forward(layers, g, hd, xd, g.edata["edge_attr"])
+    ((hh * torch.from_numpy(gh).to(cuda_device)).sum() + (xx * torch.from_numpy(gx).to(cuda_device)).sum()).backward()
+    hip = dict(h=hh.detach(), x=xx.detach(), dh0=hd.grad, dx0=xd.grad)
+    for i, layer in enumerate(layers):
+        for k, p_ in layer.named_parameters():
+            hip[f"dGCN_layers.{i}.{k}"] = p_.grad
+    f32, f64 = ref[torch.float32], ref[torch.float64]
+    H.assert_close(hip["h"].cpu(), f32["h"], 5e-5, "stack h")
+    H.assert_close(hip["x"].cpu(), f32["x"], 5e-5, "stack x")
+    worst = ("", 0.0)
+    for key in f64:
+        if not key.startswith("d"):
+            continue
+        r_hip = H.worst_ratio(hip[key].cpu(), f64[key], GRAD_TOL)
+        r_ref = H.worst_ratio(f32[key], f64[key], GRAD_TOL)
+        assert r_hip <= max(1.0, 4.0 * r_ref), f"{key}: HIP {r_hip:.2f} x the bound from the fp64 gradient, the fp32 oracle {r_ref:.2f} x"
+        if r_hip > worst[1]:
+            worst = (key, r_hip)
+    print("stress-shape stack: worst gradient", worst, "nodes", n, "edges", raw.num_edges)
+
+
 def test_egnn_golden_trajectory(cuda_device):
     gold = H.golden("egnn.npz")
     for fe, seed in ((1, 1), (8, 41)):
