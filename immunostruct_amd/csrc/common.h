@@ -44,15 +44,6 @@ __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
   dy = s * (1.0f + z * (1.0f - s));
 }
 
-// Two SiLUs at once on the packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of full-rate work per
-// issue slot; the two exp / rcp stay scalar, quarter rate): the same operations as silu_f, element by element.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 silu2(f32x2 z) {
-  const f32x2 t = z * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
-  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2{1.0f, 1.0f};
-  return z * f32x2{rcp_f(e.x), rcp_f(e.y)};
-}
-
 // |d|^2 with a FIXED contraction (the compiler otherwise picks fma chains or packed multiplies per call site,
 // and the forward / backward / v2 / v3 kernels would disagree in the last bit).
 __device__ __forceinline__ float radial3(float d0, float d1, float d2) {

@@ -241,14 +241,13 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 #pragma unroll
           for (int k = 0; k < 4; ++k) z[i4 + k] += av[k] * wa_c[f];
         }
-      // SiLU of row pairs on the packed VALU instructions (the forward kernel is issue-bound on its VALU work:
-      // 985 instructions per 128 MFMAs before this)
+      float ex[TE16];
 #pragma unroll
-      for (int i = 0; i < TE16; i += 2) {
-        const f32x2 y = silu2(f32x2{z[i], z[i + 1]});
-        act[i * LD + lane] = y.x;
-        act[(i + 1) * LD + lane] = y.y;
-      }
+      for (int i = 0; i < TE16; ++i) ex[i] = __expf(-z[i]);
+#pragma unroll
+      for (int i = 0; i < TE16; ++i) ex[i] = rcp_f(1.0f + ex[i]);
+#pragma unroll
+      for (int i = 0; i < TE16; ++i) act[i * LD + lane] = z[i] * ex[i];
     }
     __builtin_amdgcn_wave_barrier();
     STAMP3(stamp_k); ++stamp_k;
@@ -257,21 +256,15 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     // ---- MM1: z2 = m1 W2^T + b2 ; mh = SiLU(z2) ----
     {
       f32x4 acc[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{b2_c[nt], b2_c[nt], b2_c[nt], b2_c[nt]};      // the bias is the accumulators' start
+      zero_acc4(acc);
       mm16_rows<4, H>(acc, act, sm.w.w2, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int t = 0; t < 4; t += 2) {
-          const f32x2 z2 = f32x2{acc[nt][t], acc[nt][t + 1]};
-          if (SAVE) {
-            buf_store(z2.x, B.z2, tile_off + (t * H + nt * 16) * 4, tile_base);
-            buf_store(z2.y, B.z2, tile_off + ((t + 1) * H + nt * 16) * 4, tile_base);
-          }
-          const f32x2 y = silu2(z2);
-          act[tile16_row(t, q) * LD + nt * 16 + r] = y.x;
-          act[tile16_row(t + 1, q) * LD + nt * 16 + r] = y.y;
+        for (int t = 0; t < 4; ++t) {
+          const float z2 = acc[nt][t] + b2_c[nt];
+          if (SAVE) buf_store(z2, B.z2, tile_off + (t * H + nt * 16) * 4, tile_base);
+          act[tile16_row(t, q) * LD + nt * 16 + r] = silu_f(z2);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -280,23 +273,19 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     // ---- MM2: z3 = mh Wc1^T + bc1 ; s = SiLU(z3) . wc2 ----
     if constexpr (COORD) {
       f32x4 acc[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{bc1_c[nt], bc1_c[nt], bc1_c[nt], bc1_c[nt]};
+      zero_acc4(acc);
       mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
 #pragma unroll
-      for (int t = 0; t < 4; t += 2) {
-        f32x2 part = f32x2{0.0f, 0.0f};
+      for (int t = 0; t < 4; ++t) {
+        float part = 0.0f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const f32x2 z3 = f32x2{acc[nt][t], acc[nt][t + 1]};
-          if (SAVE) {
-            buf_store(z3.x, B.z3, tile_off + (t * H + nt * 16) * 4, tile_base);
-            buf_store(z3.y, B.z3, tile_off + ((t + 1) * H + nt * 16) * 4, tile_base);
-          }
-          part += silu2(z3) * f32x2{wc2_c[nt], wc2_c[nt]};
+          const float z3 = acc[nt][t] + bc1_c[nt];
+          if (SAVE) buf_store(z3, B.z3, tile_off + (t * H + nt * 16) * 4, tile_base);
+          part += silu_f(z3) * wc2_c[nt];
         }
-        const float p0 = sum_over_r16(part.x), p1 = sum_over_r16(part.y);
-        if (r == 0) { sm.e_s[wave][tile16_row(t, q)] = p0; sm.e_s[wave][tile16_row(t + 1, q)] = p1; }
+        part = sum_over_r16(part);
+        if (r == 0) sm.e_s[wave][tile16_row(t, q)] = part;
       }
     }
     __builtin_amdgcn_wave_barrier();
