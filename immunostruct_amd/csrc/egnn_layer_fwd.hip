@@ -60,10 +60,7 @@ struct Fwd3Smem {
 template <int FE_MAX>
 struct EdgeIds {     // lanes 16..63 mirror lanes 0..15 (lane & 15 = edge of the tile)
   int s, d;          // source, destination
-  int dn;            // destination of the NEXT edge slot, or -1 where this row is outside the tile's scan range / the chunk ends:
-                     // the row closes its destination node iff dn != d.  Kept RAW: deriving the flag right behind the loads
-                     // (as a first version did) makes the wave wait for them -- and, vector loads returning in order, for the 38
-                     // row gathers issued in front of them: a full memory round trip per tile (4 k cycles, tools/stage_stamps.py)
+  int flush;         // 1 if this edge closes its destination node inside this tile's scan range
   float a[FE_MAX];
 };
 
@@ -90,7 +87,9 @@ __device__ __forceinline__ EdgeIds<FE_MAX> load_edge_ids(const FwdBufs& B, int F
   const int ec = min(el, E - 1);
   id.s = buf_load_i(B.srcs, ec * 4, 0);
   id.d = buf_load_i(B.dsts, ec * 4, 0);
-  id.dn = buf_load_i(B.dsts, min(el + 1, E - 1) * 4, 0);
+  const int dn = buf_load_i(B.dsts, min(el + 1, E - 1) * 4, 0);
+  const bool mine = el >= cb && el < e1;     // rows the segment scan of this tile accumulates
+  id.flush = (mine && (el + 1 >= e1 || dn != id.d)) ? 1 : 0;
 #pragma unroll
   for (int f = 0; f < FE_MAX; ++f) {
     // ea is a valid buffer even when Fe == 0; masked by multiplication so that the load stays unconditional
@@ -293,9 +292,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 
     // ---- SEG: running segment sums by destination; flush points are wave-uniform ----
     {
-      // a row closes its destination node when the next edge slot belongs to another node or to another chunk
-      const int el0 = ts + (lane & (TE16 - 1));
-      const unsigned long long fm = __ballot(el0 >= cb && el0 < e1 && (el0 + 1 >= e1 || id0.dn != id0.d));
+      const unsigned long long fm = __ballot(id0.flush != 0);
       float hv[TE16], cs[TE16], cd[TE16];
 #pragma unroll
       for (int i = 0; i < TE16; ++i) {
