@@ -23,7 +23,8 @@ LIB_PATH = os.environ.get("IMMUNOSTRUCT_LIB") or os.path.join(_HERE, "csrc", "li
 _P, _I, _F, _LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 # symbol -> argtypes ; keep in sync with include/immunostruct_hip.h
-_RETURNS_LONGLONG = {"is_attn_colmean_probs_floats", "is_contrastive_scratch_floats", "is_contrastive_work_floats"}
+_RETURNS_LONGLONG = {"is_attn_colmean_probs_floats", "is_contrastive_scratch_floats", "is_contrastive_work_floats",
+                     "is_linear_dgrad_scratch_floats"}
 SIGNATURES = {
     "is_version": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
@@ -46,6 +47,8 @@ SIGNATURES = {
     "is_chunk_partition": [_P, _I, _I, _P, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "is_linear_dgrad_scratch_floats": [_I, _I, _I],
+    "is_linear_dgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_contrastive_scratch_floats": [_I],
     "is_contrastive_work_floats": [_I],
     "is_contrastive_fwd": [_P, _P, _I, _I, _P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, ctypes.c_float, _I, _P],
@@ -76,6 +79,9 @@ SIGNATURES = {
     "is_vae_latent_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_vae_latent_grad_floats": [_I, _I],
     "is_vae_latent_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_vae_latent_bwd_data": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "is_vae_latent_bwd_wgrad": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "is_recon_mse": [_P, _P, _P, _LL, _F, _P, _P],
     "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P],
 }
 

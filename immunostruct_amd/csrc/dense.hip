@@ -9,17 +9,19 @@
 
 namespace is {
 
-constexpr int WG_B = 128;      // batch rows staged per pass
+constexpr int WG_B = 64;       // batch rows staged per pass
 
-// One workgroup owns a 64 (n) x 64 (k) tile of dW.  Both operand panels of a pass (128 batch rows x 64 columns each) are
-// fetched with ALL loads in flight at once -- lane = column, one coalesced 256-byte row segment per load, 64 loads per lane --
-// and staged in LDS behind ONE barrier pair; wave (mt, nt) then accumulates its 32 x 32 quadrant over the 128 rows on
-// v_mfma_f32_32x32x2_f32 (bit-equal to an fmaf chain over b = 0 .. B-1).  2 workgroups per CU (70 KB LDS).
-__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __restrict__ gy, int ld_g, const float* __restrict__ x,
+// One workgroup owns a 64 (n) x 64 (k) tile of dW.  The two operand panels of a pass (64 batch rows x 64 columns each) are
+// fetched with all loads in flight at once -- lane = column, one coalesced 256-byte row segment per load, 32 loads per lane --
+// and staged in LDS; wave (mt, nt) then accumulates its 32 x 32 quadrant over the staged rows on v_mfma_f32_32x32x2_f32
+// (fixed order over the batch).  The NEXT pass' loads are issued before the MFMAs of the current one
+// (software pipeline), and with 35 KB of LDS four workgroups share a CU: the 744 workgroups of a VAE matrix are resident at
+// once and overlap each other's load latency (the one-pass, two-per-CU form of round 1 ran them in 1.5 latency-bound rounds).
+__global__ __launch_bounds__(256, 4) void linear_wgrad_kernel(const float* __restrict__ gy, int ld_g, const float* __restrict__ x,
                                                               int ld_x, float* __restrict__ dW, float* __restrict__ db,
                                                               int B, int N, int K) {
-  __shared__ float gs[WG_B * LD];   // gy panel: [128 batch rows][64 output columns n]
-  __shared__ float xs[WG_B * LD];   // x  panel: [128 batch rows][64 input columns k]
+  __shared__ float gs[WG_B * LD];   // gy panel: [64 batch rows][64 output columns n]
+  __shared__ float xs[WG_B * LD];   // x  panel: [64 batch rows][64 input columns k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int mt = wave >> 1, nt = wave & 1;            // this wave's 32 x 32 quadrant of the 64 x 64 tile
@@ -30,15 +32,18 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
   float colsum = 0.0f;                                 // lane = column n0 + lane (wave 0 of the k0 = 0 column of tiles): bias gradient
   const bool n_ok = n0 + lane < N, k_ok = k0 + lane < K;
   const int nc = min(n0 + lane, N - 1), kc = min(k0 + lane, K - 1);      // clamped: every load is unconditional
-  for (int b0 = 0; b0 < B; b0 += WG_B) {
-    constexpr int RPW = WG_B / 4;                      // rows staged per wave
-    float gv[RPW], xv[RPW];
+  constexpr int RPW = WG_B / 4;                        // rows staged per wave
+  float gv[RPW], xv[RPW];
+  auto fetch = [&](int b0) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int b = min(b0 + wave * RPW + i, B - 1);
       gv[i] = gy[(size_t)b * ld_g + nc];
       xv[i] = x[(size_t)b * ld_x + kc];
     }
+  };
+  fetch(0);
+  for (int b0 = 0; b0 < B; b0 += WG_B) {
     if (b0 > 0) __syncthreads();                       // the previous pass' MFMAs are done with the panels
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -48,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
       xs[row * LD + lane] = (b_ok && k_ok) ? xv[i] : 0.0f;
     }
     __syncthreads();
-    // acc (32 x 32) += sum over the 128 staged rows e of gs[e][mt*32 + i] * xs[e][nt*32 + j]; half hf walks rows [64 hf, 64 hf + 64)
+    if (b0 + WG_B < B) fetch(b0 + WG_B);               // in flight under this pass' MFMAs
+    // acc (32 x 32) += sum over the staged rows e of gs[e][mt*32 + i] * xs[e][nt*32 + j]; half hf walks rows [32 hf, 32 hf + 32)
 #pragma unroll 8
     for (int sidx = 0; sidx < WG_B / 2; ++sidx) {
       const int e = hf * (WG_B / 2) + sidx;
@@ -67,6 +73,102 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
   if (db != nullptr && blockIdx.y == 0 && wave == 0 && n_ok) db[n0 + lane] = colsum;
 }
 
+// ---- input gradient of a Linear layer with a LONG contraction and a small output: gx [B, K] = gy [B, N] W [N, K] --------------
+// (vae_fc4: N = 5943, K = 512, B = 128: 64 Ki outputs, each a 5943-term sum.)  The library runs this as ONE workgroup per 32 x 16
+// output tile walking the whole contraction (Cijk_Ailk_Bljk MT32x16x128: 33-38 us at 128 workgroups); here the contraction is
+// cut into chunks of 96 -- one workgroup per (64 output columns, chunk) = 8 x 62 workgroups, two per CU (75 KB of LDS: a
+// workgroup that needs a whole CU's LDS cannot start while ANY other kernel's workgroups are spread over the CUs) -- each
+// staging its gy chunk [128, 96] and W chunk [96, 64] in LDS in one go and writing a [128, 64] partial on
+// v_mfma_f32_32x32x2_f32; a second launch sums the partials in chunk order (fixed order -> bitwise reproducible).
+constexpr int DG_KC = 96;             // contraction rows per chunk
+constexpr int DG_LDA = DG_KC + 2;     // gy panel pitch: the A operand reads a column of 32 rows, 2 apart -> all 64 banks
+constexpr int DG_M = 128, DG_N = 64;
+
+__global__ __launch_bounds__(256, 2) void linear_dgrad_splitk_kernel(const float* __restrict__ gy, int ld_g,
+                                                                     const float* __restrict__ W, int ld_w,
+                                                                     float* __restrict__ part, int B, int N, int K) {
+  __shared__ float gs[DG_M * DG_LDA];       // [128 batch rows][DG_KC contraction columns]
+  __shared__ float ws[DG_KC * DG_N];        // [DG_KC contraction rows][64 output columns], odd rows rotated by 32 columns
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k0 = blockIdx.x * DG_N, c0 = blockIdx.y * DG_KC, b0 = blockIdx.z * DG_M;
+  const int r = lane & 31, hf = lane >> 5;
+  {
+    // gy chunk: wave w stages rows [32 w, 32 w + 32), lane = column (+ 64): coalesced row segments, all loads in flight
+    constexpr int CM = (DG_KC + 63) / 64;
+    float v[32][CM];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int b = min(b0 + wave * 32 + i, B - 1);
+#pragma unroll
+      for (int m = 0; m < CM; ++m) v[i][m] = gy[(size_t)b * ld_g + min(c0 + lane + 64 * m, N - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool b_ok = b0 + wave * 32 + i < B;
+#pragma unroll
+      for (int m = 0; m < CM; ++m)
+        if (lane + 64 * m < DG_KC)
+          gs[(wave * 32 + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
+    }
+  }
+  {
+    // W chunk: wave w stages rows [RW w, RW w + RW), lane = output column
+    constexpr int RW = DG_KC / 4;
+    float v[RW];
+    const int kc = min(k0 + lane, K - 1);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) v[i] = W[(size_t)min(c0 + wave * RW + i, N - 1) * ld_w + kc];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int c = wave * RW + i;
+      ws[c * DG_N + ((lane + 32 * (c & 1)) & 63)] = (c0 + c < N && k0 + lane < K) ? v[i] : 0.0f;
+    }
+  }
+  __syncthreads();
+  // wave w: rows [32 w, 32 w + 32) x both 32-column halves; step s contracts rows 2 s, 2 s + 1 of the chunk (half hf takes 2 s + hf)
+  f32x16 acc[2];
+  zero_acc(acc);
+  const float* ap = gs + (wave * 32 + r) * DG_LDA + hf;
+  const float* wp = ws + hf * DG_N;
+  const int j0 = (r + 32 * hf) & 63, j1 = (r + 32 + 32 * hf) & 63;      // un-rotate: row 2 s + hf is rotated by 32 hf
+#pragma unroll 8
+  for (int sidx = 0; sidx < DG_KC / 2; ++sidx) {
+    const float a = ap[2 * sidx];
+    const float w0 = wp[2 * sidx * DG_N + j0], w1 = wp[2 * sidx * DG_N + j1];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc[1], 0, 0, 0);
+  }
+  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][128][K]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = k0 + nt * 32 + r;
+      if (k < K) out[(size_t)(wave * 32 + tile_row(t, hf)) * K + k] = acc[nt][t];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gx,
+                                                                  int B, int K, int chunks, int mtiles) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)B * K) return;
+  const int b = (int)(e / K), k = (int)(e % K);
+  const float* p = part + ((size_t)(b / DG_M) * DG_M + (b % DG_M)) * K + k;
+  const size_t stride = (size_t)mtiles * DG_M * K;
+  float acc = 0.0f;
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; c < chunks; ++c) acc += p[(size_t)c * stride];
+  gx[e] = acc;
+}
+
 }  // namespace is
 
 // gy [B, ld_g] (N valid columns), x [B, ld_x] (K valid columns) -> dW [N, K] (row-major, the nn.Linear weight layout),
@@ -76,5 +178,26 @@ extern "C" int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld
   if (B <= 0 || N <= 0 || K <= 0) return -22;
   hipLaunchKernelGGL(is::linear_wgrad_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
                      gy, ld_g, x, ld_x, dW, db, B, N, K);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// floats of the split-contraction scratch of is_linear_dgrad
+extern "C" long long is_linear_dgrad_scratch_floats(int B, int N, int K) {
+  const long long chunks = (N + is::DG_KC - 1) / is::DG_KC, mtiles = (B + is::DG_M - 1) / is::DG_M;
+  return chunks * mtiles * is::DG_M * K;
+}
+
+// gx [B, K] = gy [B, ld_g] (N valid columns) W [N, ld_w] (K valid columns; the nn.Linear weight of a layer with K inputs and
+// N outputs, as stored).  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats.  Two launches.
+extern "C" int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld_w, float* gx, float* scratch, int B, int N, int K,
+                               void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = (N + is::DG_KC - 1) / is::DG_KC, mtiles = (B + is::DG_M - 1) / is::DG_M;
+  hipLaunchKernelGGL(is::linear_dgrad_splitk_kernel, dim3((K + is::DG_N - 1) / is::DG_N, chunks, mtiles), dim3(256), 0, st, gy, ld_g,
+                     W, ld_w, scratch, B, N, K);
+  const long long total = (long long)B * K;
+  hipLaunchKernelGGL(is::linear_dgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scratch, gx, B, K,
+                     chunks, mtiles);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -102,9 +102,26 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
 
 extern "C" int is_loss_partials_floats(void) { return 1024; }
 
+static int recon_parts(long long recon_total) {
+  const long long want = (recon_total + is::LOSS_BLOCK * 4 - 1) / (is::LOSS_BLOCK * 4);
+  return (int)(want < 1024 ? want : 1024);
+}
+
+// Stage 1 of the reconstruction term on its own: partial sums of (recon - x)^2 into partials[] and
+// d_recon = gscale * (recon - x) (gscale = c_mse * 2 / recon_total * upstream).  For callers that run it where recon is
+// produced (the sequence branch's stream) and hand is_vae_loss the partials (recon = NULL there).
+extern "C" int is_recon_mse(const float* recon, const float* x, float* d_recon, long long recon_total, float gscale,
+                            float* partials, void* stream) {
+  if (recon_total <= 0 || recon == nullptr || x == nullptr || d_recon == nullptr || partials == nullptr) return -22;
+  hipLaunchKernelGGL(is::recon_mse_kernel, dim3(recon_parts(recon_total)), dim3(is::LOSS_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     recon, x, d_recon, partials, recon_total, gscale);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 // mode 0 = regression (MSE on the logit), 1 = BCE-with-logits(pos_weight).
 // recon/x/d_recon may be NULL (recon_total = 0) and mu/logvar NULL (latent_total = 0)
-// for `sequence=False`.  out[4] = {total, prediction term, recon MSE, KLD}.
+// for `sequence=False`.  recon = NULL with recon_total > 0: partials[] already holds stage 1 (is_recon_mse).
+// out[4] = {total, prediction term, recon MSE, KLD}.
 extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, long long recon_total,
                            const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total,
                            const float* logit, const float* y, float* d_logit, int batch, int mode,
@@ -114,10 +131,10 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
   hipStream_t st = static_cast<hipStream_t>(stream);
   int nparts = 0;
   if (recon_total > 0) {
-    long long want = (recon_total + is::LOSS_BLOCK * 4 - 1) / (is::LOSS_BLOCK * 4);
-    nparts = (int)(want < 1024 ? want : 1024);
-    hipLaunchKernelGGL(is::recon_mse_kernel, dim3(nparts), dim3(is::LOSS_BLOCK), 0, st, recon, x, d_recon, partials,
-                       recon_total, c_mse * 2.0f / (float)recon_total);
+    nparts = recon_parts(recon_total);
+    if (recon != nullptr)
+      hipLaunchKernelGGL(is::recon_mse_kernel, dim3(nparts), dim3(is::LOSS_BLOCK), 0, st, recon, x, d_recon, partials,
+                         recon_total, c_mse * 2.0f / (float)recon_total);
   }
   hipLaunchKernelGGL(is::loss_finish_kernel, dim3(1), dim3(is::LOSS_BLOCK), 0, st, partials, nparts, recon_total, mu,
                      logvar, d_mu, d_logvar, latent_total, logit, y, d_logit, batch, mode, pos_weight, c_pred, c_mse,

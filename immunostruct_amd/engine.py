@@ -292,9 +292,10 @@ class CapturedTrainStep:
         from .functional import Stamps
         Stamps.mark("step start")
         self.reducer.zero()
-        loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        from .functional import SpeculativeBackward, unit_gradient
+        with SpeculativeBackward():      # the backward below is seeded with the unit gradient
+            loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         Stamps.mark("loss done")
-        from .functional import unit_gradient
         loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
         Stamps.mark("backward done (main stream)")
         return loss.detach()
@@ -333,7 +334,8 @@ class CapturedTrainStep:
         self.reducer.zero()
         HF.StackBoundary.begin()
         try:
-            loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+            with HF.SpeculativeBackward():
+                loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         finally:
             bnd = HF.StackBoundary.end()
         if self._late is None:

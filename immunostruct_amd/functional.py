@@ -242,12 +242,19 @@ class StackPrologue:
     """Outputs of the stack's prologue launch (``is_stack_prologue``): layer-0 pre-projection ``psd`` [N,128], the operand
     packs of every layer's node half, and the dense coordinates ``x`` [N,3].  A caller may launch it EARLY
     (:func:`launch_stack_prologue`) -- the models do so before they fork the sequence branch onto its side stream, so that
-    the graph branch's first kernel is not the one that pays the fork -- and hand the object to :func:`egnn_stack`."""
+    the graph branch's first kernel is not the one that pays the fork -- and hand the object to :func:`egnn_stack`.
 
-    __slots__ = ("psd", "packs", "x", "key")
+    :func:`launch_stack_forward` goes further and launches the layer kernels too (``layers`` / ``outs`` then hold what
+    ``EGNNStackFn.forward`` would have produced): the autograd node is still created by the later :func:`egnn_stack` call, so
+    the ORDER IN WHICH AUTOGRAD NODES ARE CREATED (which fixes the order of the backward) is independent of the order in which
+    the forward kernels are enqueued (which fixes how a captured HIP graph is laid out over the hardware queues)."""
+
+    __slots__ = ("psd", "packs", "x", "key", "layers", "outs", "need_grad", "final_coords", "ea_key", "fork_event")
 
     def __init__(self, psd, packs, x, key):
         self.psd, self.packs, self.x, self.key = psd, packs, x, key
+        self.layers = self.outs = self.ea_key = self.fork_event = None
+        self.need_grad = self.final_coords = False
 
 
 def _prologue_key(h0, x0, params):
@@ -315,6 +322,92 @@ def launch_stack_prologue(h0, x0, layer_params, head=None):
     return StackPrologue(psd, packs, x, key)
 
 
+def launch_stack_forward(h0, x0, ea_csr, csr, layer_params, head=None, final_coords=True, fork_after=None):
+    """Enqueue the WHOLE forward of :func:`egnn_stack` now (prologue + one launch per layer), outside autograd; the returned
+    :class:`StackPrologue` makes the later ``egnn_stack(..., prologue=...)`` call -- same tensors -- create the autograd node
+    without launching anything.  ``fork_after`` = i: an event recorded right behind layer i's launch is left in
+    ``.fork_event`` (for a caller that starts another branch on a side stream from that point of the stack)."""
+    pro = launch_stack_prologue(h0, x0, layer_params, head=head)
+    flat = [p for lp in layer_params for p in lp]
+    n_layers = len(layer_params)
+    fe = int(ea_csr.shape[1]) if ea_csr is not None else 0
+    if fe > 8:
+        raise ValueError("edge_feat_size > 8 is not supported by the HIP kernel")
+    if h0.shape[0] != csr.num_nodes:
+        raise ValueError("node feature rows must equal the number of nodes")
+    need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                for t in [h0, x0] + flat + (list(head) if head is not None else []))
+    h0c, ld_h0 = _lib.rows_ld(h0)
+    ea = _lib.f32c(ea_csr) if fe else None
+    params = [_lib.f32c(p) for p in flat]
+    hd = None
+    if head is not None:
+        wa, ba, wb, bb = (_lib.f32c(t) for t in head)
+        hd = ((wa, wb), ba, bb)
+
+    def mark():
+        pro.fork_event = torch.cuda.Event()
+        pro.fork_event.record()
+
+    with torch.no_grad():
+        layers, h_out, x_out, psd = _launch_stack_layers(
+            h0c, ld_h0, int(h0.shape[1]), ea, fe, csr, params, hd, n_layers, final_coords, need_grad, pro.psd, pro.packs, pro.x,
+            after=(min(int(fork_after), n_layers - 1), mark) if fork_after is not None else None)
+    pro.layers, pro.outs = layers, (h_out, x_out, psd)
+    pro.need_grad, pro.final_coords, pro.ea_key = need_grad, bool(final_coords), _ea_key(ea, csr)
+    return pro
+
+
+def _ea_key(ea, csr):
+    return (ea.data_ptr() if ea is not None else 0, id(csr))
+
+
+def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, final_coords, need_grad, psd, packs, x, after=None):
+    """the forward layer launches of the stack (one per layer); ``after`` = (i, fn): call fn() right behind layer i's launch.
+    -> (per-layer saved tensors, h_L, x_L | None, head projection | None)"""
+    lib = _lib.load()
+    P = PARAMS_PER_LAYER
+    n, e = csr.num_nodes, csr.num_edges
+    st = _lib.stream_ptr()
+    f32 = dict(dtype=torch.float32, device=x.device)
+    layers = []
+    kf = fwd_chunk_count(e)
+    chunks = csr.chunks(kf)
+    h_in, ld_h, din = h0, ld_h0, din0
+    for i in range(n_layers):
+        W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
+        ldw = int(W1.shape[1])
+        if ldw != 2 * din + 1 + fe:
+            raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
+        last = i == n_layers - 1
+        no_coords = (not final_coords) and last
+        h_neigh = torch.empty(n, HIDDEN, **f32)
+        x_out = torch.empty(n, 3, **f32) if not no_coords else None
+        z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # full 16-row tiles are stored
+        z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
+        zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
+        h_out = torch.empty(n, HIDDEN, **f32)
+        emit = (not last) or head is not None
+        psd_next = torch.empty(n, 2 * HIDDEN, **f32) if emit else None
+        if last:
+            b0n, b1n = (head[1], head[2]) if head is not None else (None, None)
+        else:
+            b0n, b1n = None, params[(i + 1) * P + 1]
+        KernelTimer.launch("egnn_layer_fwd_nocoord" if no_coords else "egnn_layer_fwd", lambda: _lib.check(lib.is_egnn_layer_fwd(
+            _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
+            _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(chunks), kf,
+            _lib.ptr(W1), ldw, din, _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
+            _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe,
+            _lib.ptr(h_in), ld_h, _lib.ptr(bn1), _lib.ptr(bn2), _lib.ptr(b0n), _lib.ptr(b1n), _lib.ptr(packs[i, 0]),
+            _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), st), "is_egnn_layer_fwd"))
+        layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
+                           h_out=h_out))
+        psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
+        if after is not None and after[0] == i:
+            after[1]()
+    return layers, h_in, x, psd
+
+
 class EGNNStackFn(torch.autograd.Function):
     """L chained EGNNConv layers on the fused layer kernels: one launch per layer forward (``csrc/egnn_layer_fwd.hip``),
     node data path + edge pass + source gather per layer backward, one batched weight-gradient launch and one batched
@@ -369,38 +462,12 @@ class EGNNStackFn(torch.autograd.Function):
             psd, packs, x = early.psd, early.packs, early.x      # launched by the caller (before its stream fork)
         else:
             psd, packs, x = _launch_prologue(h0, ld_h0, din0, x0, params, head, n_layers, n, dev)
-        kf = fwd_chunk_count(e)
-        chunks = csr.chunks(kf)
-        h_in, ld_h, din = h0, ld_h0, din0
-        for i in range(n_layers):
-            W1, b1, W2, b2, Wn1, bn1, Wn2, bn2, Wc1, bc1, wc2 = params[i * P:(i + 1) * P]
-            ldw = int(W1.shape[1])
-            if ldw != 2 * din + 1 + fe:
-                raise ValueError(f"layer {i}: edge_mlp.0.weight has {ldw} columns, expected {2 * din + 1 + fe}")
-            last = i == n_layers - 1
-            no_coords = (not final_coords) and last
-            h_neigh = torch.empty(n, HIDDEN, **f32)
-            x_out = torch.empty(n, 3, **f32) if not no_coords else None
-            z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # full 16-row tiles are stored
-            z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
-            zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
-            h_out = torch.empty(n, HIDDEN, **f32)
-            emit = (not last) or head is not None
-            psd_next = torch.empty(n, 2 * HIDDEN, **f32) if emit else None
-            if last:
-                b0n, b1n = (head[1], head[2]) if head is not None else (None, None)
-            else:
-                b0n, b1n = None, params[(i + 1) * P + 1]
-            KernelTimer.launch("egnn_layer_fwd_nocoord" if no_coords else "egnn_layer_fwd", lambda: _lib.check(lib.is_egnn_layer_fwd(
-                _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
-                _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(chunks), kf,
-                _lib.ptr(W1), ldw, din, _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
-                _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe,
-                _lib.ptr(h_in), ld_h, _lib.ptr(bn1), _lib.ptr(bn2), _lib.ptr(b0n), _lib.ptr(b1n), _lib.ptr(packs[i, 0]),
-                _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), st), "is_egnn_layer_fwd"))
-            layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
-                               h_out=h_out))
-            psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
+        if early is not None and early.layers is not None and early.need_grad >= need_grad and early.final_coords == bool(final_coords) \
+                and early.ea_key == _ea_key(ea, csr):
+            layers, (h_in, x, psd) = early.layers, early.outs      # the layer kernels are already enqueued (launch_stack_forward)
+        else:
+            layers, h_in, x, psd = _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, final_coords, need_grad,
+                                                        psd, packs, x)
         ctx.layers, ctx.params, ctx.csr, ctx.ea, ctx.fe, ctx.n_layers = layers, params, csr, ea, fe, n_layers
         ctx.h0_needs_grad, ctx.x0_needs_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         ctx.head = head
@@ -1061,8 +1128,9 @@ def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate=None, s
 
 
 class LinearSmallBatchFn(torch.autograd.Function):
-    """``F.linear(x, w, b)`` whose weight / bias gradients come from ``csrc/dense.hip`` (contraction over the small batch);
-    forward and input gradient are the library GEMMs."""
+    """``F.linear(x, w, b)`` whose weight / bias gradients come from ``csrc/dense.hip`` (contraction over the small batch),
+    and whose input gradient does too when the contraction is long and the output small (``is_linear_dgrad``); forward and
+    the other input gradients are the library GEMMs."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -1071,10 +1139,13 @@ class LinearSmallBatchFn(torch.autograd.Function):
         # data-parallel runs: the reducer's slice of the flat gradient bucket for this weight (distributed.FlatGradReducer);
         # the weight gradient is then written there directly instead of being copied in when the bucket is packed
         ctx.dest = getattr(w, "_grad_dest", None)
+        ctx.fwd_stream = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        ctx.spec = None
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
-    def backward(ctx, gy):
+    def launch_backward(ctx, gy, need_gx):
+        """(gx, dw, db) for the upstream gradient ``gy`` on the current stream"""
         lib = _lib.load()
         x, w = ctx.saved_tensors
         gy = _lib.f32c(gy)
@@ -1085,11 +1156,31 @@ class LinearSmallBatchFn(torch.autograd.Function):
         direct = (dest is not None and w.grad is None and dest.shape == w.shape and dest.is_contiguous() and dest.device == w.device)
         dw = dest if direct else torch.empty(n, k, dtype=torch.float32, device=w.device)
         db = torch.empty(n, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        # the input gradient first: the rest of the branch's backward waits for it, nothing waits for the weight gradient
+        gx = None
+        if need_gx:
+            wc = _lib.f32c(w)
+            if n >= 8 * k and bsz <= 1024:
+                # long contraction, small output (vae_fc4 going backward): split-contraction kernel (csrc/dense.hip)
+                gx = torch.empty(bsz, k, dtype=torch.float32, device=w.device)
+                scratch = torch.empty(int(lib.is_linear_dgrad_scratch_floats(bsz, n, k)), dtype=torch.float32, device=w.device)
+                with KernelTimer.span("linear_dgrad"):
+                    _lib.check(lib.is_linear_dgrad(_lib.ptr(gy), n, _lib.ptr(wc), k, _lib.ptr(gx), _lib.ptr(scratch), bsz, n, k,
+                                                   _lib.stream_ptr()), "is_linear_dgrad")
+            else:
+                gx = gy @ w
         with KernelTimer.span("linear_wgrad"):
             _lib.check(lib.is_linear_wgrad(_lib.ptr(gy), n, _lib.ptr(xc), k, _lib.ptr(dw), _lib.ptr(db), bsz, n, k, _lib.stream_ptr()),
                        "is_linear_wgrad")
-        gx = gy @ w if ctx.needs_input_grad[0] else None
         return gx, dw, db
+
+    @staticmethod
+    def backward(ctx, gy):
+        spec, ctx.spec = ctx.spec, None
+        if spec is not None and gy.data_ptr() == spec[0].data_ptr() and gy.shape == spec[0].shape:
+            # the gradients were launched ahead of time for exactly this upstream gradient (speculate_recon_backward)
+            return spec[1], spec[2], spec[3]
+        return LinearSmallBatchFn.launch_backward(ctx, gy, ctx.needs_input_grad[0])
 
 
 def linear_small_batch(x, weight, bias):
@@ -1101,12 +1192,20 @@ def linear_small_batch(x, weight, bias):
 
 class VaeLatentFn(torch.autograd.Function):
     """The sequence VAE's latent block (``csrc/vae_latent.hip``): from a1 = vae_fc1(x) (pre-activation) to
-    (mu, logvar, [z | p], h3 = relu(vae_fc3([z | p]))) in one launch; backward = two launches (data path, weight gradients).
+    (mu, logvar, [z | p], h3 = relu(vae_fc3([z | p]))) in one launch; backward = three launches (data path in two halves, weight gradients).
     ``eps`` is the caller's ``torch.randn_like`` draw (reference ``hybrid_models.py:301-304``); ``p`` may be None."""
 
     @staticmethod
-    def forward(ctx, a1, w21, b21, w22, b22, eps, p, w3, b3):
+    def forward(ctx, a1, w21, b21, w22, b22, eps, p, w3, b3, x=None, w1=None, b1=None):
         lib = _lib.load()
+        ctx.fc1 = w1 is not None
+        if ctx.fc1:
+            # the first layer inside this node (``a1`` is ignored): forward = the library GEMM; backward launches its weight
+            # gradient BETWEEN this block's data path and weight pass -- the order the rest of the step's schedule wants
+            # (DESIGN.md section 3.6), which separate autograd nodes cannot express
+            a1 = torch.nn.functional.linear(x, w1, b1)
+            ctx.fc1_dest = getattr(w1, "_grad_dest", None)
+            ctx.fc1_w, ctx.fc1_bias = w1, b1
         _lib.require_device(a1, w21, b21, w22, b22, eps, p, w3, b3)
         a1, w21, b21, w22, b22, eps, w3, b3 = (_lib.f32c(t) for t in (a1, w21, b21, w22, b22, eps, w3, b3))
         p = _lib.f32c(p) if p is not None else None
@@ -1125,13 +1224,13 @@ class VaeLatentFn(torch.autograd.Function):
         ctx.dims = (b, hd, lat, pw)
         ctx.has_p = p is not None
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(a1, w21, w22, eps, w3, logvar, zp, h3)
+        ctx.save_for_backward(a1, w21, w22, eps, w3, logvar, zp, h3, *((x,) if ctx.fc1 else ()))
         return mu, logvar, zp, h3
 
     @staticmethod
     def backward(ctx, g_mu, g_lv, g_zp, g_h3):
         lib = _lib.load()
-        a1, w21, w22, eps, w3, logvar, zp, h3 = ctx.saved_tensors
+        a1, w21, w22, eps, w3, logvar, zp, h3 = ctx.saved_tensors[:8]
         b, hd, lat, pw = ctx.dims
         f32 = dict(dtype=torch.float32, device=a1.device)
         g_mu, g_lv, g_zp, g_h3 = (None if g is None else _lib.f32c(g) for g in (g_mu, g_lv, g_zp, g_h3))
@@ -1139,26 +1238,52 @@ class VaeLatentFn(torch.autograd.Function):
         dmu, dlv = torch.empty(b, lat, **f32), torch.empty(b, lat, **f32)
         d_p = torch.empty(b, pw, **f32) if pw else None
         wg = torch.empty(lib.is_vae_latent_grad_floats(hd, pw), **f32)
+        st = _lib.stream_ptr()
+        dw1 = db1 = None
         with KernelTimer.span("vae_latent_bwd"):
-            _lib.check(lib.is_vae_latent_bwd(_lib.ptr(g_h3), _lib.ptr(h3), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_zp), _lib.ptr(eps),
-                                             _lib.ptr(logvar), _lib.ptr(a1), _lib.ptr(zp), _lib.ptr(w21), _lib.ptr(w22), pw, _lib.ptr(w3),
-                                             _lib.ptr(d_a3), _lib.ptr(dmu), _lib.ptr(dlv), _lib.ptr(d_p), _lib.ptr(d_a1), _lib.ptr(wg),
-                                             b, hd, lat, _lib.stream_ptr()), "is_vae_latent_bwd")
+            _lib.check(lib.is_vae_latent_bwd_data(_lib.ptr(g_h3), _lib.ptr(h3), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(g_zp),
+                                                  _lib.ptr(eps), _lib.ptr(logvar), _lib.ptr(a1), _lib.ptr(w21), _lib.ptr(w22), pw,
+                                                  _lib.ptr(w3), _lib.ptr(d_a3), _lib.ptr(dmu), _lib.ptr(dlv), _lib.ptr(d_p),
+                                                  _lib.ptr(d_a1), b, hd, lat, st), "is_vae_latent_bwd_data")
+        if ctx.fc1:
+            x, w1 = _lib.f32c(ctx.saved_tensors[8]), ctx.fc1_w
+            kin = int(w1.shape[1])
+            dest = ctx.fc1_dest
+            direct = (dest is not None and w1.grad is None and dest.shape == w1.shape and dest.is_contiguous() and dest.device == w1.device)
+            dw1 = dest if direct else torch.empty(hd, kin, **f32)
+            db1 = torch.empty(hd, **f32) if ctx.fc1_bias is not None else None
+            with KernelTimer.span("linear_wgrad"):
+                _lib.check(lib.is_linear_wgrad(_lib.ptr(d_a1), hd, _lib.ptr(x), kin, _lib.ptr(dw1), _lib.ptr(db1), b, hd, kin, st),
+                           "is_linear_wgrad")
+        with KernelTimer.span("vae_latent_bwd_wgrad"):
+            _lib.check(lib.is_vae_latent_bwd_wgrad(_lib.ptr(a1), _lib.ptr(dmu), _lib.ptr(dlv), _lib.ptr(zp), _lib.ptr(d_a3), pw,
+                                                   _lib.ptr(wg), b, hd, lat, st), "is_vae_latent_bwd_wgrad")
         n2 = lat * hd
         o = 2 * n2 + 2 * lat
         n3 = hd * (lat + pw)
-        return (d_a1, wg[:n2].view(lat, hd), wg[2 * n2:2 * n2 + lat], wg[n2:2 * n2].view(lat, hd), wg[2 * n2 + lat:o], None,
-                d_p if ctx.has_p else None, wg[o:o + n3].view(hd, lat + pw), wg[o + n3:])
+        return (None if ctx.fc1 else d_a1, wg[:n2].view(lat, hd), wg[2 * n2:2 * n2 + lat], wg[n2:2 * n2].view(lat, hd),
+                wg[2 * n2 + lat:o], None, d_p if ctx.has_p else None, wg[o:o + n3].view(hd, lat + pw), wg[o + n3:],
+                None, dw1, db1)
 
 
-def vae_latent_supported(a1, latent, p):
-    return (a1.is_cuda and a1.dim() == 2 and a1.dtype == torch.float32 and latent == 32 and a1.shape[1] % 16 == 0
-            and 16 <= a1.shape[1] <= 2048 and (p is None or (p.dim() == 2 and p.shape[1] <= 16)))
+def vae_latent_supported(a1, latent, p, hidden=None):
+    """``a1``: the first layer's output -- or its INPUT x together with ``hidden`` (the first layer's width), for the form of
+    :func:`vae_latent` that runs the first layer itself"""
+    hd = a1.shape[1] if hidden is None else hidden
+    return (a1.is_cuda and a1.dim() == 2 and a1.dtype == torch.float32 and latent == 32 and hd % 16 == 0
+            and 16 <= hd <= 2048 and (p is None or (p.dim() == 2 and p.shape[1] <= 16))
+            and (hidden is None or not a1.requires_grad))
 
 
-def vae_latent(a1, w21, b21, w22, b22, eps, p, w3, b3):
-    """-> (mu, logvar, [z | p], relu(vae_fc3([z | p])))"""
-    return VaeLatentFn.apply(a1, w21, b21, w22, b22, eps, p, w3, b3)
+def vae_latent(a1, w21, b21, w22, b22, eps, p, w3, b3, fc1=None):
+    """-> (mu, logvar, [z | p], relu(vae_fc3([z | p]))).  ``fc1`` = (x, weight, bias): compute ``a1 = vae_fc1(x)`` inside the node
+    (``a1`` is then only a shape / dtype carrier and may be None); x must not require a gradient."""
+    if fc1 is not None:
+        x, w1, b1 = fc1
+        if x.requires_grad:
+            raise ValueError("vae_latent(fc1=...): the input of the first layer must not require a gradient")
+        return VaeLatentFn.apply(None, w21, b21, w22, b22, eps, p, w3, b3, x, w1, b1)
+    return VaeLatentFn.apply(a1, w21, b21, w22, b22, eps, p, w3, b3, None, None, None)
 
 
 class SegmentPoolFn(torch.autograd.Function):
@@ -1226,7 +1351,7 @@ class VaeLossFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):
+    def forward(ctx, recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, pre=None):
         lib = _lib.load()
         _lib.require_device(logit, y, recon, x, mu, logvar)
         logit_c = _lib.f32c(logit.reshape(-1))
@@ -1239,16 +1364,18 @@ class VaeLossFn(torch.autograd.Function):
         if seq:
             recon_c, x_c = _lib.f32c(recon), _lib.f32c(x.reshape(recon.shape))
             mu_c, lv_c = _lib.f32c(mu), _lib.f32c(logvar)
-            d_recon, d_mu, d_lv = torch.empty_like(recon_c), torch.empty_like(mu_c), torch.empty_like(lv_c)
+            d_mu, d_lv = torch.empty_like(mu_c), torch.empty_like(lv_c)
+            d_recon = torch.empty_like(recon_c) if pre is None else pre[0]
             rt, lt = recon_c.numel(), mu_c.numel()
         else:
             recon_c = x_c = mu_c = lv_c = d_recon = d_mu = d_lv = None
             rt = lt = 0
         d_logit = torch.empty(b, dtype=torch.float32, device=dev)
-        partials = torch.empty(lib.is_loss_partials_floats(), dtype=torch.float32, device=dev)
+        partials = torch.empty(lib.is_loss_partials_floats(), dtype=torch.float32, device=dev) if pre is None else pre[1]
         out = torch.empty(4, dtype=torch.float32, device=dev)
         total = torch.empty((), dtype=torch.float32, device=dev)      # its own buffer: no clone launch for the differentiable result
-        code = lib.is_vae_loss(_lib.ptr(recon_c), _lib.ptr(x_c), _lib.ptr(d_recon), rt, _lib.ptr(mu_c), _lib.ptr(lv_c),
+        # (pre: stage 1 of the reconstruction term already ran -- recon = NULL tells the library so)
+        code = lib.is_vae_loss(_lib.ptr(recon_c) if pre is None else None, _lib.ptr(x_c), _lib.ptr(d_recon), rt, _lib.ptr(mu_c), _lib.ptr(lv_c),
                                _lib.ptr(d_mu), _lib.ptr(d_lv), lt, _lib.ptr(logit_c), _lib.ptr(y_c), _lib.ptr(d_logit),
                                b, int(mode), float(pos_weight), float(c_pred), float(c_mse), float(c_kld),
                                _lib.ptr(partials), _lib.ptr(out), _lib.ptr(total), _lib.stream_ptr())
@@ -1264,15 +1391,15 @@ class VaeLossFn(torch.autograd.Function):
     def backward(ctx, g, _g_terms):
         d_recon, d_mu, d_lv, d_logit = ctx.saved_tensors
         if g is None:
-            return (None,) * 11
+            return (None,) * 12
         if g is _unit_gradients.get((g.device.type, g.device.index)):
             # the engine seeds the backward with unit_gradient(): d loss / d loss = 1 exactly, no scaling launches
-            return d_recon, None, d_mu, d_lv, d_logit.reshape(ctx.logit_shape), None, None, None, None, None, None
+            return d_recon, None, d_mu, d_lv, d_logit.reshape(ctx.logit_shape), None, None, None, None, None, None, None
         if ctx.seq:
             gr, gm, gl, gz = torch._foreach_mul([d_recon, d_mu, d_lv, d_logit], g)     # one multi-tensor launch
         else:
             gr, gm, gl, gz = None, None, None, d_logit * g
-        return gr, None, gm, gl, gz.reshape(ctx.logit_shape), None, None, None, None, None, None
+        return gr, None, gm, gl, gz.reshape(ctx.logit_shape), None, None, None, None, None, None, None
 
 
 _unit_gradients = {}
@@ -1288,6 +1415,58 @@ def unit_gradient(device):
     return _unit_gradients[key]
 
 
+class SpeculativeBackward:
+    """While enabled (the captured / engine-driven train step, which seeds its backward with :func:`unit_gradient`), the fused
+    loss launches the reconstruction term's own gradient chain AHEAD of the prediction: stage 1 of the MSE (which yields
+    d loss / d recon for a unit seed), then the producing ``vae_fc4``'s input and weight gradients -- all on the stream ``recon``
+    was produced on (the sequence branch's), where they depend on nothing the graph branch computes.  They run beside the EGNN
+    forward layers (whose workgroups leave room for them) instead of beside the backward layers (whose do not: DESIGN.md
+    section 3.6).  The backward node of ``vae_fc4`` recognises the gradient it was speculated for by its buffer and hands the
+    stored results on; any other seed (a scaled loss) makes it launch normally -- the speculation is then wasted, not wrong."""
+    enabled = False
+    allowed = os.environ.get("IMMUNOSTRUCT_SPECULATIVE_BACKWARD", "1") != "0"
+
+    def __enter__(self):
+        self._saved, SpeculativeBackward.enabled = SpeculativeBackward.enabled, SpeculativeBackward.allowed
+        return self
+
+    def __exit__(self, *exc):
+        SpeculativeBackward.enabled = self._saved
+        return False
+
+
+def _speculate_recon_backward(recon, x, c_mse):
+    """-> (d_recon, partials) with stage 1 and the producer's backward launched on the producer's stream, or None"""
+    node = recon.grad_fn if torch.is_tensor(recon) else None
+    if (not SpeculativeBackward.enabled or node is None or type(node).__name__ != "LinearSmallBatchFnBackward" or not recon.is_cuda
+            or recon.dtype != torch.float32 or not recon.is_contiguous() or getattr(node, "fwd_stream", None) is None
+            or not torch.is_grad_enabled() or float(c_mse) == 0.0):
+        return None
+    lib = _lib.load()
+    main, side = torch.cuda.current_stream(recon.device), node.fwd_stream
+    xs = _lib.f32c(x.reshape(recon.shape))
+    with torch.cuda.stream(side):
+        d_recon = torch.empty_like(recon)
+        partials = torch.empty(lib.is_loss_partials_floats(), dtype=torch.float32, device=recon.device)
+        rt = recon.numel()
+        _lib.check(lib.is_recon_mse(_lib.ptr(recon), _lib.ptr(xs), _lib.ptr(d_recon), rt, float(c_mse) * 2.0 / rt, _lib.ptr(partials),
+                                    _lib.stream_ptr()), "is_recon_mse")
+        ready = torch.cuda.Event()
+        ready.record()          # the loss (caller's stream) needs stage 1 only, not the gradient chain behind it
+        with torch.no_grad():
+            gx, dw, db = LinearSmallBatchFn.launch_backward(node, d_recon, node.needs_input_grad[0])
+    node.spec = (d_recon, gx, dw, db)
+    if side != main:
+        main.wait_event(ready)
+        for t in (d_recon, partials, gx, dw, db, xs):
+            if t is not None:
+                t.record_stream(main)
+    return d_recon, partials
+
+
 def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):
     """Returns (total, terms[4] = {total, prediction, recon MSE, KLD})."""
-    return VaeLossFn.apply(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld)
+    pre = _speculate_recon_backward(recon, x, c_mse) if recon is not None else None
+    return VaeLossFn.apply(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, pre)
+
+

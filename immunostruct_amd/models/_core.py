@@ -24,11 +24,13 @@ import torch.nn.functional as F
 from .. import functional as HF
 from ..graph import PackedGraphBatch
 from ..graph import batch as graph_batch
-from ..nn import EGNNConv, egnn_stack_forward, egnn_stack_prologue
+from ..nn import EGNNConv, egnn_stack_forward, egnn_stack_prelaunch
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
+# the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer)
+FORK_AFTER_LAYER = int(os.environ.get("IMMUNOSTRUCT_FORK_AFTER_LAYER", "3"))
 MERGE_PAIRS = os.environ.get("IMMUNOSTRUCT_MERGE_PAIRS", "1") != "0"      # paired models: one encoder pass over [cancer; wild-type]
 if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
@@ -200,18 +202,23 @@ class MultimodalNet(nn.Module):
             p = prop
         if sp.vae:
             x = seq.reshape(-1, self.vae_input_dim)
-            a1 = HF.linear_small_batch(x, self.vae_fc1.weight, self.vae_fc1.bias)
-            if HF.vae_latent_supported(a1, self.vae_latent_dim, p) and self.vae_fc21.bias is not None:
+            fuse1 = (HF.vae_latent_supported(x, self.vae_latent_dim, p, hidden=self.vae_fc1.out_features)
+                     and self.vae_fc21.bias is not None)
+            a1 = None if fuse1 else HF.linear_small_batch(x, self.vae_fc1.weight, self.vae_fc1.bias)
+            if fuse1 or (HF.vae_latent_supported(a1, self.vae_latent_dim, p) and self.vae_fc21.bias is not None):
                 # fc21 | fc22, reparameterisation, cat(p), fc3 and the two ReLUs as ONE launch (csrc/vae_latent.hip); the noise
-                # is drawn exactly as the reference does (torch.randn_like of a (B, latent) tensor; two draws for a merged pair)
-                like = a1.new_empty(a1.shape[0], self.vae_latent_dim)
+                # is drawn exactly as the reference does (torch.randn_like of a (B, latent) tensor; two draws for a merged pair).
+                # With an input that needs no gradient (always, in the models) vae_fc1 runs inside the same autograd node, so
+                # that the node's backward can order its launches: data path, vae_fc1's weight gradient, small weight pass.
+                like = x.new_empty(x.shape[0], self.vae_latent_dim)
                 if self._pair_rows:
                     b = self._pair_rows
                     eps = torch.cat([torch.randn_like(like[:b]), torch.randn_like(like[b:])], dim=0)
                 else:
                     eps = torch.randn_like(like)
                 mu, logvar, z, h3 = HF.vae_latent(a1, self.vae_fc21.weight, self.vae_fc21.bias, self.vae_fc22.weight,
-                                                  self.vae_fc22.bias, eps, p, self.vae_fc3.weight, self.vae_fc3.bias)
+                                                  self.vae_fc22.bias, eps, p, self.vae_fc3.weight, self.vae_fc3.bias,
+                                                  fc1=(x, self.vae_fc1.weight, self.vae_fc1.bias) if fuse1 else None)
                 recon = HF.linear_small_batch(h3, self.vae_fc4.weight, self.vae_fc4.bias)
             else:
                 h1 = F.relu(a1)
@@ -236,13 +243,21 @@ class MultimodalNet(nn.Module):
         overlap = sp.graph and sp.vae and seq.is_cuda and OVERLAP_BRANCHES
         pro = None
         if overlap:
-            # the EGNN stack's first launch goes out BEFORE the fork: it then runs right behind the batch hand-over instead of
-            # waiting for the side branch's queue to come up (the fork costs the second branch ~ 15 us in a replayed HIP graph)
-            inp = self._graph_inputs(g)
-            pro = (inp, egnn_stack_prologue(inp[3], inp[0], inp[1], head=inp[4]))
+            # The EGNN stack's forward kernels are enqueued FIRST -- outside autograd; the stack's autograd node is created
+            # further down, after the sequence branch's, so the backward still runs the graph branch's nodes first -- and the
+            # sequence branch is forked from an event recorded part-way through the stack:
+            #  * in a captured HIP graph the layer chain is then the first-captured continuation at every node, and ROCm's graph
+            #    executor (first continuations stay on the launch queue, later ones get their own) runs the graph branch, the
+            #    head, the loss and the main backward on ONE queue -- no cross-queue hop on the critical chain;
+            #  * the sequence branch (and, behind it on the same stream, the speculative backward of its reconstruction term)
+            #    runs beside the LAST layer and the attention / head / loss kernels, whose small grids leave half the CUs
+            #    idle, instead of beside the 512-workgroup layer kernels, which it slows.
             main = torch.cuda.current_stream()
             side = _side_stream(seq.device)
-            side.wait_stream(main)
+            inp = self._graph_inputs(g)
+            pro = (inp, egnn_stack_prelaunch(inp[3], g, inp[0], inp[1], inp[2], head=inp[4], final_coords=False,
+                                             fork_after=FORK_AFTER_LAYER))
+            side.wait_event(pro[1].fork_event)
             with torch.cuda.stream(side):
                 HF.Stamps.mark("fwd seq-branch start")
                 o.update(self._encode_sequence(seq, prop))

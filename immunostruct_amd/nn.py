@@ -67,13 +67,17 @@ def egnn_stack_prologue(layers, node_feat, coord_feat, head=None):
     return HF.launch_stack_prologue(node_feat, coord_feat, [layer.native_parameters() for layer in layers], head=head)
 
 
-def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True, prologue=None):
-    """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``).
+def egnn_stack_prelaunch(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True, fork_after=None):
+    """Enqueue the whole forward of :func:`egnn_stack_forward` now, outside autograd, and return the handle to pass as
+    ``prologue=`` to the later call with the same arguments (which then only creates the autograd node).  ``fork_after`` = i
+    leaves an event recorded behind layer i's launch in ``.fork_event``."""
+    _check_stack(layers, graph, edge_feat)
+    ea = graph.edge_feat_csr(edge_feat) if layers[0].edge_feat_size > 0 else None
+    return HF.launch_stack_forward(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers],
+                                   head=head, final_coords=final_coords, fork_after=fork_after)
 
-    ``head`` = optional (Wa, ba, Wb, bb): also return the 128-wide projection [h Wa^T + ba | h Wb^T + bb] of the
-    final node features (the node attention's query / key projection), computed by the last layer's node kernel.
-    ``final_coords=False``: the caller ignores the last layer's coordinates; its coordinate MLP is then skipped and the
-    returned x may be None."""
+
+def _check_stack(layers, graph, edge_feat):
     if not isinstance(graph, PackedGraphBatch):
         raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
     fe = layers[0].edge_feat_size
@@ -84,7 +88,17 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, hea
         raise ValueError("Edge features must be provided.")
     if edge_feat is not None and edge_feat.requires_grad:
         raise NotImplementedError("gradients w.r.t. edge features are not produced by the HIP kernel")
-    ea = graph.edge_feat_csr(edge_feat) if fe > 0 else None
+
+
+def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, head=None, final_coords=True, prologue=None):
+    """Run consecutive :class:`EGNNConv` layers as one fused HIP stack (what the models do with ``GCN_layers``).
+
+    ``head`` = optional (Wa, ba, Wb, bb): also return the 128-wide projection [h Wa^T + ba | h Wb^T + bb] of the
+    final node features (the node attention's query / key projection), computed by the last layer's node kernel.
+    ``final_coords=False``: the caller ignores the last layer's coordinates; its coordinate MLP is then skipped and the
+    returned x may be None."""
+    _check_stack(layers, graph, edge_feat)
+    ea = graph.edge_feat_csr(edge_feat) if layers[0].edge_feat_size > 0 else None
     return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head,
                          final_coords=final_coords, prologue=prologue)
 

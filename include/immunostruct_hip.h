@@ -158,6 +158,14 @@ int is_vae_latent_bwd(const float* g_h3, const float* h3, const float* g_mu, con
                       const float* eps, const float* logvar, const float* a1, const float* zp, const float* W21,
                       const float* W22, int P, const float* W3, float* d_a3, float* dmu, float* dlv, float* d_p,
                       float* d_a1, float* wgrad, int B, int Hd, int L, void* stream);
+/* the two halves of is_vae_latent_bwd as their own entry points (data path: two launches; weight pass: one), for callers
+ * that put other work of the data path between them (functional.VaeLatentFn: the weight gradient of vae_fc1) */
+int is_vae_latent_bwd_data(const float* g_h3, const float* h3, const float* g_mu, const float* g_lv, const float* g_zp,
+                           const float* eps, const float* logvar, const float* a1, const float* W21, const float* W22,
+                           int P, const float* W3, float* d_a3, float* dmu, float* dlv, float* d_p, float* d_a1, int B,
+                           int Hd, int L, void* stream);
+int is_vae_latent_bwd_wgrad(const float* a1, const float* dmu, const float* dlv, const float* zp, const float* d_a3,
+                            int P, float* wgrad, int B, int Hd, int L, void* stream);
 
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
  * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
@@ -211,6 +219,14 @@ int is_mlp2_bwd(const float* x, int ld_x, const float* W1, const float* W2, cons
  * matrices of the sequence VAE (vae_fc1 512 x 5943, vae_fc4 5943 x 512; models/hybrid_models.py:297-308); forward and
  * input gradient stay on the library GEMMs.                                                                   */
 int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld_x, float* dW, float* db, int B, int N, int K,
+                    void* stream);
+
+/* Input gradient of a Linear layer with a long contraction and a small output (vae_fc4: 5943 -> 512 going backward;
+ * models/hybrid_models.py:306-308): gx [B, K] = gy [B, ld_g] (N columns) W [N, ld_w] (K columns; the weight as nn.Linear
+ * stores it).  The contraction is cut into chunks of 96, one workgroup per (64 output columns, chunk), partial results summed
+ * in chunk order by a second launch.  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats.                          */
+long long is_linear_dgrad_scratch_floats(int B, int N, int K);
+int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld_w, float* gx, float* scratch, int B, int N, int K,
                     void* stream);
 
 /* Multi-tensor Adam / AdamW step with torch.optim semantics (reference: torch.optim.Adam in train_IEDB_wFT.py:69-74,
@@ -328,7 +344,12 @@ int is_loss_partials_floats(void);
  * + c_mse*MSE(recon,x) + c_kld*(-0.5*mean(1+logvar-mu^2-exp(logvar))).
  * recon/x/d_recon may be NULL with recon_total = 0, mu/logvar likewise with latent_total = 0.
  * out[4] = {total, prediction term, recon MSE, KLD}; total (may be NULL) receives out[0] as well (its own buffer:
- * the differentiable result); d_* receive d total / d input.                                                        */
+ * the differentiable result); d_* receive d total / d input.
+ * recon = NULL with recon_total > 0: partials[] already holds stage 1 of the reconstruction term, produced by
+ * is_recon_mse (partial sums of (recon - x)^2 and d_recon = gscale * (recon - x), gscale = c_mse * 2 / recon_total) --
+ * for callers that run stage 1 where recon is produced (the sequence branch's stream), ahead of the prediction.      */
+int is_recon_mse(const float* recon, const float* x, float* d_recon, long long recon_total, float gscale,
+                 float* partials, void* stream);
 int is_vae_loss(const float* recon, const float* x, float* d_recon, long long recon_total,
                 const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total,
                 const float* logit, const float* y, float* d_logit, int batch, int mode,

@@ -630,9 +630,11 @@ def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,n,k", [(128, 512, 5943), (128, 5943, 512), (37, 100, 70), (1, 64, 64)])
+@pytest.mark.parametrize("b,n,k", [(128, 512, 5943), (128, 5943, 512), (37, 100, 70), (1, 64, 64), (37, 1000, 70), (130, 777, 33),
+                                   (300, 193, 5)])
 def test_linear_small_batch_weight_gradient(cuda_device, b, n, k):
-    """csrc/dense.hip: dW = gy^T x, db = sum gy (the VAE's two large layers) vs torch in fp64; dx through the library GEMM."""
+    """csrc/dense.hip: dW = gy^T x, db = sum gy (the VAE's two large layers) vs torch in fp64; dx through the library GEMM, or
+    (n >= 8 k: the last four cases) through the split-contraction kernel is_linear_dgrad."""
     g = torch.Generator().manual_seed(b + n)
     x, w, bias, gup = (torch.randn(b, k, generator=g), torch.randn(n, k, generator=g) * 0.05, torch.randn(n, generator=g),
                        torch.randn(b, n, generator=g))
