@@ -240,30 +240,37 @@ __device__ __forceinline__ void egnn_node_wgrad16_node(WgradSmem& sm, const floa
   f32x4 dW2[4], dWn[8];
   zero_acc4(dW2);
   zero_acc4(dWn);
-  float s_g = 0.f, s_z = 0.f;   // lane = column partial sums
-  float rg[4], rz[4], rzn[4], rxh[4], rxn[4];
+  // staging role of a lane: row 4 wave + rr of the chunk, columns 4 c4 .. 4 c4 + 3 -- ONE 16-byte load per matrix and chunk
+  // (a wave fetches its four 256-byte rows with one instruction), one 16-byte LDS store each
+  const int rr = lane >> 4, c4 = lane & 15;
+  const bool h4 = DIN == 64 && (ld_h & 3) == 0 && (reinterpret_cast<uintptr_t>(h) & 15) == 0;      // h rows 16-byte aligned
+  f32x4 s_g = f32x4{0.f, 0.f, 0.f, 0.f}, s_z = s_g;      // partial column sums of columns 4 c4 .. + 3 over rows == rr (mod 4)
+  f32x4 rg, rz, rzn, rxh, rxn;
   auto fetch = [&](int c0) {
+    const int row = c0 + wave * 4 + rr;
+    rg = buf_load4(rs_g, row * (H * 4) + c4 * 16, 0);
+    rz = buf_load4(rs_z, row * (H * 4) + c4 * 16, 0);
+    rzn = buf_load4(rs_zn, row * (H * 4) + c4 * 16, 0);
+    rxn = buf_load4(rs_hn, row * (ld_hn * 4) + c4 * 16, 0);
+    if (h4) {
+      rxh = buf_load4(rs_h, row * (ld_h * 4) + c4 * 16, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = c0 + wave * 4 + i;      // wave-uniform
-      rg[i] = buf_load(rs_g, lane * 4 + row * (H * 4), 0);
-      rz[i] = buf_load(rs_z, lane * 4 + row * (H * 4), 0);
-      rzn[i] = buf_load(rs_zn, lane * 4 + row * (H * 4), 0);
-      rxh[i] = (lane < DIN) ? buf_load(rs_h, lane * 4 + row * (ld_h * 4), 0) : 0.0f;
-      rxn[i] = buf_load(rs_hn, lane * 4 + row * (ld_hn * 4), 0);
+      for (int j = 0; j < 4; ++j) rxh[j] = (4 * c4 + j < DIN) ? buf_load(rs_h, row * (ld_h * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
     }
   };
-  auto stage = [&](int buf) {      // registers -> LDS set `buf`: wave w stages rows 4w .. 4w+3 (lane = column)
+  auto stage = [&](int buf) {      // registers -> LDS set `buf`
     float *Xs = Xs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
+    const int lr = wave * 4 + rr;
+    *reinterpret_cast<f32x4*>(Gs + lr * LD + 4 * c4) = rg;
+    *reinterpret_cast<f32x4*>(Zs + lr * LD + 4 * c4) = rz;
+    s_g += rg; s_z += rz;
+    f32x4 a;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int lr = wave * 4 + i;
-      Gs[lr * LD + lane] = rg[i]; Zs[lr * LD + lane] = rz[i];
-      s_g += rg[i]; s_z += rz[i];
-      As[lr * LD + lane] = silu_f(rzn[i]);      // rows past N: SiLU(0) = 0
-      Xs[lr * LDP + lane] = rxh[i];
-      Xs[lr * LDP + 64 + lane] = rxn[i];
-    }
+    for (int j = 0; j < 4; ++j) a[j] = silu_f(rzn[j]);      // rows past N: SiLU(0) = 0
+    *reinterpret_cast<f32x4*>(As + lr * LD + 4 * c4) = a;
+    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 4 * c4) = rxh;
+    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 64 + 4 * c4) = rxn;
   };
   if (r_begin < r_end) {
     fetch(r_begin);
@@ -301,7 +308,15 @@ __device__ __forceinline__ void egnn_node_wgrad16_node(WgradSmem& sm, const floa
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) pn[(wave * 16 + lr) * 128 + nt * 16 + r] = dWn[nt][t];
   }
-  sm.vec[wave][0][lane] = s_z; sm.vec[wave][1][lane] = s_g;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {      // rows (mod 4) in a fixed order: (0 + 1) + (2 + 3)
+    s_z[j] += __shfl_xor(s_z[j], 16, 64); s_z[j] += __shfl_xor(s_z[j], 32, 64);
+    s_g[j] += __shfl_xor(s_g[j], 16, 64); s_g[j] += __shfl_xor(s_g[j], 32, 64);
+  }
+  if (rr == 0) {
+    *reinterpret_cast<f32x4*>(&sm.vec[wave][0][4 * c4]) = s_z;
+    *reinterpret_cast<f32x4*>(&sm.vec[wave][1][4 * c4]) = s_g;
+  }
   __syncthreads();
   if (tid < 128) {
     const int which = tid >> 6;   // 0: dbn1, 1: dbn2
@@ -322,26 +337,28 @@ __device__ __forceinline__ void egnn_node_wgrad16_proj(WgradSmem& sm, const floa
   f32x4 dW1[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a) zero_acc4(dW1[a]);
-  float s_p0 = 0.f, s_p1 = 0.f;
-  float rp0[4], rp1[4], rho[4];
+  const int rr = lane >> 4, c4 = lane & 15;      // staging role: row 4 wave + rr, columns 4 c4 .. + 3 (see the node kind)
+  const bool h4 = dho == 64 && (ld_ho & 3) == 0 && (reinterpret_cast<uintptr_t>(h_out) & 15) == 0;
+  f32x4 s_p0 = f32x4{0.f, 0.f, 0.f, 0.f}, s_p1 = s_p0;
+  f32x4 rp0, rp1, rho;
   auto fetch = [&](int c0) {
+    const int row = c0 + wave * 4 + rr;
+    rp0 = buf_load4(rs_p, row * 512 + c4 * 16, 0);
+    rp1 = buf_load4(rs_p, row * 512 + 256 + c4 * 16, 0);
+    if (h4) {
+      rho = buf_load4(rs_ho, row * (ld_ho * 4) + c4 * 16, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = c0 + wave * 4 + i;
-      rp0[i] = buf_load(rs_p, lane * 4 + row * 512, 0);
-      rp1[i] = buf_load(rs_p, lane * 4 + 256 + row * 512, 0);
-      rho[i] = (lane < dho) ? buf_load(rs_ho, lane * 4 + row * (ld_ho * 4), 0) : 0.0f;
+      for (int j = 0; j < 4; ++j) rho[j] = (4 * c4 + j < dho) ? buf_load(rs_ho, row * (ld_ho * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
     }
   };
   auto stage = [&](int buf) {
     float *Ps = Ps2[buf], *Hs = Hs2[buf];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int lr = wave * 4 + i;
-      Ps[lr * LDP + lane] = rp0[i]; Ps[lr * LDP + 64 + lane] = rp1[i];
-      s_p0 += rp0[i]; s_p1 += rp1[i];
-      Hs[lr * LD + lane] = rho[i];
-    }
+    const int lr = wave * 4 + rr;
+    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 4 * c4) = rp0;
+    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 64 + 4 * c4) = rp1;
+    s_p0 += rp0; s_p1 += rp1;
+    *reinterpret_cast<f32x4*>(Hs + lr * LD + 4 * c4) = rho;
   };
   if (r_begin < r_end) {
     fetch(r_begin);
@@ -378,7 +395,15 @@ __device__ __forceinline__ void egnn_node_wgrad16_proj(WgradSmem& sm, const floa
       part[((2 * wave + 1) * 16 + lr) * H + nt * 16 + r] = dW1[1][nt][t];
     }
   }
-  sm.vec[wave][0][lane] = s_p1; sm.vec[wave][1][lane] = s_p0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s_p0[j] += __shfl_xor(s_p0[j], 16, 64); s_p0[j] += __shfl_xor(s_p0[j], 32, 64);
+    s_p1[j] += __shfl_xor(s_p1[j], 16, 64); s_p1[j] += __shfl_xor(s_p1[j], 32, 64);
+  }
+  if (rr == 0) {
+    *reinterpret_cast<f32x4*>(&sm.vec[wave][0][4 * c4]) = s_p1;
+    *reinterpret_cast<f32x4*>(&sm.vec[wave][1][4 * c4]) = s_p0;
+  }
   __syncthreads();
   if (tid < 128) {
     const int which = tid >> 6;   // 0: db1, 1: db0
