@@ -352,7 +352,7 @@ def launch_stack_forward(h0, x0, ea_csr, csr, layer_params, head=None, final_coo
     with torch.no_grad():
         layers, h_out, x_out, psd = _launch_stack_layers(
             h0c, ld_h0, int(h0.shape[1]), ea, fe, csr, params, hd, n_layers, final_coords, need_grad, pro.psd, pro.packs, pro.x,
-            after=(min(int(fork_after), n_layers - 1), mark) if fork_after is not None else None)
+            after=(max(0, min(int(fork_after), n_layers - 1)), mark) if fork_after is not None else None)
     pro.layers, pro.outs = layers, (h_out, x_out, psd)
     pro.need_grad, pro.final_coords, pro.ea_key = need_grad, bool(final_coords), _ea_key(ea, csr)
     return pro
