@@ -43,29 +43,31 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// stage 2 (one workgroup): finish MSE, KLD + grads, prediction term + grads, total
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
+// stage 2 (one workgroup of 1024 threads: the kernel is a latency chain on the step's critical path, so the three loops are
+// kept to at most four trips): finish MSE, KLD + grads, prediction term + grads, total
+constexpr int FIN_BLOCK = 1024, FIN_WAVES = FIN_BLOCK / 64;
+__global__ __launch_bounds__(FIN_BLOCK) void loss_finish_kernel(
     const float* __restrict__ partials, int nparts, long long recon_total,
     const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ d_mu,
     float* __restrict__ d_logvar, int latent_total,
     const float* __restrict__ logit, const float* __restrict__ y, float* __restrict__ d_logit, int batch,
     int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ out, float* __restrict__ total) {
-  __shared__ float red[3][LOSS_BLOCK / 64];
+  __shared__ float red[3][FIN_WAVES];
   const int tid = threadIdx.x;
   // the three per-thread partial sums first (their loads are independent: all in flight together), then ONE pass of
-  // wave reductions and one barrier for all three -- same per-thread order and same reduction tree as three block sums
+  // wave reductions and one barrier for all three; fixed order throughout
   float acc_m = 0.0f, acc_k = 0.0f, acc_p = 0.0f;
   if (recon_total > 0)
-    for (int i = tid; i < nparts; i += LOSS_BLOCK) acc_m += partials[i];
+    for (int i = tid; i < nparts; i += FIN_BLOCK) acc_m += partials[i];
   const float inv = latent_total > 0 ? 1.0f / (float)latent_total : 0.0f;
-  for (int i = tid; i < latent_total; i += LOSS_BLOCK) {
+  for (int i = tid; i < latent_total; i += FIN_BLOCK) {
     const float m = mu[i], lv = logvar[i], ev = __expf(lv);
     acc_k += 1.0f + lv - m * m - ev;
     d_mu[i] = c_kld * m * inv;
     d_logvar[i] = c_kld * (-0.5f) * (1.0f - ev) * inv;
   }
   const float invb = 1.0f / (float)batch;
-  for (int i = tid; i < batch; i += LOSS_BLOCK) {
+  for (int i = tid; i < batch; i += FIN_BLOCK) {
     const float z = logit[i], t = y[i];
     if (mode == 0) {
       const float d = z - t;
@@ -88,10 +90,18 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(
   }
   if ((tid & 63) == 0) { red[0][tid >> 6] = acc_m; red[1][tid >> 6] = acc_k; red[2][tid >> 6] = acc_p; }
   __syncthreads();
-  const float mse = recon_total > 0 ? (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)recon_total : 0.0f;
-  const float kld = latent_total > 0 ? -0.5f * (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) * inv : 0.0f;
-  const float pred = (((red[2][0] + red[2][1]) + red[2][2]) + red[2][3]) * invb;
   if (tid == 0) {
+    float s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < FIN_WAVES; ++w) v += red[k][w];
+      s[k] = v;
+    }
+    const float mse = recon_total > 0 ? s[0] / (float)recon_total : 0.0f;
+    const float kld = latent_total > 0 ? -0.5f * s[1] * inv : 0.0f;
+    const float pred = s[2] * invb;
     out[0] = c_pred * pred + c_mse * mse + c_kld * kld;
     if (total != nullptr) total[0] = out[0];
     out[1] = pred; out[2] = mse; out[3] = kld;
@@ -136,7 +146,7 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
       hipLaunchKernelGGL(is::recon_mse_kernel, dim3(nparts), dim3(is::LOSS_BLOCK), 0, st, recon, x, d_recon, partials,
                          recon_total, c_mse * 2.0f / (float)recon_total);
   }
-  hipLaunchKernelGGL(is::loss_finish_kernel, dim3(1), dim3(is::LOSS_BLOCK), 0, st, partials, nparts, recon_total, mu,
+  hipLaunchKernelGGL(is::loss_finish_kernel, dim3(1), dim3(is::FIN_BLOCK), 0, st, partials, nparts, recon_total, mu,
                      logvar, d_mu, d_logvar, latent_total, logit, y, d_logit, batch, mode, pos_weight, c_pred, c_mse,
                      c_kld, out, total);
   return hipGetLastError() == hipSuccess ? 0 : -5;
