@@ -48,6 +48,7 @@ SIGNATURES = {
     "is_adam_step": [_P, _I, _P, _P, _P],
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_linear_dgrad_scratch_floats": [_I, _I, _I],
+    "is_linear_fwd_long": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "is_linear_dgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_contrastive_scratch_floats": [_I],
     "is_contrastive_work_floats": [_I],

@@ -149,8 +149,80 @@ __global__ __launch_bounds__(256, 2) void linear_dgrad_splitk_kernel(const float
     }
 }
 
+// ---- forward of a Linear layer with a LONG contraction and a small output: y [B, K] = x [B, N] W^T + b, W [K, N] as stored
+// (vae_fc1: N = 5943, K = 512).  Same split of the contraction as the input gradient above; the weight chunk is [64 output
+// rows, 96 contraction columns] here (rows of W are contiguous along the contraction), staged with the same pitch as the x
+// chunk, so both MFMA operands are read with the conflict-free column pattern.  The library's kernel for this shape
+// (Cijk_Alik_Bljk MT16x16x128) takes 22 us alone and 40-46 us beside the layer kernels.
+__global__ __launch_bounds__(256, 2) void linear_fwd_splitk_kernel(const float* __restrict__ x, int ld_x,
+                                                                   const float* __restrict__ W, int ld_w,
+                                                                   float* __restrict__ part, int B, int N, int K) {
+  __shared__ float xs[DG_M * DG_LDA];       // [128 batch rows][DG_KC contraction columns]
+  __shared__ float ws[DG_N * DG_LDA];       // [64 output rows][DG_KC contraction columns]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k0 = blockIdx.x * DG_N, c0 = blockIdx.y * DG_KC, b0 = blockIdx.z * DG_M;
+  const int r = lane & 31, hf = lane >> 5;
+  constexpr int CM = (DG_KC + 63) / 64;
+  {
+    float v[32][CM];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int b = min(b0 + wave * 32 + i, B - 1);
+#pragma unroll
+      for (int m = 0; m < CM; ++m) v[i][m] = x[(size_t)b * ld_x + min(c0 + lane + 64 * m, N - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool b_ok = b0 + wave * 32 + i < B;
+#pragma unroll
+      for (int m = 0; m < CM; ++m)
+        if (lane + 64 * m < DG_KC)
+          xs[(wave * 32 + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
+    }
+  }
+  {
+    float v[16][CM];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = min(k0 + wave * 16 + i, K - 1);
+#pragma unroll
+      for (int m = 0; m < CM; ++m) v[i][m] = W[(size_t)k * ld_w + min(c0 + lane + 64 * m, N - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool k_ok = k0 + wave * 16 + i < K;
+#pragma unroll
+      for (int m = 0; m < CM; ++m)
+        if (lane + 64 * m < DG_KC)
+          ws[(wave * 16 + i) * DG_LDA + lane + 64 * m] = (k_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
+    }
+  }
+  __syncthreads();
+  f32x16 acc[2];
+  zero_acc(acc);
+  const float* ap = xs + (wave * 32 + r) * DG_LDA + hf;
+  const float* wp = ws + r * DG_LDA + hf;
+#pragma unroll 8
+  for (int sidx = 0; sidx < DG_KC / 2; ++sidx) {
+    const float a = ap[2 * sidx];
+    const float w0 = wp[2 * sidx], w1 = wp[32 * DG_LDA + 2 * sidx];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc[1], 0, 0, 0);
+  }
+  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][128][K]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = k0 + nt * 32 + r;
+      if (k < K) out[(size_t)(wave * 32 + tile_row(t, hf)) * K + k] = acc[nt][t];
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gx,
-                                                                  int B, int K, int chunks, int mtiles) {
+                                                                  int B, int K, int chunks, int mtiles,
+                                                                  const float* __restrict__ bias = nullptr) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)B * K) return;
   const int b = (int)(e / K), k = (int)(e % K);
@@ -166,7 +238,7 @@ __global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* _
     for (int u = 0; u < 8; ++u) acc += v[u];
   }
   for (; c < chunks; ++c) acc += p[(size_t)c * stride];
-  gx[e] = acc;
+  gx[e] = bias != nullptr ? acc + bias[k] : acc;
 }
 
 }  // namespace is
@@ -199,5 +271,20 @@ extern "C" int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld
   const long long total = (long long)B * K;
   hipLaunchKernelGGL(is::linear_dgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scratch, gx, B, K,
                      chunks, mtiles);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// y [B, K] = x [B, ld_x] (N valid columns) W^T + bias, W [K, ld_w] (N valid columns; the nn.Linear weight as stored), bias [K]
+// or NULL.  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats (the same split of the contraction).  Two launches.
+extern "C" int is_linear_fwd_long(const float* x, int ld_x, const float* W, int ld_w, const float* bias, float* y, float* scratch,
+                                  int B, int N, int K, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0) return -22;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = (N + is::DG_KC - 1) / is::DG_KC, mtiles = (B + is::DG_M - 1) / is::DG_M;
+  hipLaunchKernelGGL(is::linear_fwd_splitk_kernel, dim3((K + is::DG_N - 1) / is::DG_N, chunks, mtiles), dim3(256), 0, st, x, ld_x, W,
+                     ld_w, scratch, B, N, K);
+  const long long total = (long long)B * K;
+  hipLaunchKernelGGL(is::linear_dgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scratch, y, B, K,
+                     chunks, mtiles, bias);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

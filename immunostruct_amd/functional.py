@@ -1127,6 +1127,23 @@ def paired_contrastive(emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate=None, s
     return PairedContrastiveFn.apply(emb_c, emb_w, pos, w1, gamma, beta, w2, lam, gate, scale)
 
 
+def _linear_forward(x, w, b):
+    """``F.linear(x, w, b)`` for a small batch; a long contraction into a small output (vae_fc1) goes through the
+    split-contraction kernel (``is_linear_fwd_long``), everything else through the library"""
+    n, k = int(w.shape[0]), int(w.shape[1])
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and k >= 8 * n and x.shape[0] <= 1024
+            and x.is_contiguous() and w.is_contiguous() and (b is None or (b.dtype == torch.float32 and b.is_contiguous()))):
+        lib = _lib.load()
+        bsz = int(x.shape[0])
+        y = torch.empty(bsz, n, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(int(lib.is_linear_dgrad_scratch_floats(bsz, k, n)), dtype=torch.float32, device=x.device)
+        with KernelTimer.span("linear_fwd_long"):
+            _lib.check(lib.is_linear_fwd_long(_lib.ptr(x), k, _lib.ptr(w), k, _lib.ptr(b), _lib.ptr(y), _lib.ptr(scratch), bsz, k, n,
+                                              _lib.stream_ptr()), "is_linear_fwd_long")
+        return y
+    return torch.nn.functional.linear(x, w, b)
+
+
 class LinearSmallBatchFn(torch.autograd.Function):
     """``F.linear(x, w, b)`` whose weight / bias gradients come from ``csrc/dense.hip`` (contraction over the small batch),
     and whose input gradient does too when the contraction is long and the output small (``is_linear_dgrad``); forward and
@@ -1141,7 +1158,7 @@ class LinearSmallBatchFn(torch.autograd.Function):
         ctx.dest = getattr(w, "_grad_dest", None)
         ctx.fwd_stream = torch.cuda.current_stream(x.device) if x.is_cuda else None
         ctx.spec = None
-        return torch.nn.functional.linear(x, w, b)
+        return _linear_forward(x, w, b)
 
     @staticmethod
     def launch_backward(ctx, gy, need_gx):
@@ -1203,7 +1220,7 @@ class VaeLatentFn(torch.autograd.Function):
             # the first layer inside this node (``a1`` is ignored): forward = the library GEMM; backward launches its weight
             # gradient BETWEEN this block's data path and weight pass -- the order the rest of the step's schedule wants
             # (DESIGN.md section 3.6), which separate autograd nodes cannot express
-            a1 = torch.nn.functional.linear(x, w1, b1)
+            a1 = _linear_forward(x, w1, b1)
             ctx.fc1_dest = getattr(w1, "_grad_dest", None)
             ctx.fc1_w, ctx.fc1_bias = w1, b1
         _lib.require_device(a1, w21, b21, w22, b22, eps, p, w3, b3)

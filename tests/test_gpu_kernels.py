@@ -631,7 +631,7 @@ def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,n,k", [(128, 512, 5943), (128, 5943, 512), (37, 100, 70), (1, 64, 64), (37, 1000, 70), (130, 777, 33),
-                                   (300, 193, 5)])
+                                   (300, 193, 5), (37, 70, 1000), (130, 33, 777), (300, 5, 193)])
 def test_linear_small_batch_weight_gradient(cuda_device, b, n, k):
     """csrc/dense.hip: dW = gy^T x, db = sum gy (the VAE's two large layers) vs torch in fp64; dx through the library GEMM, or
     (n >= 8 k: the last four cases) through the split-contraction kernel is_linear_dgrad."""
@@ -642,6 +642,8 @@ def test_linear_small_batch_weight_gradient(cuda_device, b, n, k):
     (torch.nn.functional.linear(*ref) * gup.double()).sum().backward()
     hip = [t.to(cuda_device).requires_grad_(True) for t in (x, w, bias)]
     y = HF.linear_small_batch(*hip)
+    # (k >= 8 n -- the first and the last three cases: the forward is the split-contraction kernel is_linear_fwd_long too)
+    H.assert_close(y.detach().cpu(), torch.nn.functional.linear(*[t.detach() for t in ref]), 1e-5, "linear forward")
     (y * gup.to(cuda_device)).sum().backward()
     for name, a, r in zip(("dx", "dW", "db"), hip, ref):
         H.assert_close(a.grad.cpu(), r.grad, 1e-5, f"linear {name}")
