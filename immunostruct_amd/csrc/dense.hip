@@ -76,40 +76,41 @@ __global__ __launch_bounds__(256, 4) void linear_wgrad_kernel(const float* __res
 // ---- input gradient of a Linear layer with a LONG contraction and a small output: gx [B, K] = gy [B, N] W [N, K] --------------
 // (vae_fc4: N = 5943, K = 512, B = 128: 64 Ki outputs, each a 5943-term sum.)  The library runs this as ONE workgroup per 32 x 16
 // output tile walking the whole contraction (Cijk_Ailk_Bljk MT32x16x128: 33-38 us at 128 workgroups); here the contraction is
-// cut into chunks of 96 -- one workgroup per (64 output columns, chunk) = 8 x 62 workgroups, two per CU (75 KB of LDS: a
-// workgroup that needs a whole CU's LDS cannot start while ANY other kernel's workgroups are spread over the CUs) -- each
-// staging its gy chunk [128, 96] and W chunk [96, 64] in LDS in one go and writing a [128, 64] partial on
+// cut into chunks of 96 -- one workgroup per (64 batch rows, 64 output columns, chunk) = 2 x 8 x 62 workgroups of 50 KB LDS and
+// 84 registers: small enough to sit BESIDE the two resident workgroups of a forward layer kernel (52 KB and 128 registers
+// per lane are free there) instead of waiting for one to leave, or blocking one that wants to start -- each
+// staging its gy chunk [64, 96] and W chunk [96, 64] in LDS in one go and writing a [64, 64] partial on
 // v_mfma_f32_32x32x2_f32; a second launch sums the partials in chunk order (fixed order -> bitwise reproducible).
 constexpr int DG_KC = 96;             // contraction rows per chunk
 constexpr int DG_LDA = DG_KC + 2;     // gy panel pitch: the A operand reads a column of 32 rows, 2 apart -> all 64 banks
-constexpr int DG_M = 128, DG_N = 64;
+constexpr int DG_M = 64, DG_N = 64;      // 64 x 64 partial tile per workgroup: one 32 x 32 MFMA tile per wave
 
 __global__ __launch_bounds__(256, 2) void linear_dgrad_splitk_kernel(const float* __restrict__ gy, int ld_g,
                                                                      const float* __restrict__ W, int ld_w,
                                                                      float* __restrict__ part, int B, int N, int K) {
-  __shared__ float gs[DG_M * DG_LDA];       // [128 batch rows][DG_KC contraction columns]
+  __shared__ float gs[DG_M * DG_LDA];       // [DG_M batch rows][DG_KC contraction columns]
   __shared__ float ws[DG_KC * DG_N];        // [DG_KC contraction rows][64 output columns], odd rows rotated by 32 columns
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k0 = blockIdx.x * DG_N, c0 = blockIdx.y * DG_KC, b0 = blockIdx.z * DG_M;
   const int r = lane & 31, hf = lane >> 5;
   {
-    // gy chunk: wave w stages rows [32 w, 32 w + 32), lane = column (+ 64): coalesced row segments, all loads in flight
-    constexpr int CM = (DG_KC + 63) / 64;
-    float v[32][CM];
+    // gy chunk: wave w stages rows [RG w, RG w + RG), lane = column (+ 64): coalesced row segments, all loads in flight
+    constexpr int CM = (DG_KC + 63) / 64, RG = DG_M / 4;
+    float v[RG][CM];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int b = min(b0 + wave * 32 + i, B - 1);
+    for (int i = 0; i < RG; ++i) {
+      const int b = min(b0 + wave * RG + i, B - 1);
 #pragma unroll
       for (int m = 0; m < CM; ++m) v[i][m] = gy[(size_t)b * ld_g + min(c0 + lane + 64 * m, N - 1)];
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const bool b_ok = b0 + wave * 32 + i < B;
+    for (int i = 0; i < RG; ++i) {
+      const bool b_ok = b0 + wave * RG + i < B;
 #pragma unroll
       for (int m = 0; m < CM; ++m)
         if (lane + 64 * m < DG_KC)
-          gs[(wave * 32 + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
+          gs[(wave * RG + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
     }
   }
   {
@@ -126,27 +127,24 @@ __global__ __launch_bounds__(256, 2) void linear_dgrad_splitk_kernel(const float
     }
   }
   __syncthreads();
-  // wave w: rows [32 w, 32 w + 32) x both 32-column halves; step s contracts rows 2 s, 2 s + 1 of the chunk (half hf takes 2 s + hf)
-  f32x16 acc[2];
-  zero_acc(acc);
-  const float* ap = gs + (wave * 32 + r) * DG_LDA + hf;
+  // wave w: the 32 x 32 tile (rows 32 (w >> 1), columns 32 (w & 1)); step s contracts rows 2 s, 2 s + 1 of the chunk (half hf
+  // takes 2 s + hf)
+  const int mt = wave >> 1, nt = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+  const float* ap = gs + (mt * 32 + r) * DG_LDA + hf;
   const float* wp = ws + hf * DG_N;
-  const int j0 = (r + 32 * hf) & 63, j1 = (r + 32 + 32 * hf) & 63;      // un-rotate: row 2 s + hf is rotated by 32 hf
+  const int j0 = (r + 32 * nt + 32 * hf) & 63;      // un-rotate: row 2 s + hf is rotated by 32 hf
 #pragma unroll 8
-  for (int sidx = 0; sidx < DG_KC / 2; ++sidx) {
-    const float a = ap[2 * sidx];
-    const float w0 = wp[2 * sidx * DG_N + j0], w1 = wp[2 * sidx * DG_N + j1];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc[1], 0, 0, 0);
+  for (int sidx = 0; sidx < DG_KC / 2; ++sidx)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sidx], wp[2 * sidx * DG_N + j0], acc, 0, 0, 0);
+  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][DG_M][K]
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int k = k0 + nt * 32 + r;
+    if (k < K) out[(size_t)(mt * 32 + tile_row(t, hf)) * K + k] = acc[t];
   }
-  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][128][K]
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = k0 + nt * 32 + r;
-      if (k < K) out[(size_t)(wave * 32 + tile_row(t, hf)) * K + k] = acc[nt][t];
-    }
 }
 
 // ---- forward of a Linear layer with a LONG contraction and a small output: y [B, K] = x [B, N] W^T + b, W [K, N] as stored
@@ -157,28 +155,28 @@ __global__ __launch_bounds__(256, 2) void linear_dgrad_splitk_kernel(const float
 __global__ __launch_bounds__(256, 2) void linear_fwd_splitk_kernel(const float* __restrict__ x, int ld_x,
                                                                    const float* __restrict__ W, int ld_w,
                                                                    float* __restrict__ part, int B, int N, int K) {
-  __shared__ float xs[DG_M * DG_LDA];       // [128 batch rows][DG_KC contraction columns]
+  __shared__ float xs[DG_M * DG_LDA];       // [DG_M batch rows][DG_KC contraction columns]
   __shared__ float ws[DG_N * DG_LDA];       // [64 output rows][DG_KC contraction columns]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k0 = blockIdx.x * DG_N, c0 = blockIdx.y * DG_KC, b0 = blockIdx.z * DG_M;
   const int r = lane & 31, hf = lane >> 5;
-  constexpr int CM = (DG_KC + 63) / 64;
+  constexpr int CM = (DG_KC + 63) / 64, RG = DG_M / 4;
   {
-    float v[32][CM];
+    float v[RG][CM];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int b = min(b0 + wave * 32 + i, B - 1);
+    for (int i = 0; i < RG; ++i) {
+      const int b = min(b0 + wave * RG + i, B - 1);
 #pragma unroll
       for (int m = 0; m < CM; ++m) v[i][m] = x[(size_t)b * ld_x + min(c0 + lane + 64 * m, N - 1)];
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const bool b_ok = b0 + wave * 32 + i < B;
+    for (int i = 0; i < RG; ++i) {
+      const bool b_ok = b0 + wave * RG + i < B;
 #pragma unroll
       for (int m = 0; m < CM; ++m)
         if (lane + 64 * m < DG_KC)
-          xs[(wave * 32 + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
+          xs[(wave * RG + i) * DG_LDA + lane + 64 * m] = (b_ok && c0 + lane + 64 * m < N) ? v[i][m] : 0.0f;
     }
   }
   {
@@ -199,25 +197,21 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_splitk_kernel(const float* 
     }
   }
   __syncthreads();
-  f32x16 acc[2];
-  zero_acc(acc);
-  const float* ap = xs + (wave * 32 + r) * DG_LDA + hf;
-  const float* wp = ws + r * DG_LDA + hf;
+  const int mt = wave >> 1, nt = wave & 1;      // this wave's 32 x 32 tile
+  f32x16 acc;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+  const float* ap = xs + (mt * 32 + r) * DG_LDA + hf;
+  const float* wp = ws + (nt * 32 + r) * DG_LDA + hf;
 #pragma unroll 8
-  for (int sidx = 0; sidx < DG_KC / 2; ++sidx) {
-    const float a = ap[2 * sidx];
-    const float w0 = wp[2 * sidx], w1 = wp[32 * DG_LDA + 2 * sidx];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc[1], 0, 0, 0);
+  for (int sidx = 0; sidx < DG_KC / 2; ++sidx)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sidx], wp[2 * sidx], acc, 0, 0, 0);
+  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][DG_M][K]
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int k = k0 + nt * 32 + r;
+    if (k < K) out[(size_t)(mt * 32 + tile_row(t, hf)) * K + k] = acc[t];
   }
-  float* out = part + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * DG_M * K;      // [chunk][batch tile][128][K]
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = k0 + nt * 32 + r;
-      if (k < K) out[(size_t)(wave * 32 + tile_row(t, hf)) * K + k] = acc[nt][t];
-    }
 }
 
 __global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gx,

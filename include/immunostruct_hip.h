@@ -223,7 +223,7 @@ int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld_x, float* 
 
 /* Input gradient of a Linear layer with a long contraction and a small output (vae_fc4: 5943 -> 512 going backward;
  * models/hybrid_models.py:306-308): gx [B, K] = gy [B, ld_g] (N columns) W [N, ld_w] (K columns; the weight as nn.Linear
- * stores it).  The contraction is cut into chunks of 96, one workgroup per (64 output columns, chunk), partial results summed
+ * stores it).  The contraction is cut into chunks of 96, one workgroup per (64 batch rows, 64 output columns, chunk), partial results summed
  * in chunk order by a second launch.  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats.                          */
 /* ... and the forward of a layer with a long contraction and a small output (vae_fc1: 5943 -> 512; models/hybrid_models.py:297):
  * y [B, K] = x [B, ld_x] (N columns) W^T + bias, W [K, ld_w] as nn.Linear stores it, bias [K] or NULL; same split of the
