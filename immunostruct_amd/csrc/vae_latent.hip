@@ -1,6 +1,6 @@
 // The latent block of the sequence VAE as one forward and two backward launches (reference models/hybrid_models.py:297-308, 334-340):
 //
-//   h1 = relu(a1)                      a1 = vae_fc1(x) [B, Hd] (pre-activation, from the library GEMM)
+//   h1 = relu(a1)                      a1 = vae_fc1(x) [B, Hd] (pre-activation; csrc/dense.hip, is_linear_fwd_long)
 //   mu = W21 h1 + b21 ; logvar = W22 h1 + b22            [B, 32]
 //   z  = mu + eps * exp(0.5 logvar)                      eps supplied by the caller (torch.randn_like, the reference's draw)
 //   zp = [z | p]                                         p = property embedding [B, P] (P <= 16, may be 0)

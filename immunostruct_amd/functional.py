@@ -1209,7 +1209,8 @@ def linear_small_batch(x, weight, bias):
 
 class VaeLatentFn(torch.autograd.Function):
     """The sequence VAE's latent block (``csrc/vae_latent.hip``): from a1 = vae_fc1(x) (pre-activation) to
-    (mu, logvar, [z | p], h3 = relu(vae_fc3([z | p]))) in one launch; backward = three launches (data path in two halves, weight gradients).
+    (mu, logvar, [z | p], h3 = relu(vae_fc3([z | p]))) in one launch; backward = two launches (data path, weight gradients) -- with ``vae_fc1``'s weight gradient between them
+    when that layer runs inside the node (``fc1=``).
     ``eps`` is the caller's ``torch.randn_like`` draw (reference ``hybrid_models.py:301-304``); ``p`` may be None."""
 
     @staticmethod

@@ -158,7 +158,7 @@ int is_vae_latent_bwd(const float* g_h3, const float* h3, const float* g_mu, con
                       const float* eps, const float* logvar, const float* a1, const float* zp, const float* W21,
                       const float* W22, int P, const float* W3, float* d_a3, float* dmu, float* dlv, float* d_p,
                       float* d_a1, float* wgrad, int B, int Hd, int L, void* stream);
-/* the two halves of is_vae_latent_bwd as their own entry points (data path: two launches; weight pass: one), for callers
+/* the two halves of is_vae_latent_bwd as their own entry points (data path: one launch; weight pass: one), for callers
  * that put other work of the data path between them (functional.VaeLatentFn: the weight gradient of vae_fc1) */
 int is_vae_latent_bwd_data(const float* g_h3, const float* h3, const float* g_mu, const float* g_lv, const float* g_zp,
                            const float* eps, const float* logvar, const float* a1, const float* W21, const float* W22,
