@@ -668,6 +668,46 @@ def test_contrastive_targets_kernel(cuda_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,hd,pw,kin", [(128, 512, 8, 5943), (37, 64, 3, 777), (5, 512, 0, 100)])
+def test_vae_latent_block_with_first_layer_inside(cuda_device, b, hd, pw, kin):
+    """``vae_latent(..., fc1=(x, W1, b1))``: vae_fc1 inside the latent node (forward through is_linear_fwd_long when the
+    contraction is long; backward = data path, vae_fc1's weight gradient, weight pass) against torch in fp64."""
+    rng = np.random.RandomState(b + hd + kin)
+    t = lambda *shape, s=1.0: torch.from_numpy((rng.normal(size=shape) * s).astype(np.float32))
+    x = (torch.from_numpy(rng.rand(b, kin).astype(np.float32)) < 0.05).float()      # sparse 0 / 1 rows like the one-hot sequence
+    w1, b1 = t(hd, kin, s=0.1), t(hd, s=0.1)
+    eps = t(b, 32)
+    w21, b21, w22, b22 = t(32, hd, s=hd ** -0.5), t(32, s=0.1), t(32, hd, s=hd ** -0.5), t(32, s=0.1)
+    w3, b3 = t(hd, 32 + pw, s=0.2), t(hd, s=0.1)
+    p = t(b, pw).abs() if pw else None
+    ups = [t(b, 32), t(b, 32), t(b, 32 + pw), t(b, hd)]
+
+    def run(dtype, dev, fused):
+        leaves = [v.to(dev, dtype).requires_grad_(True) if v is not None else None for v in (w1, b1, w21, b21, w22, b22, p, w3, b3)]
+        W1, B1, W21, B21, W22, B22, P_, W3, B3 = leaves
+        e, xx = eps.to(dev, dtype), x.to(dev, dtype)
+        if fused:
+            mu, lv, zp, h3 = HF.vae_latent(None, W21, B21, W22, B22, e, P_, W3, B3, fc1=(xx, W1, B1))
+        else:
+            h1 = torch.relu(xx @ W1.T + B1)
+            mu, lv = h1 @ W21.T + B21, h1 @ W22.T + B22
+            z = mu + e * torch.exp(0.5 * lv)
+            zp = torch.cat([z, P_], dim=1) if P_ is not None else z
+            h3 = torch.relu(zp @ W3.T + B3)
+        outs = [mu, lv, zp, h3]
+        sum((o * u.to(dev, dtype)).sum() for o, u in zip(outs, ups)).backward()
+        return [o.detach().cpu() for o in outs], [l.grad.cpu() if l is not None else None for l in leaves]
+
+    outs_h, grads_h = run(torch.float32, cuda_device, True)
+    outs_r, grads_r = run(torch.float64, torch.device("cpu"), False)
+    for name, h, r in zip(("mu", "logvar", "z|p", "h3"), outs_h, outs_r):
+        H.assert_close(h, r, FWD_TOL, name)
+    for name, h, r in zip(("W1", "b1", "W21", "b21", "W22", "b22", "p", "W3", "b3"), grads_h, grads_r):
+        if r is not None:
+            H.assert_close(h, r, GRAD_TOL, "grad " + name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,hd,pw", [(128, 512, 8), (5, 512, 2), (16, 64, 0), (37, 2048, 16)])
 def test_vae_latent_block_matches_torch(cuda_device, b, hd, pw):
     """fc21 | fc22 -> reparameterise -> cat(p) -> fc3 -> ReLU (hybrid_models.py:297-308,334-340) as one HIP launch, and its
