@@ -106,6 +106,47 @@ def test_comparative_train_step_matches_reference_golden(cuda_device, name, wt):
     print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
 
 
+@pytest.mark.parametrize("seed_kind", ["unit", "scaled", "plain"])
+def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, seed_kind):
+    """functional.SpeculativeBackward (the engine's steps): the reconstruction term's backward launched from the loss gives,
+    bit for bit, the gradients of the ordinary backward when the backward is seeded with ``unit_gradient()``; with any other
+    seed (a scaled loss, a plain ``backward()``) the speculated results are dropped and the ordinary path runs."""
+    from immunostruct_amd import functional as HF
+    dev = cuda_device
+    raw = synthetic.make_batch(6, seed=71, deg_extra=2)
+    sd = H.det_sd(H.model_shapes("HybridModelv2"), seed=3)
+    eps = H.make_eps(4, 6)
+    seq, prop, y = torch.from_numpy(raw.one_hot_sequence()).to(dev), torch.from_numpy(raw.prop).to(dev), torch.from_numpy(raw.y_reg).to(dev)
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+
+    def run(speculate):
+        model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+        model.load_state_dict(sd)
+        model.eval()
+        g = H.product_graph(raw, dev)
+        ctx = HF.SpeculativeBackward() if speculate else mock.patch.object(HF.SpeculativeBackward, "enabled", False)
+        with ctx:
+            res = _with_eps(lambda: model(g, seq, prop), [eps], dev)
+            loss = losses.regression_loss(res[0], seq, res[1], res[2], res[3], y)
+        node = res[0].grad_fn
+        assert (getattr(node, "spec", None) is not None) == speculate      # launched ahead only when asked to
+        if seed_kind == "unit":
+            loss.backward(HF.unit_gradient(dev))
+        elif seed_kind == "scaled":
+            (0.5 * loss).backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), f"{k}: speculative and plain backward differ ({seed_kind} seed)"
+
+
 @pytest.mark.parametrize("n_pad,b", [(190, 8), (40, 5), (100, 3), (150, 4), (250, 2), (190, 128)])
 def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
     """HybridModelv2: loss and every parameter gradient vs oracle autograd -- at BASELINE config 2's full size (B = 128 x 190
