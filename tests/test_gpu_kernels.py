@@ -169,6 +169,42 @@ def test_egnn_vs_fp64_error_budget(cuda_device):
     H.assert_close(x.cpu(), outs[torch.float32][1], 5e-5, "6-layer x vs fp32 oracle")
 
 
+def test_egnn_stack_prelaunched_forward_is_the_plain_stack(cuda_device):
+    """nn.egnn_stack_prelaunch + egnn_stack_forward(prologue=handle): the forward kernels enqueued ahead, outside autograd, and
+    the autograd node created later give bit-identical outputs and gradients to the one-call form; a handle made for OTHER
+    tensors is ignored (the stack launches itself); the fork event sits behind the requested layer."""
+    from immunostruct_amd.nn import egnn_stack_forward, egnn_stack_prelaunch
+    raw = synthetic.make_batch(5, seed=19, deg_extra=3)
+    g = H.product_graph(raw, cuda_device)
+    torch.manual_seed(3)
+    layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(cuda_device) for i in range(4)]
+    feats = g.ndata["x"]
+    gh = torch.randn(raw.num_nodes, 64, device=cuda_device) / raw.num_nodes
+    gx = torch.randn(raw.num_nodes, 3, device=cuda_device) / raw.num_nodes
+
+    def run(mode):
+        for layer in layers:
+            layer.zero_grad(set_to_none=True)
+        h0, x0 = feats[:, :20], feats[:, 20:]
+        pro = None
+        if mode == "prelaunch":
+            pro = egnn_stack_prelaunch(layers, g, h0, x0, g.edata["edge_attr"], fork_after=2)
+            assert pro.layers is not None and len(pro.layers) == 4 and pro.fork_event is not None and pro.need_grad
+        elif mode == "stale":      # a handle for a different input tensor must not be used
+            pro = egnn_stack_prelaunch(layers, g, h0.clone(), x0, g.edata["edge_attr"])
+        hh, xx = egnn_stack_forward(layers, g, h0, x0, g.edata["edge_attr"], prologue=pro)
+        if mode == "prelaunch":
+            assert hh.data_ptr() == pro.outs[0].data_ptr()      # the node adopted the pre-launched results
+        ((hh * gh).sum() + (xx * gx).sum()).backward()
+        torch.cuda.synchronize()
+        return [hh.detach().clone(), xx.detach().clone()] + [p.grad.clone() for layer in layers for p in layer.parameters() if p.grad is not None]
+
+    plain, pre, stale = run("plain"), run("prelaunch"), run("stale")
+    assert len(plain) == len(pre) == len(stale)
+    for a, b, c in zip(plain, pre, stale):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_egnn_stack_gradients_at_the_stress_shape(cuda_device):
     """BASELINE config 5's shape through the fused stack: 6 layers (64 -> 64 channels), Fe = 8, graphs of ~N(200, 15) nodes padded
     to 245, average in-degree 8 (chain + 7 contacts) -- outputs and EVERY gradient against the oracle's ``egnn_conv`` chain
