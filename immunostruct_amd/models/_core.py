@@ -30,7 +30,7 @@ from .layers import MultiHeadAttention, SelfAttention
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
 # the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer)
-FORK_AFTER_LAYER = int(os.environ.get("IMMUNOSTRUCT_FORK_AFTER_LAYER", "3"))
+FORK_AFTER_LAYER = int(os.environ.get("IMMUNOSTRUCT_FORK_AFTER_LAYER", "2"))
 MERGE_PAIRS = os.environ.get("IMMUNOSTRUCT_MERGE_PAIRS", "1") != "0"      # paired models: one encoder pass over [cancer; wild-type]
 if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
