@@ -250,8 +250,9 @@ class MultimodalNet(nn.Module):
             #    executor (first continuations stay on the launch queue, later ones get their own) runs the graph branch, the
             #    head, the loss and the main backward on ONE queue -- no cross-queue hop on the critical chain;
             #  * the sequence branch (and, behind it on the same stream, the speculative backward of its reconstruction term)
-            #    runs beside the LAST layer and the attention / head / loss kernels, whose small grids leave half the CUs
-            #    idle, instead of beside the 512-workgroup layer kernels, which it slows.
+            #    runs beside the second half of the stack and the attention / head / loss kernels (whose small grids leave
+            #    half the CUs idle), and its backward entirely between the head's and the stack's backward -- not beside the
+            #    backward layer kernels, which own every wave slot (the fork point is a measured sweep).
             main = torch.cuda.current_stream()
             side = _side_stream(seq.device)
             inp = self._graph_inputs(g)
