@@ -239,12 +239,19 @@ def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=T
     return amino
 
 
-def mask_sequence_on_device(seq, count, peptide_length=11, generator=None):
-    """In place on the one-hot sequences ``seq`` (B x L x 21): ``count`` random non-peptide positions -> padding symbol"""
+def mask_sequence_on_device(seq, count, peptide_length=11, generator=None, pairs=False):
+    """In place on the one-hot sequences ``seq`` (B x L x 21): ``count`` random non-peptide positions -> padding symbol.
+    ``pairs``: ``seq`` is a merged ``[cancer; wild-type]`` batch of 2b rows and rows i and b + i get the SAME positions, as
+    ``ImmunoPredDatasetComparative.mask_sequence`` pads ``full`` and ``full_wt`` (``data/immmunopred_dataloader.py:216-231``)"""
     if count <= 0:
         return seq
     b, length = seq.shape[0], seq.shape[1] - peptide_length
-    pos = torch.rand(b, length, device=seq.device, generator=generator).topk(count, dim=1).indices
+    if pairs:
+        if b % 2:
+            raise ValueError("a merged pair batch has an even number of rows")
+        pos = torch.rand(b // 2, length, device=seq.device, generator=generator).topk(count, dim=1).indices.repeat(2, 1)
+    else:
+        pos = torch.rand(b, length, device=seq.device, generator=generator).topk(count, dim=1).indices
     r = torch.arange(b, device=seq.device)[:, None].expand_as(pos)
     seq[r, pos] = torch.nn.functional.one_hot(torch.tensor(PAD_INDEX, device=seq.device), seq.shape[2]).to(seq.dtype)
     return seq

@@ -105,6 +105,20 @@ class PackedDataset:
             out.attach_labels(labels)
         return out
 
+    def padded_to(self, n):
+        """the same dataset with every graph zero-padded to ``n`` >= the current node count (padded nodes have no edges, so
+        the per-graph CSR rows just repeat their last entry; edges, slots and labels are untouched)"""
+        cur = int(self.x.shape[1])
+        if n == cur:
+            return self
+        if n < cur:
+            raise ValueError(f"cannot pad {cur}-node graphs down to {n}")
+        grow = lambda rp: torch.cat([rp, rp[:, -1:].expand(-1, n - cur)], 1).contiguous()
+        arrays = {k: getattr(self, k) for k in _ARRAYS + _OPTIONAL}
+        arrays["x"] = torch.nn.functional.pad(self.x, (0, 0, 0, n - cur))
+        arrays["rowptr_dst"], arrays["rowptr_src"] = grow(self.rowptr_dst), grow(self.rowptr_src)
+        return PackedDataset(arrays, self.names, self.binary)
+
     def attach_labels(self, labels):
         """``labels[name] = (full_sequence, mprop1, mprop2, immunogenicity, foreignness)``; sequences are right-padded
         with the padding symbol to the longest one (``data/preprocess.py:351-362``)"""
@@ -194,13 +208,16 @@ _ALLOWED_GLOBALS = {
 
 class _Unpickler(pickle.Unpickler):
     """allow-list unpickler: torch_geometric classes become inert bags, tensors / storages / plain containers load, every other
-    global (``os.system``, ``builtins.eval``, ...) raises -- a crafted ``.pt`` file cannot run code through this reader"""
+    global (``os.system``, ``builtins.eval``, ...) raises -- a crafted ``.pt`` file cannot run code through this reader.
+    ``torch.storage._load_from_bytes`` is NOT on the list: it is ``torch.load(BytesIO(b), weights_only=False)``, i.e. the
+    unrestricted unpickler over attacker-chosen bytes; ``torch.save`` files carry their storages through ``persistent_load``
+    and never need it."""
 
     def find_class(self, module, name):
         if module.split(".")[0] == "torch_geometric":
             return _Bag
         if (module, name) in _ALLOWED_GLOBALS or (module == "torch" and name.endswith("Storage")) \
-                or (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage", "_load_from_bytes")):
+                or (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage")):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"global {module}.{name} is not allowed in a graph file")
 
@@ -244,13 +261,15 @@ def list_structure_names(directory):
     return names
 
 
-def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=3, labels=None, drop_features=2, order=None):
+def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=3, labels=None, drop_features=2, order=None,
+                          pad_to=None):
     """The reference's ``preprocess_graphs`` + ``graph.x = cat(x, coords)`` + ``preprocess_graph`` for a directory of
     ``*.pt`` files, as a :class:`PackedDataset` (saved to ``out_path`` when given).  Rules kept: names containing ``X``
     are skipped, the first graph of every name (the part after ``Immuno``) wins, the last ``drop_features`` node
     features (hydrogen bonding) are cut, every graph is padded to the largest node count.  ``order``: structure names in
     the order the dataset should have (the reference's datasets follow the TABLE's row order, ``data.tables``); names
-    without a file are an error, files outside ``order`` are left out."""
+    without a file are an error, files outside ``order`` are left out.  ``pad_to``: node count to pad to instead of the
+    directory's largest graph (the two directories of a cancer / wild-type pair share one count)."""
     graphs, names, seen = [], [], set()
     for fname in [f for f in os.listdir(directory) if f.endswith(".pt")]:     # directory order, as the reference
         x, coords, edge_index, name = load_pyg_pickle(os.path.join(directory, fname))
@@ -271,7 +290,7 @@ def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=
         if missing:
             raise KeyError(f"no graph file for {len(missing)} structure(s), e.g. {missing[0]}")
         graphs, names = [graphs[at[k]] for k in order], list(order)
-    packed = PackedDataset.from_graphs(graphs, names, labels=labels)
+    packed = PackedDataset.from_graphs(graphs, names, pad_to=pad_to, labels=labels)
     if out_path is not None:
         packed.save(out_path)
     return packed

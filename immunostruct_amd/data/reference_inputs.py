@@ -60,14 +60,17 @@ class PairedDataset(Dataset):
 def paired_from_reference_inputs(graph_dir_cancer, graph_dir_wt, property_path_cancer, property_path_wt, hla_path,
                                  feature_size=23, coord_size=3, binary=True):
     """(cancer, wild-type) pair dataset (``ImmunoPredDatasetComparative``) in the joined table's row order; both members are
-    padded to the same node count (the larger of the two directories' maxima, ``data/immmunopred_dataloader.py:146-147``
-    pads each side on its own; one common count lets a pair share a batch layout)"""
+    padded to the same node count: the larger of the two directories' maxima over the SELECTED graphs
+    (``data/immmunopred_dataloader.py:146-147`` pads each side on its own; one common count lets a pair share a batch
+    layout -- ``DeviceResidentDataset.concat`` and the merged 2B-graph encoder pass require it)"""
     names_c, names_w = list_structure_names(graph_dir_cancer), list_structure_names(graph_dir_wt)
     lab_c, lab_w, pairs = tables.paired_labels_from_tables(property_path_cancer, property_path_wt, hla_path, names_c, names_w)
     pc = convert_pyg_directory(graph_dir_cancer, feature_size=feature_size, coord_size=coord_size, labels=lab_c,
                                order=_unique([p[0] for p in pairs]))
     pw = convert_pyg_directory(graph_dir_wt, feature_size=feature_size, coord_size=coord_size, labels=lab_w,
                                order=_unique([p[1] for p in pairs]))
+    n = max(int(pc.x.shape[1]), int(pw.x.shape[1]))
+    pc, pw = pc.padded_to(n), pw.padded_to(n)
     pc.binary = pw.binary = binary
     at_c = {n: i for i, n in enumerate(pc.names)}
     at_w = {n: i for i, n in enumerate(pw.names)}

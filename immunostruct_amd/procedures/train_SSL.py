@@ -128,7 +128,7 @@ def train_model_comparative_SSL_device(config, device, model, dataset_cancer, da
             if b not in amino:
                 amino[b] = torch.zeros(b, dtype=torch.int64, device=device)
             amino[b].copy_(augment_pair_on_device(g2.ndata["x"], b, dgen, structure_pad_count=pad_structure))
-            mask_sequence_on_device(seq2, pad_sequence, generator=dgen)
+            mask_sequence_on_device(seq2, pad_sequence, generator=dgen, pairs=True)
         return g2, seq2, prop2, y2
 
     return _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index,

@@ -121,6 +121,12 @@ def test_augment_batch_on_device_form():
     changed = (s != seq).any(2)
     assert int(changed[:, -11:].sum()) == 0 and bool((changed.sum(1) <= 5).all())
     assert bool((s[changed].argmax(1) == A.PAD_INDEX).all())
+    # merged pair batch: rows i and b + i are padded at the same positions (data/immmunopred_dataloader.py:216-231)
+    base = torch.nn.functional.one_hot(torch.randint(0, 20, (8, seq.shape[1]), generator=torch.Generator().manual_seed(3)), 21).float()
+    sp = A.mask_sequence_on_device(base.clone(), 5, generator=gen, pairs=True)
+    ch = (sp != base).any(2)
+    assert torch.equal(ch[:4], ch[4:]) and bool((ch.sum(1) == 5).all()) and int(ch[:, -11:].sum()) == 0
+    assert not torch.equal(ch[0], ch[1])
 
 
 def test_augment_pair_on_device_rules():

@@ -232,7 +232,18 @@ def test_reference_path_flags_build_the_datasets(tmp_path):
     assert len(pairs) == 3 and pairs.class_weights == {0: 2.0, 1: 1.0}
     (gc, gw), (sc, sw), y, (pc, pw) = pairs[1]
     assert float(y) == 0.0 and pc.tolist() == pytest.approx([0.2, 0.5]) and pw.tolist() == pytest.approx([0.7, 0.9])
-    assert gc.num_nodes() == gw.num_nodes() or True      # each directory pads to its own maximum, as the reference
+    # the directories' largest graphs differ (9 vs 8 nodes): both members are padded to the common maximum, so that the pair
+    # can share one batch layout on the device (`concat` used to raise on the reference's real inputs)
+    assert gc.num_nodes() == gw.num_nodes() == 9
+    assert pairs.c.packed.x.shape[1] == pairs.w.packed.x.shape[1] == 9
+    both = D.DeviceResidentDataset.concat(D.DeviceResidentDataset(pairs.c, "cpu"), D.DeviceResidentDataset(pairs.w, "cpu"))
+    assert both.nodes_per_graph == 9 and both.num_graphs == 6
+    # re-padding leaves the graph itself alone
+    small = D.convert_pyg_directory(dw, labels=None)
+    wide = small.padded_to(12)
+    assert wide.x.shape[1] == 12 and torch.equal(wide.x[:, :8], small.x) and float(wide.x[:, 8:].abs().sum()) == 0.0
+    assert torch.equal(wide.rowptr_dst[:, :9], small.rowptr_dst) and bool((wide.rowptr_dst[:, 9:] == small.rowptr_dst[:, -1:]).all())
+    assert torch.equal(D.convert_pyg_directory(dw, pad_to=12).x, wide.x)
     assert torch.equal(pairs[0][1][1], pairs[1][1][1])    # pairs 0 and 1 share the wild-type member
 
 
@@ -247,3 +258,17 @@ def test_graph_file_reader_refuses_foreign_globals(tmp_path):
     torch.save({"x": Evil()}, path)
     with pytest.raises(pickle.UnpicklingError):
         D.load_pyg_pickle(path)
+
+    # torch.storage._load_from_bytes is torch.load(weights_only=False) over embedded bytes -- the unrestricted unpickler
+    # by another name: refused as well
+    import io
+    inner = io.BytesIO()
+    torch.save({"x": Evil()}, inner)
+
+    class Smuggle:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+    path2 = os.path.join(tmp_path, "smuggle.pt")
+    torch.save({"x": Smuggle()}, path2)
+    with pytest.raises(pickle.UnpicklingError, match="_load_from_bytes"):
+        D.load_pyg_pickle(path2)

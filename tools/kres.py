@@ -1,5 +1,5 @@
 """Register / LDS / scratch usage of every kernel of one .hip file (hipcc -Rpass-analysis=kernel-resource-usage), one line each:
-    python tools/kres.py immunostruct_amd/csrc/egnn_edge_bwd16.hip [extra hipcc flags]"""
+    python tools/kres.py immunostruct_amd/csrc/egnn_layer_bwd.hip [extra hipcc flags]"""
 import re
 import subprocess
 import sys

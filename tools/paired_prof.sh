@@ -1,3 +1,6 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/paired_prof.sh   -- rocprofv3 kernel trace of the paired (cancer / wild-type) bench step:
+#   gpurun_out/paired_timeline.txt = per-queue timeline of the last replayed step (tools/rocpd_timeline.py)
 export TMPDIR=/tmp
 rm -rf /tmp/prof_p
 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o rr -- python3 bench.py --workload paired --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-e2e > gpurun_out/paired_prof.log 2> gpurun_out/paired_prof.err
