@@ -91,11 +91,13 @@ def mask_sequence(full, peptide, count):
 
 class SplitDataset:
     """``dataset[idx]`` -> ``(graph, sequence, target, property)`` or the same with (cancer, wild-type) pairs;
-    ``peptide_length`` tells ``mask_sequence`` how many trailing positions belong to the peptide."""
+    ``peptide_length`` tells ``mask_sequence`` how many trailing positions belong to the peptide; ``full`` = False: the
+    items carry the peptide alone, which the reference never masks (``data/util_dataloader.py:52-66``)."""
 
     def __init__(self, dataset, split, comparative=False, return_amino_acid=False, structure_pad_count=0,
-                 sequence_pad_count=0, peptide_length=11):
+                 sequence_pad_count=0, peptide_length=11, full=True):
         self.dataset, self.split, self.comparative = dataset, split, comparative
+        self.full = full
         self.return_amino_acid = return_amino_acid
         self.structure_pad_count, self.sequence_pad_count, self.peptide_length = structure_pad_count, sequence_pad_count, peptide_length
 
@@ -127,7 +129,7 @@ class SplitDataset:
                 if self.structure_pad_count > 0:
                     a, b = mask_structure(a, self.structure_pad_count), mask_structure(b, self.structure_pad_count)
                 updated = (a, b)
-            if self.sequence_pad_count > 0:
+            if self.full and self.sequence_pad_count > 0:
                 tail = slice(-self.peptide_length, None)
                 if not self.comparative:
                     sequence = mask_sequence(sequence.clone(), sequence[tail], self.sequence_pad_count)

@@ -78,7 +78,7 @@ class DeviceResidentDataset:
                             ("src", packed.src), ("dst", packed.dst), ("pos", packed.pos), ("ea", packed.ea), ("prop", packed.prop)):
             setattr(self, name, value.contiguous().to(device))
         # tokens -> one-hot on the device (the file stores one byte per position)
-        self.seq = torch.nn.functional.one_hot(packed.seq.to(device).long(), 21).float()
+        self.seq = torch.nn.functional.one_hot(packed.sequence_tokens().to(device).long(), 21).float()
         binary = packed.binary if binary is None else binary
         self.y = (packed.y_bin if binary else packed.y_reg).contiguous().to(device)
         self.device = self.x.device

@@ -17,6 +17,7 @@ batcher reads (``DeviceResidentDataset.from_packed``):
 ``ea``           (E, Fe) float32        edge features in destination-sorted order (the reference: ones, Fe = 1)
 ``names``        (G,) str               graph names (the part after "Immuno", the reference's join key)
 ``seq``          (G, L) uint8           optional: tokens of the padded full sequence, 0..19 = ACDEFGHIKLMNPQRSTVWY, 20 = J
+``pep``          (G, Lp) uint8          optional: tokens of the padded peptide alone (the model input WITHOUT ``--full-sequence``)
 ``prop``         (G, 2) float32         optional: Mprop1, Mprop2
 ``y_reg/y_bin``  (G,) float32           optional: (normalised) foreignness / immunogenicity
 ===============  =====================  ==========================================================================
@@ -46,7 +47,7 @@ __all__ = ["PackedDataset", "convert_pyg_directory", "load_pyg_pickle", "list_st
 
 _TOKEN = {ch: i for i, ch in enumerate(AMINO_ACIDS + PADDING_CHAR)}
 _ARRAYS = ("x", "eoff", "rowptr_dst", "rowptr_src", "src", "dst", "pos", "ea")
-_OPTIONAL = ("seq", "prop", "y_reg", "y_bin")
+_OPTIONAL = ("seq", "pep", "prop", "y_reg", "y_bin")
 
 
 class PackedDataset:
@@ -59,6 +60,9 @@ class PackedDataset:
             setattr(self, k, torch.as_tensor(arrays[k]) if arrays.get(k) is not None else None)
         self.names = list(names) if names is not None else [str(i) for i in range(self.x.shape[0])]
         self.binary = binary
+        # which sequence an item carries: the padded HLA + peptide (``--full-sequence``, 283 x 21) or the padded peptide alone
+        # (11 x 21, the reference's default: ``SplitDataset(..., full=config.full_sequence)``, data/util_dataloader.py:52-66)
+        self.full_sequence = True
 
     # ---- construction -----------------------------------------------------------------------------
     @classmethod
@@ -117,20 +121,25 @@ class PackedDataset:
         arrays = {k: getattr(self, k) for k in _ARRAYS + _OPTIONAL}
         arrays["x"] = torch.nn.functional.pad(self.x, (0, 0, 0, n - cur))
         arrays["rowptr_dst"], arrays["rowptr_src"] = grow(self.rowptr_dst), grow(self.rowptr_src)
-        return PackedDataset(arrays, self.names, self.binary)
+        out = PackedDataset(arrays, self.names, self.binary)
+        out.full_sequence = self.full_sequence
+        return out
 
     def attach_labels(self, labels):
-        """``labels[name] = (full_sequence, mprop1, mprop2, immunogenicity, foreignness)``; sequences are right-padded
-        with the padding symbol to the longest one (``data/preprocess.py:351-362``)"""
+        """``labels[name] = (full_sequence, mprop1, mprop2, immunogenicity, foreignness[, peptide])``; sequences (and, when
+        given, peptides) are right-padded with the padding symbol to the longest one (``data/preprocess.py:351-362``)"""
         rows = [labels[name] for name in self.names]
-        length = max(len(r[0]) for r in rows)
-        seq = np.full((len(rows), length), _TOKEN[PADDING_CHAR], dtype=np.uint8)
-        for i, r in enumerate(rows):
-            try:
-                seq[i, :len(r[0])] = [_TOKEN[ch] for ch in r[0]]
-            except KeyError as exc:
-                raise ValueError(f"{self.names[i]}: unknown residue {exc} in its sequence") from None
-        self.seq = torch.from_numpy(seq)
+
+        def tokens(strings):
+            out = np.full((len(strings), max(len(t) for t in strings)), _TOKEN[PADDING_CHAR], dtype=np.uint8)
+            for i, t in enumerate(strings):
+                try:
+                    out[i, :len(t)] = [_TOKEN[ch] for ch in t]
+                except KeyError as exc:
+                    raise ValueError(f"{self.names[i]}: unknown residue {exc} in its sequence") from None
+            return torch.from_numpy(out)
+        self.seq = tokens([r[0] for r in rows])
+        self.pep = tokens([r[5] for r in rows]) if all(len(r) > 5 for r in rows) else None
         self.prop = torch.tensor([[r[1], r[2]] for r in rows], dtype=torch.float32)
         self.y_bin = torch.tensor([r[3] for r in rows], dtype=torch.float32)
         self.y_reg = torch.tensor([r[4] for r in rows], dtype=torch.float32)
@@ -166,8 +175,17 @@ class PackedDataset:
         pos = float(self.y_bin.sum())
         return {0: float(len(self) - pos), 1: max(pos, 1.0)}
 
+    def sequence_tokens(self):
+        """(G, L) tokens of the sequence the items carry (``full_sequence``: HLA + peptide, otherwise the peptide alone)"""
+        if self.full_sequence:
+            return self.seq
+        if self.pep is None:
+            raise ValueError("this packed dataset holds no peptide tokens (written before they were stored, or labels without "
+                             "the peptide): convert it again, or train with --full-sequence")
+        return self.pep
+
     def one_hot_sequence(self, i):
-        return torch.nn.functional.one_hot(self.seq[i].long(), len(_TOKEN)).float()
+        return torch.nn.functional.one_hot(self.sequence_tokens()[i].long(), len(_TOKEN)).float()
 
     def graph(self, i):
         lo, hi = int(self.eoff[i]), int(self.eoff[i + 1])

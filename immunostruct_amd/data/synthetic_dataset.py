@@ -28,12 +28,16 @@ def _graphs_of(raw):
 
 
 class SyntheticImmunoDataset(Dataset):
-    """items: (graph, full sequence (283,21), target, property (2,)); ``binary`` picks the target."""
+    """items: (graph, sequence, target, property (2,)); ``binary`` picks the target; ``full_sequence``: the sequence is the
+    padded HLA + peptide (283, 21), otherwise the padded peptide alone (11, 21) -- the reference's default input
+    (``SplitDataset(..., full=config.full_sequence)``, ``data/util_dataloader.py:52-66``)."""
 
-    def __init__(self, num_items, seed=1, binary=False, deg_extra=2):
+    def __init__(self, num_items, seed=1, binary=False, deg_extra=2, full_sequence=True):
         raw = synthetic.make_batch(num_items, seed=seed, deg_extra=deg_extra)
         self.graphs = _graphs_of(raw)
         self.seq = torch.from_numpy(raw.one_hot_sequence())
+        if not full_sequence:
+            self.seq = self.seq[:, synthetic.HLA_LEN:].contiguous()
         self.prop = torch.from_numpy(raw.prop)
         self.y = torch.from_numpy(raw.y_bin if binary else raw.y_reg)
         counts = Counter(raw.y_bin.tolist())
@@ -49,9 +53,9 @@ class SyntheticImmunoDataset(Dataset):
 class SyntheticPairedDataset(Dataset):
     """cancer / wild-type pairs: every field but the label is a 2-tuple."""
 
-    def __init__(self, num_items, seed=1, binary=True):
-        self.c = SyntheticImmunoDataset(num_items, seed=seed, binary=binary)
-        self.w = SyntheticImmunoDataset(num_items, seed=seed + 7919, binary=binary)
+    def __init__(self, num_items, seed=1, binary=True, full_sequence=True):
+        self.c = SyntheticImmunoDataset(num_items, seed=seed, binary=binary, full_sequence=full_sequence)
+        self.w = SyntheticImmunoDataset(num_items, seed=seed + 7919, binary=binary, full_sequence=full_sequence)
         self.class_weights = self.c.class_weights
 
     def __len__(self):

@@ -142,15 +142,15 @@ def match_pairs(combined, mapper_cancer, mapper_wt, names_cancer, names_wt):
 
 
 def labels_from_tables(property_path, hla_path, structure_names, cancer=False):
-    """``labels[structure name] = (full sequence, Mprop1, Mprop2, immunogenicity, smoothed foreignness)`` for
+    """``labels[structure name] = (full sequence, Mprop1, Mprop2, immunogenicity, smoothed foreignness, peptide)`` for
     ``data.convert_pyg_directory(..., labels=labels)`` -- what ``ImmunoPredDataset.__init__`` + ``organize`` assemble
     (``data/immmunopred_dataloader.py:28-60``); also returns the keys in dataset order"""
     f_dict, fp2_dict, imm_dict, keys = preprocess_properties(property_path, cancer)
     mapper, _ = match_structures(preprocess_hla(keys, hla_path), structure_names)
     labels = {}
-    for key, (full, name, _pep) in mapper.items():
+    for key, (full, name, pep) in mapper.items():
         m1, m2 = fp2_dict[key]
-        labels[name] = (full, float(m1), float(m2), float(imm_dict[key]), float(f_dict[key]))
+        labels[name] = (full, float(m1), float(m2), float(imm_dict[key]), float(f_dict[key]), pep)
     return labels, list(mapper.keys())
 
 
@@ -165,9 +165,9 @@ def paired_labels_from_tables(path_cancer, path_wt, hla_path, names_cancer, name
     fmin = float(combined["smoothed_foreign"].min()) if len(combined) else float("nan")
     lab_c, lab_w, pairs = {}, {}, []
     for row in combined.itertuples(index=False):
-        fc, nc, _ = mc[row.pep_pair_cancer]
-        fw, nw, _ = mw[row.pep_pair_wt]
-        lab_c[nc] = (fc, float(row.Mprop1), float(row.Mprop2), float(row.immunogenicity), float(row.smoothed_foreign))
-        lab_w[nw] = (fw, float(row.Mprop1_wt), float(row.Mprop2_wt), 0.0, fmin)
+        fc, nc, pep_c = mc[row.pep_pair_cancer]
+        fw, nw, pep_w = mw[row.pep_pair_wt]
+        lab_c[nc] = (fc, float(row.Mprop1), float(row.Mprop2), float(row.immunogenicity), float(row.smoothed_foreign), pep_c)
+        lab_w[nw] = (fw, float(row.Mprop1_wt), float(row.Mprop2_wt), 0.0, fmin, pep_w)
         pairs.append((nc, nw))
     return lab_c, lab_w, pairs

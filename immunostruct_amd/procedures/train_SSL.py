@@ -60,7 +60,7 @@ def train_model_SSL_device(config, device, model, dataset, train_index, val_inde
     from ..data import augment_batch_on_device, mask_sequence_on_device
     device = dataset.device
     pad_structure = int(getattr(config, "structure_pad_count", 0) or 0)
-    pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0)
+    pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0) if getattr(config, "full_sequence", True) else 0     # the peptide alone is never masked (data/util_dataloader.py:52-66)
     dgen = torch.Generator(device=device).manual_seed(int(seed) + 1 + 104729 * _rank())
     amino = {}
 
@@ -99,7 +99,7 @@ def train_model_comparative_SSL_device(config, device, model, dataset_cancer, da
     if contrastive is not None:
         contrastive.capturable = True
     pad_structure = int(getattr(config, "structure_pad_count", 0) or 0)
-    pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0)
+    pad_sequence = int(getattr(config, "sequence_pad_count", 0) or 0) if getattr(config, "full_sequence", True) else 0     # the peptide alone is never masked (data/util_dataloader.py:52-66)
     dgen = torch.Generator(device=device).manual_seed(int(seed) + 1 + 104729 * _rank())
     both = DeviceResidentDataset.concat(dataset_cancer, dataset_wt)
     shift = len(dataset_cancer)

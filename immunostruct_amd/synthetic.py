@@ -29,6 +29,7 @@ from dataclasses import dataclass
 import numpy as np
 
 SEQ_LEN = 283
+HLA_LEN = 272          # all 27 shipped alleles; the peptide (9..11 residues, padded to 11) follows
 SEQ_ALPHABET = 21
 NODE_FEATS = 23
 AA = 20
@@ -105,7 +106,7 @@ def make_batch(num_graphs, seed=1, n_pad=190, deg_extra=2, edge_feats=1, n_real_
         eas.append(ea)
         pep_len = 9 + (n_real - min(n_real_choices)) if n_real >= min(n_real_choices) else 9
         pep_len = int(np.clip(pep_len, 9, 11))
-        tokens[g, : 272 + pep_len] = rng.randint(0, AA, size=272 + pep_len)
+        tokens[g, : HLA_LEN + pep_len] = rng.randint(0, AA, size=HLA_LEN + pep_len)
     return RawBatch(
         x=np.concatenate(xs, axis=0),
         src=np.concatenate(srcs), dst=np.concatenate(dsts),

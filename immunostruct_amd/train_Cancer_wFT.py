@@ -66,8 +66,6 @@ _Extended = ExtendedDataset      # modulo oversampling (reference data/util_data
 def main(argv=None):
     config = parse_args(argv)
     update_paths(config)
-    if not config.full_sequence:
-        raise SystemExit("only --full-sequence inputs (283 x 21) are supported")
     from_reference = config.synthetic <= 0
     if from_reference:
         # the reference's own inputs (train_Cancer_wFT.py:77-91): three graph directories, three property tables, the HLA table
@@ -106,7 +104,9 @@ def main(argv=None):
             torch.distributed.barrier()      # rank 0 has written the checkpoint every rank loads next
     seed_everything(config.seed)
     gen = torch.Generator().manual_seed(config.seed)
-    input_dim = 283 * 21
+    # 283 x 21 (HLA + peptide) with --full-sequence, otherwise the peptide alone, 11 x 21 (train_Cancer_wFT.py:71-72)
+    full = config.full_sequence
+    input_dim = 283 * 21 if full else 11 * 21
     model = model_map[config.model](vae_input_dim=input_dim, device=device,
                                     use_wt_for_downstream=config.use_wt_for_downstream).to(device)
     ssl = config.self_supervision
@@ -117,7 +117,7 @@ def main(argv=None):
 
     def mk(d, split, comparative=False):
         # the reference's split wrapper: train-time augmentation; with --self-supervision a fifth field (masked residue)
-        wrapped = SplitDataset(d, split, comparative=comparative, return_amino_acid=ssl, **pads)
+        wrapped = SplitDataset(d, split, comparative=comparative, return_amino_acid=ssl, full=full, **pads)
         return DataLoader(wrapped, batch_size=config.batch_size, collate_fn=collate_amino_acid if ssl else collate,
                           shuffle=split == "train", num_workers=config.num_workers)
 
@@ -126,8 +126,9 @@ def main(argv=None):
     if from_reference:
         ds1 = packed_from_reference_inputs(config.graph_dir_IEDB, config.property_path_IEDB, config.hla_path, **sizes)
         ds1.normalize()                  # foreignness -> [-1, 1] (data/immmunopred_dataloader.py:67-70)
+        ds1.full_sequence = full
     else:
-        ds1 = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=False)
+        ds1 = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=False, full_sequence=full)
     tr, va, _ = random_split(ds1, [0.8, 0.1, 0.1], gen)
     losses = Losses(input_dim, ds1.class_weights, sequence=config.sequence_loss)
     opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
@@ -149,9 +150,10 @@ def main(argv=None):
                                              config.property_path_wildtype, config.hla_path, binary=False, **sizes)
         lo, hi = pairs.c.packed.normalize()
         pairs.w.packed.y_reg = 2 * (pairs.w.packed.y_reg - (hi + lo) / 2) / (hi - lo)      # one scale for both members
+        pairs.c.packed.full_sequence = pairs.w.packed.full_sequence = full
         ds2 = pairs
     else:
-        ds2 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=False)
+        ds2 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=False, full_sequence=full)
     tr2, va2, te2 = random_split(ds2, [0.8, 0.1, 0.1], gen)
     opt = optim.AdamW(model.parameters(), lr=config.learning_rate_pretrain, weight_decay=1e-6)
     def fit_pairs(ds, tr_, va_, opt_, loss_fn, sched_=None, stage="pretrain"):
@@ -174,7 +176,7 @@ def main(argv=None):
         pairs.c.packed.binary = pairs.w.packed.binary = True      # same pairs, binary target (train_Cancer_wFT.py:160-162)
         ds3 = pairs
     else:
-        ds3 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=True)
+        ds3 = SyntheticPairedDataset(config.synthetic, seed=config.seed + 1, binary=True, full_sequence=full)
     tr3, va3, te3 = random_split(ds3, [0.8, 0.1, 0.1], gen)
     want = config.min_finetuning_batches * config.batch_size
     tr3 = _Extended(tr3, want) if len(tr3) < want else tr3

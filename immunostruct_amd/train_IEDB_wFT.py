@@ -59,8 +59,6 @@ def parse_args(argv=None):
 def main(argv=None):
     config = parse_args(argv)
     update_paths(config)
-    if not config.full_sequence:
-        raise SystemExit("only --full-sequence inputs (283 x 21) are supported")
     from_reference = config.synthetic <= 0 and not config.packed
     if from_reference:
         # the reference's own inputs (train_IEDB_wFT.py:55-57): graph directory + property table + HLA table
@@ -94,7 +92,10 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank) if world > 1 else torch.device("cuda")
     seed_everything(config.seed)
-    input_dim = 283 * 21
+    # sequence length (283: HLA + peptide with --full-sequence, 11: the peptide alone, the reference's default) x 21 symbols
+    # (train_IEDB_wFT.py:59-60)
+    full = config.full_sequence
+    input_dim = 283 * 21 if full else 11 * 21
     model = model_map[config.model](vae_input_dim=input_dim, device=device).to(device)
 
     ssl = config.self_supervision
@@ -114,10 +115,12 @@ def main(argv=None):
             ds = PackedDataset.load(config.packed, binary=binary)
             ds.normalize()                   # foreignness -> [-1, 1] (reference data/immmunopred_dataloader.py:67-70)
         else:
-            ds = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=binary)
+            ds = SyntheticImmunoDataset(config.synthetic, seed=config.seed, binary=binary, full_sequence=full)
+        if isinstance(ds, PackedDataset):
+            ds.full_sequence = full
         tr, va, te = random_split(ds, [0.8, 0.1, 0.1], torch.Generator().manual_seed(config.seed))
         # the reference's split wrapper (train-time augmentation; with --self-supervision a fifth field, the masked residue)
-        wrap = lambda d, split: SplitDataset(d, split, comparative=False, return_amino_acid=ssl, **pads)
+        wrap = lambda d, split: SplitDataset(d, split, comparative=False, return_amino_acid=ssl, full=full, **pads)
         mk = lambda d, split: DataLoader(wrap(d, split), batch_size=config.batch_size, shuffle=split == "train",
                                          collate_fn=collate_amino_acid if ssl else collate, num_workers=config.num_workers)
         return ds, (tr, va, te), mk(tr, "train"), mk(va, "val"), mk(te, "test")

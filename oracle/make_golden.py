@@ -64,8 +64,8 @@ def make_eps(seed, batch=BATCH, latent=32):
     return np.random.RandomState(seed).normal(size=(batch, latent)).astype(np.float32)
 
 
-def build_reference_model(model_map, name, seed, **kw):
-    model = model_map[name](vae_input_dim=VAE_IN, device="cpu", **kw)
+def build_reference_model(model_map, name, seed, vae_in=VAE_IN, **kw):
+    model = model_map[name](vae_input_dim=vae_in, device="cpu", **kw)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synthetic.det_state_dict(shapes, seed=seed).items()}
     model.load_state_dict(sd)
@@ -115,6 +115,43 @@ def golden_forward(model_map, out):
             for a, b in zip(res, mine):
                 if torch.is_tensor(a):
                     assert torch.equal(a, b.detach()), f"oracle != reference for {tag}"
+
+
+PEP_IN = (synthetic.SEQ_LEN - synthetic.HLA_LEN) * synthetic.SEQ_ALPHABET      # 11 x 21 = 231
+PEPTIDE_VARIANTS = ["HybridModelv2", "SequenceFpModel", "SequenceModel", "HybridModelv2_Comparative"]
+
+
+def golden_forward_peptide(model_map, Losses, out):
+    """The reference's DEFAULT input width (no ``--full-sequence``): ``vae_input_dim = 11 * 21`` and the sequence tensor is
+    the padded peptide's one-hot (``train_IEDB_wFT.py:59-60``, ``data/util_dataloader.py:52-66``).  Forward outputs, the
+    regression loss and a few parameter gradients of one train step."""
+    raw = synthetic.make_batch(BATCH, seed=1)
+    g = ref_graph(raw)
+    seq = torch.from_numpy(raw.one_hot_sequence()[:, synthetic.HLA_LEN:]).contiguous()
+    prop = torch.from_numpy(raw.prop)
+    eps = torch.from_numpy(make_eps(11))
+    y = torch.from_numpy(raw.y_reg)
+    assert seq.shape[1:] == (11, 21)
+    for name in PEPTIDE_VARIANTS:
+        tag = f"pep/{name}"
+        model, sd, _ = build_reference_model(model_map, name, seed=3, vae_in=PEP_IN)
+        for p in model.parameters():
+            p.requires_grad_(True)
+        res = run_with_eps(lambda: model(g, seq, prop), [eps])
+        out[f"{tag}/recon_x"] = res[0].detach().numpy()
+        out[f"{tag}/mu"] = res[1].detach().numpy()
+        out[f"{tag}/logvar"] = res[2].detach().numpy()
+        out[f"{tag}/final_output"] = res[3].detach().numpy()
+        loss = Losses(PEP_IN, {0: 81.0, 1: 19.0}, sequence=True).regression_loss(res[0], seq, res[1], res[2], res[3], y)
+        loss.backward()
+        out[f"{tag}/loss"] = np.float32(loss.item())
+        named = dict(model.named_parameters())
+        for key in ("vae_fc1.weight", "vae_fc4.bias", "vae_fc21.weight"):
+            out[f"{tag}/grad/{key}"] = named[key].grad.numpy().copy()
+        mine = FR.as_reference_tuple(name, FR.forward(name, sd, g, seq, prop, eps=eps))
+        for a, b in zip(res, mine):
+            if torch.is_tensor(a):
+                assert torch.equal(a.detach(), b.detach()), f"oracle != reference for {tag}"
 
 
 def golden_comparative(model_map, Losses, PCL, out):
@@ -258,6 +295,7 @@ def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     groups = {}
     for fname, fn in (("forward.npz", lambda o: golden_forward(model_map, o)),
+                      ("forward_peptide.npz", lambda o: golden_forward_peptide(model_map, Losses, o)),
                       ("comparative.npz", lambda o: golden_comparative(model_map, Losses, PCL, o)),
                       ("losses.npz", lambda o: golden_losses(Losses, PCL, o)),
                       ("egnn.npz", golden_egnn)):

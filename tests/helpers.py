@@ -37,9 +37,17 @@ def det_sd(shapes, seed):
     return {k: torch.from_numpy(v) for k, v in synthetic.det_state_dict(shapes, seed=seed).items()}
 
 
-def model_shapes(name, **kw):
+PEP_IN = (synthetic.SEQ_LEN - synthetic.HLA_LEN) * synthetic.SEQ_ALPHABET      # the reference's default width: 11 x 21
+
+
+def peptide_one_hot(raw):
+    """the padded peptide's one-hot (B, 11, 21): the sequence input WITHOUT --full-sequence (data/util_dataloader.py:52-66)"""
+    return torch.from_numpy(raw.one_hot_sequence()[:, synthetic.HLA_LEN:]).contiguous()
+
+
+def model_shapes(name, vae_in=VAE_IN, **kw):
     from immunostruct_amd.models import model_map
-    m = model_map[name](vae_input_dim=VAE_IN, device="cpu", **kw)
+    m = model_map[name](vae_input_dim=vae_in, device="cpu", **kw)
     return {k: tuple(v.shape) for k, v in m.state_dict().items()}
 
 
@@ -77,9 +85,10 @@ def worst_ratio(a, b, tol):
 
 
 def assert_close(a, b, tol, what=""):
-    """ELEMENT-WISE |a - b| <= atol + rtol * |b| with rtol = ``tol`` and atol = 0.5 * tol * max|b| (an absolute floor tied to
-    the tensor's scale: entries that are small against the largest one carry cancellation error of that size).  Every
-    entry is checked on its own: a kernel that is wrong in the small entries only does not hide behind the large ones.
+    """MIXED tolerance, per entry: |a - b| <= atol + rtol * |b| with rtol = ``tol`` and atol = 0.5 * tol * max|b|.  The
+    absolute floor is tied to the tensor's scale (entries that are small against the largest one carry cancellation error
+    of that size), so for entries much smaller than max|b| this is a max-norm check at 0.5 x ``tol``, and a relative one
+    (up to 1.5 x ``tol``) only for the entries near the maximum -- it is NOT a pure relative check.
     Returns the scaled max error (max|a-b| / max|b|) for reporting."""
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()

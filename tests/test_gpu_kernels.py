@@ -639,10 +639,12 @@ def test_mlp2_matches_torch(cuda_device, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,e", [(16, 104), (37, 104), (128, 104), (200, 208)])
+@pytest.mark.parametrize("b,e", [(16, 104), (37, 104), (128, 104), (200, 208), (300, 104)])
 def test_contrastive_kernel_matches_fp64_oracle(cuda_device, b, e):
     """csrc/contrastive.hip (value + both embedding gradients) vs oracle/functional_ref.paired_contrastive_loss in fp64,
-    ragged and multi-tile batch sizes; north-star tolerance 1e-4 relative on the loss."""
+    ragged and multi-tile batch sizes; north-star tolerance 1e-4 relative on the loss.  B = 300 pairs is past the fused
+    kernels' 256-pair limit: ``PairedContrastiveLoss._loss`` then composes the same loss from device-side torch ops
+    (utils/contrastive.py), held to the same bound."""
     from immunostruct_amd.utils import PairedContrastiveLoss
     g = torch.Generator().manual_seed(100 + b)
     pcl = PairedContrastiveLoss(embedding_dim=e, device=cuda_device)

@@ -60,6 +60,25 @@ def test_forward_matches_reference_golden(name, kw):
         np.testing.assert_array_equal(it["node_prediction"].numpy(), gold[f"{tag}/node_prediction"])
 
 
+@pytest.mark.parametrize("name", ["HybridModelv2", "SequenceFpModel", "SequenceModel", "HybridModelv2_Comparative"])
+def test_peptide_width_forward_matches_reference_golden(name):
+    """the reference's default input: vae_input_dim = 11 * 21, sequence = the padded peptide (train_IEDB_wFT.py:59-60)"""
+    gold = H.golden("forward_peptide.npz")
+    raw = synthetic.make_batch(BATCH, seed=1)
+    g = H.oracle_graph(raw)
+    seq, prop = H.peptide_one_hot(raw), torch.from_numpy(raw.prop)
+    sd = {k: v.requires_grad_(True) for k, v in H.det_sd(H.model_shapes(name, vae_in=H.PEP_IN), seed=3).items()}
+    it = FR.forward(name, sd, g, seq, prop, eps=H.make_eps(11, BATCH))
+    tag = f"pep/{name}"
+    for k in ("recon_x", "mu", "logvar", "final_output"):
+        np.testing.assert_array_equal(it[k].detach().numpy(), gold[f"{tag}/{k}"])
+    loss = FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], torch.from_numpy(raw.y_reg), H.PEP_IN)
+    assert abs(float(loss.detach()) - float(gold[f"{tag}/loss"])) <= 1e-6 * abs(float(gold[f"{tag}/loss"]))
+    loss.backward()
+    for key in ("vae_fc1.weight", "vae_fc4.bias", "vae_fc21.weight"):
+        H.assert_close(sd[key].grad, gold[f"{tag}/grad/{key}"], 1e-5, key)
+
+
 @pytest.mark.parametrize("name", ["HybridModelv2_Comparative", "HybridModel_Comparative"])
 @pytest.mark.parametrize("wt", [True, False])
 def test_comparative_step_matches_reference_golden(name, wt):
@@ -83,7 +102,7 @@ def test_comparative_step_matches_reference_golden(name, wt):
     loss = (lc + lw) / 2 + 0.01 * lcon
     assert abs(float(lc) - float(gold[f"{tag}/bce_cancer"])) <= 1e-6 * abs(float(lc))
     assert abs(float(lcon) - float(gold[f"{tag}/contrastive"])) <= 1e-5 * abs(float(lcon))
-    assert abs(float(loss) - float(gold[f"{tag}/loss"])) <= 1e-6 * abs(float(loss))
+    assert abs(float(loss.detach()) - float(gold[f"{tag}/loss"])) <= 1e-6 * abs(float(loss))
     loss.backward()
     for key in [k for k in gold.files if k.startswith(f"{tag}/grad/")]:
         pname = key.split("/grad/")[1]
