@@ -169,6 +169,41 @@ __device__ __forceinline__ void mm16_rows(f32x4 (&acc)[NT], const float* a_lds, 
   }
 }
 
+// acc[nt] (16 x 16) += A[16 x K] * Wt[K x (nt*16 .. nt*16+16)]  -- the same product as mm16_rows, but with the weight matrix
+// stored TRANSPOSED (wt_lds[k][j] = W[j][k], row stride LDW): lets a kernel that keeps W^T staged for the data-gradient
+// product (dX = dY W) also run the forward product (Y = X W^T) from the same LDS tile.  The B operand is then one
+// ds_read_b32 per MFMA (lane (r, q) reads wt[k][nt*16 + r]); quarter q walks k = 16 g + 4 q + j (g, j = 0..3), so that the
+// A operand is still one ds_read_b128 per four MFMAs and the two quarters of a 32-lane LDS group (32 banks for b32 reads)
+// hit disjoint bank halves: bank = (4 k + r) mod 32 = (16 q + 4 j + r) mod 32.
+template <int NT, int K, int LDA = LD, int LDW = LD>
+__device__ __forceinline__ void mm16_rows_bt(f32x4 (&acc)[NT], const float* a_lds, const float* wt_lds, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const float* ap = a_lds + r * LDA + 4 * q;
+  const float* wp = wt_lds + (4 * q) * LDW + r;
+  // the B operands of step (g, j + 1) are fetched before the MFMAs of step (g, j) are issued: 2 * NT registers in flight
+  f32x4 a = *reinterpret_cast<const f32x4*>(ap);
+  float b[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
+#pragma unroll
+  for (int g = 0; g < K / 16; ++g) {
+    f32x4 an = a;
+    if (g + 1 < K / 16) an = *reinterpret_cast<const f32x4*>(ap + 16 * (g + 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float bn[NT];
+      const int kn = 16 * g + j + 1 + (j == 3 ? 12 : 0);      // k row (before the + 4 q of wp) of the next step
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bn[nt] = (g + 1 < K / 16 || j < 3) ? wp[kn * LDW + nt * 16] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+    }
+    a = an;
+  }
+}
+
 // acc[mt][nt] (16 x 16) += sum over the 16 tile rows e of G[e][mt*16 + i] * M[e][nt*16 + j]
 template <int MT, int NT, int LDG = LD, int LDM = LD>
 __device__ __forceinline__ void mm16_outer(f32x4 (&acc)[MT][NT], const float* g_lds, const float* m_lds, int lane) {

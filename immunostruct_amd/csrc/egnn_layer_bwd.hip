@@ -82,13 +82,16 @@ struct NodeBwdArgs {
   float* gxtot;             // [N, 3]   out (GATHER): dL/dx_out of this layer = dxn + gather(dDn), read back by P3
 };
 
-template <int FE_MAX, int NVB, bool GX, bool GATHER, int DIN>
+// Z3R: the coordinate MLP's pre-activation z3 = SiLU(z2) Wc1^T + bc1 is RECOMPUTED per tile (one more 16 x 64 x 64 product on
+// the MFMA pipe, B operand read from the transposed weight tile that MM3 needs anyway) instead of being streamed back from
+// HBM: the forward then stores one [E, 64] array per layer less and this kernel reads one less (18.5 MB each way at B = 128).
+template <int FE_MAX, int NVB, bool GX, bool GATHER, int DIN, bool Z3R>
 __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
     const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs,
     const float* __restrict__ W1, int ldw, int din,
-    const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ wc2,
+    const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ bc1, const float* __restrict__ wc2,
     const float* __restrict__ z2s, const float* __restrict__ z3s,
     const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
@@ -331,10 +334,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
       sm.wa[idx] = (f < Fe) ? W1[c * ldw + 2 * din + 1 + f] : 0.0f;
     }
   }
-  float wc2_c[4], wr_t[4];
+  float wc2_c[4], wr_t[4], bc1_c[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     wc2_c[nt] = GX ? wc2[nt * 16 + r] : 0.0f;
+    bc1_c[nt] = (GX && Z3R) ? bc1[nt * 16 + r] : 0.0f;
     wr_t[nt] = W1[(nt * 16 + r) * ldw + 2 * din];
   }
 
@@ -392,13 +396,13 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
       // bounded views of this wave's 16 rows: rows past the tile's last edge read as z = 0 (SiLU(0) = 0: such rows then
       // contribute nothing below without any mask) and are not written
       const rsrc_t rz2 = make_rsrc_n(z2s + (size_t)cb * H, nvalid * H * 4);
-      const rsrc_t rz3 = make_rsrc_n(GX ? z3s + (size_t)cb * H : z2s, GX ? nvalid * H * 4 : 0);
+      const rsrc_t rz3 = make_rsrc_n((GX && !Z3R) ? z3s + (size_t)cb * H : z2s, (GX && !Z3R) ? nvalid * H * 4 : 0);
       const rsrc_t rdz1 = make_rsrc_n(dZ1 + (size_t)cb * H, nvalid * H * 4);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          if constexpr (GX) z3v[t][nt] = buf_load(rz3, vt + (t * H + nt * 16) * 4, 0);
+          if constexpr (GX && !Z3R) z3v[t][nt] = buf_load(rz3, vt + (t * H + nt * 16) * 4, 0);
           z2v[t][nt] = buf_load(rz2, vt + (t * H + nt * 16) * 4, 0);
         }
       int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
@@ -461,6 +465,26 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 
         // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
         if constexpr (GX) {
+          if constexpr (Z3R) {
+            // mh = SiLU(z2) -> bufB first (this wave's own tile), then z3 = mh Wc1^T + bc1 on the MFMA pipe.  Rows past
+            // nvalid: mh = 0, z3 = bc1 -- finite, and multiplied by ds = 0 below
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) {
+                float mh;
+                silu_fg(z2v[t][nt], mh, dy[t][nt]);
+                bufB[tile16_row(t, q) * LD + nt * 16 + r] = mh;
+              }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 z3a[4];
+            zero_acc4(z3a);
+            mm16_rows_bt<4, H>(z3a, bufB, sm.wc1t, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) z3v[t][nt] = z3a[nt][t] + bc1_c[nt];
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int row = tile16_row(t, q);
@@ -470,9 +494,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
             for (int nt = 0; nt < 4; ++nt) {
               silu_fg(z3v[t][nt], tt[nt], sp[nt]);
               part += tt[nt] * wc2_c[nt];
-              float mh;
-              silu_fg(z2v[t][nt], mh, dy[t][nt]);
-              bufB[row * LD + nt * 16 + r] = mh;      // rows past nvalid: SiLU(0) = 0
+              if constexpr (!Z3R) {
+                float mh;
+                silu_fg(z2v[t][nt], mh, dy[t][nt]);
+                bufB[row * LD + nt * 16 + r] = mh;      // rows past nvalid: SiLU(0) = 0
+              }
             }
             part = sum_over_r16(part);
             if (r == 0) sm.e_s[wave][row] = part;
@@ -748,9 +774,11 @@ extern "C" int is_debug_stamps_bwd(long long* out) {
 //     index; the kernel then completes g_psd[:, :64] = gather(dZ1n) (written: the weight-gradient kernel reads it) and uses
 //     dxn + gather(dDn) (written to gxtot [N,3], scratch) as the coordinate gradient; g_xout must be NULL.  Otherwise g_xout [N,3] (or NULL: no coordinate
 //     gradient; the coordinate-MLP half of the pass is skipped, z3s / Wc1 / wc2 are not read).
+//   z3s == NULL with a coordinate gradient: the forward did not save z3; it is recomputed per tile as SiLU(z2) Wc1^T + bc1
+//     (bc1 = coord_mlp.0.bias, required then).
 extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                  const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                                 const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                                 const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                                  const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
                                  float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
                                  const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
@@ -765,20 +793,21 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
       d_hn == nullptr || (g_psd != nullptr && dh_total == nullptr) || (g_psd == nullptr && g_h == nullptr) ||
       (gather && (g_xout != nullptr || dDn == nullptr || dxn == nullptr || rowptr_src == nullptr || pos_by_src == nullptr ||
                   g_psd == nullptr || gxtot == nullptr)) ||
-      (gx && z3s == nullptr) || (tiles != nullptr && Fe > 1))
+      (gx && z3s == nullptr && bc1 == nullptr) || (tiles != nullptr && Fe > 1))
     return -22;
+  const bool z3r = gx && z3s == nullptr;      // z3 was not saved by the forward: recomputed from z2
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
-#define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                           \
-  hipLaunchKernelGGL((is::egnn_layer_bwd_kernel<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, \
-                     W1, ldw, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb)
-#define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
-#define IS_LAUNCH_LB_G(FE, NVB)                                        \
-  do {                                                                 \
-    if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true);                   \
-    else if (gx) IS_LAUNCH_LB_D(FE, NVB, true, false);                 \
-    else IS_LAUNCH_LB_D(FE, NVB, false, false);                        \
+#define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI, ZR)                                                                                           \
+  hipLaunchKernelGGL((is::egnn_layer_bwd_kernel<FE, NVB, GXF, GA, DI, ZR>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, \
+                     W1, ldw, din, W2, Wc1, bc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb)
+#define IS_LAUNCH_LB_D(FE, NVB, GXF, GA, ZR) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20, ZR); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64, ZR); } while (0)
+#define IS_LAUNCH_LB_G(FE, NVB)                                                                                    \
+  do {                                                                                                             \
+    if (gather) { if (z3r) IS_LAUNCH_LB_D(FE, NVB, true, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, true, false); }   \
+    else if (gx) { if (z3r) IS_LAUNCH_LB_D(FE, NVB, true, false, true); else IS_LAUNCH_LB_D(FE, NVB, true, false, false); } \
+    else IS_LAUNCH_LB_D(FE, NVB, false, false, false);                                                             \
   } while (0)
   if (Fe <= 1) {
     if (tiles != nullptr) IS_LAUNCH_LB_G(1, is::NVB_LISTED); else IS_LAUNCH_LB_G(1, is::NV16);

@@ -41,8 +41,10 @@ constexpr int W3 = 4;  // waves per workgroup (they only share the LDS weight ti
 #ifdef IS_STAGE_STAMPS
 __device__ long long g_stamps3[64];
 #define STAMP3(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps3[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP3N() do { STAMP3(stamp_k); ++stamp_k; } while (0)
 #else
 #define STAMP3(k) do { } while (0)
+#define STAMP3N() do { } while (0)
 #endif
 
 struct Fwd3Weights { float w2[H * LD]; float wc1[H * LD]; };
@@ -134,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
   STAMP3(0);
+#ifdef IS_STAGE_STAMPS
   int stamp_k = 2;
+#endif
+  const bool save3 = SAVE && COORD && z3s != nullptr;      // kernel-uniform: z3 is saved only for a backward that does not recompute it
 
   // ---- chunk of this wave ----
   const int c = blockIdx.x * W3 + wave;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   }
   FwdBufs B;
   B.ps = make_rsrc(ps); B.pd = make_rsrc(pd); B.x = make_rsrc(x); B.srcs = make_rsrc(srcs); B.dsts = make_rsrc(dsts);
-  B.ea = make_rsrc(ea); B.hn = make_rsrc(h_neigh); B.z2 = make_rsrc(z2s); B.z3 = make_rsrc(z3s);
+  B.ea = make_rsrc(ea); B.hn = make_rsrc(h_neigh); B.z2 = make_rsrc(z2s); B.z3 = make_rsrc(z3s != nullptr ? z3s : z2s);
   const int ld_p_bytes = ld_p * 4, ld_hn_bytes = ld_hn * 4;
 
   // first index / row loads are in flight while the weights are staged
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       for (int f = 0; f < FE_MAX; ++f) sm.e_a[wave][f][lane] = id0.a[f];
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP3(stamp_k); ++stamp_k;
+    STAMP3N();
 
     // ---- SA: first edge-MLP layer, lane = channel.  Written stage by stage over the 16 rows so that the
     //      LDS broadcasts, the exp and the rcp of different rows overlap (a row-by-row chain exposes every latency
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       for (int i = 0; i < TE16; ++i) act[i * LD + lane] = z[i] * ex[i];
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP3(stamp_k); ++stamp_k;
+    STAMP3N();
 
     const int tile_base = ts * (H * 4);      // scalar byte offset of the tile inside z2s / z3s
     // ---- MM1: z2 = m1 W2^T + b2 ; mh = SiLU(z2) ----
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP3(stamp_k); ++stamp_k;
+    STAMP3N();
 
     // ---- MM2: z3 = mh Wc1^T + bc1 ; s = SiLU(z3) . wc2 ----
     if constexpr (COORD) {
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const float z3 = acc[nt][t] + bc1_c[nt];
-          if (SAVE) buf_store(z3, B.z3, tile_off + (t * H + nt * 16) * 4, tile_base);
+          if (save3) buf_store(z3, B.z3, tile_off + (t * H + nt * 16) * 4, tile_base);
           part += silu_f(z3) * wc2_c[nt];
         }
         part = sum_over_r16(part);
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       }
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP3(stamp_k); ++stamp_k;
+    STAMP3N();
 
     // ---- SEG: running segment sums by destination; flush points are wave-uniform ----
     {
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       }
     }
     __builtin_amdgcn_wave_barrier();
-    STAMP3(stamp_k); ++stamp_k;
+    STAMP3N();
     r0 = r1;
     id0 = id1;
     id1 = id2;
@@ -451,7 +456,8 @@ extern "C" int is_debug_stamps3(long long* out) {
 // One EGNNConv layer forward (edge pass + node MLP + next pre-projection).  h [N, ld_h] (din = 20 | 64 columns): the
 // layer's input node features; ps / pd [N, ld_p]: its pre-projections; chunk_ptr: nchunks + 1 rows (node, first edge);
 // fpack: the layer's forward operand pack (is_stack_prologue); x_out == NULL: the coordinate branch is not evaluated
-// (z3s unused); z2s == NULL: nothing is saved for a backward pass (z3s, zn1 unused); psd_next == NULL: no next
+// (z3s unused); z2s == NULL: nothing is saved for a backward pass (z3s, zn1 unused); z3s == NULL with z2s: the coordinate
+// MLP's pre-activation is not saved (is_egnn_layer_bwd recomputes it from z2); psd_next == NULL: no next
 // projection (b0n / b1n unused); b0n may be NULL.
 extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                  const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
@@ -465,7 +471,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
   const bool coord = x_out != nullptr;
   const bool save = z2s != nullptr;
   if (nchunks <= 0 || (nchunks % is::W3) != 0 || Fe < 0 || Fe > 8 || (din != 20 && din != 64) || fpack == nullptr || h == nullptr ||
-      h_out == nullptr || (save && ((coord && z3s == nullptr) || zn1 == nullptr)) || (psd_next != nullptr && b1n == nullptr))
+      h_out == nullptr || (save && zn1 == nullptr) || (psd_next != nullptr && b1n == nullptr))
     return -22;
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
   const long long lim = 0x7fffffffLL;

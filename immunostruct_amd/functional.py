@@ -16,6 +16,7 @@ import os
 
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
+SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "0") == "1"      # stream z3 through HBM instead of recomputing it (A/B switch)
 WGRAD_GRID = 56      # workgroups per layer and kind of the batched node weight-gradient launch: 13 x 56 = 728 <= 3 x 256 resident
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
@@ -384,7 +385,9 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
         h_neigh = torch.empty(n, HIDDEN, **f32)
         x_out = torch.empty(n, 3, **f32) if not no_coords else None
         z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # full 16-row tiles are stored
-        z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords) else None
+        # the coordinate MLP's pre-activation is recomputed by the backward layer kernel (one more product per tile) unless
+        # IMMUNOSTRUCT_SAVE_Z3=1: one [E, 64] store per layer forward and one load per layer backward less
+        z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords and SAVE_Z3) else None
         zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
         h_out = torch.empty(n, HIDDEN, **f32)
         emit = (not last) or head is not None
@@ -535,7 +538,7 @@ class EGNNStackFn(torch.autograd.Function):
                 lib.is_egnn_layer_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
-                    _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
+                    _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
                     _lib.ptr(g_xc) if above is None else None, _lib.ptr(dZ1), _lib.ptr(dD),
                     _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), _lib.ptr(tiles), grid_e, n, fe,
                     _lib.ptr(dZ1n), _lib.ptr(dDn), _lib.ptr(dxn), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),

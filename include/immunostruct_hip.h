@@ -67,13 +67,15 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *     W1 [64, ldw]       NATIVE edge_mlp.0.weight, ldw = 2*din + 1 + Fe; only the radial / edge-feature columns are read
  *     W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
  *     h [N, ld_h]        the layer's input node features (din = 20 | 64 columns); fpack = its forward operand pack
- *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward (z2s == NULL: none saved)
+ *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward (z2s == NULL: none saved;
+ *                        z3s == NULL: z3 is not saved -- is_egnn_layer_bwd then recomputes it from z2, the default)
  *     x_out == NULL      the coordinate branch is not evaluated (last layer of a stack whose coordinates are unused,
  *                        hybrid_models.py:323-324); z3s is then unused.   psd_next == NULL: no next projection.
  *
  * is_egnn_layer_bwd   per tile of destination nodes: (optional) source-side gather of the layer ABOVE -> node data path
  *                     -> edge pass backward.
- *     edge half: forward arguments + z2s / z3s; out: dZ1 [E,64], dD [E,3] (per-edge gradients of the first edge-MLP
+ *     edge half: forward arguments + z2s / z3s (z3s == NULL: z3 = SiLU(z2) Wc1^T + bc1 is recomputed per tile, bc1 =
+ *       coord_mlp.0.bias required then; otherwise bc1 is unused); out: dZ1 [E,64], dD [E,3] (per-edge gradients of the first edge-MLP
  *       pre-activation and of x_src - x_dst, CSR slot order: gathered by source by the NEXT call or by
  *       is_gather_segment_sum), dPd [N, ld_dpd] and dx [N,3] (destination-side parts, identity path included), ONE
  *       partial weight-gradient record per workgroup (`grid` persistent workgroups, 8960 floats):
@@ -101,7 +103,7 @@ int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x
                       float* zn1, float* h_out, float* psd_next, void* stream);
 int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                       const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
-                      const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                      const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                       const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
                       float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
                       const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,

@@ -243,7 +243,8 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
 def test_other_attention_head_counts_vs_oracle(cuda_device, name, heads):
     """``self_attention_heads`` is a constructor argument of the reference's models (hybrid_models.py:241-251).  The fused node
     attention covers 1 and 8 heads; other counts run the scores / softmax / column mean as device-side torch ops
-    (models/layers.py) around the same HIP value / output projection.  Loss and every parameter gradient vs the oracle."""
+    (models/layers.py) around the same HIP value / output projection.  Loss and every parameter gradient vs the oracle (fp64
+    yardstick: within the element-wise bound of the fp64 gradient, or within 5 x the fp32 oracle's own distance from it)."""
     dev = cuda_device
     b = 5
     raw = synthetic.make_batch(b, seed=61, deg_extra=3)
@@ -254,18 +255,23 @@ def test_other_attention_head_counts_vs_oracle(cuda_device, name, heads):
     model.eval()
     eps, y = H.make_eps(6, b), torch.from_numpy(raw.y_reg)
     seq, prop = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop)
-    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    it = FR.forward(name, sd_o, H.oracle_graph(raw), seq, prop, eps=eps, heads=heads)
     seq_loss = name != "StructureModel"
-    if seq_loss:
-        lo = FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, H.VAE_IN)
-    else:
-        lo = FR.regression_loss(None, seq, None, None, it["final_output"], y, H.VAE_IN, sequence=False)
-    lo.backward()
+
+    def oracle(dtype):
+        sd_o = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+        it = FR.forward(name, sd_o, H.oracle_graph(raw, dtype), seq.to(dtype), prop.to(dtype), eps=eps.to(dtype), heads=heads)
+        if seq_loss:
+            lo = FR.regression_loss(it["recon_x"], seq.to(dtype), it["mu"], it["logvar"], it["final_output"], y.to(dtype), H.VAE_IN)
+        else:
+            lo = FR.regression_loss(None, seq, None, None, it["final_output"], y.to(dtype), H.VAE_IN, sequence=False)
+        lo.backward()
+        return float(lo.detach()), sd_o
+    lo, sd_o = oracle(torch.float32)
+    lo64, sd_64 = oracle(torch.float64)
     res = _with_eps(lambda: model(H.product_graph(raw, dev), seq.to(dev), prop.to(dev)), [eps], dev)
     lh = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=seq_loss).regression_loss(res[0], seq.to(dev), res[1], res[2], res[3], y.to(dev))
     lh.backward()
-    assert abs(float(lh.detach()) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    assert abs(float(lh.detach()) - lo64) <= 1e-5 * abs(lo64)
     gmax = max(float(v.grad.abs().max()) for v in sd_o.values() if v.grad is not None)
     for pname, p in model.named_parameters():
         ref_grad = sd_o[pname].grad
@@ -274,7 +280,10 @@ def test_other_attention_head_counts_vs_oracle(cuda_device, name, heads):
         elif float(ref_grad.abs().max()) < 1e-6 * gmax:
             assert float(p.grad.abs().max()) < 1e-5 * gmax, f"{pname} should be ~0"
         else:
-            H.assert_close(p.grad.cpu(), ref_grad, GRAD_TOL, f"grad {pname}")
+            r_hip = H.worst_ratio(p.grad.cpu(), sd_64[pname].grad, GRAD_TOL)
+            r_ref = H.worst_ratio(ref_grad, sd_64[pname].grad, GRAD_TOL)
+            assert r_hip <= max(1.0, 5.0 * r_ref), (f"grad {pname}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
+                                                    f"gradient, the fp32 oracle {r_ref:.2f} x")
 
 
 @pytest.mark.parametrize("optimizer", ["torch", "hip"])
