@@ -52,7 +52,7 @@ VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 H = 64
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
 def layer_algorithmic(n_nodes, n_edges, din, fe):
@@ -73,45 +73,81 @@ def layer_algorithmic(n_nodes, n_edges, din, fe):
     return bytes_fwd, bytes_bwd, edge_fwd + node, edge_bwd + node, edge_fwd, edge_bwd
 
 
-def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key):
-    """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included)"""
-    if "egnn_layer_bwd" not in timers or "egnn_layer_fwd" not in timers:
+def kernel_sources_sha256():
+    """digest of the sources the layer kernels are built from: a PMC traffic figure measured for other sources is stale"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("egnn_layer_fwd.hip", "egnn_layer_bwd.hip", "common.h", "node16.h"):
+        with open(os.path.join(ROOT, "immunostruct_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(traffic_key):
+    """(bytes per egnn_layer_bwd launch | None, where it comes from / why it is missing)"""
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
+    if traffic_key is None:
+        return None, "no PMC measurement for this batch size / density"
+    if not os.path.isfile(tpath):
+        return None, f"{TRAFFIC_FILE} not found"
+    rec = json.load(open(tpath))
+    want, have = kernel_sources_sha256(), rec.get("kernel_sources_sha256")
+    if have != want:
+        return None, (f"{TRAFFIC_FILE} was measured for other kernel sources (sha256 {str(have)[:12]}..., this tree {want[:12]}...): "
+                      f"re-run tools/pmc_traffic.sh")
+    ent = rec.get(traffic_key, {}).get("egnn_layer_bwd_kernel")
+    if not ent:
+        return None, f"{TRAFFIC_FILE} holds no {traffic_key} entry"
+    return ent.get("bytes"), f"{TRAFFIC_FILE} ({rec.get('commit', '?')}): separate rocprofv3 --pmc passes of this workload, same kernel sources"
+
+
+def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None):
+    """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included).
+    ``insitu``: {"bwd": [us per launch ...], "fwd": [...], "gather": [...]} from the workgroup clocks of the REPLAYED step
+    (functional.LaunchClock) -- the primary timing of every entry; ``timers`` (HIP events around eager launches) are reported as
+    the secondary ``eager_us`` figures.  Without ``insitu`` (``--eager`` / ``--no-kernel-timers`` runs) the HIP events are used."""
+    ev = {k: timers[k][1] * 1e3 for k in ("egnn_layer_bwd", "egnn_layer_fwd", "gather_segment_sum") if k in timers}
+    src = {}
+    for key, name in (("bwd", "egnn_layer_bwd"), ("fwd", "egnn_layer_fwd"), ("gather", "gather_segment_sum")):
+        if insitu and insitu.get(key):
+            src[key] = (float(np.mean(insitu[key])), len(insitu[key]), "insitu")
+        elif name in ev:
+            src[key] = (ev[name], timers[name][0], "events")
+    if "bwd" not in src or "fwd" not in src:
         return None
     per = [layer_algorithmic(n_nodes, n_edges, din, fe) for din in dins]
     b_fwd, b_bwd = np.mean([p[0] for p in per]), np.mean([p[1] for p in per])
     f_fwd, f_bwd = np.mean([p[2] for p in per]), np.mean([p[3] for p in per])
     e_fwd, e_bwd = np.mean([p[4] for p in per]), np.mean([p[5] for p in per])
-    n_b, ms_b = timers["egnn_layer_bwd"]
-    n_f, ms_f = timers["egnn_layer_fwd"]
-    tf_b, tf_f = f_bwd / (ms_b * 1e-3) / 1e12, f_fwd / (ms_f * 1e-3) / 1e12
-    traffic = traffic_src = None
-    tpath = os.path.join(ROOT, TRAFFIC_FILE)
-    if os.path.isfile(tpath) and traffic_key is not None:
-        rec = json.load(open(tpath))
-        ent = rec.get(traffic_key, {}).get("egnn_layer_bwd_kernel")
-        if ent:
-            traffic = ent.get("bytes")
-            traffic_src = f"{TRAFFIC_FILE} ({rec.get('commit', '?')}): separate rocprofv3 --pmc passes of this workload"
+    (us_b, n_b, how), (us_f, n_f, _) = src["bwd"], src["fwd"]
+    tf_b, tf_f = f_bwd / (us_b * 1e-6) / 1e12, f_fwd / (us_f * 1e-6) / 1e12
+    traffic, traffic_src = measured_traffic(traffic_key)
+    method = ("workgroup clocks inside the launches of the REPLAYED step (every workgroup stores the device wall clock at its start "
+              "and end; a launch = smallest start to largest end; csrc/common.h wg_clock_*): the same captured graph whose "
+              "throughput is `value`, co-running branches included" if how == "insitu" else
+              "HIP events on the launching stream around eager launches")
+    sec = lambda name: round(ev[name], 2) if (how == "insitu" and name in ev) else None
     roof = dict(kernel="egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src, launches=n_b,
-                mean_launch_us=round(ms_b * 1e3, 2), algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
-                edge_half_only=dict(algorithmic_flop_per_launch=e_bwd, tflops=round(e_bwd / (ms_b * 1e-3) / 1e12, 2),
-                                    frac=round(e_bwd / (ms_b * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                mean_launch_us=round(us_b, 2), timing=method, eager_us=sec("egnn_layer_bwd"),
+                algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
+                edge_half_only=dict(algorithmic_flop_per_launch=e_bwd, tflops=round(e_bwd / (us_b * 1e-6) / 1e12, 2),
+                                    frac=round(e_bwd / (us_b * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                     note="FLOP of the per-edge products only over the whole launch's duration (round 1's accounting, "
                                          "when the node data path and the source gather were their own launches)"),
-                hbm_view=dict(achieved=round(b_bwd / (ms_b * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                              frac=round(b_bwd / (ms_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)),
-                forward_kernel=dict(kernel="egnn_layer_fwd_kernel", mean_launch_us=round(ms_f * 1e3, 2), launches=n_f,
-                                    tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
-                                    edge_half_only_frac_mfma=round(e_fwd / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                    hbm_gbs=round(b_fwd / (ms_f * 1e-3) / 1e9, 1),
-                                    frac_hbm=round(b_fwd / (ms_f * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
-    if "gather_segment_sum" in timers:
-        n_g, ms_g = timers["gather_segment_sum"]
+                hbm_view=dict(achieved=round(b_bwd / (us_b * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                              frac=round(b_bwd / (us_b * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)),
+                forward_kernel=dict(kernel="egnn_layer_fwd_kernel", mean_launch_us=round(us_f, 2), launches=n_f,
+                                    eager_us=sec("egnn_layer_fwd"), tflops=round(tf_f, 2), frac_mfma=round(tf_f / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    edge_half_only_frac_mfma=round(e_fwd / (us_f * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    hbm_gbs=round(b_fwd / (us_f * 1e-6) / 1e9, 1),
+                                    frac_hbm=round(b_fwd / (us_f * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)))
+    if "gather" in src:
+        us_g, n_g, _ = src["gather"]
         gbytes = n_edges * (H * 4 + 12 + 4) + n_nodes * (H * 4 + 12 + 4)
-        roof["gather_kernel"] = dict(kernel="gather_segment_sum_kernel", bound="hbm", mean_launch_us=round(ms_g * 1e3, 2),
-                                     launches=n_g, achieved=round(gbytes / (ms_g * 1e-3) / 1e9, 1), unit="GB/s",
-                                     frac=round(gbytes / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+        roof["gather_kernel"] = dict(kernel="gather_segment_sum_kernel", bound="hbm", mean_launch_us=round(us_g, 2),
+                                     launches=n_g, eager_us=sec("gather_segment_sum"), achieved=round(gbytes / (us_g * 1e-6) / 1e9, 1),
+                                     unit="GB/s", frac=round(gbytes / (us_g * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                                      note="one launch per step (layer 0); the other layers' source gathers run inside "
                                           "egnn_layer_bwd_kernel")
     return roof
@@ -206,10 +242,16 @@ class IedbWorkload(TrainStepWorkload):
         self.model = model_map[args.model](vae_input_dim=VAE_IN, device=dev).to(dev)
         D.broadcast_parameters(self.model)
         self.model.train()
-        self.opt = optim.Adam(self.model.parameters(), lr=1e-3)      # csrc/optimizer.hip
+        # stage "pretrain": regression on the normalised foreignness, Adam lr 1e-3 (train_IEDB_wFT.py:74-88); stage "finetune":
+        # BCE on immunogenicity, Adam lr 1e-4, weight decay 1e-6 (train_IEDB_wFT.py:97-113) -- config 2's second stage
+        self.finetune = args.stage == "finetune"
+        if self.finetune:
+            self.opt = optim.Adam(self.model.parameters(), lr=1e-4, weight_decay=1e-6)      # csrc/optimizer.hip
+        else:
+            self.opt = optim.Adam(self.model.parameters(), lr=1e-3)
         self.losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
-        self.pool = [device_batch(synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + i, deg_extra=args.deg_extra), dev, "y_reg")
-                     for i in range(4)]
+        self.pool = [device_batch(synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + i, deg_extra=args.deg_extra), dev,
+                                  "y_bin" if self.finetune else "y_reg") for i in range(4)]
         self.graphs_per_step = args.batch
         self.n_nodes = self.pool[0]["raw"].num_nodes
         self.n_edges = float(np.mean([b["raw"].num_edges for b in self.pool]))
@@ -217,6 +259,8 @@ class IedbWorkload(TrainStepWorkload):
 
     def forward_loss(self, m, g, seq, prop, y):
         recon, mu, logvar, final = m(g, seq, prop)
+        if self.finetune:
+            return self.losses.BCE_loss(recon, seq, mu, logvar, final, y)
         return self.losses.regression_loss(recon, seq, mu, logvar, final, y)
 
     def batch(self, i):
@@ -225,14 +269,18 @@ class IedbWorkload(TrainStepWorkload):
 
     def describe(self):
         a = self.args
+        if self.finetune:
+            return (f"IEDB finetune step (BASELINE config 2, second stage): {a.model}, full-sequence + sequence-loss, BCE loss "
+                    f"(pos_weight 81/19), Adam lr 1e-4 weight decay 1e-6; B={a.batch} graphs/GPU x 190 padded nodes, "
+                    f"E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}), Fe=1")
         return (f"IEDB pretrain step (BASELINE config 2): {a.model}, full-sequence + sequence-loss, regression loss, Adam; "
                 f"B={a.batch} graphs/GPU x 190 padded nodes, E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}), Fe=1")
 
-    def roofline(self, timers):
+    def roofline(self, timers, insitu=None):
         # the timed launches are the five full ones per step (layer 0: Din = 20, layers 1-4: Din = 64); the last layer's
         # launch skips the coordinate MLP (its output is unused by the model) and is timed under its own name
         key = "iedb_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
-        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key)
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu)
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import functional_ref as FR
@@ -241,17 +289,22 @@ class IedbWorkload(TrainStepWorkload):
         raw = synthetic.make_batch(a.batch, seed=1, deg_extra=a.deg_extra)
         shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
         sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
-        opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+        fine = self.finetune
+        opt = torch.optim.Adam(list(sd.values()), lr=1e-4, weight_decay=1e-6) if fine else torch.optim.Adam(list(sd.values()), lr=1e-3)
         g = graph_ref.RefGraph(raw.src, raw.dst, raw.num_nodes, raw.batch_num_nodes)
         g.ndata["x"], g.edata["edge_attr"] = torch.from_numpy(raw.x), torch.from_numpy(raw.edge_attr)
-        seq, prop, y = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop), torch.from_numpy(raw.y_reg)
+        seq, prop = torch.from_numpy(raw.one_hot_sequence()), torch.from_numpy(raw.prop)
+        y = torch.from_numpy(raw.y_bin if fine else raw.y_reg)
 
         def step():
             opt.zero_grad()
             it = FR.forward("HybridModelv2", sd, g, seq, prop)
-            FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN).backward()
+            if fine:
+                FR.bce_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN, 81.0 / 19.0).backward()
+            else:
+                FR.regression_loss(it["recon_x"], seq, it["mu"], it["logvar"], it["final_output"], y, VAE_IN).backward()
             opt.step()
-        return timed_cpu(step, a.batch, budget_s, f"B={a.batch} (oracle/functional_ref.py HybridModelv2, fwd+loss+bwd+Adam)")
+        return timed_cpu(step, a.batch, budget_s, f"B={a.batch} (oracle/functional_ref.py HybridModelv2, fwd+{'BCE' if fine else 'regression'} loss+bwd+Adam)")
 
 
     def e2e(self, num_graphs=27000):
@@ -350,9 +403,9 @@ class PairedWorkload(TrainStepWorkload):
                 f"contrastive loss, AdamW; B={a.batch} (cancer, wild-type) pairs = {2 * a.batch} graphs/GPU x 190 padded nodes, "
                 f"E~{int(self.n_edges)} edges/step (deg_extra={a.deg_extra}), Fe=1; graphs/s counts both members")
 
-    def roofline(self, timers):
+    def roofline(self, timers, insitu=None):
         key = "paired_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
-        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key)
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu)
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import functional_ref as FR
@@ -483,9 +536,9 @@ class StressWorkload:
                     grad_allreduce=None if not self.reducer.packing else
                     dict(form="serial", buckets=[int(b["flat"].numel()) for b in self.reducer.buckets]))
 
-    def roofline(self, timers):
+    def roofline(self, timers, insitu=None):
         key = "stress_B256" if self.args.batch == 256 else None
-        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (64,) * self.LAYERS, 8, key)
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (64,) * self.LAYERS, 8, key, insitu)
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import graph_ref
@@ -575,7 +628,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="iedb")
+    # (the driver runs the plain command line: IMMUNOSTRUCT_BENCH_WORKLOAD / IMMUNOSTRUCT_BENCH_STAGE select another line)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("IMMUNOSTRUCT_BENCH_WORKLOAD", "iedb"))
+    ap.add_argument("--stage", choices=("pretrain", "finetune"), default=os.environ.get("IMMUNOSTRUCT_BENCH_STAGE", "pretrain"),
+                    help="iedb: regression stage (Adam 1e-3) or the BCE finetune stage (Adam 1e-4, weight decay 1e-6)")
     ap.add_argument("--batch", type=int, default=None, help="graphs (paired: pairs) per GPU per step; default 128 (stress: 256)")
     ap.add_argument("--deg-extra", type=int, default=2, help="iedb / paired: random contact edges per residue (E/N - 1)")
     ap.add_argument("--model", default="HybridModelv2", help="iedb: the model class")
@@ -608,6 +664,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # in-situ launch timing of the layer kernels (workgroup clocks; functional.LaunchClock): the buffers must exist before the
+    # step is captured, and cost two 8-byte stores per workgroup
+    HF.LaunchClock.enabled = not args.no_kernel_timers
     wl = WORKLOADS[args.workload](args, dev, rank, world)
     step = wl.step
 
@@ -674,6 +733,18 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(last.detach()) if last is not None else None
+    insitu = None
+    if HF.LaunchClock.enabled:
+        # the replayed graph's launches stamp their workgroups' start / end clocks on every replay: sample a few more replays of
+        # the SAME graph(s) the timed region ran (every rank steps -- the step may hold a collective; rank 0 reads the clocks back
+        # after each replay; outside the timed region)
+        insitu = {}
+        for i in range(min(args.steps, 12)):
+            step(args.warmup + i)
+            torch.cuda.synchronize()
+            if rank == 0:
+                for (kind, _idx, _grid), us in HF.LaunchClock.read().items():
+                    insitu.setdefault(kind, []).append(us)
     timers_mode = "HIP events around each launch inside the timed region (eager launches)"
     if not args.eager and not args.no_kernel_timers:
         # the timed region replays a captured HIP graph (individual launches cannot be bracketed there): measure per-kernel
@@ -702,9 +773,12 @@ def main():
     if rank == 0:
         graphs = wl.graphs_per_step * world * args.steps
         timers = HF.KernelTimer.summary()
-        roof = wl.roofline(timers)
+        roof = wl.roofline(timers, insitu)
         if roof is not None:
-            roof["measured"] = timers_mode
+            roof["eager_us_measured"] = timers_mode
+            if insitu:
+                roof["insitu_us"] = {k: dict(mean=round(float(np.mean(v)), 2), min=round(float(np.min(v)), 2),
+                                             max=round(float(np.max(v)), 2), samples=len(v)) for k, v in sorted(insitu.items())}
         cpu = e2e = None
         if world == 1 and not args.no_e2e and not args.eager and hasattr(wl, "e2e"):
             e2e = wl.e2e(args.e2e_graphs)

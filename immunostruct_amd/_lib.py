@@ -30,8 +30,8 @@ SIGNATURES = {
     "is_mfma_selftest": [_P, _P, _P, _P],
     "is_mfma_outer_selftest": [_P, _P, _P, _P],
     "is_egnn_layer_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
-                          _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "is_egnn_layer_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _P, _I, _I, _I] + [_P] * 14 + [_P],
+                          _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "is_egnn_layer_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _P, _I, _I, _I] + [_P] * 15 + [_P],
     "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     "is_node_proj_bwd": [_P, _P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P],
     "is_reduce_partials_scratch_floats": [_I],
@@ -60,7 +60,7 @@ SIGNATURES = {
     "is_mlp2_bwd_records": [_I],
     "is_mlp2_bwd_record_floats": [_I, _I, _I],
     "is_debug_timestamp": [_P, _P],
-    "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
+    "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "is_attn_colmean_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

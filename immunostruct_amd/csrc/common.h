@@ -352,6 +352,20 @@ __device__ __forceinline__ void load_matrix_lds_t(float* dst_lds, const float* _
   }
 }
 
+// In-kernel launch timing (bench.py's roofline): with a non-NULL `wg_clock` [gridDim.x][2] every workgroup stores the device
+// wall clock (100 MHz constant-rate counter) when it starts and when it has finished; the launch lasted from the smallest start
+// to the largest end.  Works inside a replayed HIP graph (where HIP events cannot bracket a launch), costs two 8-byte stores per
+// workgroup and no register that lives across the kernel.
+__device__ __forceinline__ void wg_clock_start(long long* wg_clock) {
+  if (wg_clock != nullptr && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = (long long)wall_clock64();
+}
+__device__ __forceinline__ void wg_clock_end(long long* wg_clock) {
+  if (wg_clock != nullptr) {      // kernel-uniform
+    __syncthreads();
+    if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = (long long)wall_clock64();
+  }
+}
+
 // Generic staged copy: element i (0 <= i < COUNT) is fetched by `load(i)` and placed by `store(i, v)`;
 // each of the NT threads issues all of its loads before its first store (one memory round trip).
 template <int COUNT, int NT, typename LoadF, typename StoreF>

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
     const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, int ld_dpd, float* __restrict__ dx,
-    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb) {
+    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
   constexpr int MT = 4, PROWS = 16 * MT, LDP = 132;          // node phase: up to 64 rows (several tiles) per pass
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
   static_assert(sizeof(float) * PROWS * (LDP + 2 * LD) <= sizeof(float) * (2 * H * LD + 2 * WB16 * TE16 * LD),
                 "the node phase's tiles must fit the (not yet staged) weight tiles + window buffers");
   __shared__ Bwd16Smem<FE_MAX, NVB> sm;
+  wg_clock_start(wg_clock);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
@@ -407,29 +408,37 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         }
       int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
       if (nvalid > 0) {
-        // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
+        // ---- S0: geometry + upstream coordinate gradient, lane = edge.  S0a: ids and loads; S0b: the arithmetic.  With
+        //      EARLY (= Z3R) the z2 half of E3 and the z3 product run BETWEEN the two: z2v was requested before the source ids
+        //      (vector loads return in order), so it is there when the ids are, and its SiLU + the 64 MFMAs of the z3
+        //      recompute then cover the coordinates' round trip instead of adding to the window's chain ----
+        constexpr bool EARLY = GX && Z3R;
+        const int l16 = lane & (TE16 - 1);
+        const bool valid = l16 < nvalid;
+        // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
+        const int e = min(cb + l16, e_end - 1);
+        const int s = buf_load_i(rs_srcs, e * 4, 0);
+        src_lane = s;
+        int dl;
         {
-          // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
-          const int l16 = lane & (TE16 - 1);
-          const bool valid = l16 < nvalid;
-          const int e = min(cb + l16, e_end - 1);
-          const int s = buf_load_i(rs_srcs, e * 4, 0);
-          src_lane = s;
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (sm.rp[mid] <= e) lo = mid; else hi = mid;
           }
-          const int dl = valid ? lo : 0;
-          const int v = v0 + dl;
-          float xs0, xs1, xs2, xv0, xv1, xv2;
-          buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
-          buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
-          float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
-          if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
-          float av[FE_MAX];
+          dl = valid ? lo : 0;
+        }
+        const int v = v0 + dl;
+        if (lane < TE16) sm.e_dl[wave][lane] = dl;
+        float xs0, xs1, xs2, xv0, xv1, xv2;
+        buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
+        buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
+        float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
+        if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
+        float av[FE_MAX];
 #pragma unroll
-          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
+        for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
+        auto s0b = [&]() {
           float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
           float rad = radial3(d0, d1, d2);
           float rr = sqrtf(rad);
@@ -438,7 +447,6 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
           if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
           if (lane < TE16) {
-            sm.e_dl[wave][lane] = dl;
             sm.e_ra[wave][lane * RA_LD] = rad;
             sm.e_r[wave][lane] = rr;
             sm.e_inv[wave][lane] = inv;
@@ -450,7 +458,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
             for (int f = 0; f < FE_MAX; ++f) sm.e_ra[wave][lane * RA_LD + 1 + f] = valid ? av[f] : 0.0f;
           }
-        }
+        };
+        if constexpr (!EARLY) s0b();
         __builtin_amdgcn_wave_barrier();
         STAMPB(2);
         // prefetch dL/dh_neigh rows of this tile's destinations: consumed after WG1 + MM3
@@ -484,6 +493,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
               for (int nt = 0; nt < 4; ++nt) z3v[t][nt] = z3a[nt][t] + bc1_c[nt];
+            s0b();      // the coordinates have arrived by now
+            __builtin_amdgcn_wave_barrier();
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -751,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
     }
   }
   STAMPP(19);
+  wg_clock_end(wg_clock);
 }
 
 }  // namespace is
@@ -774,6 +786,7 @@ extern "C" int is_debug_stamps_bwd(long long* out) {
 //     index; the kernel then completes g_psd[:, :64] = gather(dZ1n) (written: the weight-gradient kernel reads it) and uses
 //     dxn + gather(dDn) (written to gxtot [N,3], scratch) as the coordinate gradient; g_xout must be NULL.  Otherwise g_xout [N,3] (or NULL: no coordinate
 //     gradient; the coordinate-MLP half of the pass is skipped, z3s / Wc1 / wc2 are not read).
+//   wg_clock: NULL, or [grid][2] int64 -- every workgroup's start / end device wall clock (bench.py's in-situ launch timing).
 //   z3s == NULL with a coordinate gradient: the forward did not save z3; it is recomputed per tile as SiLU(z2) Wc1^T + bc1
 //     (bc1 = coord_mlp.0.bias, required then).
 extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
@@ -784,7 +797,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                                  const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
-                                 void* stream) {
+                                 long long* wg_clock, void* stream) {
   if (N <= 0) return 0;
   if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
   const bool gather = dZ1n != nullptr;
@@ -801,7 +814,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
 #define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI, ZR)                                                                                           \
   hipLaunchKernelGGL((is::egnn_layer_bwd_kernel<FE, NVB, GXF, GA, DI, ZR>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, \
-                     W1, ldw, din, W2, Wc1, bc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb)
+                     W1, ldw, din, W2, Wc1, bc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb, wg_clock)
 #define IS_LAUNCH_LB_D(FE, NVB, GXF, GA, ZR) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20, ZR); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64, ZR); } while (0)
 #define IS_LAUNCH_LB_G(FE, NVB)                                                                                    \
   do {                                                                                                             \

@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     float* __restrict__ z2s, float* __restrict__ z3s, int E, int Fe,
     const float* __restrict__ h, int ld_h, const float* __restrict__ bn1, const float* __restrict__ bn2,
     const float* __restrict__ b0n, const float* __restrict__ b1n, const float* __restrict__ fpack,
-    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next) {
+    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, long long* __restrict__ wg_clock) {
   __shared__ Fwd3Smem<FE_MAX> sm;
+  wg_clock_start(wg_clock);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     }
     if (row0 + ROWS < n1) __syncthreads();     // the next pass restages X over h'
   }
+  wg_clock_end(wg_clock);
 }
 
 }  // namespace is
@@ -458,7 +460,8 @@ extern "C" int is_debug_stamps3(long long* out) {
 // fpack: the layer's forward operand pack (is_stack_prologue); x_out == NULL: the coordinate branch is not evaluated
 // (z3s unused); z2s == NULL: nothing is saved for a backward pass (z3s, zn1 unused); z3s == NULL with z2s: the coordinate
 // MLP's pre-activation is not saved (is_egnn_layer_bwd recomputes it from z2); psd_next == NULL: no next
-// projection (b0n / b1n unused); b0n may be NULL.
+// projection (b0n / b1n unused); b0n may be NULL.  wg_clock: NULL, or [nchunks / 4][2] int64 -- every workgroup's start / end
+// device wall clock (common.h wg_clock_start / _end; bench.py's in-situ launch timing).
 extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                  const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                                  const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
@@ -466,7 +469,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
                                  const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                                  float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
                                  const float* bn2, const float* b0n, const float* b1n, const float* fpack,
-                                 float* zn1, float* h_out, float* psd_next, void* stream) {
+                                 float* zn1, float* h_out, float* psd_next, long long* wg_clock, void* stream) {
   if (N <= 0) return 0;
   const bool coord = x_out != nullptr;
   const bool save = z2s != nullptr;
@@ -482,7 +485,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
 #define IS_LAUNCH_LF(FE, SV, CO, DI)                                                                                           \
   hipLaunchKernelGGL((is::egnn_layer_fwd_kernel<FE, SV, CO, DI>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe, h, ld_h, \
-                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next)
+                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next, wg_clock)
 #define IS_LAUNCH_LF_D(FE, SV, CO) do { if (din == 20) IS_LAUNCH_LF(FE, SV, CO, 20); else IS_LAUNCH_LF(FE, SV, CO, 64); } while (0)
 #define IS_LAUNCH_LF_C(FE, SV) do { if (coord) IS_LAUNCH_LF_D(FE, SV, true); else IS_LAUNCH_LF_D(FE, SV, false); } while (0)
   if (Fe <= 1) { if (save) IS_LAUNCH_LF_C(1, true); else IS_LAUNCH_LF_C(1, false); }

@@ -61,10 +61,12 @@ __global__ __launch_bounds__(FIN_BLOCK) void loss_finish_kernel(
     for (int i = tid; i < nparts; i += FIN_BLOCK) acc_m += partials[i];
   const float inv = latent_total > 0 ? 1.0f / (float)latent_total : 0.0f;
   for (int i = tid; i < latent_total; i += FIN_BLOCK) {
-    const float m = mu[i], lv = logvar[i], ev = __expf(lv);
-    acc_k += 1.0f + lv - m * m - ev;
+    // exp(lv) - 1 through expm1f: for a freshly initialised model logvar is close to 0 and (1 - exp(lv)) formed from a fast exp
+    // loses most of its digits (the bias gradients of vae_fc22 are sums of these terms)
+    const float m = mu[i], lv = logvar[i], em1 = expm1f(lv);
+    acc_k += lv - m * m - em1;
     d_mu[i] = c_kld * m * inv;
-    d_logvar[i] = c_kld * (-0.5f) * (1.0f - ev) * inv;
+    d_logvar[i] = c_kld * 0.5f * em1 * inv;
   }
   const float invb = 1.0f / (float)batch;
   for (int i = tid; i < batch; i += FIN_BLOCK) {

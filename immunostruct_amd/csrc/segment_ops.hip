@@ -22,10 +22,11 @@ namespace is {
 __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
     const float* __restrict__ rows, const float* __restrict__ vec3,
     const int* __restrict__ ptr, const int* __restrict__ pos,
-    float* __restrict__ out_rows, int ld_out, float* __restrict__ out_vec3, int N) {
+    float* __restrict__ out_rows, int ld_out, float* __restrict__ out_vec3, int N, long long* __restrict__ wg_clock) {
+  wg_clock_start(wg_clock);
   const int sub = threadIdx.x & 15;
   const int v = blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (v >= N) return;
+  if (v < N) {
   const int lo = ptr[v], hi = ptr[v + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float acc3 = 0.0f;
@@ -55,6 +56,8 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
     o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
   }
   if (has3) out_vec3[v * 3 + sub] += acc3;
+  }   // v < N
+  wg_clock_end(wg_clock);
 }
 
 // one workgroup per (segment, 64-channel slab)
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void segment_pool_bwd_kernel(
 }  // namespace is
 
 extern "C" int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
-                                     float* out_rows, int ld_out, float* out_vec3, int N, void* stream) {
+                                     float* out_rows, int ld_out, float* out_vec3, int N, long long* wg_clock, void* stream) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL(is::gather_segment_sum_kernel, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     rows, vec3, ptr, pos, out_rows, ld_out, out_vec3, N);
+                     rows, vec3, ptr, pos, out_rows, ld_out, out_vec3, N, wg_clock);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -16,7 +16,7 @@ import os
 
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
-SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "0") == "1"      # stream z3 through HBM instead of recomputing it (A/B switch)
+SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "1") == "1"      # 0: the backward recomputes z3 per tile instead of reading it back (measured: -37 MB per layer pair, +6 us per backward launch)
 WGRAD_GRID = 56      # workgroups per layer and kind of the batched node weight-gradient launch: 13 x 56 = 728 <= 3 x 256 resident
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
@@ -92,6 +92,46 @@ class Stamps:
         vals = cls.buf[:len(cls.names)].tolist()
         t0 = min(v for v in vals if v > 0)
         return sorted(((v - t0) / 100.0, n) for v, n in zip(vals, cls.names))     # microseconds (100 MHz clock)
+
+
+class LaunchClock:
+    """In-situ duration of the layer-kernel launches (bench.py's roofline): when enabled, every launch of ``is_egnn_layer_fwd`` /
+    ``is_egnn_layer_bwd`` / ``is_gather_segment_sum`` gets a [grid, 2] int64 buffer in which its workgroups store the device wall
+    clock at their start and end (``csrc/common.h`` ``wg_clock_start`` / ``_end``); a launch lasted from the smallest start to the
+    largest end.  Unlike HIP events this works inside a replayed HIP graph -- the buffers are allocated on the first (eager)
+    step, keyed by launch site, and the captured launches keep writing into them -- so the numbers are those of the step whose
+    throughput is reported, co-running branches included.  Enable BEFORE the first step of a model."""
+    enabled = False
+    sites = {}      # (kind, layer index, grid) -> int64 tensor [grid, 2]
+    TICKS_PER_US = 100.0      # wall_clock64: 100 MHz
+
+    @classmethod
+    def slot(cls, kind, index, grid, device):
+        if not cls.enabled:
+            return None
+        key = (kind, index, grid)
+        buf = cls.sites.get(key)
+        if buf is None or buf.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                return None       # never allocate inside a capture: such a launch stays untimed
+            buf = torch.zeros(grid, 2, dtype=torch.int64, device=device)
+            cls.sites[key] = buf
+        return buf
+
+    @classmethod
+    def read(cls):
+        """{(kind, index, grid): microseconds of the most recent launch at that site} -- call after a synchronize"""
+        out = {}
+        for key, buf in cls.sites.items():
+            t = buf.cpu()
+            ok = (t[:, 0] > 0) & (t[:, 1] >= t[:, 0])
+            if bool(ok.any()):
+                out[key] = float(t[ok, 1].max() - t[ok, 0].min()) / cls.TICKS_PER_US
+        return out
+
+    @classmethod
+    def reset(cls):
+        cls.sites = {}
 
 
 class KernelTimer:
@@ -385,8 +425,9 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
         h_neigh = torch.empty(n, HIDDEN, **f32)
         x_out = torch.empty(n, 3, **f32) if not no_coords else None
         z2s = torch.empty(max(e, 16), HIDDEN, **f32) if need_grad else None     # full 16-row tiles are stored
-        # the coordinate MLP's pre-activation is recomputed by the backward layer kernel (one more product per tile) unless
-        # IMMUNOSTRUCT_SAVE_Z3=1: one [E, 64] store per layer forward and one load per layer backward less
+        # IMMUNOSTRUCT_SAVE_Z3=0: the coordinate MLP's pre-activation is not saved -- the backward layer kernel recomputes it (one
+        # more product per tile): one [E, 64] store per layer forward and one load per layer backward less, but the backward
+        # window is issue-bound and the 64 extra MFMAs cost more than the loads they replace (HISTORY.md), so saving stays default
         z3s = torch.empty(max(e, 16), HIDDEN, **f32) if (need_grad and not no_coords and SAVE_Z3) else None
         zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
         h_out = torch.empty(n, HIDDEN, **f32)
@@ -396,13 +437,14 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
             b0n, b1n = (head[1], head[2]) if head is not None else (None, None)
         else:
             b0n, b1n = None, params[(i + 1) * P + 1]
+        clk = LaunchClock.slot("fwd_nocoord" if no_coords else "fwd", i, kf // 4, x.device)
         KernelTimer.launch("egnn_layer_fwd_nocoord" if no_coords else "egnn_layer_fwd", lambda: _lib.check(lib.is_egnn_layer_fwd(
             _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(x), _lib.ptr(ea),
             _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(chunks), kf,
             _lib.ptr(W1), ldw, din, _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
             _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe,
             _lib.ptr(h_in), ld_h, _lib.ptr(bn1), _lib.ptr(bn2), _lib.ptr(b0n), _lib.ptr(b1n), _lib.ptr(packs[i, 0]),
-            _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), st), "is_egnn_layer_fwd"))
+            _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), _lib.ptr(clk), st), "is_egnn_layer_fwd"))
         layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
                            h_out=h_out))
         psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
@@ -534,6 +576,7 @@ class EGNNStackFn(torch.autograd.Function):
             # ONE launch: source gather of the layer above (completes g_psd_next[:, :64] and the coordinate gradient) ->
             # node data path (dh = g_h + g_psd W1sd(next), node-MLP backward) -> fused edge pass backward
             # (idempotent: every output is written from inputs the launch does not change -- bench.py times it K times back to back)
+            clk = LaunchClock.slot("bwd_nocoord" if (g_xc is None and above is None) else "bwd", i, grid_e, dev)
             KernelTimer.launch("egnn_layer_bwd_nocoord" if (g_xc is None and above is None) else "egnn_layer_bwd", lambda: _lib.check(
                 lib.is_egnn_layer_bwd(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
@@ -543,7 +586,8 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), _lib.ptr(tiles), grid_e, n, fe,
                     _lib.ptr(dZ1n), _lib.ptr(dDn), _lib.ptr(dxn), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
                     _lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["zn1"]), _lib.ptr(ctx.packs[i, 1]),
-                    _lib.ptr(dh_total) if has_psd else None, _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), _lib.ptr(gxtot), st),
+                    _lib.ptr(dh_total) if has_psd else None, _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), _lib.ptr(gxtot),
+                    _lib.ptr(clk), st),
                 "is_egnn_layer_bwd"))
             pw = torch.empty(grid_w * wg_stride, **f32)
             keep.extend([dh_total, dzn1, g_psd_next, g_hd, pw, part_e, d_hn, above, gxtot])
@@ -562,7 +606,8 @@ class EGNNStackFn(torch.autograd.Function):
         dZ1, dD, dx = above
         with KernelTimer.span("gather_segment_sum"):      # (accumulates into dx: not repeatable)
             _lib.check(lib.is_gather_segment_sum(_lib.ptr(dZ1), _lib.ptr(dD), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
-                                                 _lib.ptr(g_psd_next), 2 * HIDDEN, _lib.ptr(dx), n, st), "is_gather_segment_sum")
+                                                 _lib.ptr(g_psd_next), 2 * HIDDEN, _lib.ptr(dx), n,
+                                                 _lib.ptr(LaunchClock.slot("gather", 0, (n + 15) // 16, dev)), st), "is_gather_segment_sum")
         # (4) layer-0 pre-projection: weight gradient (+ input-feature gradient when requested)
         lay0 = layers[0]
         W1_0 = params[0]

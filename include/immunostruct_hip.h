@@ -69,6 +69,7 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *     h [N, ld_h]        the layer's input node features (din = 20 | 64 columns); fpack = its forward operand pack
  *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward (z2s == NULL: none saved;
  *                        z3s == NULL: z3 is not saved -- is_egnn_layer_bwd then recomputes it from z2, the default)
+ *     wg_clock           NULL, or [nchunks / 4][2] int64: every workgroup's start / end device wall clock (100 MHz)
  *     x_out == NULL      the coordinate branch is not evaluated (last layer of a stack whose coordinates are unused,
  *                        hybrid_models.py:323-324); z3s is then unused.   psd_next == NULL: no next projection.
  *
@@ -100,7 +101,7 @@ int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x
                       const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                       float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
                       const float* bn2, const float* b0n, const float* b1n, const float* fpack,
-                      float* zn1, float* h_out, float* psd_next, void* stream);
+                      float* zn1, float* h_out, float* psd_next, long long* wg_clock, void* stream);
 int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                       const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                       const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
@@ -109,7 +110,7 @@ int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x
                       const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                       const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                       const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
-                      void* stream);
+                      long long* wg_clock, void* stream);
 
 /* Node pre-projection on its own (any caller of a 128-wide two-bias projection of 64-wide rows: with W1 = [Wq | Wk]
  * it is the fused query/key projection of the node attention, models/layers.py:13-16,68) and its backward:
@@ -170,9 +171,11 @@ int is_vae_latent_bwd_wgrad(const float* a1, const float* dmu, const float* dlv,
                             int P, float* wgrad, int B, int Hd, int L, void* stream);
 
 /* out_rows[v, 0:64] = sum_{p in [ptr[v], ptr[v+1])} rows[pos[p], 0:64]   (written)
- * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL) */
+ * out_vec3[v, 0:3] += sum_{p} vec3[pos[p], 0:3]                          (accumulated; vec3 may be NULL)
+ * wg_clock: NULL, or [(N + 15) / 16][2] int64 -- every workgroup's start / end device wall clock (100 MHz), as for the two
+ * layer kernels: the in-situ launch timing bench.py's roofline uses (works inside a replayed HIP graph) */
 int is_gather_segment_sum(const float* rows, const float* vec3, const int32_t* ptr, const int32_t* pos,
-                          float* out_rows, int ld_out, float* out_vec3, int N, void* stream);
+                          float* out_rows, int ld_out, float* out_vec3, int N, long long* wg_clock, void* stream);
 
 /* Paired cancer / wild-type contrastive loss (utils/contrastive.py:18-83), forward and backward.
  * emb_c, emb_w [B, ld_e] (E valid columns; E = 104), pos [B] (1.0 where the pair is immunogenic), projector

@@ -3,6 +3,8 @@
 #   bench_{iedb,paired,stress}.json  the JSON lines of python bench.py [--workload W]
 #   kernel_stats.txt / timeline.txt  rocprofv3 --kernel-trace of a short default bench (per-kernel table, last step's timeline)
 #   pmc_{iedb,paired,stress}.json    HBM traffic per launch (two PMC passes per workload, tools/pmc_traffic.sh)
+#   pmc_traffic.json                 the three merged + the digest of the kernel sources (-> profiles/rNN_pmc_traffic.json)
+#   bench_iedb_finetune.json, sweep.json   config 2's BCE stage; deg_extra = 1 / 2 / 5 / 8 (-> profiles/rNN_sweep.json)
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
@@ -19,4 +21,8 @@ python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
 for wl in iedb paired stress; do
   bash tools/pmc_traffic.sh $wl $out/pmc_$wl.json
 done
+python tools/assemble_traffic.py $out $out/pmc_traffic.json
+# config 2's second stage and the edge-density sweep
+python bench.py --stage finetune --steps 30 --warmup 5 > $out/bench_iedb_finetune.json 2> $out/bench_iedb_finetune.err
+bash tools/density_sweep.sh $out/sweep.json > /dev/null
 ls -la $out
