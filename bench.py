@@ -103,14 +103,16 @@ def measured_traffic(traffic_key):
 
 def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None):
     """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included).
-    ``insitu``: {"bwd": [us per launch ...], "fwd": [...], "gather": [...]} from the workgroup clocks of the REPLAYED step
-    (functional.LaunchClock) -- the primary timing of every entry; ``timers`` (HIP events around eager launches) are reported as
-    the secondary ``eager_us`` figures.  Without ``insitu`` (``--eager`` / ``--no-kernel-timers`` runs) the HIP events are used."""
+    ``insitu``: {"bwd": {"slot": [us ...], "span": [...]}, "fwd": ..., "gather": ...} from the workgroup clocks of the REPLAYED
+    step (functional.LaunchClock.durations) -- the primary timing of every entry is the ``slot`` time (end of the previous layer
+    launch -> end of this one: dispatch gap and ramp included, what a kernel trace reports for back-to-back launches);
+    ``timers`` (HIP events around eager launches) are reported as the secondary ``eager_us`` figures.  Without ``insitu``
+    (``--eager`` / ``--no-kernel-timers`` runs) the HIP events are used."""
     ev = {k: timers[k][1] * 1e3 for k in ("egnn_layer_bwd", "egnn_layer_fwd", "gather_segment_sum") if k in timers}
     src = {}
     for key, name in (("bwd", "egnn_layer_bwd"), ("fwd", "egnn_layer_fwd"), ("gather", "gather_segment_sum")):
-        if insitu and insitu.get(key):
-            src[key] = (float(np.mean(insitu[key])), len(insitu[key]), "insitu")
+        if insitu and insitu.get(key) and insitu[key]["slot"]:
+            src[key] = (float(np.mean(insitu[key]["slot"])), len(insitu[key]["slot"]), "insitu")
         elif name in ev:
             src[key] = (ev[name], timers[name][0], "events")
     if "bwd" not in src or "fwd" not in src:
@@ -123,8 +125,10 @@ def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu
     tf_b, tf_f = f_bwd / (us_b * 1e-6) / 1e12, f_fwd / (us_f * 1e-6) / 1e12
     traffic, traffic_src = measured_traffic(traffic_key)
     method = ("workgroup clocks inside the launches of the REPLAYED step (every workgroup stores the device wall clock at its start "
-              "and end; a launch = smallest start to largest end; csrc/common.h wg_clock_*): the same captured graph whose "
-              "throughput is `value`, co-running branches included" if how == "insitu" else
+              "and end; csrc/common.h wg_clock_*): a launch is charged from the last workgroup end of the previous layer launch to "
+              "its own last workgroup end (its slot on the step's critical chain, dispatch gap and ramp included; `insitu_us.*.span` "
+              "= first start to last end of the launch alone) -- the same captured graph whose throughput is `value`, co-running "
+              "branches included" if how == "insitu" else
               "HIP events on the launching stream around eager launches")
     sec = lambda name: round(ev[name], 2) if (how == "insitu" and name in ev) else None
     roof = dict(kernel="egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -227,10 +231,18 @@ class TrainStepWorkload:
 
     def extra_config(self):
         c, r = self.captured, self.reducer
-        return dict(launch="eager" if c is None else "hipGraph replay",
-                    grad_allreduce=(None if (c is None or not r.packing) else
-                                    dict(form="two-stage backward, bucket 0 overlapped" if c.two_stage else "serial",
-                                         buckets=[int(b["flat"].numel()) for b in r.buckets], tuned_ms=c.dp_times)))
+        if c is None or not r.packing:
+            return dict(launch="eager" if c is None else "hipGraph replay", grad_allreduce=None)
+        # everything a multi-GPU line needs to explain its own efficiency: the form the engine kept and the step time of every
+        # form it timed at construction (serial; two-stage per number of reserved CUs), the standalone all-reduce time of every
+        # bucket (all ranks call this: it holds collectives), and the RCCL channel bound in effect
+        return dict(launch="hipGraph replay",
+                    grad_allreduce=dict(form="two-stage backward, bucket 0 overlapped" if c.two_stage else "serial",
+                                        reserved_cus=c.reserved if c.two_stage else None,
+                                        buckets=[int(b["flat"].numel()) for b in r.buckets], tuned_ms=c.dp_times,
+                                        standalone_allreduce=D.time_all_reduce(r),
+                                        nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"),
+                                        nccl_min_nchannels=os.environ.get("NCCL_MIN_NCHANNELS")))
 
 
 class IedbWorkload(TrainStepWorkload):
@@ -743,8 +755,10 @@ def main():
             step(args.warmup + i)
             torch.cuda.synchronize()
             if rank == 0:
-                for (kind, _idx, _grid), us in HF.LaunchClock.read().items():
-                    insitu.setdefault(kind, []).append(us)
+                for kind, d in HF.LaunchClock.durations().items():
+                    ent = insitu.setdefault(kind, {"span": [], "slot": []})
+                    ent["span"] += d["span"]
+                    ent["slot"] += d["slot"]
     timers_mode = "HIP events around each launch inside the timed region (eager launches)"
     if not args.eager and not args.no_kernel_timers:
         # the timed region replays a captured HIP graph (individual launches cannot be bracketed there): measure per-kernel
@@ -770,6 +784,7 @@ def main():
                        "HIP graph, where a launch cannot be bracketed); the two layer kernels are issued 4 x back to back inside one "
                        "event pair (duration / 4), every other kernel once per pair")
 
+    extra_config = wl.extra_config()      # every rank: it times the standalone all-reduce of the buckets (collectives)
     if rank == 0:
         graphs = wl.graphs_per_step * world * args.steps
         timers = HF.KernelTimer.summary()
@@ -777,8 +792,9 @@ def main():
         if roof is not None:
             roof["eager_us_measured"] = timers_mode
             if insitu:
-                roof["insitu_us"] = {k: dict(mean=round(float(np.mean(v)), 2), min=round(float(np.min(v)), 2),
-                                             max=round(float(np.max(v)), 2), samples=len(v)) for k, v in sorted(insitu.items())}
+                st = lambda v: dict(mean=round(float(np.mean(v)), 2), min=round(float(np.min(v)), 2), max=round(float(np.max(v)), 2),
+                                    samples=len(v)) if v else None
+                roof["insitu_us"] = {k: dict(slot=st(v["slot"]), span=st(v["span"])) for k, v in sorted(insitu.items())}
         cpu = e2e = None
         if world == 1 and not args.no_e2e and not args.eager and hasattr(wl, "e2e"):
             e2e = wl.e2e(args.e2e_graphs)
@@ -790,7 +806,7 @@ def main():
                       final_loss=None if final_loss is None else round(final_loss, 5),
                       rccl_ranks=torch.distributed.get_world_size() if ddp else 1,
                       dist_backend=torch.distributed.get_backend() if ddp else None)
-        config.update(wl.extra_config())
+        config.update(extra_config)
         line = dict(metric="peptide-MHC graphs/sec (train step)", value=round(graphs / dt, 1), unit="graphs/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=config,

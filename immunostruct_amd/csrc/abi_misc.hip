@@ -65,3 +65,28 @@ extern "C" int is_debug_timestamp(long long* slot, void* stream) {
   hipLaunchKernelGGL(is::timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+
+// Debug aid (tools/dp_overlap_emulation.py): a stand-in for an RCCL all-reduce that behaves like one towards the compute
+// stream -- `grid` persistent workgroups (RCCL: one per channel, NCCL_MIN/MAX_NCHANNELS) that hold their CU slots for
+// `ticks` of the 100 MHz device clock and stream their slice of the bucket `passes` times in place (read + write of every
+// element: the local HBM traffic of reduce-scatter + all-gather), then wait out the rest of the duration.  The data is
+// unchanged (x * 1.0f).  A sleeping one-thread kernel (torch.cuda._sleep) holds neither slots nor bandwidth.
+namespace is {
+__global__ __launch_bounds__(512) void emulated_collective_kernel(float* buf, long long n, int passes, long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
+  for (int p = 0; p < passes; ++p)
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      volatile float* q = buf + i;
+      *q = *q * 1.0f;
+    }
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}
+extern "C" int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, void* stream) {
+  if (grid <= 0 || n < 0) return -22;
+  hipLaunchKernelGGL(is::emulated_collective_kernel, dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream), buf, n, passes, ticks);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

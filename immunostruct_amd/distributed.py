@@ -30,6 +30,10 @@ def init_from_env(backend=None):
             backend = os.environ.get("IMMUNOSTRUCT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+            # RCCL runs one persistent workgroup per channel; the overlapped (two-stage) step leaves the slots of
+            # functional.RESERVED_CUS compute units free for them, so the channel count is bounded to what fits there
+            # (25 MB buckets over 7 xGMI links do not need more).  Respected only when the user has not set it.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -154,6 +158,28 @@ class FlatGradReducer:
         for i in range(len(self.buckets)):
             work = self.reduce_bucket(i, async_op=async_op)
         return work
+
+
+def time_all_reduce(reducer, repeats=10):
+    """standalone duration (ms, max over ranks) of the all-reduce of every gradient bucket -- nothing beside it on the GPU; what a
+    data-parallel bench line needs to explain its own efficiency.  None without a process group."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1) or not reducer.buckets:
+        return None
+    import time
+    out = []
+    for b in reducer.buckets:
+        scratch = torch.zeros_like(b["flat"])
+        for k in range(2 + repeats):
+            if k == 2:
+                dist.barrier()
+                torch.cuda.synchronize() if scratch.is_cuda else None
+                t0 = time.perf_counter()
+            dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize() if scratch.is_cuda else None
+        t = torch.tensor([(time.perf_counter() - t0) / repeats * 1e3], dtype=torch.float64, device=scratch.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out.append(dict(floats=int(scratch.numel()), ms=round(float(t.item()), 4)))
+    return out
 
 
 def broadcast_parameters(module, src=0):

@@ -213,6 +213,14 @@ class CapturedTrainStep:
             _restore(model, optimizer, snap)      # the warm-up steps leave no trace: training starts from the caller's state
         self.graph_a = self.graph_a1 = self.graph_a2 = self.graph_b = None
         self._forms = {}
+        # graph A2 (the stack backward) is what runs BESIDE the collective: it is captured once per candidate number of CUs its
+        # persistent layer kernels leave free for the collective's workgroups (functional.RESERVED_CUS;
+        # IMMUNOSTRUCT_DP_RESERVED_CUS = comma-separated candidates, default "0,16" when collectives are issued, else "0");
+        # "auto" times every candidate and keeps the fastest
+        default_res = "0,16" if getattr(reducer, "_collective", False) else "0"
+        self._reserved_candidates = sorted({max(0, int(v)) for v in os.environ.get("IMMUNOSTRUCT_DP_RESERVED_CUS", default_res).split(",") if v.strip() != ""}) or [0]
+        self._a2 = {}
+        self.reserved = self._reserved_candidates[0]
         if self.two_stage:
             self.graph_a1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a1):
@@ -220,12 +228,22 @@ class CapturedTrainStep:
             # a graph always writes the gradient buffers it allocated while capturing: pack from those
             self.reducer.bind_sources(0)
             self.reducer.reduce_bucket(0)         # .grad of the first bucket now aliases its persistent flat buffer
-            self.graph_a2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a2, pool=self.graph_a1.pool()):
-                self._stage2()
-            self.reducer.bind_sources(1)
-            self.reducer.reduce_bucket(1)
-            self._forms[True] = (loss, self.reducer.sources())
+            bnd, bnd_grads = self._bnd, self._bnd_grads
+            for res in self._reserved_candidates:
+                self._bnd, self._bnd_grads = bnd, bnd_grads      # every capture walks the same autograd graph (retained below)
+                graph = torch.cuda.CUDAGraph()
+                saved = HF.RESERVED_CUS
+                HF.RESERVED_CUS = res
+                try:
+                    with torch.cuda.graph(graph, pool=self.graph_a1.pool()):
+                        self._stage2(retain=res != self._reserved_candidates[-1])
+                finally:
+                    HF.RESERVED_CUS = saved
+                self.reducer.bind_sources(1)
+                self.reducer.reduce_bucket(1)
+                self._a2[res] = (graph, self.reducer.sources())
+            self.graph_a2, sources = self._a2[self.reserved]
+            self._forms[True] = (loss, sources)
         if not self.two_stage or mode == "auto":
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a):
@@ -247,8 +265,12 @@ class CapturedTrainStep:
         else:
             self._use_form(self.two_stage)
 
-    def _use_form(self, two_stage):
+    def _use_form(self, two_stage, reserved=None):
         self.two_stage = two_stage
+        if two_stage and reserved is not None:
+            self.reserved = reserved
+            self.graph_a2, sources = self._a2[reserved]
+            self._forms[True] = (self._forms[True][0], sources)
         self.loss, sources = self._forms[two_stage]
         self.reducer.sources(sources)
 
@@ -259,9 +281,10 @@ class CapturedTrainStep:
         import torch.distributed as dist
         multi = dist.is_initialized() and dist.get_world_size() > 1
         snap = _snapshot(model, optimizer)
-        times = {}
-        for form in (True, False):
-            self._use_form(form)
+        cands = [(True, r) for r in self._reserved_candidates] + [(False, None)]
+        times = []
+        for form, res in cands:
+            self._use_form(form, res)
             for k in range(2 + steps):
                 if k == 2:
                     if multi:
@@ -270,14 +293,19 @@ class CapturedTrainStep:
                     t0 = time.perf_counter()
                 self.replay()
             torch.cuda.synchronize()
-            times[form] = time.perf_counter() - t0
-        t = torch.tensor([times[True], times[False]], dtype=torch.float64, device=self.y.device)
+            times.append(time.perf_counter() - t0)
+        t = torch.tensor(times, dtype=torch.float64, device=self.y.device)
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
-        t = t.tolist()
-        self.dp_times = {"two_stage_ms": 1e3 * t[0] / steps, "serial_ms": 1e3 * t[1] / steps}
+        t = [1e3 * v / steps for v in t.tolist()]
+        best = min(range(len(cands) - 1), key=lambda i: t[i])
+        self.dp_times = {"two_stage_ms": t[best], "serial_ms": t[-1],
+                         "two_stage_ms_by_reserved_cus": {str(r): t[i] for i, (_, r) in enumerate(cands[:-1])}}
         _restore(model, optimizer, snap)
-        self._use_form(t[0] < t[1])
+        if t[best] < t[-1]:
+            self._use_form(True, cands[best][1])
+        else:
+            self._use_form(False)
 
     def _load(self, g, seq, prop, y):
         if self.paired:
@@ -351,10 +379,10 @@ class CapturedTrainStep:
             p.grad = g
         return loss.detach()
 
-    def _stage2(self):
+    def _stage2(self, retain=False):
         """backward of the EGNN stack(s) from the gradients stage 1 left at their outputs"""
         if self._bnd:
-            outs = torch.autograd.grad(self._bnd, self._late, grad_outputs=self._bnd_grads, allow_unused=True)
+            outs = torch.autograd.grad(self._bnd, self._late, grad_outputs=self._bnd_grads, allow_unused=True, retain_graph=retain)
             for p, g in zip(self._late, outs):
                 p.grad = g
         self._bnd = self._bnd_grads = None

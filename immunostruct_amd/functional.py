@@ -20,6 +20,17 @@ SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "1") == "1"      # 0: the backw
 WGRAD_GRID = 56      # workgroups per layer and kind of the batched node weight-gradient launch: 13 x 56 = 728 <= 3 x 256 resident
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
+# Data-parallel mode of the two persistent layer kernels: their grids normally fill EVERY workgroup slot of the chip (2 per CU),
+# and a static partition means that a slot taken by a co-running kernel -- under data parallelism RCCL's all-reduce, which cannot
+# be scheduled away -- costs the launch a whole extra round.  With RESERVED_CUS = R the grids stop at 2 * (256 - R) workgroups
+# (forward: 8 * (256 - R) wave chunks), so that a collective of up to 2 R workgroup slots (NCCL_MAX_NCHANNELS bounds its footprint)
+# fits BESIDE a layer kernel.  Set by engine.CapturedTrainStep for the overlapped (two-stage) form; 0 = single-GPU behaviour.
+RESERVED_CUS = int(os.environ.get("IMMUNOSTRUCT_RESERVED_CUS", "0"))
+
+
+def layer_slots():
+    """workgroup slots the persistent layer kernels may fill"""
+    return 2 * (_MAX_BWD_GRID - max(0, min(RESERVED_CUS, _MAX_BWD_GRID - 1)))
 
 
 def use_bwd_tiles(num_nodes, num_edges, slots, fe):
@@ -35,7 +46,7 @@ def use_bwd_tiles(num_nodes, num_edges, slots, fe):
 def fwd_chunk_count(num_edges):
     """number of wave-chunks of the forward layer kernel: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves,
     a multiple of the 4 waves of a workgroup"""
-    k = max(4, min(FWD_CHUNKS_MAX, (num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES))
+    k = max(4, min(FWD_CHUNKS_MAX, 4 * layer_slots(), (num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES))
     return (k + 3) // 4 * 4
 
 
@@ -120,13 +131,36 @@ class LaunchClock:
 
     @classmethod
     def read(cls):
-        """{(kind, index, grid): microseconds of the most recent launch at that site} -- call after a synchronize"""
+        """{(kind, index, grid): (first workgroup start, last workgroup end) in microseconds of the device clock} for the most
+        recent launch at every site -- call after a synchronize"""
         out = {}
         for key, buf in cls.sites.items():
             t = buf.cpu()
             ok = (t[:, 0] > 0) & (t[:, 1] >= t[:, 0])
             if bool(ok.any()):
-                out[key] = float(t[ok, 1].max() - t[ok, 0].min()) / cls.TICKS_PER_US
+                out[key] = (float(t[ok, 0].min()) / cls.TICKS_PER_US, float(t[ok, 1].max()) / cls.TICKS_PER_US)
+        return out
+
+    @classmethod
+    def durations(cls):
+        """Per launch kind, the in-situ durations (microseconds) of the most recent step's launches, two ways:
+        ``span`` = first workgroup start -> last workgroup end of the launch itself;
+        ``slot`` = last workgroup end of the PREVIOUS layer launch on the same chain -> last workgroup end of this one, i.e. the
+        launch's share of the step's critical chain, dispatch gap and ramp included (what a kernel trace reports as its
+        duration when launches are back to back) -- defined for launches whose predecessor is clocked too (forward layers
+        1.., backward layers L-2..0, the layer-0 gather)."""
+        raw = cls.read()
+        fwd = sorted((k for k in raw if k[0].startswith("fwd")), key=lambda k: k[1])
+        bwd = sorted((k for k in raw if k[0].startswith("bwd")), key=lambda k: -k[1]) + [k for k in raw if k[0] == "gather"]
+        out = {}
+        for chain in (fwd, bwd):
+            prev = None
+            for k in chain:
+                ent = out.setdefault(k[0], {"span": [], "slot": []})
+                ent["span"].append(raw[k][1] - raw[k][0])
+                if prev is not None and raw[k][1] > raw[prev][1]:
+                    ent["slot"].append(raw[k][1] - raw[prev][1])
+                prev = k
         return out
 
     @classmethod
@@ -537,11 +571,11 @@ class EGNNStackFn(torch.autograd.Function):
         # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
         g_xc = _lib.f32c(g_x) if g_x is not None else None
         # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
-        tiles = csr.tiles(64, 24) if use_bwd_tiles(n, e, 2 * _MAX_BWD_GRID, fe) else None
+        tiles = csr.tiles(64, 24) if use_bwd_tiles(n, e, layer_slots(), fe) else None
         if tiles is not None:
-            grid_e = max(1, min(2 * _MAX_BWD_GRID, tiles.numel() - 2))
+            grid_e = max(1, min(layer_slots(), tiles.numel() - 2))
         else:
-            grid_e = max(1, min(2 * _MAX_BWD_GRID, (n + 15) // 16))
+            grid_e = max(1, min(layer_slots(), (n + 15) // 16))
         wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
         grid_w = max(1, min(WGRAD_GRID, (n + 15) // 16))
         wjobs, rjobs = [], []     # weight-gradient layers / reduction jobs of the two batched launches at the end

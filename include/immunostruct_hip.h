@@ -251,6 +251,11 @@ int is_adam_step(const void* chunks, int nchunks, float* state, const float* hyp
  * HIP graph to time-stamp points of a replayed step without a profiler attached.                             */
 int is_debug_timestamp(long long* slot, void* stream);
 
+/* Debug aid (tools/dp_overlap_emulation.py): a stand-in for an RCCL all-reduce on a single GPU -- `grid` persistent
+ * workgroups of 512 threads that stream buf[0, n) `passes` times in place (values unchanged) and hold their CU slots for
+ * `ticks` of the 100 MHz device clock: occupies slots AND HBM bandwidth like a collective's kernel does.      */
+int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, void* stream);
+
 /* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
  * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
  * bytes a multiple of 4.                                                                                   */

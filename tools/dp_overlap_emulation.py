@@ -1,14 +1,24 @@
-"""Single-GPU emulation of the data-parallel step: the gradient all-reduce is replaced by a kernel of a chosen duration
-on its own stream (what an RCCL collective is to the compute stream), so that the serial and the two-stage (overlapped)
-forms of engine.CapturedTrainStep can be compared without a second GPU.   python tools/dp_overlap_emulation.py [us ...]"""
+"""Single-GPU emulation of the data-parallel step: the gradient all-reduce is replaced by a stand-in kernel on its own stream
+that behaves like RCCL's towards the compute stream -- CHANNELS persistent workgroups of 512 threads (RCCL runs one workgroup per
+channel; NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS bound the count) that stream the bucket three times in place (the local HBM
+traffic of reduce-scatter + all-gather) and hold their CU slots for the emulated duration (csrc/abi_misc.hip
+``is_debug_emulated_collective``).  Round 2's stand-in was ``torch.cuda._sleep`` -- one idle thread, no slots, no bandwidth -- which
+made the overlapped form look better than it can be.  For every (duration, channels) the serial form, the two-stage form with 0 and
+with R reserved CUs (the layer kernels' grids leave 2 R workgroup slots free, functional.RESERVED_CUS) and the engine's own choice
+are timed.
+
+    python tools/dp_overlap_emulation.py [--channels 16,32] [--reserved 0,16,32] [us ...]      -> one JSON line per row"""
+import argparse
+import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import immunostruct_amd.distributed as D  # noqa: E402
-from immunostruct_amd import optim, synthetic  # noqa: E402
+from immunostruct_amd import _lib, optim, synthetic  # noqa: E402
 from immunostruct_amd.engine import CapturedTrainStep  # noqa: E402
 from immunostruct_amd.graph import PackedGraphBatch  # noqa: E402
 from immunostruct_amd.models import model_map  # noqa: E402
@@ -17,8 +27,7 @@ from immunostruct_amd.utils import Losses  # noqa: E402
 dev = torch.device("cuda:0")
 VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
 comm_stream = torch.cuda.Stream()
-CYCLES_PER_US = 2400.0     # torch.cuda._sleep counts shader-clock ticks; calibrated below
-state = {"us": 0.0}
+state = {"us": 0.0, "channels": 16}
 
 
 class FakeWork:
@@ -30,10 +39,13 @@ class FakeWork:
 
 
 def fake_all_reduce(t, op=None, async_op=False):
-    """a 'collective' of state['us'] microseconds per 25 MB, scaled by the bucket size, on the communication stream"""
+    """a 'collective' of state['us'] microseconds per 25 MB (scaled by the bucket size) on the communication stream"""
     comm_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(comm_stream):
-        torch.cuda._sleep(int(state["us"] * CYCLES_PER_US * t.numel() / 6.33e6) + 1)
+        ticks = int(state["us"] * 100.0 * t.numel() / 6.33e6)
+        if ticks > 0:
+            _lib.check(_lib.load().is_debug_emulated_collective(_lib.ptr(t), t.numel(), state["channels"], 3, ticks, _lib.stream_ptr()),
+                       "is_debug_emulated_collective")
         ev = torch.cuda.Event()
         ev.record(comm_stream)
     work = FakeWork(ev)
@@ -43,18 +55,12 @@ def fake_all_reduce(t, op=None, async_op=False):
     return work
 
 
-def calibrate():
-    global CYCLES_PER_US
-    torch.cuda._sleep(1000)        # first call: module load
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    torch.cuda._sleep(20_000_000)
-    torch.cuda.synchronize()
-    CYCLES_PER_US = 20_000_000 / ((time.perf_counter() - t0) * 1e6)
-
-
 def main():
-    calibrate()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("us", nargs="*", type=float, default=[0.0, 100.0, 200.0, 350.0, 500.0])
+    ap.add_argument("--channels", default="16,32")
+    ap.add_argument("--reserved", default="0,16,32")
+    args = ap.parse_args()
     D.dist.all_reduce = fake_all_reduce
     raws = [synthetic.make_batch(128, seed=100 + i, deg_extra=2) for i in range(3)]
     batches = [(PackedGraphBatch.from_raw(r, device=dev), torch.from_numpy(r.one_hot_sequence()).to(dev),
@@ -65,28 +71,34 @@ def main():
         recon, mu, logvar, final = m(g, seq, prop)
         return losses.regression_loss(recon, seq, mu, logvar, final, y)
 
-    import os
-    print(f"sleep calibration: {CYCLES_PER_US:.1f} ticks/us")
-    print(f"{'all-reduce of 25 MB':>22} {'serial':>10} {'two-stage':>10} {'auto picks':>12}")
-    for us in [float(a) for a in sys.argv[1:]] or [0.0, 100.0, 200.0, 350.0, 500.0]:
-        state["us"] = us
-        res = {}
-        for mode in ("0", "1", "auto"):
-            os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = mode
-            model = model_map["HybridModelv2"](vae_input_dim=VAE_IN, device=dev).to(dev)
-            model.train()
-            red = D.FlatGradReducer(model.parameters(), world=2)       # packing + "collectives" (the fake above); grads / 2
-            opt = optim.Adam(model.parameters(), lr=1e-3)
-            eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws))
-            for i in range(5):
-                eng(*batches[i % 3])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(30):
-                eng(*batches[i % 3])
-            torch.cuda.synchronize()
-            res[mode] = ((time.perf_counter() - t0) / 30 * 1e3, eng.two_stage)
-        print(f"{us:>19.0f} us {res['0'][0]:>8.3f}ms {res['1'][0]:>8.3f}ms {'two-stage' if res['auto'][1] else 'serial':>12} ({res['auto'][0]:.3f} ms)")
+    def run(mode, reserved):
+        os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = mode
+        os.environ["IMMUNOSTRUCT_DP_RESERVED_CUS"] = reserved
+        model = model_map["HybridModelv2"](vae_input_dim=VAE_IN, device=dev).to(dev)
+        model.train()
+        red = D.FlatGradReducer(model.parameters(), world=2)       # packing + "collectives" (the stand-in above); grads / 2
+        red._collective = True
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws))
+        for i in range(5):
+            eng(*batches[i % 3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(30):
+            eng(*batches[i % 3])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 30 * 1e3, eng
+
+    for ch in [int(c) for c in args.channels.split(",")]:
+        for us in args.us:
+            state["us"], state["channels"] = us, ch
+            row = {"allreduce_us_per_25MB": us, "channels": ch, "serial_ms": round(run("0", "0")[0], 3)}
+            for r in args.reserved.split(","):
+                row[f"two_stage_reserved{r}_ms"] = round(run("1", r)[0], 3)
+            ms, eng = run("auto", args.reserved)
+            row["auto"] = {"ms": round(ms, 3), "form": "two-stage" if eng.two_stage else "serial",
+                           "reserved_cus": eng.reserved if eng.two_stage else None}
+            print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
