@@ -44,7 +44,7 @@ SIGNATURES = {
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
     "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P, _I, _P],
-    "is_chunk_partition": [_P, _I, _I, _P, _P],
+    "is_chunk_partition": [_P, _I, _I, _I, _P, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_linear_dgrad_scratch_floats": [_I, _I, _I],

@@ -87,10 +87,10 @@ class StaticGraphBatch(PackedGraphBatch):
         """Recompute the edge kernels' work partitions from the rowptr currently in the buffers (after the on-device
         batcher wrote a new batch): vectorised torch ops on the device, no host sync, capturable."""
         from . import _lib
-        from .graph import greedy_node_tiles
+        from .graph import CHUNK_PATTERN, greedy_node_tiles
         lib = _lib.load()
         for k, dst in self._csr._chunks.items():      # == graph.balanced_node_chunks, one launch each
-            _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), _lib.ptr(dst),
+            _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), CHUNK_PATTERN, _lib.ptr(dst),
                                               _lib.stream_ptr()), "is_chunk_partition")
         for key, dst in self._csr._tiles.items():
             t = greedy_node_tiles(self._csr.rowptr_dst, self.edge_capacity, *key)
@@ -222,6 +222,16 @@ class CapturedTrainStep:
         self._a2 = {}
         self.reserved = self._reserved_candidates[0]
         if self.two_stage:
+            # the partitions every candidate's grids need exist BEFORE any capture (one built while capturing would live in
+            # the capture's memory pool and be overwritten by the next capture)
+            for res in self._reserved_candidates:
+                saved = HF.RESERVED_CUS
+                HF.RESERVED_CUS = res
+                try:
+                    for sg in (self.sgraph if self.paired else (self.sgraph,)):
+                        HF.prepare_layer_partitions(sg._csr, fe)
+                finally:
+                    HF.RESERVED_CUS = saved
             self.graph_a1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a1):
                 loss = self._stage1()

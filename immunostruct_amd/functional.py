@@ -43,6 +43,14 @@ def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
 
+def prepare_layer_partitions(csr, fe):
+    """build (and cache in ``csr``) the work partitions the two layer kernels will ask for under the CURRENT ``RESERVED_CUS`` --
+    to be called outside a stream capture: a partition built while capturing lives in the capture's memory pool"""
+    csr.chunks(fwd_chunk_count(csr.num_edges))
+    if use_bwd_tiles(csr.num_nodes, csr.num_edges, layer_slots(), fe):
+        csr.tiles(64, 24)
+
+
 def fwd_chunk_count(num_edges):
     """number of wave-chunks of the forward layer kernel: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves,
     a multiple of the 4 waves of a workgroup"""

@@ -93,6 +93,18 @@ def test_balanced_node_chunks_cover_all_nodes():
         b = t[:, 0].tolist()
         assert b[0] == 0 and b[-1] == 8 and len(b) == k + 1 and all(x <= y for x, y in zip(b, b[1:]))
         assert t[:, 1].tolist() == [int(rowptr[v]) for v in b]
+    # position-dependent shares (3 : 2 patterns of graph.CHUNK_PATTERNS): still a cover by node-aligned ranges, and the chunks'
+    # edge counts follow the weights on a regular graph
+    reg = torch.arange(0, 4 * 2049, 4, dtype=torch.int32)          # 2048 nodes of in-degree 4
+    for mode, heavy in ((1, lambda c: c < 32), (2, lambda c: (c // 4) % 2 == 0), (3, lambda c: c % 2 == 0)):
+        t = balanced_node_chunks(reg, 64, mode)
+        b = t[:, 0].tolist()
+        assert b[0] == 0 and b[-1] == 2048 and all(x <= y for x, y in zip(b, b[1:]))
+        edges = [(t[c + 1, 1] - t[c, 1]).item() for c in range(64)]
+        assert sum(edges) == 4 * 2048
+        for c in range(64):
+            want = 4 * 2048 * (3 if heavy(c) else 2) / (32 * 3 + 32 * 2)
+            assert abs(edges[c] - want) <= 8, (mode, c, edges[c], want)
 
 
 def test_batch_concatenates_existing_csr_pieces():
