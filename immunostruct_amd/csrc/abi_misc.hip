@@ -69,24 +69,34 @@ extern "C" int is_debug_timestamp(long long* slot, void* stream) {
 
 // Debug aid (tools/dp_overlap_emulation.py): a stand-in for an RCCL all-reduce that behaves like one towards the compute
 // stream -- `grid` persistent workgroups (RCCL: one per channel, NCCL_MIN/MAX_NCHANNELS) that hold their CU slots for
-// `ticks` of the 100 MHz device clock and stream their slice of the bucket `passes` times in place (read + write of every
-// element: the local HBM traffic of reduce-scatter + all-gather), then wait out the rest of the duration.  The data is
-// unchanged (x * 1.0f).  A sleeping one-thread kernel (torch.cuda._sleep) holds neither slots nor bandwidth.
+// `ticks` of the 100 MHz device clock and stream their slice of the bucket `passes` times in place (16-byte non-temporal loads
+// and stores of every element: the local HBM traffic of reduce-scatter + all-gather), then wait out the rest of the duration.
+// The data is unchanged.  `elapsed` (NULL or [grid] int64): ticks every workgroup spent streaming -- when that exceeds `ticks`
+// the stand-in ran longer than asked for.  A sleeping one-thread kernel (torch.cuda._sleep) holds neither slots nor bandwidth.
 namespace is {
-__global__ __launch_bounds__(512) void emulated_collective_kernel(float* buf, long long n, int passes, long long ticks) {
+__global__ __launch_bounds__(512) void emulated_collective_kernel(float* buf, long long n, int passes, long long ticks,
+                                                                  long long* elapsed) {
   const long long t0 = (long long)wall_clock64();
-  const long long per = (n + gridDim.x - 1) / gridDim.x;
-  const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
+  const long long n4 = n / 4;
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = min(n4, lo + per);
+  f32x4* b4 = reinterpret_cast<f32x4*>(buf);
   for (int p = 0; p < passes; ++p)
-    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      volatile float* q = buf + i;
-      *q = *q * 1.0f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 4 * 512) {      // four 16-byte loads in flight per thread
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + u * 512 < hi) v[u] = __builtin_nontemporal_load(b4 + i + u * 512);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + u * 512 < hi) __builtin_nontemporal_store(v[u], b4 + i + u * 512);
     }
+  if (elapsed != nullptr && threadIdx.x == 0) elapsed[blockIdx.x] = (long long)wall_clock64() - t0;      // the streaming part alone
   while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 }
-extern "C" int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, void* stream) {
-  if (grid <= 0 || n < 0) return -22;
-  hipLaunchKernelGGL(is::emulated_collective_kernel, dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream), buf, n, passes, ticks);
+extern "C" int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, long long* elapsed,
+                                            void* stream) {
+  if (grid <= 0 || n < 0 || (reinterpret_cast<uintptr_t>(buf) & 15) != 0) return -22;
+  hipLaunchKernelGGL(is::emulated_collective_kernel, dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream), buf, n, passes, ticks,
+                     elapsed);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -27,7 +27,7 @@ constexpr int CA_HEADS = 8;
 constexpr int CA_THREADS = 1024;   // one (token, head) item per thread for T <= 128: the block is pure latency (one workgroup per
                                    // graph, 128 graphs on 256 CUs), so the serial exp loops per thread are what it costs
 constexpr int CA_TMAX = 256;
-constexpr int CA_NSTAT = 5;   // gamma, mx, 1/den, m, second moment
+constexpr int CA_NSTAT = 5;   // gamma, mx, 1/den, m, variance (second moment about the token mean - centred mean^2)
 constexpr int CA_PART = 3 * CA_HEADS + 1;
 
 // The T tokens of a graph may come from up to four row-major pieces laid side by side ([x_gat | z_vae], or the four pieces of a
@@ -63,32 +63,64 @@ struct CaCoef {
   float A2[CA_HEADS], C2[CA_HEADS], alpha[CA_HEADS], beta;
 };
 
+// The 25 scalars above from the block's parameters.  Every parameter element is fetched by its own thread in one batch of loads
+// (F * F + 6 F elements over 1024 threads: one or two memory round trips), the column sums of Wc and the head sums then come from LDS -- the
+// earlier form let 9 threads walk the matrices with serial loads (the last one 256 + of them), a few microseconds of pure
+// latency at the top of two kernels on the step's critical chain.  Contains two barriers; every sum keeps its ascending order.
 template <int F>
-__device__ __forceinline__ void ca_coefficients(CaCoef& co, const float* wq, const float* bq, const float* wk,
+struct CaCoefScratch { float Wc[F * F]; float v[6][F]; float wbar[F]; };      // v: wq bq wk wv bv bc
+
+template <int F>
+__device__ __forceinline__ void ca_coefficients(CaCoef& co, CaCoefScratch<F>& sc, const float* wq, const float* bq, const float* wk,
                                                 const float* wv, const float* bv, const float* Wc, const float* bc,
                                                 int tid) {
   constexpr int D = F / CA_HEADS;
+  for (int i = tid; i < F * F + 6 * F; i += CA_THREADS) {      // F = 16: one pass; F = 32: two
+    if (i < F * F) {
+      sc.Wc[i] = Wc[i];
+    } else {
+      const int k = (i - F * F) / F, f = (i - F * F) % F;
+      const float* src = k == 0 ? wq : (k == 1 ? bq : (k == 2 ? wk : (k == 3 ? wv : (k == 4 ? bv : bc))));
+      sc.v[k][f] = src[f];
+    }
+  }
+  __syncthreads();
+  if (tid < F) {
+    float wbar = 0.f;
+    for (int fp = 0; fp < F; ++fp) wbar += sc.Wc[fp * F + tid];
+    sc.wbar[tid] = wbar;
+  }
+  __syncthreads();
   if (tid < CA_HEADS) {
     float a2 = 0.f, c2 = 0.f, al = 0.f;
     for (int e = 0; e < D; ++e) {
       const int f = tid * D + e;
-      a2 += wq[f] * wk[f];
-      c2 += bq[f] * wk[f];
-      float wbar = 0.f;
-      for (int fp = 0; fp < F; ++fp) wbar += Wc[fp * F + f];
-      al += wbar * wv[f];
+      a2 += sc.v[0][f] * sc.v[2][f];
+      c2 += sc.v[1][f] * sc.v[2][f];
+      al += sc.wbar[f] * sc.v[3][f];
     }
     co.A2[tid] = a2; co.C2[tid] = c2; co.alpha[tid] = al / (float)F;
   }
   if (tid == CA_HEADS) {
     float b = 0.f;
-    for (int f = 0; f < F; ++f) {
-      float wbar = 0.f;
-      for (int fp = 0; fp < F; ++fp) wbar += Wc[fp * F + f];
-      b += wbar * bv[f] + bc[f];
-    }
+    for (int f = 0; f < F; ++f) b += sc.wbar[f] * sc.v[4][f] + sc.v[5][f];
     co.beta = b / (float)F;
   }
+}
+
+// Mean of the T token values c[0 .. T) (LDS), in a fixed order: the reference point of the centred moments below.  Called by all
+// threads after a barrier that made c visible; contains one barrier.  red: CA_THREADS / 64 floats of LDS.
+__device__ __forceinline__ float ca_token_mean(const float* c, float* red, int T, int tid) {
+  float s = 0.f;
+  for (int j = tid; j < T; j += CA_THREADS) s += c[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < CA_THREADS / 64; ++k) tot += red[k];
+  return tot / (float)T;
 }
 
 // The classifier behind the combined attention (models/hybrid_models.py:288-295: Flatten, Linear(T, hid), ReLU, Dropout,
@@ -112,7 +144,8 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
   constexpr int D = F / CA_HEADS;
   __shared__ float c[CA_TMAX];
   __shared__ CaCoef co;
-  __shared__ float red[2][CA_THREADS / 64];
+  __shared__ CaCoefScratch<F> csc;
+  __shared__ float red[3][CA_THREADS / 64];
   __shared__ float w1t[CLS ? CA_TMAX * (CA_CLS_HID + 1) : 1];      // W1 transposed [T][hid + 1]
   __shared__ float zs[CLS ? CA_TMAX : 1], hs[CLS ? CA_CLS_HID : 1];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -126,17 +159,17 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
       for (int u = 0; u < 4; ++u) { const int i = i0 + u * CA_THREADS; if (i < cls.hid * T) w1t[(i % T) * ldw + i / T] = v[u]; }
     }
   }
-  ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   float lo = INFINITY, hi = -INFINITY;
-  for (int j = tid; j < T; j += CA_THREADS) {
+  for (int j = tid; j < T; j += CA_THREADS) {      // (issued before the coefficients' loads are waited for)
     const float v = ca_load(X, b, j);
     c[j] = v;
     lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
+  ca_coefficients<F>(co, csc, wq, bq, wk, wv, bv, Wc, bc, tid);      // (its barriers also publish c)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m, 64)); hi = fmaxf(hi, __shfl_xor(hi, m, 64)); }
   if ((tid & 63) == 0) { red[0][tid >> 6] = lo; red[1][tid >> 6] = hi; }
-  __syncthreads();
+  const float c0 = ca_token_mean(c, red[2], T, tid);      // (its barrier also publishes red[0], red[1] and co)
   float cmin = red[0][0], cmax = red[1][0];
 #pragma unroll
   for (int k = 1; k < CA_THREADS / 64; ++k) { cmin = fminf(cmin, red[0][k]); cmax = fmaxf(cmax, red[1][k]); }
@@ -148,14 +181,18 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     const int i = on ? (w >> 3) : 0, hd = tid & 7;
     const float gamma = (co.A2[hd] * c[i] + co.C2[hd]) * rs;
     const float mx = gamma > 0.f ? gamma * cmax : gamma * cmin;
+    // first and second moment of the row's softmax ABOUT THE TOKEN MEAN c0: the backward needs the variance sq / den - m^2, and
+    // formed from raw moments it loses the digits |c0|^2 / var has (the values of a graph share an offset)
     float den = 0.f, num = 0.f, sq = 0.f;
     for (int j = 0; j < T; ++j) {
       const float cj = c[j];
       const float e = __expf(gamma * cj - mx);
-      den += e; num += e * cj; sq += e * cj * cj;
+      const float dj = cj - c0;
+      den += e; num += e * dj; sq += e * dj * dj;
     }
     const float inv = 1.0f / den;
-    const float m = num * inv;
+    const float mc = num * inv;          // centred mean
+    const float m = c0 + mc;
     float contrib = on ? co.alpha[hd] * m : 0.f;
     contrib += __shfl_xor(contrib, 1, 64);
     contrib += __shfl_xor(contrib, 2, 64);
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
       }
       if (stats != nullptr) {
         float* st = stats + ((size_t)b * items + w) * CA_NSTAT;
-        st[0] = gamma; st[1] = mx; st[2] = inv; st[3] = m; st[4] = sq * inv;
+        st[0] = gamma; st[1] = mx; st[2] = inv; st[3] = m; st[4] = sq * inv - mc * mc;      // [4]: the row's variance
       }
     }
   }
@@ -299,6 +336,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
   float (*acc)[CA_THREADS] = reinterpret_cast<float (*)[CA_THREADS]>(s_dm + CA_HEADS * CA_TMAX);
   __shared__ float dzs[CLS ? CA_TMAX : 1], ghs[CLS ? CA_CLS_HID : 1];
   __shared__ CaCoef co;
+  __shared__ CaCoefScratch<F> csc;
   const int tid = threadIdx.x, b = blockIdx.x;
   if constexpr (CLS) {
     if (b == cls.B) {      // the extra workgroup: the classifier's parameter gradients
@@ -336,8 +374,8 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     }
     __syncthreads();      // w1s is dead: the phases below reuse the block
   }
-  ca_coefficients<F>(co, wq, bq, wk, wv, bv, Wc, bc, tid);
   for (int j = tid; j < T; j += CA_THREADS) c[j] = ca_load(X, b, j);
+  ca_coefficients<F>(co, csc, wq, bq, wk, wv, bv, Wc, bc, tid);
   __syncthreads();
   const float rs = rsqrtf((float)D);
   const int items = CA_HEADS * T, hd = tid & 7;
@@ -350,7 +388,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     float direct = 0.f;
     if (on) {
       const float* st = stats + ((size_t)b * items + w) * CA_NSTAT;
-      const float gamma = st[0], m = st[3], var = st[4] - st[3] * st[3];
+      const float gamma = st[0], m = st[3], var = st[4];
       const float g = CLS ? dzs[i] : dz[(size_t)b * T + i];
       const float dm = g * co.alpha[hd];
       const float dgamma = dm * var;

@@ -258,18 +258,20 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const long long* __re
 
 // chunk_ptr [k + 1][2] = (b_j, rowptr[b_j]) with b_0 = 0, b_k = N, b_j = first node whose first in-edge index is >= j * E / k:
 // the node-aligned, edge-balanced partition of graph.py `balanced_node_chunks`, straight from the rowptr in device memory
-// mode: the chunks' shares of the edges by position (graph.py CHUNK_PATTERNS): W(j) = total weight of the chunks [0, j)
-__device__ __forceinline__ long long chunk_weight_prefix(long long x, int k, int mode) {
-  if (mode == 1) { const long long half = (k / 8) * 4; return 3 * min(x, half) + 2 * max(x - half, 0LL); }
-  if (mode == 2) { const int pre[8] = {0, 3, 6, 9, 12, 14, 16, 18}; return (x / 8) * 20 + pre[x % 8]; }
-  if (mode == 3) return (x / 2) * 5 + (x % 2) * 3;
-  return x;
-}
-__global__ __launch_bounds__(256) void chunk_partition_kernel(const int* __restrict__ rowptr, int N, int k, int mode, int* __restrict__ out) {
+// shares != 0: the chunks of the first / second half of the workgroups get (P + 1) / 2 : (P - 1) / 2 parts of the edges when
+// P = ceil(edges per wave pair / 16) is odd and the node-aligned chunks have slack (graph.py chunk_shares: same integer rule)
+__global__ __launch_bounds__(256) void chunk_partition_kernel(const int* __restrict__ rowptr, int N, int k, int shares, int* __restrict__ out) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j > k) return;
   const long long E = rowptr[N];
-  const long long target = (chunk_weight_prefix(j, k, mode) * E) / chunk_weight_prefix(k, k, mode);
+  long long wa = 1, wb = 1;
+  if (shares) {
+    const long long p = (2 * E + 16LL * k - 1) / (16LL * k);
+    if ((p % 2 == 1) && p >= 3 && (p * 16 * k - 2 * E >= 6LL * k)) { wa = (p + 1) / 2; wb = (p - 1) / 2; }
+  }
+  const long long half = k / 2;
+  const long long wj = wa * min((long long)j, half) + wb * max((long long)j - half, 0LL);
+  const long long target = (wj * E) / (wa * half + wb * (k - half));
   int lo = 0, hi = N + 1;      // first index i in [0, N] with rowptr[i] >= target (N + 1: none)
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -306,9 +308,9 @@ extern "C" int is_batch_gather(const long long* idx, int B, int n, int F, int Fe
 
 // rowptr [N + 1] (device) -> chunk_ptr [k + 1][2] int32: the edge-balanced node partition the layer kernels walk (graph.py
 // `balanced_node_chunks`), recomputed on the device after the batcher wrote a new rowptr -- one launch, no host sync.
-// mode: 0 = equal shares; 1 .. 3 = the position-dependent 3 : 2 shares of graph.py CHUNK_PATTERNS.
-extern "C" int is_chunk_partition(const int32_t* rowptr, int N, int k, int mode, int32_t* chunk_ptr, void* stream) {
-  if (N < 0 || k <= 0 || mode < 0 || mode > 3 || rowptr == nullptr || chunk_ptr == nullptr) return -22;
-  hipLaunchKernelGGL(is::chunk_partition_kernel, dim3((k + 256) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, N, k, mode, chunk_ptr);
+// shares: 0 = equal shares; 1 = the two-level shares of graph.py chunk_shares (the caller passes 1 only for the full grid).
+extern "C" int is_chunk_partition(const int32_t* rowptr, int N, int k, int shares, int32_t* chunk_ptr, void* stream) {
+  if (N < 0 || k <= 0 || rowptr == nullptr || chunk_ptr == nullptr) return -22;
+  hipLaunchKernelGGL(is::chunk_partition_kernel, dim3((k + 256) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, N, k, shares, chunk_ptr);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

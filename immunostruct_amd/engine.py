@@ -87,10 +87,10 @@ class StaticGraphBatch(PackedGraphBatch):
         """Recompute the edge kernels' work partitions from the rowptr currently in the buffers (after the on-device
         batcher wrote a new batch): vectorised torch ops on the device, no host sync, capturable."""
         from . import _lib
-        from .graph import CHUNK_PATTERN, greedy_node_tiles
+        from .graph import CHUNK_SHARES, FULL_GRID_CHUNKS, greedy_node_tiles
         lib = _lib.load()
         for k, dst in self._csr._chunks.items():      # == graph.balanced_node_chunks, one launch each
-            _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), CHUNK_PATTERN, _lib.ptr(dst),
+            _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), int(CHUNK_SHARES == "auto" and int(k) == FULL_GRID_CHUNKS), _lib.ptr(dst),
                                               _lib.stream_ptr()), "is_chunk_partition")
         for key, dst in self._csr._tiles.items():
             t = greedy_node_tiles(self._csr.rowptr_dst, self.edge_capacity, *key)

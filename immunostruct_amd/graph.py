@@ -100,44 +100,41 @@ def greedy_node_tiles(rowptr, num_edges, cap_edges, max_nodes):
     return torch.cat([count, pos]).to(torch.int32)
 
 
-# Share of the edges a chunk gets, by its position (the forward layer kernel: chunk c = wave c % 4 of workgroup c // 4).
-#   0 "flat"      every chunk E / k edges
-#   1 "half"      the chunks of the first half of the workgroups 3 parts, the others 2
-#   2 "alt_wg"    even workgroups 3 parts, odd workgroups 2
-#   3 "alt_wave"  even waves 3 parts, odd waves 2
-# A wave walks its chunk in 16-edge tiles and two waves share a SIMD: with ~35 edges per wave both need 3 tiles (6 per SIMD);
-# 42 + 28 edges are 3 + 2 tiles (5 per SIMD) -- IF the two kinds of waves end up on the same SIMD, which depends on how the
-# hardware places workgroups / waves; hence the patterns (measured: DESIGN.md section 3.2).
-CHUNK_PATTERNS = {"flat": 0, "half": 1, "alt_wg": 2, "alt_wave": 3}
-CHUNK_PATTERN = CHUNK_PATTERNS[__import__("os").environ.get("IMMUNOSTRUCT_FWD_PATTERN", "flat")]
+# Shares of the edges in the forward layer kernel's chunk partition (chunk c = wave c % 4 of workgroup c // 4).
+# A wave walks its chunk in 16-edge tiles, and the kernel is issue-bound with two waves per SIMD: what counts is the number of
+# tiles per SIMD.  At full residency (512 workgroups = 2 per CU) the hardware places workgroups i and i + 256 on the same CU
+# (measured: profiles/r03_*), so their waves share the SIMDs.  With P = ceil(edges per wave pair / 16) ODD, equal shares make
+# both waves walk (P + 1) / 2 tiles -- P + 1 per SIMD -- while shares (P + 1) / 2 : (P - 1) / 2 for the first / second half of the
+# workgroups make it P (B = 128, E = 72 k: 35 + 35 edges = 3 + 3 tiles -> 42 + 28 edges = 3 + 2 tiles; forward layer launch 48 ->
+# 43.5 us).  Used only when the chunks are node-aligned with some slack (>= 6 edges per pair) and the grid is the full one.
+FULL_GRID_CHUNKS = 2048
+CHUNK_SHARES = __import__("os").environ.get("IMMUNOSTRUCT_FWD_SHARES", "auto")      # "auto" | "flat"
 
 
-def chunk_weight_prefix(j, k, mode):
-    """W(j) = total weight of the chunks [0, j) (integer tensor in, integer tensor out) and W(k) -- the device kernel
-    (csrc/segment_ops.hip ``chunk_partition_kernel``) evaluates the same closed forms"""
-    if mode == 1:
-        half = (k // 8) * 4                         # chunks of the first half of the workgroups (4 waves each)
-        w = lambda x: 3 * torch.clamp(x, max=half) + 2 * torch.clamp(x - half, min=0)
-    elif mode == 2:
-        pre = torch.tensor([0, 3, 6, 9, 12, 14, 16, 18], device=j.device, dtype=torch.int64)
-        w = lambda x: (x // 8) * 20 + pre[x % 8]
-    elif mode == 3:
-        w = lambda x: (x // 2) * 5 + (x % 2) * 3
-    else:
-        w = lambda x: x
-    return w(j), w(torch.full_like(j[:1], k))
+def chunk_shares(e, k):
+    """(wa, wb): weight of a chunk of the first / second half of the workgroups; ``e`` a 0-d / 1-element integer tensor (no sync).
+    The device kernel (csrc/segment_ops.hip ``chunk_partition_kernel``) evaluates the same integer rule."""
+    one = torch.ones_like(e)
+    if CHUNK_SHARES != "auto" or k != FULL_GRID_CHUNKS:
+        return one, one
+    p = (2 * e + 16 * k - 1) // (16 * k)
+    use = (p % 2 == 1) & (p >= 3) & (p * 16 * k - 2 * e >= 6 * k)
+    return torch.where(use, (p + 1) // 2, one), torch.where(use, (p - 1) // 2, one)
 
 
-def balanced_node_chunks(rowptr, k, mode=None):
+def balanced_node_chunks(rowptr, k):
     """Rows (b_j, rowptr[b_j]) of the boundaries b_0 = 0 <= b_1 <= ... <= b_k = N with b_j = first node whose first in-edge index is
-    >= E * W(j) / W(k) (``flat``: j * E / k): node-aligned chunks of about E/k edges (a node of very high degree leaves its
-    neighbours' chunks short or empty; nodes without in-edges ride along with the following node)."""
-    mode = CHUNK_PATTERN if mode is None else mode
+    >= E * W(j) / W(k), W = running weight of the chunks (equal shares: j * E / k; see ``chunk_shares``): node-aligned chunks of
+    about E/k edges (a node of very high degree leaves its neighbours' chunks short or empty; nodes without in-edges ride
+    along with the following node)."""
     n = rowptr.numel() - 1
     rp = rowptr.long()
     e = rp[-1:]                                                   # stays on the device: no sync
-    wj, wk = chunk_weight_prefix(torch.arange(k + 1, device=rowptr.device, dtype=torch.int64), k, mode)
-    targets = (wj * e) // wk
+    wa, wb = chunk_shares(e, k)
+    half = k // 2
+    j = torch.arange(k + 1, device=rowptr.device, dtype=torch.int64)
+    wj = wa * torch.clamp(j, max=half) + wb * torch.clamp(j - half, min=0)
+    targets = (wj * e) // (wa * half + wb * (k - half))
     b = torch.searchsorted(rp, targets, right=False)
     b[0] = 0
     b[-1] = n

@@ -253,8 +253,10 @@ int is_debug_timestamp(long long* slot, void* stream);
 
 /* Debug aid (tools/dp_overlap_emulation.py): a stand-in for an RCCL all-reduce on a single GPU -- `grid` persistent
  * workgroups of 512 threads that stream buf[0, n) `passes` times in place (values unchanged) and hold their CU slots for
- * `ticks` of the 100 MHz device clock: occupies slots AND HBM bandwidth like a collective's kernel does.      */
-int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, void* stream);
+ * `ticks` of the 100 MHz device clock: occupies slots AND HBM bandwidth like a collective's kernel does.  elapsed: NULL or
+ * [grid] int64, the ticks every workgroup spent streaming (longer than `ticks`: the stand-in overran).        */
+int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, long long* elapsed,
+                                 void* stream);
 
 /* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
  * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
@@ -276,10 +278,11 @@ int is_batch_gather(const long long* idx, int B, int n, int F, int Fe, const flo
                     int32_t* pos_by_src, float* ea, const void* rows, int nrows, void* stream);
 /* rowptr [N+1] (device) -> chunk_ptr [k+1][2] int32 = (b_j, rowptr[b_j]), b_0 = 0, b_k = N, b_j = first node whose first
  * in-edge index is >= j * E / k: the edge-balanced node partition the layer kernels walk, recomputed on the device after
- * the batcher wrote a new rowptr (one launch, no host sync).  mode 0: equal shares; 1 / 2 / 3: chunks get 3 or 2 parts of
- * the edges by position (first / second half of the workgroups; even / odd workgroups; even / odd waves), the b_j then
- * follow E * W(j) / W(k) with W the running weight (immunostruct_amd/graph.py CHUNK_PATTERNS).                     */
-int is_chunk_partition(const int32_t* rowptr, int N, int k, int mode, int32_t* chunk_ptr, void* stream);
+ * the batcher wrote a new rowptr (one launch, no host sync).  shares = 1 (the caller: only for the full grid of 2048 wave
+ * chunks): when P = ceil(edges per wave pair / 16) is odd and the node-aligned chunks have slack, the chunks of the first /
+ * second half of the workgroups get (P + 1) / 2 : (P - 1) / 2 parts of the edges (the b_j follow E * W(j) / W(k)) -- workgroups
+ * i and i + 256 share a CU, so each SIMD then walks P instead of P + 1 tiles (immunostruct_amd/graph.py chunk_shares).      */
+int is_chunk_partition(const int32_t* rowptr, int N, int k, int shares, int32_t* chunk_ptr, void* stream);
 
 /* Per-segment mean and/or max over rows seg_ptr[s] .. seg_ptr[s+1] of x [rows, ld_x] (C channels).
  * out_mean / out_max [num_segments, C] may each be NULL.  Empty segment: mean 0, max 0.            */

@@ -93,18 +93,20 @@ def test_balanced_node_chunks_cover_all_nodes():
         b = t[:, 0].tolist()
         assert b[0] == 0 and b[-1] == 8 and len(b) == k + 1 and all(x <= y for x, y in zip(b, b[1:]))
         assert t[:, 1].tolist() == [int(rowptr[v]) for v in b]
-    # position-dependent shares (3 : 2 patterns of graph.CHUNK_PATTERNS): still a cover by node-aligned ranges, and the chunks'
-    # edge counts follow the weights on a regular graph
-    reg = torch.arange(0, 4 * 2049, 4, dtype=torch.int32)          # 2048 nodes of in-degree 4
-    for mode, heavy in ((1, lambda c: c < 32), (2, lambda c: (c // 4) % 2 == 0), (3, lambda c: c % 2 == 0)):
-        t = balanced_node_chunks(reg, 64, mode)
-        b = t[:, 0].tolist()
-        assert b[0] == 0 and b[-1] == 2048 and all(x <= y for x, y in zip(b, b[1:]))
-        edges = [(t[c + 1, 1] - t[c, 1]).item() for c in range(64)]
-        assert sum(edges) == 4 * 2048
-        for c in range(64):
-            want = 4 * 2048 * (3 if heavy(c) else 2) / (32 * 3 + 32 * 2)
-            assert abs(edges[c] - want) <= 8, (mode, c, edges[c], want)
+    # two-level shares (graph.chunk_shares): only for the full grid of 2048 chunks, when the tiles per wave pair are odd
+    from immunostruct_amd.graph import chunk_shares
+    for e in (72313, 144700, 410000, 40000, 110000):
+        wa, wb = chunk_shares(torch.tensor([e]), 2048)
+        p = -(-2 * e // (16 * 2048))
+        exp = ((p + 1) // 2, (p - 1) // 2) if (p % 2 == 1 and p >= 3 and p * 16 * 2048 - 2 * e >= 6 * 2048) else (1, 1)
+        assert (int(wa), int(wb)) == exp, (e, p, int(wa), int(wb))
+        assert tuple(int(v) for v in chunk_shares(torch.tensor([e]), 1024)) == (1, 1)
+    assert tuple(int(v) for v in chunk_shares(torch.tensor([72313]), 2048)) == (3, 2)
+    reg = torch.arange(0, 35 * 2049, 35, dtype=torch.int32)        # 2048 nodes of in-degree 35: one node per flat chunk
+    t = balanced_node_chunks(reg, 2048)
+    edges = (t[1:, 1] - t[:-1, 1]).tolist()
+    assert sum(edges) == 35 * 2048 and t[0, 0] == 0 and t[-1, 0] == 2048
+    assert abs(sum(edges[:1024]) / sum(edges[1024:]) - 1.5) < 0.02      # 3 : 2 between the halves
 
 
 def test_batch_concatenates_existing_csr_pieces():
