@@ -25,6 +25,16 @@ def oracle_graph(raw, dtype=torch.float32):
     return g
 
 
+def oracle_graph_permuted(raw, seed, dtype=torch.float32):
+    """the same graph with its edge list in another order: mathematically identical, but every scatter-add of the oracle runs in
+    another summation order -- a second realisation of the reference arithmetic's own fp32 round-off"""
+    perm = np.random.RandomState(seed).permutation(raw.src.shape[0])
+    g = graph_ref.RefGraph(raw.src[perm], raw.dst[perm], raw.num_nodes, raw.batch_num_nodes)
+    g.ndata["x"] = torch.from_numpy(raw.x).to(dtype)
+    g.edata["edge_attr"] = torch.from_numpy(raw.edge_attr[perm]).to(dtype)
+    return g
+
+
 def product_graph(raw, device):
     return PackedGraphBatch.from_raw(raw, device=device)
 
