@@ -145,25 +145,26 @@ __global__ __launch_bounds__(256) void reduce_partials_stage1(const float* __res
                                                               int stride, int count, float* __restrict__ scratch) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= count) return;
-  // 4 independent chains keep several loads in flight; the summation order is fixed (deterministic)
-  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+  // 4 independent chains keep several loads in flight; the summation order is fixed (deterministic); fp64 accumulators (see
+  // reduce_partials_batched_stage1)
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
   int p = blockIdx.y;
   for (; p + 3 * RED_SPLIT < nparts; p += 4 * RED_SPLIT) {
-    v0 += partials[(size_t)p * stride + idx];
-    v1 += partials[(size_t)(p + RED_SPLIT) * stride + idx];
-    v2 += partials[(size_t)(p + 2 * RED_SPLIT) * stride + idx];
-    v3 += partials[(size_t)(p + 3 * RED_SPLIT) * stride + idx];
+    v0 += (double)partials[(size_t)p * stride + idx];
+    v1 += (double)partials[(size_t)(p + RED_SPLIT) * stride + idx];
+    v2 += (double)partials[(size_t)(p + 2 * RED_SPLIT) * stride + idx];
+    v3 += (double)partials[(size_t)(p + 3 * RED_SPLIT) * stride + idx];
   }
-  for (; p < nparts; p += RED_SPLIT) v0 += partials[(size_t)p * stride + idx];
-  scratch[(size_t)blockIdx.y * count + idx] = (v0 + v1) + (v2 + v3);
+  for (; p < nparts; p += RED_SPLIT) v0 += (double)partials[(size_t)p * stride + idx];
+  scratch[(size_t)blockIdx.y * count + idx] = (float)((v0 + v1) + (v2 + v3));
 }
 __global__ __launch_bounds__(256) void reduce_partials_stage2(const float* __restrict__ scratch, int count,
                                                               const int* __restrict__ map, float* __restrict__ dst) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= count) return;
-  float v = 0.0f;
+  double v = 0.0;
 #pragma unroll
-  for (int s = 0; s < RED_SPLIT; ++s) v += scratch[(size_t)s * count + idx];  // loads are independent: issued together
+  for (int s = 0; s < RED_SPLIT; ++s) v += (double)scratch[(size_t)s * count + idx];  // loads are independent: issued together
   const int d = map != nullptr ? map[idx] : idx;
   if (d >= 0) dst[d] = v;
 }
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(256) void reduce_partials_direct(const float* __res
   float r[RED_SPLIT];
 #pragma unroll
   for (int s = 0; s < RED_SPLIT; ++s) r[s] = (s < nparts) ? partials[(size_t)s * stride + idx] : 0.0f;   // issued together
-  float v = 0.0f;
+  double v = 0.0;
 #pragma unroll
-  for (int s = 0; s < RED_SPLIT; ++s) v += r[s];
+  for (int s = 0; s < RED_SPLIT; ++s) v += (double)r[s];
   const int d = map != nullptr ? map[idx] : idx;
-  if (d >= 0) dst[d] = v;
+  if (d >= 0) dst[d] = (float)v;
 }
 
 // Batched form: up to RED_MAX_JOBS independent reductions (one per kernel's partial records) in two launches.
@@ -199,26 +200,29 @@ __global__ __launch_bounds__(256) void reduce_partials_batched_stage1(ReduceBatc
   const ReduceJob& J = batch.job[blockIdx.z];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= J.count) return;
-  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+  // the records are fp32; their SUM is formed in fp64 (one rounding per stage instead of one per record): weight gradients
+  // such as coord_mlp.2.weight are sums over 150 k edges that cancel to a small fraction of their terms, and the 512-record
+  // tail of that sum was where most of the fp32 round-off entered.  The launch is bandwidth-bound: the wider adds are free.
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
   int p = blockIdx.y;
   for (; p + 3 * RED_SPLIT < J.nparts; p += 4 * RED_SPLIT) {
-    v0 += J.partials[(size_t)p * J.stride + idx];
-    v1 += J.partials[(size_t)(p + RED_SPLIT) * J.stride + idx];
-    v2 += J.partials[(size_t)(p + 2 * RED_SPLIT) * J.stride + idx];
-    v3 += J.partials[(size_t)(p + 3 * RED_SPLIT) * J.stride + idx];
+    v0 += (double)J.partials[(size_t)p * J.stride + idx];
+    v1 += (double)J.partials[(size_t)(p + RED_SPLIT) * J.stride + idx];
+    v2 += (double)J.partials[(size_t)(p + 2 * RED_SPLIT) * J.stride + idx];
+    v3 += (double)J.partials[(size_t)(p + 3 * RED_SPLIT) * J.stride + idx];
   }
-  for (; p < J.nparts; p += RED_SPLIT) v0 += J.partials[(size_t)p * J.stride + idx];
-  J.scratch[(size_t)blockIdx.y * J.count + idx] = (v0 + v1) + (v2 + v3);
+  for (; p < J.nparts; p += RED_SPLIT) v0 += (double)J.partials[(size_t)p * J.stride + idx];
+  J.scratch[(size_t)blockIdx.y * J.count + idx] = (float)((v0 + v1) + (v2 + v3));
 }
 __global__ __launch_bounds__(256) void reduce_partials_batched_stage2(ReduceBatch batch) {
   const ReduceJob& J = batch.job[blockIdx.z];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= J.count) return;
-  float v = 0.0f;
+  double v = 0.0;
 #pragma unroll
-  for (int s = 0; s < RED_SPLIT; ++s) v += J.scratch[(size_t)s * J.count + idx];
+  for (int s = 0; s < RED_SPLIT; ++s) v += (double)J.scratch[(size_t)s * J.count + idx];
   const int d = J.map != nullptr ? J.map[idx] : idx;
-  if (d >= 0) J.dst[d] = v;
+  if (d >= 0) J.dst[d] = (float)v;
 }
 
 }  // namespace is

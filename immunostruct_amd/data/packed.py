@@ -126,9 +126,15 @@ class PackedDataset:
         return out
 
     def attach_labels(self, labels):
-        """``labels[name] = (full_sequence, mprop1, mprop2, immunogenicity, foreignness[, peptide])``; sequences (and, when
-        given, peptides) are right-padded with the padding symbol to the longest one (``data/preprocess.py:351-362``)"""
-        rows = [labels[name] for name in self.names]
+        """``labels[name] = (full_sequence, mprop1, mprop2, immunogenicity, foreignness[, peptide])``, or a LIST of such rows, one
+        per item in dataset order (items that share a structure keep their own values); sequences (and, when given, peptides)
+        are right-padded with the padding symbol to the longest one (``data/preprocess.py:351-362``)"""
+        if isinstance(labels, dict):
+            rows = [labels[name] for name in self.names]
+        else:
+            rows = list(labels)
+            if len(rows) != len(self.names):
+                raise ValueError(f"{len(rows)} label rows for {len(self.names)} items")
 
         def tokens(strings):
             out = np.full((len(strings), max(len(t) for t in strings)), _TOKEN[PADDING_CHAR], dtype=np.uint8)
@@ -285,16 +291,23 @@ def convert_pyg_directory(directory, out_path=None, feature_size=23, coord_size=
     ``*.pt`` files, as a :class:`PackedDataset` (saved to ``out_path`` when given).  Rules kept: names containing ``X``
     are skipped, the first graph of every name (the part after ``Immuno``) wins, the last ``drop_features`` node
     features (hydrogen bonding) are cut, every graph is padded to the largest node count.  ``order``: structure names in
-    the order the dataset should have (the reference's datasets follow the TABLE's row order, ``data.tables``); names
+    the order the dataset should have (the reference's datasets follow the TABLE's row order, ``data.tables``; a name may
+    occur several times: items that share a structure -- ``labels`` is then the list of their rows, aligned with ``order``); names
     without a file are an error, files outside ``order`` are left out.  ``pad_to``: node count to pad to instead of the
     directory's largest graph (the two directories of a cancer / wild-type pair share one count)."""
     graphs, names, seen = [], [], set()
+    if labels is not None and not isinstance(labels, dict):
+        if order is None or len(order) != len(labels):
+            raise ValueError("a list of label rows needs `order` (one structure name per row)")
+        wanted = set(order)
+    else:
+        wanted = set(labels) if labels is not None else None
     for fname in [f for f in os.listdir(directory) if f.endswith(".pt")]:     # directory order, as the reference
         x, coords, edge_index, name = load_pyg_pickle(os.path.join(directory, fname))
         if "X" in name:
             continue
         key = name.split("Immuno")[1]
-        if key in seen or (labels is not None and key not in labels):
+        if key in seen or (wanted is not None and key not in wanted):
             continue
         seen.add(key)
         x = torch.cat([x[:, :x.shape[1] - drop_features].float(), coords.float()], dim=-1)

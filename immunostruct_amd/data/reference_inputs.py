@@ -22,18 +22,14 @@ def require_paths(**paths):
 
 
 def packed_from_reference_inputs(graph_dir, property_path, hla_path, cancer=None, feature_size=23, coord_size=3, binary=False):
-    """single-graph dataset (``ImmunoPredDataset``): ``cancer`` defaults to the reference's rule ("Cancer" in the directory name)"""
+    """single-graph dataset (``ImmunoPredDataset``): ``cancer`` defaults to the reference's rule ("Cancer" in the directory name).
+    One item per table key that has a structure, in the table's row order, each with ITS key's values -- keys that map to the
+    same structure (alleles with identical sequences) are separate items that share a graph, as in the reference
+    (``data/immmunopred_dataloader.py:38-60``); the packed dataset then holds that graph once per item."""
     cancer = ("Cancer" in graph_dir) if cancer is None else cancer
-    names = list_structure_names(graph_dir)
-    labels, keys = tables.labels_from_tables(property_path, hla_path, names, cancer=cancer)
-    mapper = tables.preprocess_hla(keys, hla_path)
-    order, seen = [], set()
-    for k in keys:                      # the dataset follows the table's row order (one item per key; keys may share a structure)
-        n = mapper[k][1]
-        if n not in seen:
-            seen.add(n)
-            order.append(n)
-    packed = convert_pyg_directory(graph_dir, feature_size=feature_size, coord_size=coord_size, labels=labels, order=order)
+    rows = tables.item_rows_from_tables(property_path, hla_path, list_structure_names(graph_dir), cancer=cancer)
+    packed = convert_pyg_directory(graph_dir, feature_size=feature_size, coord_size=coord_size, labels=[r[1] for r in rows],
+                                   order=[r[0] for r in rows])
     packed.binary = binary
     return packed
 
@@ -59,22 +55,21 @@ class PairedDataset(Dataset):
 
 def paired_from_reference_inputs(graph_dir_cancer, graph_dir_wt, property_path_cancer, property_path_wt, hla_path,
                                  feature_size=23, coord_size=3, binary=True):
-    """(cancer, wild-type) pair dataset (``ImmunoPredDatasetComparative``) in the joined table's row order; both members are
-    padded to the same node count: the larger of the two directories' maxima over the SELECTED graphs
-    (``data/immmunopred_dataloader.py:146-147`` pads each side on its own; one common count lets a pair share a batch
-    layout -- ``DeviceResidentDataset.concat`` and the merged 2B-graph encoder pass require it)"""
+    """(cancer, wild-type) pair dataset (``ImmunoPredDatasetComparative``): one item per row of the joined table, in its row
+    order, each with THAT row's values -- pairs that share a cancer or a wild-type structure are separate items
+    (``data/immmunopred_dataloader.py:156-190``).  Both members are padded to the same node count: the larger of the two
+    directories' maxima over the selected graphs (the reference pads each side on its own, ``:146-147``; one common count
+    lets a pair share a batch layout -- ``DeviceResidentDataset.concat`` and the merged 2B-graph encoder pass require it)."""
     names_c, names_w = list_structure_names(graph_dir_cancer), list_structure_names(graph_dir_wt)
-    lab_c, lab_w, pairs = tables.paired_labels_from_tables(property_path_cancer, property_path_wt, hla_path, names_c, names_w)
-    pc = convert_pyg_directory(graph_dir_cancer, feature_size=feature_size, coord_size=coord_size, labels=lab_c,
-                               order=_unique([p[0] for p in pairs]))
-    pw = convert_pyg_directory(graph_dir_wt, feature_size=feature_size, coord_size=coord_size, labels=lab_w,
-                               order=_unique([p[1] for p in pairs]))
+    rows = tables.paired_item_rows_from_tables(property_path_cancer, property_path_wt, hla_path, names_c, names_w)
+    pc = convert_pyg_directory(graph_dir_cancer, feature_size=feature_size, coord_size=coord_size, labels=[r[1] for r in rows],
+                               order=[r[0] for r in rows])
+    pw = convert_pyg_directory(graph_dir_wt, feature_size=feature_size, coord_size=coord_size, labels=[r[3] for r in rows],
+                               order=[r[2] for r in rows])
     n = max(int(pc.x.shape[1]), int(pw.x.shape[1]))
     pc, pw = pc.padded_to(n), pw.padded_to(n)
     pc.binary = pw.binary = binary
-    at_c = {n: i for i, n in enumerate(pc.names)}
-    at_w = {n: i for i, n in enumerate(pw.names)}
-    return PairedDataset(_View(pc, [at_c[p[0]] for p in pairs]), _View(pw, [at_w[p[1]] for p in pairs]))
+    return PairedDataset(_View(pc, range(len(pc))), _View(pw, range(len(pw))))
 
 
 def _unique(seq):

@@ -27,7 +27,7 @@ import numpy as np
 import pandas as pd
 
 __all__ = ["structure_name", "preprocess_properties", "preprocess_properties_cancer_wt", "preprocess_hla", "match_structures",
-           "match_pairs", "labels_from_tables", "paired_labels_from_tables"]
+           "match_pairs", "labels_from_tables", "paired_labels_from_tables", "item_rows_from_tables", "paired_item_rows_from_tables"]
 
 
 def structure_name(full_sequence):
@@ -67,7 +67,12 @@ def preprocess_properties(table, cancer=False):
 
 def _one_row_per_triplet(df):
     """duplicates of (mut_pep, wt_pep, allele): keep the row with the highest foreignness when immunogenic, the lowest
-    otherwise (first such row on ties, as ``argmax`` / ``argmin``); contradictory immunogenicity is an error"""
+    otherwise (first such row on ties, as ``argmax`` / ``argmin``); contradictory immunogenicity is an error.
+    INTENTIONAL difference from ``__dedup_property_df`` (``data/preprocess.py:92-130``): the reference collects the duplicates'
+    POSITIONS and then looks them up as index LABELS (``df.loc[duplicate_rows]``), which is the same thing only while the frame's
+    index is 0..n-1; after ``dropna`` removed a row it reads (or drops) other rows, or raises a KeyError.  Here the rows are
+    addressed by label throughout -- the rule in the reference's own docstring; identical on the shipped tables
+    (``tests/test_tables.py``)."""
     key = ["mut_pep", "wt_pep", "allele"]
     if df.groupby(key, sort=False)["immunogenicity"].nunique().max() > 1:
         raise AssertionError("same ('mut_pep', 'wt_pep', 'allele') but different immunogenicity")
@@ -139,6 +144,39 @@ def match_pairs(combined, mapper_cancer, mapper_wt, names_cancer, names_wt):
     mapper_wt = {k: v for k, v in mapper_wt.items() if w2c[k] in mapper_cancer}
     keep = combined["pep_pair_cancer"].isin(mapper_cancer.keys()) & combined["pep_pair_wt"].isin(mapper_wt.keys())
     return combined[keep], mapper_cancer, mapper_wt
+
+
+def item_rows_from_tables(property_path, hla_path, structure_names, cancer=False):
+    """One row PER DATASET ITEM, in the reference's order (``ImmunoPredDataset.organize``, ``data/immmunopred_dataloader.py:38-60``:
+    one item per table key that has a structure; two keys that map to the same structure -- alleles with identical sequences --
+    are two items sharing a graph, each with its own key's values):
+    ``[(structure name, (full sequence, Mprop1, Mprop2, immunogenicity, smoothed foreignness, peptide)), ...]``"""
+    f_dict, fp2_dict, imm_dict, keys = preprocess_properties(property_path, cancer)
+    mapper, _ = match_structures(preprocess_hla(keys, hla_path), structure_names)
+    rows = []
+    for key, (full, name, pep) in mapper.items():
+        m1, m2 = fp2_dict[key]
+        rows.append((name, (full, float(m1), float(m2), float(imm_dict[key]), float(f_dict[key]), pep)))
+    return rows
+
+
+def paired_item_rows_from_tables(path_cancer, path_wt, hla_path, names_cancer, names_wt):
+    """One row per (cancer, wild-type) pair of the joined table, in its row order (``ImmunoPredDatasetComparative.organize``,
+    ``data/immmunopred_dataloader.py:156-190``): ``[(name_c, row_c, name_w, row_w), ...]`` with the label tuples of
+    :func:`item_rows_from_tables`; pairs may share a structure, every pair keeps ITS row's values (the wild-type member is
+    labelled non-immunogenic with the table's minimal foreignness)."""
+    combined = preprocess_properties_cancer_wt(path_cancer, path_wt)
+    mc = preprocess_hla(combined["pep_pair_cancer"], hla_path)
+    mw = preprocess_hla(combined["pep_pair_wt"], hla_path)
+    combined, mc, mw = match_pairs(combined, mc, mw, names_cancer, names_wt)
+    fmin = float(combined["smoothed_foreign"].min()) if len(combined) else float("nan")
+    out = []
+    for row in combined.itertuples(index=False):
+        fc, nc, pep_c = mc[row.pep_pair_cancer]
+        fw, nw, pep_w = mw[row.pep_pair_wt]
+        out.append((nc, (fc, float(row.Mprop1), float(row.Mprop2), float(row.immunogenicity), float(row.smoothed_foreign), pep_c),
+                    nw, (fw, float(row.Mprop1_wt), float(row.Mprop2_wt), 0.0, fmin, pep_w)))
+    return out
 
 
 def labels_from_tables(property_path, hla_path, structure_names, cancer=False):
