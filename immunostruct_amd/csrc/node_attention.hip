@@ -25,6 +25,7 @@
 //                 A operand of dK = dS^T Q.
 //             dx_j += sum_h abar_h[j] g_ctx_h (direct term).
 #include "common.h"
+#include <cstdlib>
 
 namespace is {
 
@@ -331,18 +332,28 @@ __device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t
 
 constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop
 
-template <int NT, int D>
+// HALVES = 2 (experimental, see attn_bwd_split): TWO workgroups per graph (blockIdx.x = 2 * graph + half; adjacent ids land on
+// different CUs).  A graph's
+// backward is 2 * NT matrix passes of 192 MFMAs (32x32x2: 12 k cycles each); with one workgroup per graph NT = 6 waves sit on 4
+// SIMDs, two of which carry two passes' worth -- and half of the chip's CUs idle (128 graphs, 256 CUs).  Here every workgroup
+// still stages K / Q, forms dabar and the t_i of ALL query blocks (cheap, and pass B needs them all), but runs the dQ / dK matrix
+// passes -- and stores the direct term -- only for ITS half of the query / key blocks: one pass per SIMD.  The outputs of the two
+// halves are disjoint rows of dqk / dx: no reduction, bit-identical to the one-workgroup form.
+template <int NT, int D, int HALVES>
 __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
     const float* __restrict__ probs, const float* __restrict__ g_ctx, float* __restrict__ dqk,
     float* __restrict__ dx, int n, int heads, AttnTailBwd tail) {
   constexpr int LDQ = AttnBwdSmem<NT, D>::LDQ;
   constexpr int CT = (D + 31) / 32;
+  static_assert(HALVES == 1 || (HALVES == 2 && NT % 2 == 0), "two halves need an even number of 32-row blocks");
   __shared__ AttnBwdSmem<NT, D> sm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / HALVES, half = blockIdx.x % HALVES;
+  const bool mine = (wave / (NT / HALVES)) == half;      // this wave's query / key block belongs to this workgroup's half
   if constexpr (D == 64) {
     if (tail.gy != nullptr && b >= tail.B) {      // the extra workgroups: parameter gradients of the pooled tail
-      attn_tail_wgrad<64 * NT>(sm.kq, tail, b - tail.B, tid);
+      if (half == 0) attn_tail_wgrad<64 * NT>(sm.kq, tail, b - tail.B, tid);
       return;
     }
   }
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
           d += __shfl_xor(d, 16, 64);
           d += __shfl_xor(d, 32, 64);
           if (j < NT * 32 && lane == 0) sm.dab[j] = d;
-          if (j < n) {
+          if (j < n && (j / (NT * 32 / HALVES)) == half) {      // (the direct term's rows: this half's only)
             float* dst = dx + (size_t)(b * n + j) * 64 + lane;
             *dst = (hd == 0 ? 0.0f : *dst) + ab[u] * g;
           }
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
       zero_acc(dq);
       float* tr = sm.tr[wave];
 #pragma unroll 1
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int nt = 0; nt < (mine ? NT : 0); ++nt) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pq[nt][t];      // [query row][key col]
         __builtin_amdgcn_wave_barrier();
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const int ii = wave * 32 + tile_row(t, hf), c = ct * 32 + r;
-          if (ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
+          if (mine && ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
         }
     }
     STAMPA(5);
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
     __syncthreads();
     STAMPA(7);
     // ---- pass B: key block `wave` (keys on the lanes, queries on the registers): dK[j][c] = sum_i dS[i][j] Q[i][c] ----
-    {
+    if (mine) {      // (wave-uniform)
       f32x16 dk[CT];
       zero_acc(dk);
       const float dabj = sm.dab[wave * 32 + r];
@@ -509,6 +520,17 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
   }
 }
 
+// Two workgroups per graph: OFF unless IMMUNOSTRUCT_ATTN_SPLIT=1.  Measured at B = 128 (HISTORY.md): the launch got slower, 55 -> ~66
+// us -- a wave's dQ pass is its OWN serial chain (per key tile: transposition through LDS, 48 LDS reads, then 32 MFMAs: 5.4 k cycles
+// of which 2 k are MFMA issue), which two waves sharing a SIMD already overlapped completely, so giving every pass a SIMD of its
+// own bought nothing in pass A (32.8 k vs 31.4 k cycles) and 10 k cycles in pass B, less than the duplicated staging, dabar and
+// t_i work and the second XCD's reads of the same Q / K / P rows cost.  The form stays (bit-identical, tested) for experiments.
+inline bool attn_bwd_split(int graphs) {
+  (void)graphs;
+  const char* e = getenv("IMMUNOSTRUCT_ATTN_SPLIT");      // (read per call: the tests flip it)
+  return e != nullptr && e[0] != '\0' && atoi(e) != 0;
+}
+
 }  // namespace is
 
 #ifdef IS_STAGE_STAMPS
@@ -532,6 +554,29 @@ extern "C" int is_debug_stamps_attn(long long* out) {
       else if (nt <= 6) hipLaunchKernelGGL((is::KERNEL<6, 8>), dim3(B), dim3(384), 0, st, __VA_ARGS__);               \
       else hipLaunchKernelGGL((is::KERNEL<8, 8>), dim3(B), dim3(512), 0, st, __VA_ARGS__);                            \
     }                                                                                                                \
+  } while (0)
+
+// the backward: one or two workgroups per graph (HV); grid = HV * (graphs + extra workgroups)
+#define ATTN_DISPATCH_BWD_HV(HV, ...)                                                                                        \
+  do {                                                                                                                       \
+    const int nt = (n + 31) / 32;                                                                                            \
+    hipStream_t st = static_cast<hipStream_t>(stream);                                                                       \
+    if (heads == 1) {                                                                                                        \
+      if (nt <= 2) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<2, 64, HV>), dim3(HV * B), dim3(128), 0, st, __VA_ARGS__);      \
+      else if (nt <= 4) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<4, 64, HV>), dim3(HV * B), dim3(256), 0, st, __VA_ARGS__); \
+      else if (nt <= 6) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<6, 64, HV>), dim3(HV * B), dim3(384), 0, st, __VA_ARGS__); \
+      else hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<8, 64, HV>), dim3(HV * B), dim3(512), 0, st, __VA_ARGS__);              \
+    } else {                                                                                                                 \
+      if (nt <= 2) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<2, 8, HV>), dim3(HV * B), dim3(128), 0, st, __VA_ARGS__);       \
+      else if (nt <= 4) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<4, 8, HV>), dim3(HV * B), dim3(256), 0, st, __VA_ARGS__);  \
+      else if (nt <= 6) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<6, 8, HV>), dim3(HV * B), dim3(384), 0, st, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<8, 8, HV>), dim3(HV * B), dim3(512), 0, st, __VA_ARGS__);               \
+    }                                                                                                                        \
+  } while (0)
+// one workgroup per graph unless IMMUNOSTRUCT_ATTN_SPLIT=1 (see attn_bwd_split)
+#define ATTN_DISPATCH_BWD(GRAPHS, ...)                                                                    \
+  do {                                                                                                    \
+    if (is::attn_bwd_split(GRAPHS)) ATTN_DISPATCH_BWD_HV(2, __VA_ARGS__); else ATTN_DISPATCH_BWD_HV(1, __VA_ARGS__); \
   } while (0)
 
 // qk [B*n, 128] = [Q | K], x [B*n, 64]; heads in {1, 8}; n <= 256 nodes per graph (all graphs equal, padded).
@@ -571,7 +616,7 @@ extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float*
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
   const is::AttnTailBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, none);
+  ATTN_DISPATCH_BWD(B, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, none);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -588,6 +633,6 @@ extern "C" int is_attn_colmean_bwd_tail(const float* qk, const float* x, const f
   const float* g_ctx = nullptr;
   const is::AttnTailBwd tail{gy, wv, wc, pooled, a1, gtail, B_};
   const int B = B_ + is::TAIL_SLABS;      // grid: the graphs + the parameter-gradient workgroups
-  ATTN_DISPATCH(attn_colmean_bwd_kernel, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
+  ATTN_DISPATCH_BWD(B_, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
