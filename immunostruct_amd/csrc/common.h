@@ -357,9 +357,14 @@ __device__ __forceinline__ void load_matrix_lds_t(float* dst_lds, const float* _
 // to the largest end.  Works inside a replayed HIP graph (where HIP events cannot bracket a launch), costs two 8-byte stores per
 // workgroup and no register that lives across the kernel.
 __device__ __forceinline__ void wg_clock_start(long long* wg_clock) {
+#ifndef IS_NO_WG_CLOCK      // (-DIS_NO_WG_CLOCK: A/B builds that measure what the stamps cost)
   if (wg_clock != nullptr && threadIdx.x == 0) wg_clock[2 * blockIdx.x] = (long long)wall_clock64();
+#endif
 }
 __device__ __forceinline__ void wg_clock_end(long long* wg_clock) {
+#ifdef IS_NO_WG_CLOCK
+  return;
+#endif
   if (wg_clock != nullptr) {      // kernel-uniform
     __syncthreads();
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = (long long)wall_clock64();

@@ -22,6 +22,20 @@
 //     degree-3 graphs: the fourth wave of the 64-edge window idles in the row phases), or -- when the caller
 //     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= 24 nodes per tile) -- a
 //     node range that fills the window (63 of 64 rows on the same graphs, 24 % fewer passes).
+// This file is compiled TWICE: as itself (z3 read back from HBM: the default) and, through egnn_layer_bwd_z3r.hip, with
+// IS_BWD_Z3R = 1 (z3 recomputed per tile: IMMUNOSTRUCT_SAVE_Z3=0).  A preprocessor switch, not a template parameter: with both
+// forms in one kernel template the discarded `if constexpr` branch still changed the register allocation of the default
+// instantiations (listed-tile launch 170 -> 176 us, 4 -> 12 spilled registers) -- the default build must not see the other form.
+#ifndef IS_BWD_Z3R
+#define IS_BWD_Z3R 0
+#endif
+#if IS_BWD_Z3R
+#define IS_BWD_KERNEL egnn_layer_bwd_z3r_kernel
+#define IS_BWD_LAUNCHER launch_layer_bwd_z3r
+#else
+#define IS_BWD_KERNEL egnn_layer_bwd_kernel
+#define IS_BWD_LAUNCHER launch_layer_bwd
+#endif
 #include "common.h"
 #include "node16.h"
 
@@ -85,17 +99,17 @@ struct NodeBwdArgs {
 // Z3R: the coordinate MLP's pre-activation z3 = SiLU(z2) Wc1^T + bc1 is RECOMPUTED per tile (one more 16 x 64 x 64 product on
 // the MFMA pipe, B operand read from the transposed weight tile that MM3 needs anyway) instead of being streamed back from
 // HBM: the forward then stores one [E, 64] array per layer less and this kernel reads one less (18.5 MB each way at B = 128).
-template <int FE_MAX, int NVB, bool GX, bool GATHER, int DIN, bool Z3R>
-__global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
-    const float* __restrict__ ps, const float* __restrict__ pd, int ld_p,
+template <int FE_MAX, int NVB, bool GX, bool GATHER, int DIN>
+__global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
+    const float* __restrict__ ps, const float* __restrict__ pd,
     const float* __restrict__ x, const float* __restrict__ ea,
     const int* __restrict__ rowptr, const int* __restrict__ srcs,
-    const float* __restrict__ W1, int ldw, int din,
-    const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ bc1, const float* __restrict__ wc2,
-    const float* __restrict__ z2s, const float* __restrict__ z3s,
+    const float* __restrict__ W1,
+    const float* __restrict__ W2, const float* __restrict__ Wc1, const float* __restrict__ wc2,
+    const float* __restrict__ z2s, const float* __restrict__ z3s_or_bc1,      // Z3R: coord_mlp.0.bias; otherwise the saved z3
     const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
-    float* __restrict__ dPd, int ld_dpd, float* __restrict__ dx,
+    float* __restrict__ dPd, float* __restrict__ dx,
     float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
@@ -106,6 +120,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
                 "the node phase's tiles must fit the (not yet staged) weight tiles + window buffers");
   __shared__ Bwd16Smem<FE_MAX, NVB> sm;
   wg_clock_start(wg_clock);
+  // (kernel arguments live in scalar registers for the whole launch and this kernel has ~45 of them: what can be derived is --
+  //  every caller's pre-projection / gradient rows are 128 wide, din is the DIN instantiation, ldw follows from it, and the
+  //  z3 recompute's bias shares the slot of the array it replaces.  Two more pointers once cost the listed-tile form 6 us.)
+  constexpr bool Z3R = IS_BWD_Z3R != 0;
+  constexpr int ld_p = 2 * H, ld_dpd = 2 * H, din = DIN;
+  const int ldw = 2 * DIN + 1 + Fe;
+  const float* __restrict__ z3s = Z3R ? nullptr : z3s_or_bc1;
+  const float* __restrict__ bc1 = Z3R ? z3s_or_bc1 : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
@@ -408,37 +430,32 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
         }
       int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
       if (nvalid > 0) {
-        // ---- S0: geometry + upstream coordinate gradient, lane = edge.  S0a: ids and loads; S0b: the arithmetic.  With
-        //      EARLY (= Z3R) the z2 half of E3 and the z3 product run BETWEEN the two: z2v was requested before the source ids
-        //      (vector loads return in order), so it is there when the ids are, and its SiLU + the 64 MFMAs of the z3
-        //      recompute then cover the coordinates' round trip instead of adding to the window's chain ----
-        constexpr bool EARLY = GX && Z3R;
-        const int l16 = lane & (TE16 - 1);
-        const bool valid = l16 < nvalid;
-        // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
-        const int e = min(cb + l16, e_end - 1);
-        const int s = buf_load_i(rs_srcs, e * 4, 0);
-        src_lane = s;
-        int dl;
+        // Two forms of the window's first half, selected by the PREPROCESSOR (see the top of the file): the plain form of rounds
+        // 1 - 2, and the z3-recompute form.
+#if !IS_BWD_Z3R
+        // ---- S0: geometry + upstream coordinate gradient, lane = edge ----
         {
+          // lanes 16..63 mirror lanes 0..15; every load is unconditional (edge index clamped into the tile's range)
+          const int l16 = lane & (TE16 - 1);
+          const bool valid = l16 < nvalid;
+          const int e = min(cb + l16, e_end - 1);
+          const int s = buf_load_i(rs_srcs, e * 4, 0);
+          src_lane = s;
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (sm.rp[mid] <= e) lo = mid; else hi = mid;
           }
-          dl = valid ? lo : 0;
-        }
-        const int v = v0 + dl;
-        if (lane < TE16) sm.e_dl[wave][lane] = dl;
-        float xs0, xs1, xs2, xv0, xv1, xv2;
-        buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
-        buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
-        float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
-        if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
-        float av[FE_MAX];
+          const int dl = valid ? lo : 0;
+          const int v = v0 + dl;
+          float xs0, xs1, xs2, xv0, xv1, xv2;
+          buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
+          buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
+          float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
+          if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
+          float av[FE_MAX];
 #pragma unroll
-        for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
-        auto s0b = [&]() {
+          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
           float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
           float rad = radial3(d0, d1, d2);
           float rr = sqrtf(rad);
@@ -447,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
           float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
           if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
           if (lane < TE16) {
+            sm.e_dl[wave][lane] = dl;
             sm.e_ra[wave][lane * RA_LD] = rad;
             sm.e_r[wave][lane] = rr;
             sm.e_inv[wave][lane] = inv;
@@ -458,8 +476,108 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 #pragma unroll
             for (int f = 0; f < FE_MAX; ++f) sm.e_ra[wave][lane * RA_LD + 1 + f] = valid ? av[f] : 0.0f;
           }
+        }
+        __builtin_amdgcn_wave_barrier();
+        STAMPB(2);
+        // prefetch dL/dh_neigh rows of this tile's destinations: consumed after WG1 + MM3
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = tile16_row(t, q);
+          // rows past nvalid: out of range => zero => dz2 = 0 there
+          const int vo = (row < nvalid) ? ((v0 + sm.e_dl[wave][row]) * H + r) * 4 : BUF_OOB;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) up[t][nt] = buf_load(rs_ghn, vo + nt * 64, 0);      // written by the node phase
+        }
+
+        // ---- E3: coord-MLP tail backward; dz3 -> bufA, mh -> bufB, SiLU'(z2) -> registers ----
+        if constexpr (GX) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int row = tile16_row(t, q);
+            float tt[4], sp[4];
+            float part = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              silu_fg(z3v[t][nt], tt[nt], sp[nt]);
+              part += tt[nt] * wc2_c[nt];
+              float mh;
+              silu_fg(z2v[t][nt], mh, dy[t][nt]);
+              bufB[row * LD + nt * 16 + r] = mh;      // rows past nvalid: SiLU(0) = 0
+            }
+            part = sum_over_r16(part);
+            if (r == 0) sm.e_s[wave][row] = part;
+            const float ds = sm.e_gxd[wave][row];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const float dz3 = ds * wc2_c[nt] * sp[nt];
+              dwc2_a[nt] += ds * tt[nt];
+              dbc1_a[nt] += dz3;
+              bufA[row * LD + nt * 16 + r] = dz3;
+            }
+          }
+        } else {
+          // no gradient arrives at the coordinate branch: dz3 = 0, so only SiLU'(z2) is needed
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              float mh;
+              silu_fg(z2v[t][nt], mh, dy[t][nt]);
+            }
+        }
+#else
+        if constexpr (!GX) {
+          // no coordinate gradient: nothing to recompute -- not instantiated (the launcher routes GX = false to the default build)
+        } else {
+        // ---- S0: geometry + upstream coordinate gradient, lane = edge.  Two forms: the plain one (ids, loads, arithmetic in one
+        //      block), and -- EARLY (= Z3R) -- S0a (ids and loads) / S0b (the arithmetic) with the z2 half of E3 and the z3 product
+        //      BETWEEN the two: z2v was requested before the source ids (vector loads return in order), so it is there when the
+        //      ids are, and its SiLU + the 64 MFMAs of the z3 recompute then cover the coordinates' round trip.  (One shared form
+        //      with the arithmetic in a lambda cost the plain path registers: the listed-tile instantiation 170 -> 183 us.) ----
+
+        float xs0 = 0.f, xs1 = 0.f, xs2 = 0.f, xv0 = 0.f, xv1 = 0.f, xv2 = 0.f, gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+        float av[FE_MAX];
+        int dl_e = 0;
+        bool valid_e = false;
+        {
+          const int l16 = lane & (TE16 - 1);
+          valid_e = l16 < nvalid;
+          const int e = min(cb + l16, e_end - 1);
+          const int s = buf_load_i(rs_srcs, e * 4, 0);
+          src_lane = s;
+          int lo = 0, hi = nv;
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sm.rp[mid] <= e) lo = mid; else hi = mid;
+          }
+          dl_e = valid_e ? lo : 0;
+          const int v = v0 + dl_e;
+          if (lane < TE16) sm.e_dl[wave][lane] = dl_e;
+          buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
+          buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
+          buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
+#pragma unroll
+          for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;
+        }
+        auto s0b = [&]() {      // EARLY only
+          float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
+          float rad = radial3(d0, d1, d2);
+          float rr = sqrtf(rad);
+          float inv = 1.0f / (rr + 1e-30f);
+          const float invdeg = 1.0f / (float)max(sm.rp[dl_e + 1] - sm.rp[dl_e], 1);
+          float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
+          if (!valid_e) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
+          if (lane < TE16) {
+            sm.e_ra[wave][lane * RA_LD] = rad;
+            sm.e_r[wave][lane] = rr;
+            sm.e_inv[wave][lane] = inv;
+            sm.e_d[wave][0][lane] = d0; sm.e_d[wave][1][lane] = d1; sm.e_d[wave][2][lane] = d2;
+            sm.e_gx[wave][0][lane] = g0; sm.e_gx[wave][1][lane] = g1; sm.e_gx[wave][2][lane] = g2;
+            sm.e_gxd[wave][lane] = (g0 * d0 + g1 * d1 + g2 * d2) * inv;
+#pragma unroll
+            for (int f = 0; f < FE_MAX; ++f) sm.e_ra[wave][lane * RA_LD + 1 + f] = valid_e ? av[f] : 0.0f;
+          }
         };
-        if constexpr (!EARLY) s0b();
         __builtin_amdgcn_wave_barrier();
         STAMPB(2);
         // prefetch dL/dh_neigh rows of this tile's destinations: consumed after WG1 + MM3
@@ -532,6 +650,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
               silu_fg(z2v[t][nt], mh, dy[t][nt]);
             }
         }
+        }
+#endif
         // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
 #pragma unroll
         for (int i = 0; i < TE16; ++i)      // one v_readlane + s_mul + buffer_load per row; not consumed before SA
@@ -767,12 +887,55 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_bwd_kernel(
 
 }  // namespace is
 
+#if !IS_BWD_Z3R
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps_bwd(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b), sizeof(long long) * 24) == hipSuccess ? 0 : -5;
 }
 #endif
+#endif
 
+// the launches of this translation unit's form (default build: z3 read back; egnn_layer_bwd_z3r.hip: z3 recomputed, GX only)
+namespace is {
+int launch_layer_bwd_z3r(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
+                         const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                         const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
+                         const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
+                         long long* wg_clock, hipStream_t st);
+int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
+                    const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
+                    const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
+                    const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
+                    long long* wg_clock, hipStream_t st) {
+  const dim3 block(256);
+#define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                       \
+  hipLaunchKernelGGL((is::IS_BWD_KERNEL<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, x, ea, rowptr, srcs, W1, W2, Wc1, \
+                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock)
+#define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
+#if IS_BWD_Z3R
+#define IS_LAUNCH_LB_G(FE, NVB) do { if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, false); } while (0)
+  if (!gx) return -22;
+#else
+#define IS_LAUNCH_LB_G(FE, NVB)                                        \
+  do {                                                                 \
+    if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true);                   \
+    else if (gx) IS_LAUNCH_LB_D(FE, NVB, true, false);                 \
+    else IS_LAUNCH_LB_D(FE, NVB, false, false);                        \
+  } while (0)
+#endif
+  if (Fe <= 1) {
+    if (tiles != nullptr) IS_LAUNCH_LB_G(1, is::NVB_LISTED); else IS_LAUNCH_LB_G(1, is::NV16);
+  } else {
+    IS_LAUNCH_LB_G(8, is::NV16);
+  }
+#undef IS_LAUNCH_LB_G
+#undef IS_LAUNCH_LB_D
+#undef IS_LAUNCH_LB
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+}  // namespace is
+
+#if !IS_BWD_Z3R
 // One EGNNConv layer backward (source gather of the layer above + node data path + edge pass).
 //   edge half: arguments of the forward plus z2s / z3s (saved pre-activations), outputs dZ1 [E,64] / dD [E,3] (per-edge
 //     gradients in CSR slot order, gathered by source by the NEXT call or by is_gather_segment_sum), dPd [N, ld_dpd] and dx
@@ -806,29 +969,16 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
       d_hn == nullptr || (g_psd != nullptr && dh_total == nullptr) || (g_psd == nullptr && g_h == nullptr) ||
       (gather && (g_xout != nullptr || dDn == nullptr || dxn == nullptr || rowptr_src == nullptr || pos_by_src == nullptr ||
                   g_psd == nullptr || gxtot == nullptr)) ||
-      (gx && z3s == nullptr && bc1 == nullptr) || (tiles != nullptr && Fe > 1))
+      (gx && z3s == nullptr && bc1 == nullptr) || (tiles != nullptr && Fe > 1) ||
+      ld_p != 2 * is::H || ld_dpd != 2 * is::H || ldw != 2 * din + 1 + Fe)      // the layouts the kernels are built for
     return -22;
-  const bool z3r = gx && z3s == nullptr;      // z3 was not saved by the forward: recomputed from z2
+  const bool z3r = gx && z3s == nullptr;      // z3 was not saved by the forward: recomputed from z2 (the other translation unit)
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 block(256);
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
-#define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI, ZR)                                                                                           \
-  hipLaunchKernelGGL((is::egnn_layer_bwd_kernel<FE, NVB, GXF, GA, DI, ZR>), dim3(grid), block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, \
-                     W1, ldw, din, W2, Wc1, bc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, ld_dpd, dx, partials, tiles, N, Fe, nb, wg_clock)
-#define IS_LAUNCH_LB_D(FE, NVB, GXF, GA, ZR) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20, ZR); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64, ZR); } while (0)
-#define IS_LAUNCH_LB_G(FE, NVB)                                                                                    \
-  do {                                                                                                             \
-    if (gather) { if (z3r) IS_LAUNCH_LB_D(FE, NVB, true, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, true, false); }   \
-    else if (gx) { if (z3r) IS_LAUNCH_LB_D(FE, NVB, true, false, true); else IS_LAUNCH_LB_D(FE, NVB, true, false, false); } \
-    else IS_LAUNCH_LB_D(FE, NVB, false, false, false);                                                             \
-  } while (0)
-  if (Fe <= 1) {
-    if (tiles != nullptr) IS_LAUNCH_LB_G(1, is::NVB_LISTED); else IS_LAUNCH_LB_G(1, is::NV16);
-  } else {
-    IS_LAUNCH_LB_G(8, is::NV16);
-  }
-#undef IS_LAUNCH_LB_G
-#undef IS_LAUNCH_LB_D
-#undef IS_LAUNCH_LB
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  if (z3r)
+    return is::launch_layer_bwd_z3r(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, bc1, g_xout, dZ1, dD, dPd, dx, partials,
+                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, st);
+  return is::launch_layer_bwd(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, dx, partials,
+                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, st);
 }
+#endif
