@@ -46,6 +46,8 @@ SIGNATURES = {
     "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P, _I, _P],
     "is_chunk_partition": [_P, _I, _I, _I, _P, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
+    "is_adam_prepare": [_P, _P, _P],
+    "is_adam_apply": [_P, _I, _P, _P, _P],
     "is_linear_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "is_linear_dgrad_scratch_floats": [_I, _I, _I],
     "is_linear_fwd_long": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],

@@ -80,3 +80,18 @@ extern "C" int is_adam_step(const void* chunks, int nchunks, float* state, const
   hipLaunchKernelGGL(is::adam_step_kernel, dim3(nchunks), dim3(256), 0, st, static_cast<const is::AdamChunk*>(chunks), state, hyper);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// The same step in parts, for a caller that updates the parameters of one group in SEVERAL launches (the engine: the parameters
+// whose gradients are final early on a side stream beside the tail of the backward pass, the rest at the end): is_adam_prepare
+// advances the step count and derives the step's scalars ONCE, is_adam_apply updates the parameters of a chunk table with them.
+// is_adam_step == is_adam_prepare + is_adam_apply.
+extern "C" int is_adam_prepare(float* state, const float* hyper, void* stream) {
+  hipLaunchKernelGGL(is::adam_prepare_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), state, hyper);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int is_adam_apply(const void* chunks, int nchunks, const float* state, const float* hyper, void* stream) {
+  if (nchunks <= 0) return 0;
+  hipLaunchKernelGGL(is::adam_step_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const is::AdamChunk*>(chunks), state, hyper);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

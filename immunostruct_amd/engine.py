@@ -201,6 +201,9 @@ class CapturedTrainStep:
         self._want_two_stage = reducer.packing and mode != "0"
         self._late = None
         self.dp_times = None
+        # None: not classified yet; False: no overlapped optimizer step; list: the EGNN stack's own parameters
+        # (IMMUNOSTRUCT_ADAM_OVERLAP=1: measured, no gain -- the tail is bandwidth-bound, HISTORY.md -- hence off by default)
+        self._tail_late = None if os.environ.get("IMMUNOSTRUCT_ADAM_OVERLAP", "0") == "1" else False
         snap = _snapshot(model, optimizer) if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -259,7 +262,7 @@ class CapturedTrainStep:
             with torch.cuda.graph(self.graph_a):
                 loss = self._fwd_bwd()
                 if self.fused_optimizer:
-                    self.optimizer.step()
+                    self._optimizer_step()
                     from .functional import Stamps
                     Stamps.mark("optimizer done")
             if not self.fused_optimizer:
@@ -327,16 +330,61 @@ class CapturedTrainStep:
             multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
 
     def _fwd_bwd(self):
+        from . import functional as HF
         from .functional import Stamps
         Stamps.mark("step start")
         self.reducer.zero()
         from .functional import SpeculativeBackward, unit_gradient
-        with SpeculativeBackward():      # the backward below is seeded with the unit gradient
-            loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        overlap = self.fused_optimizer and self._tail_late is not False and hasattr(self.optimizer, "step_overlapped")
+        if overlap and self._tail_late is None:
+            HF.StackBoundary.begin()
+        try:
+            with SpeculativeBackward():      # the backward below is seeded with the unit gradient
+                loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
+        finally:
+            bnd = HF.StackBoundary.end() if (overlap and self._tail_late is None) else None
+        if bnd is not None:
+            # first (eager) step: the parameters that get their gradients from the EGNN stack's tail -- everything else may be
+            # updated beside that tail (False: the model has no such split, plain optimizer step)
+            late = self._stack_only_params(loss, bnd) if bnd else []
+            self._tail_late = late if (late and len(late) < len(self.reducer.params)) else False
         Stamps.mark("loss done")
-        loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
+        HF.TailGate.enabled, HF.TailGate.event = bool(overlap and self._tail_late), None
+        try:
+            loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
+        finally:
+            HF.TailGate.enabled = False
         Stamps.mark("backward done (main stream)")
         return loss.detach()
+
+    def _optimizer_step(self):
+        """single-GPU step: the update of everything but the EGNN stack's own parameters runs on the models' side stream beside the
+        stack backward's tail (functional.TailGate) when IMMUNOSTRUCT_ADAM_OVERLAP=1; default: one launch at the end"""
+        from . import functional as HF
+        gate = HF.TailGate.event
+        HF.TailGate.event = None
+        if self._tail_late and gate is not None:
+            from .models import _core
+            self.optimizer.step_overlapped(self._tail_late, gate, _core._side_stream(self.y.device))
+        else:
+            self.optimizer.step()
+
+    def _stack_only_params(self, loss, bnd):
+        """the parameters reachable from the loss ONLY through the EGNN stack outputs ``bnd`` (autograd graph walk)"""
+        def leaves(roots, stop):
+            seen, todo, out = set(), [r for r in roots if r is not None], set()
+            while todo:
+                fn = todo.pop()
+                if fn in seen or fn in stop:
+                    continue
+                seen.add(fn)
+                if hasattr(fn, "variable"):
+                    out.add(id(fn.variable))
+                todo.extend(f for f, _ in fn.next_functions if f is not None)
+            return out
+        cut = set(t.grad_fn for t in bnd if t.grad_fn is not None)
+        below, above = leaves(list(cut), set()), leaves([loss.grad_fn], cut)
+        return [p for p in self.reducer.params if id(p) in below and id(p) not in above]
 
     # ---- two-stage backward (data-parallel overlap) ---------------------------------
     def _classify(self, loss, bnd):
@@ -412,7 +460,10 @@ class CapturedTrainStep:
             return loss
         loss = self._fwd_bwd()
         self.reducer.all_reduce_mean()
-        self.optimizer.step()
+        if self.fused_optimizer:
+            self._optimizer_step()
+        else:
+            self.optimizer.step()
         return loss
 
     def __call__(self, g, seq, prop, y):

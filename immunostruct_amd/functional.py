@@ -113,6 +113,21 @@ class Stamps:
         return sorted(((v - t0) / 100.0, n) for v, n in zip(vals, cls.names))     # microseconds (100 MHz clock)
 
 
+class TailGate:
+    """Marks, inside the EGNN stack's backward, the point in front of its tail (the batched node weight-gradient launch and the
+    reduction of the partial records: ~110 us in which only the stack's own parameters still wait for their gradients).  The
+    engine waits for this event on its side stream before it applies the optimizer update of every OTHER parameter there -- the
+    bandwidth-bound update then runs beside the tail instead of behind it (engine.CapturedTrainStep, optim.Adam.step_overlapped)."""
+    enabled = False
+    event = None
+
+    @classmethod
+    def mark(cls):
+        if cls.enabled:
+            cls.event = torch.cuda.Event()
+            cls.event.record()
+
+
 class LaunchClock:
     """In-situ duration of the layer-kernel launches (bench.py's roofline): when enabled, every launch of ``is_egnn_layer_fwd`` /
     ``is_egnn_layer_bwd`` / ``is_gather_segment_sum`` gets a [grid, 2] int64 buffer in which its workgroups store the device wall
@@ -672,6 +687,7 @@ class EGNNStackFn(torch.autograd.Function):
                            "is_node_proj_bwd")
             rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
         arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
+        TailGate.mark()
         with KernelTimer.span("egnn_node_wgrad_batched"):
             _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
                        "is_egnn_node_wgrad_batched")

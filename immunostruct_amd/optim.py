@@ -44,7 +44,7 @@ class Adam(torch.optim.Optimizer):
         dev = params[0].device
         gs = self._groups.get(id(group))
         if gs is None:
-            gs = dict(key=None, table=None, hyper_host=None, captured={}, pending=[], spares=[],
+            gs = dict(tables={}, hyper_host=None, captured={}, pending=[], spares={},
                       state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(8, dtype=torch.float32, device=dev))
             self._groups[id(group)] = gs
         return gs
@@ -76,6 +76,50 @@ class Adam(torch.optim.Optimizer):
                              st["exp_avg_sq"].data_ptr() + 4 * off, cnt))
         return torch.from_numpy(np.asarray(rows, dtype=np.int64))
 
+    def _table(self, group, params, capturing):
+        """(group state, device chunk table) for the update of ``params`` (a subset of the group's parameters, each with a
+        gradient); tables are cached per parameter / gradient address set"""
+        _lib.require_device(*params)
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise ValueError("Adam (HIP) needs contiguous fp32 parameters and gradients")
+            st = self.state[p]
+            if not st:
+                if capturing:
+                    raise RuntimeError("optimizer state must exist before a HIP-graph capture: run one eager step first")
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        gs = self._group_state(group, params)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+        if capturing:
+            # gradients produced inside a capture live at fixed addresses of the graph's memory pool.  The step being
+            # captured gets a chunk table of its OWN, kept alive with the optimizer: eager steps before or after never
+            # rebind or overwrite it.  It comes from the spares the last eager step left (memory allocated while
+            # capturing belongs to the graph's pool and may alias a buffer the replayed graph writes earlier in the
+            # step).  Its rows are uploaded by flush_tables() once the capture has ended -- the kernel only reads
+            # them at replay time, so the graph needs no upload node.
+            ent = gs["captured"].get(key)
+            if ent is None:
+                host = self._rows(params)
+                pool = gs["spares"].get(tuple(host.shape), [])
+                if not pool:
+                    raise RuntimeError("the chunk table of a captured step is allocated by an eager step with the same "
+                                       "parameters (and the same split): run one eager step before the HIP-graph capture")
+                ent = pool.pop()
+                gs["captured"][key] = ent
+                gs["pending"].append((ent, host))
+            return gs, ent
+        self._flush_group(gs)
+        table = gs["tables"].get(key)
+        if table is None:
+            if len(gs["tables"]) > 8:
+                gs["tables"].clear()
+            table = gs["tables"][key] = self._rows(params).to(params[0].device)
+        pool = gs["spares"].setdefault(tuple(table.shape), [])
+        while len(pool) < 3:
+            pool.append(torch.empty_like(table))
+        return gs, table
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -88,50 +132,50 @@ class Adam(torch.optim.Optimizer):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            _lib.require_device(*params)
-            for p in params:
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
-                    raise ValueError("Adam (HIP) needs contiguous fp32 parameters and gradients")
-                st = self.state[p]
-                if not st:
-                    if capturing:
-                        raise RuntimeError("optimizer state must exist before a HIP-graph capture: run one eager step first")
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            gs = self._group_state(group, params)
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
-            if capturing:
-                # gradients produced inside a capture live at fixed addresses of the graph's memory pool.  The step being
-                # captured gets a chunk table of its OWN, kept alive with the optimizer: eager steps before or after never
-                # rebind or overwrite it.  It comes from the spares the last eager step left (memory allocated while
-                # capturing belongs to the graph's pool and may alias a buffer the replayed graph writes earlier in the
-                # step).  Its rows are uploaded by flush_tables() once the capture has ended -- the kernel only reads
-                # them at replay time, so the graph needs no upload node.
-                ent = gs["captured"].get(key)
-                if ent is None:
-                    host = self._rows(params)
-                    ent = next((t for t in gs["spares"] if t.shape == host.shape), None)
-                    if ent is None:
-                        raise RuntimeError("the chunk table of a captured step is allocated by an eager step with the same "
-                                           "parameters: run one eager step before the HIP-graph capture")
-                    gs["spares"] = [t for t in gs["spares"] if t is not ent]
-                    gs["captured"][key] = ent
-                    gs["pending"].append((ent, host))
-                table = ent
-            else:
-                self._flush_group(gs)
-                if gs["key"] != key:
-                    gs["table"] = self._rows(params).to(params[0].device)
-                    gs["key"] = key
-                table = gs["table"]
-                gs["spares"] = [t for t in gs["spares"] if t.shape == table.shape]
-                while len(gs["spares"]) < 3:
-                    gs["spares"].append(torch.empty_like(table))
+            gs, table = self._table(group, params, capturing)
             if not capturing:
                 self.refresh_group(group, gs)
             _lib.check(lib.is_adam_step(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
                                         _lib.stream_ptr()), "is_adam_step")
         return loss
+
+    @torch.no_grad()
+    def step_overlapped(self, late, gate, side):
+        """The same update as :meth:`step`, in two launches per group: the parameters NOT in ``late`` on the stream ``side`` as soon
+        as the event ``gate`` has passed (the engine records it in front of the tail of the backward pass: their gradients are
+        final by then, and the bandwidth-bound update then runs BESIDE that tail instead of behind it), the ``late`` ones on the
+        current stream after ``side`` has finished.  Same arithmetic, same step count (advanced once)."""
+        lib = _lib.load()
+        capturing = torch.cuda.is_current_stream_capturing()
+        main = torch.cuda.current_stream()
+        late_ids = set(id(p) for p in late)
+        work = []
+        for group in self.param_groups:
+            early_p = [p for p in group["params"] if p.grad is not None and id(p) not in late_ids]
+            late_p = [p for p in group["params"] if p.grad is not None and id(p) in late_ids]
+            if not early_p and not late_p:
+                continue
+            te = self._table(group, early_p, capturing) if early_p else None
+            tl = self._table(group, late_p, capturing) if late_p else None
+            gs = (te or tl)[0]
+            if not capturing:
+                self.refresh_group(group, gs)
+            work.append((gs, te[1] if te else None, tl[1] if tl else None))
+        # the early gradients come from launches on the main stream in front of ``gate`` (heads, attention tail) or from the side
+        # stream itself (sequence branch): waiting for the gate orders this update behind both -- NOT behind the tail of the
+        # backward pass, which the main stream runs meanwhile
+        with torch.cuda.stream(side):
+            side.wait_event(gate)
+            for gs, te, _ in work:
+                _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+                if te is not None:
+                    _lib.check(lib.is_adam_apply(_lib.ptr(te), int(te.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+                                                 _lib.stream_ptr()), "is_adam_apply")
+        main.wait_stream(side)
+        for gs, _, tl in work:
+            if tl is not None:
+                _lib.check(lib.is_adam_apply(_lib.ptr(tl), int(tl.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+                                             _lib.stream_ptr()), "is_adam_apply")
 
     def refresh_group(self, group, gs):
         hh = self._hyper_host(group)

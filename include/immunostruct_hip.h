@@ -246,6 +246,11 @@ int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld_w, float* 
  * {lr, beta1, beta2, eps, weight_decay, decoupled (AdamW) flag, gradient scale (1 = none), unused}.
  * Capturable in a HIP graph.                                                                                   */
 int is_adam_step(const void* chunks, int nchunks, float* state, const float* hyper, void* stream);
+/* The same step in parts (is_adam_step == is_adam_prepare + is_adam_apply): prepare advances the step count and derives the
+ * step's scalars once; apply updates the parameters of ONE chunk table with them -- for a caller that updates a group's
+ * parameters in several launches (those whose gradients are final early beside the tail of the backward, the rest after it). */
+int is_adam_prepare(float* state, const float* hyper, void* stream);
+int is_adam_apply(const void* chunks, int nchunks, const float* state, const float* hyper, void* stream);
 
 /* Debug aid: one single-thread launch that writes the device wall clock (100 MHz) to *slot; can be captured in a
  * HIP graph to time-stamp points of a replayed step without a profiler attached.                             */
