@@ -29,6 +29,17 @@
 #ifndef IS_BWD_Z3R
 #define IS_BWD_Z3R 0
 #endif
+// IS_LAYER_M1 (build-time, Makefile M1=0|1|2): 1 = the first edge-MLP activation m1 = SiLU(z1) and SiLU'(z1) are READ BACK (two
+// [E, 64] arrays the forward saves), 2 = z1 is read back (one array; the SiLU pair is evaluated here), 0 = z1 is recomputed from
+// gathered Ps rows + the Pd tile + geometry.  The windows of this
+// kernel are issue-bound (HISTORY.md: 64 extra MFMAs cost exactly their issue time), HBM runs at a third of its rate: the
+// recompute's 16 row gathers by source id, the Pd tile, 16 x (3 LDS reads + 3 FMAs + LDS write) and a wave barrier per wave and
+// window are traded for 16 (form 2) or 32 (form 1) coalesced loads.  Measured at B = 128: backward launch 83.2 (0) / 77.2 (1) /
+// 75.0 us (2), forward 48.8 / 52.2 / 50.2 us (its extra stores), step 1.155 / 1.152 / 1.12 ms: form 2 is the default.
+// is_layer_saves_m1() tells the host which form the library was built as.
+#ifndef IS_LAYER_M1
+#define IS_LAYER_M1 2
+#endif
 #if IS_BWD_Z3R
 #define IS_BWD_KERNEL egnn_layer_bwd_z3r_kernel
 #define IS_BWD_LAUNCHER launch_layer_bwd_z3r
@@ -60,11 +71,11 @@ struct Bwd16Smem {
   float wc1t[H * LD];
   float bufA[WB16][TE16 * LD];
   float bufB[WB16][TE16 * LD];
-  float pdt[NVB * H];   // Pd rows of this tile's destination nodes
+  float pdt[IS_LAYER_M1 ? 1 : NVB * H];   // Pd rows of this tile's destination nodes (z1 recompute only)
   int rp[NVB + 1];
   int e_dl[WB16][TE16];
   float e_ra[WB16][TE16 * (FE_MAX + 1)];   // per edge: [radial | edge features]: the B operand of the dw_r / dW_a outer product
-  float wa[FE_MAX > 1 ? FE_MAX * H : 1];   // W_a columns, lane = channel (registers when FE_MAX == 1)
+  float wa[(FE_MAX > 1 && !IS_LAYER_M1) ? FE_MAX * H : 1];   // W_a columns, lane = channel (registers when FE_MAX == 1; z1 recompute only)
   float e_r[WB16][TE16];
   float e_inv[WB16][TE16];
   float e_d[WB16][3][TE16];
@@ -110,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, float* __restrict__ dx,
-    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock) {
+    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock,
+    const float* __restrict__ m1s, const float* __restrict__ dy1s) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
   constexpr int MT = 4, PROWS = 16 * MT, LDP = 132;          // node phase: up to 64 rows (several tiles) per pass
@@ -346,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   load_matrix_lds_t(sm.w2t, W2, tid, 256);
   if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
 
+#if !IS_LAYER_M1
   const float wr_c = W1[lane * ldw + 2 * din];
   // W_a: one register when there is a single edge feature, LDS otherwise (eight more live registers spill this kernel)
   float wa_c = 0.0f;
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       sm.wa[idx] = (f < Fe) ? W1[c * ldw + 2 * din + 1 + f] : 0.0f;
     }
   }
+#endif
   float wc2_c[4], wr_t[4], bc1_c[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -379,8 +393,11 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   // raw-buffer views: scalar bases, one lane-constant byte offset per access pattern, range-checked where rows past a
   // tile's end must read as zero / must not be written (no per-element predication, no 64-bit vector address math)
   const int voff_tile = (4 * q * H + r) * 4;            // element (row 4q [+ t], column r [+ 16 nt]) of a [16][64] tile
+#if !IS_LAYER_M1
   const int ld_p_bytes = ld_p * 4;
-  const rsrc_t rs_ps = make_rsrc(ps), rs_pd = make_rsrc(pd), rs_x = make_rsrc(x), rs_srcs = make_rsrc(srcs);
+  const rsrc_t rs_ps = make_rsrc(ps), rs_pd = make_rsrc(pd);
+#endif
+  const rsrc_t rs_x = make_rsrc(x), rs_srcs = make_rsrc(srcs);
   const rsrc_t rs_ghn = make_rsrc_n(g_hn, N * H * 4);
   const rsrc_t rs_gx = make_rsrc(gxsrc), rs_ea = make_rsrc(ea);
 
@@ -390,11 +407,13 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     const int nv = (tiles != nullptr) ? min(NVB, tiles[2 + tile] - v0) : min(NV16, N - v0);
     __syncthreads();
     if (tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
+#if !IS_LAYER_M1
 #pragma unroll
     for (int i = 0; i < NVB / WB16; ++i) {
       const int nl = wave * (NVB / WB16) + i;
       sm.pdt[nl * H + lane] = (nl < nv) ? buf_load(rs_pd, lane * 4, (v0 + nl) * ld_p_bytes) : 0.0f;
     }
+#endif
     __syncthreads();
     const int e_begin = __builtin_amdgcn_readfirstlane(sm.rp[0]), e_end = __builtin_amdgcn_readfirstlane(sm.rp[nv]);
     // destination-side segment sums as MFMA products with the 0 / 1 incidence of the tile (exact products; fixed order):
@@ -412,7 +431,16 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       STAMPB(1);
       float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
       float up[4][4];   // dL/dh_neigh[dst] for this tile (prefetched)
+#if IS_LAYER_M1 == 1
+      float m1v[4][4], d1v[4][4];      // saved m1 = SiLU(z1) and SiLU'(z1) of this tile (prefetched where the gathers were)
+      const rsrc_t rm1 = make_rsrc_n(m1s + (size_t)cb * H, nvalid * H * 4);
+      const rsrc_t rd1 = make_rsrc_n(dy1s + (size_t)cb * H, nvalid * H * 4);
+#elif IS_LAYER_M1 == 2
+      float m1v[4][4];                 // saved z1 of this tile (prefetched where the gathers were)
+      const rsrc_t rm1 = make_rsrc_n(m1s + (size_t)cb * H, nvalid * H * 4);
+#else
       float gth[TE16];  // Ps[src] gathers for the z1 recompute (prefetched; Pd[dst] comes from the LDS tile)
+#endif
       // the saved pre-activation tiles only depend on the window position: issue their loads first so that
       // they are in flight during S0's dependent (src index -> coordinates) chain
       float z3v[4][4], z2v[4][4];
@@ -652,10 +680,23 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
         }
         }
 #endif
+#if IS_LAYER_M1
+        // prefetch the saved first activation (tile layout, rows past nvalid read as 0): in flight during WG1 + MM3
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            m1v[t][nt] = buf_load(rm1, vt + (t * H + nt * 16) * 4, 0);
+#if IS_LAYER_M1 == 1
+            d1v[t][nt] = buf_load(rd1, vt + (t * H + nt * 16) * 4, 0);
+#endif
+          }
+#else
         // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
 #pragma unroll
         for (int i = 0; i < TE16; ++i)      // one v_readlane + s_mul + buffer_load per row; not consumed before SA
           gth[i] = buf_load(rs_ps, lane * 4, __builtin_amdgcn_readlane(src_lane, i) * ld_p_bytes);
+#endif
       }
       if constexpr (GX) {
         STAMPB(3);
@@ -695,6 +736,26 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) bufA[tile16_row(t, q) * LD + nt * 16 + r] = dy[t][nt];   // dz2
 
+#if IS_LAYER_M1 == 1
+        // ---- E1: m1 -> bufB, SiLU'(z1) -> registers (both read back) ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            bufB[tile16_row(t, q) * LD + nt * 16 + r] = m1v[t][nt];
+            dy[t][nt] = d1v[t][nt];
+          }
+#elif IS_LAYER_M1 == 2
+        // ---- E1: m1 = SiLU(z1) -> bufB, SiLU'(z1) -> registers, from the z1 read back (rows past nvalid: z1 = 0 -> m1 = 0) ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            float y;
+            silu_fg(m1v[t][nt], y, dy[t][nt]);
+            bufB[tile16_row(t, q) * LD + nt * 16 + r] = y;
+          }
+#else
         // ---- SA: recompute z1 (lane = channel) -> bufB ----
         {
 #pragma unroll
@@ -723,6 +784,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
             bufB[row * LD + nt * 16 + r] = y;
           }
         }
+#endif
       }
       STAMPB(7);
       __syncthreads();   // every wave's dz2 / m1 tiles are staged
@@ -901,16 +963,16 @@ int launch_layer_bwd_z3r(const float* ps, const float* pd, const float* x, const
                          const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                          const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
                          const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
-                         long long* wg_clock, hipStream_t st);
+                         long long* wg_clock, const float* m1s, const float* dy1s, hipStream_t st);
 int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
                     const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                     const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
                     const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
-                    long long* wg_clock, hipStream_t st) {
+                    long long* wg_clock, const float* m1s, const float* dy1s, hipStream_t st) {
   const dim3 block(256);
 #define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                       \
   hipLaunchKernelGGL((is::IS_BWD_KERNEL<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, x, ea, rowptr, srcs, W1, W2, Wc1, \
-                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock)
+                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock, m1s, dy1s)
 #define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
 #if IS_BWD_Z3R
 #define IS_LAUNCH_LB_G(FE, NVB) do { if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, false); } while (0)
@@ -949,6 +1011,8 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
 //     index; the kernel then completes g_psd[:, :64] = gather(dZ1n) (written: the weight-gradient kernel reads it) and uses
 //     dxn + gather(dDn) (written to gxtot [N,3], scratch) as the coordinate gradient; g_xout must be NULL.  Otherwise g_xout [N,3] (or NULL: no coordinate
 //     gradient; the coordinate-MLP half of the pass is skipped, z3s / Wc1 / wc2 are not read).
+//   m1s / dy1s [E, 64]: the first edge-MLP activation SiLU(z1) and SiLU'(z1) saved by is_egnn_layer_fwd -- read when the library
+//     was built with IS_LAYER_M1 = 1 (is_layer_saves_m1()), ignored otherwise.
 //   wg_clock: NULL, or [grid][2] int64 -- every workgroup's start / end device wall clock (bench.py's in-situ launch timing).
 //   z3s == NULL with a coordinate gradient: the forward did not save z3; it is recomputed per tile as SiLU(z2) Wc1^T + bc1
 //     (bc1 = coord_mlp.0.bias, required then).
@@ -960,9 +1024,10 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                                  const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
-                                 long long* wg_clock, void* stream) {
+                                 long long* wg_clock, const float* m1s, const float* dy1s, void* stream) {
   if (N <= 0) return 0;
   if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
+  if ((IS_LAYER_M1 != 0 && m1s == nullptr) || (IS_LAYER_M1 == 1 && dy1s == nullptr)) return -22;      // this build reads them
   const bool gather = dZ1n != nullptr;
   const bool gx = gather || g_xout != nullptr;
   if (Fe < 0 || Fe > 8 || grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||
@@ -977,8 +1042,12 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
   if (z3r)
     return is::launch_layer_bwd_z3r(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, bc1, g_xout, dZ1, dD, dPd, dx, partials,
-                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, st);
+                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, st);
   return is::launch_layer_bwd(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, dx, partials,
-                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, st);
+                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, st);
 }
+
+// 1: this library's is_egnn_layer_bwd reads the first edge-MLP activation from m1s / dy1s (the caller lets is_egnn_layer_fwd save
+// them); 0: it recomputes it (m1s / dy1s ignored, the forward need not save them).  Build-time choice (Makefile M1=...).
+extern "C" int is_layer_saves_m1(void) { return IS_LAYER_M1; }
 #endif

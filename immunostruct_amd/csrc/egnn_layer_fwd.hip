@@ -73,7 +73,7 @@ struct FwdRows {     // prefetched operands of one tile
 };
 
 struct FwdBufs {
-  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3;
+  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3, m1, d1;
 };
 
 __device__ __forceinline__ int tile_start(int cb, int e1) { return (cb + TE16 <= e1) ? cb : max(e1 - TE16, 0); }
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     float* __restrict__ z2s, float* __restrict__ z3s, int E, int Fe,
     const float* __restrict__ h, int ld_h, const float* __restrict__ bn1, const float* __restrict__ bn2,
     const float* __restrict__ b0n, const float* __restrict__ b1n, const float* __restrict__ fpack,
-    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, long long* __restrict__ wg_clock) {
+    float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, long long* __restrict__ wg_clock,
+    float* __restrict__ m1s, float* __restrict__ dy1s) {
   __shared__ Fwd3Smem<FE_MAX> sm;
   wg_clock_start(wg_clock);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,6 +142,9 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   int stamp_k = 2;
 #endif
   const bool save3 = SAVE && COORD && z3s != nullptr;      // kernel-uniform: z3 is saved only for a backward that does not recompute it
+  // kernel-uniform: the first edge-MLP activation m1 = SiLU(z1) and its derivative are saved for a backward that reads them
+  // back instead of recomputing z1 from gathered rows (the backward's windows are issue-bound: HBM has room, the SIMDs do not)
+  const bool save1 = SAVE && m1s != nullptr;
 
   // ---- chunk of this wave ----
   const int c = blockIdx.x * W3 + wave;
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   FwdBufs B;
   B.ps = make_rsrc(ps); B.pd = make_rsrc(pd); B.x = make_rsrc(x); B.srcs = make_rsrc(srcs); B.dsts = make_rsrc(dsts);
   B.ea = make_rsrc(ea); B.hn = make_rsrc(h_neigh); B.z2 = make_rsrc(z2s); B.z3 = make_rsrc(z3s != nullptr ? z3s : z2s);
+  B.m1 = make_rsrc(m1s != nullptr ? m1s : z2s); B.d1 = make_rsrc(dy1s != nullptr ? dy1s : z2s);
   const int ld_p_bytes = ld_p * 4, ld_hn_bytes = ld_hn * 4;
 
   // first index / row loads are in flight while the weights are staged
@@ -251,6 +256,23 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       for (int i = 0; i < TE16; ++i) ex[i] = __expf(-z[i]);
 #pragma unroll
       for (int i = 0; i < TE16; ++i) ex[i] = rcp_f(1.0f + ex[i]);
+      if (save1) {
+        // rows in slot order, lane = channel: one coalesced 256-byte row per store.  dy1s != NULL: m1 = SiLU(z1) and
+        // SiLU'(z1) = sigma + m1 (1 - sigma) (two arrays, nothing left to evaluate in the backward); dy1s == NULL: z1 itself
+        // (one array: the backward evaluates the SiLU pair but no longer gathers / recomputes z1)
+        const int row_base = ts * (H * 4);
+        if (dy1s != nullptr) {
+#pragma unroll
+          for (int i = 0; i < TE16; ++i) {
+            const float y = z[i] * ex[i];
+            buf_store(y, B.m1, lane * 4, row_base + i * (H * 4));
+            buf_store(__builtin_fmaf(y, 1.0f - ex[i], ex[i]), B.d1, lane * 4, row_base + i * (H * 4));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TE16; ++i) buf_store(z[i], B.m1, lane * 4, row_base + i * (H * 4));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TE16; ++i) act[i * LD + lane] = z[i] * ex[i];
     }
@@ -461,7 +483,9 @@ extern "C" int is_debug_stamps3(long long* out) {
 // (z3s unused); z2s == NULL: nothing is saved for a backward pass (z3s, zn1 unused); z3s == NULL with z2s: the coordinate
 // MLP's pre-activation is not saved (is_egnn_layer_bwd recomputes it from z2); psd_next == NULL: no next
 // projection (b0n / b1n unused); b0n may be NULL.  wg_clock: NULL, or [nchunks / 4][2] int64 -- every workgroup's start / end
-// device wall clock (common.h wg_clock_start / _end; bench.py's in-situ launch timing).
+// device wall clock (common.h wg_clock_start / _end; bench.py's in-situ launch timing).  m1s / dy1s [max(E,16), 64]: NULL, or out: the
+// first edge-MLP activation SiLU(z1) and SiLU'(z1) per edge slot -- or, with dy1s == NULL, the pre-activation z1 in m1s -- for a
+// backward built to read them (is_layer_saves_m1(): 1 = both arrays, 2 = z1 only).
 extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                  const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                                  const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
@@ -469,12 +493,13 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
                                  const float* wc2, float* h_neigh, int ld_hn, float* x_out, float* z2s,
                                  float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
                                  const float* bn2, const float* b0n, const float* b1n, const float* fpack,
-                                 float* zn1, float* h_out, float* psd_next, long long* wg_clock, void* stream) {
+                                 float* zn1, float* h_out, float* psd_next, long long* wg_clock, float* m1s, float* dy1s,
+                                 void* stream) {
   if (N <= 0) return 0;
   const bool coord = x_out != nullptr;
   const bool save = z2s != nullptr;
   if (nchunks <= 0 || (nchunks % is::W3) != 0 || Fe < 0 || Fe > 8 || (din != 20 && din != 64) || fpack == nullptr || h == nullptr ||
-      h_out == nullptr || (save && zn1 == nullptr) || (psd_next != nullptr && b1n == nullptr))
+      h_out == nullptr || (save && zn1 == nullptr) || (psd_next != nullptr && b1n == nullptr) || (m1s == nullptr && dy1s != nullptr))
     return -22;
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
   const long long lim = 0x7fffffffLL;
@@ -485,7 +510,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
 #define IS_LAUNCH_LF(FE, SV, CO, DI)                                                                                           \
   hipLaunchKernelGGL((is::egnn_layer_fwd_kernel<FE, SV, CO, DI>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe, h, ld_h, \
-                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next, wg_clock)
+                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next, wg_clock, m1s, dy1s)
 #define IS_LAUNCH_LF_D(FE, SV, CO) do { if (din == 20) IS_LAUNCH_LF(FE, SV, CO, 20); else IS_LAUNCH_LF(FE, SV, CO, 64); } while (0)
 #define IS_LAUNCH_LF_C(FE, SV) do { if (coord) IS_LAUNCH_LF_D(FE, SV, true); else IS_LAUNCH_LF_D(FE, SV, false); } while (0)
   if (Fe <= 1) { if (save) IS_LAUNCH_LF_C(1, true); else IS_LAUNCH_LF_C(1, false); }
