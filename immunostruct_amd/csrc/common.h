@@ -291,6 +291,9 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t rs, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_store(float v, rsrc_t rs, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
 }

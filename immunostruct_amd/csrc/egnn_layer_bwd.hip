@@ -40,6 +40,15 @@
 #ifndef IS_LAYER_M1
 #define IS_LAYER_M1 2
 #endif
+// IS_LAYER_GEO (build-time, Makefile GEO=0|1; needs M1 != 0): 1 = the edge geometry (x_src - x_dst, |.|^2) is READ BACK from a
+// [E, 4] array the forward saves instead of recomputed from the two endpoints' coordinates: the window's first dependent chain
+// (source id -> coordinates) disappears -- with z1 read back nothing in the edge phase needs the source id any more.
+#ifndef IS_LAYER_GEO
+#define IS_LAYER_GEO 1
+#endif
+#if IS_LAYER_GEO && !IS_LAYER_M1
+#error "IS_LAYER_GEO needs IS_LAYER_M1 != 0 (the z1 recompute gathers by source id)"
+#endif
 #if IS_BWD_Z3R
 #define IS_BWD_KERNEL egnn_layer_bwd_z3r_kernel
 #define IS_BWD_LAUNCHER launch_layer_bwd_z3r
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, float* __restrict__ dx,
     float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock,
-    const float* __restrict__ m1s, const float* __restrict__ dy1s) {
+    const float* __restrict__ m1s, const float* __restrict__ dy1s, const float* __restrict__ geos) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
   constexpr int MT = 4, PROWS = 16 * MT, LDP = 132;          // node phase: up to 64 rows (several tiles) per pass
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   //  every caller's pre-projection / gradient rows are 128 wide, din is the DIN instantiation, ldw follows from it, and the
   //  z3 recompute's bias shares the slot of the array it replaces.  Two more pointers once cost the listed-tile form 6 us.)
   constexpr bool Z3R = IS_BWD_Z3R != 0;
-  constexpr int ld_p = 2 * H, ld_dpd = 2 * H, din = DIN;
+  [[maybe_unused]] constexpr int ld_p = 2 * H;
+  constexpr int ld_dpd = 2 * H, din = DIN;
   const int ldw = 2 * DIN + 1 + Fe;
   const float* __restrict__ z3s = Z3R ? nullptr : z3s_or_bc1;
   const float* __restrict__ bc1 = Z3R ? z3s_or_bc1 : nullptr;
@@ -397,7 +407,11 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   const int ld_p_bytes = ld_p * 4;
   const rsrc_t rs_ps = make_rsrc(ps), rs_pd = make_rsrc(pd);
 #endif
+#if IS_LAYER_GEO
+  const rsrc_t rs_geo = make_rsrc(geos);
+#else
   const rsrc_t rs_x = make_rsrc(x), rs_srcs = make_rsrc(srcs);
+#endif
   const rsrc_t rs_ghn = make_rsrc_n(g_hn, N * H * 4);
   const rsrc_t rs_gx = make_rsrc(gxsrc), rs_ea = make_rsrc(ea);
 
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           if constexpr (GX && !Z3R) z3v[t][nt] = buf_load(rz3, vt + (t * H + nt * 16) * 4, 0);
           z2v[t][nt] = buf_load(rz2, vt + (t * H + nt * 16) * 4, 0);
         }
-      int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
+      [[maybe_unused]] int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
       if (nvalid > 0) {
         // Two forms of the window's first half, selected by the PREPROCESSOR (see the top of the file): the plain form of rounds
         // 1 - 2, and the z3-recompute form.
@@ -467,8 +481,12 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           const int l16 = lane & (TE16 - 1);
           const bool valid = l16 < nvalid;
           const int e = min(cb + l16, e_end - 1);
+#if IS_LAYER_GEO
+          const f32x4 geo = buf_load4(rs_geo, e * 16, 0);      // (x_src - x_dst, |.|^2) as the forward formed them
+#else
           const int s = buf_load_i(rs_srcs, e * 4, 0);
           src_lane = s;
+#endif
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -476,16 +494,23 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           }
           const int dl = valid ? lo : 0;
           const int v = v0 + dl;
+#if !IS_LAYER_GEO
           float xs0, xs1, xs2, xv0, xv1, xv2;
           buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
           buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
+#endif
           float gx0 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;      // GX = false: the layer's coordinate output has no gradient
           if constexpr (GX) buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
           float av[FE_MAX];
 #pragma unroll
           for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;      // Fe is kernel-uniform
+#if IS_LAYER_GEO
+          float d0 = geo[0], d1 = geo[1], d2 = geo[2];
+          float rad = geo[3];
+#else
           float d0 = xs0 - xv0, d1 = xs1 - xv1, d2 = xs2 - xv2;
           float rad = radial3(d0, d1, d2);
+#endif
           float rr = sqrtf(rad);
           float inv = 1.0f / (rr + 1e-30f);
           const float invdeg = 1.0f / (float)max(sm.rp[dl + 1] - sm.rp[dl], 1);
@@ -571,8 +596,13 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           const int l16 = lane & (TE16 - 1);
           valid_e = l16 < nvalid;
           const int e = min(cb + l16, e_end - 1);
+#if IS_LAYER_GEO
+          const f32x4 geo = buf_load4(rs_geo, e * 16, 0);
+          xs0 = geo[0]; xs1 = geo[1]; xs2 = geo[2];      // (x_src - x_dst as saved; xv stays 0: s0b forms xs - xv)
+#else
           const int s = buf_load_i(rs_srcs, e * 4, 0);
           src_lane = s;
+#endif
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -581,8 +611,10 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           dl_e = valid_e ? lo : 0;
           const int v = v0 + dl_e;
           if (lane < TE16) sm.e_dl[wave][lane] = dl_e;
+#if !IS_LAYER_GEO
           buf_load3(rs_x, s * 12, 0, xs0, xs1, xs2);
           buf_load3(rs_x, v * 12, 0, xv0, xv1, xv2);
+#endif
           buf_load3(rs_gx, v * 12, 0, gx0, gx1, gx2);
 #pragma unroll
           for (int f = 0; f < FE_MAX; ++f) av[f] = (f < Fe) ? buf_load(rs_ea, (e * Fe + f) * 4, 0) : 0.0f;
@@ -963,16 +995,16 @@ int launch_layer_bwd_z3r(const float* ps, const float* pd, const float* x, const
                          const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                          const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
                          const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
-                         long long* wg_clock, const float* m1s, const float* dy1s, hipStream_t st);
+                         long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, hipStream_t st);
 int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
                     const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                     const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
                     const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
-                    long long* wg_clock, const float* m1s, const float* dy1s, hipStream_t st) {
+                    long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, hipStream_t st) {
   const dim3 block(256);
 #define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                       \
   hipLaunchKernelGGL((is::IS_BWD_KERNEL<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, x, ea, rowptr, srcs, W1, W2, Wc1, \
-                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock, m1s, dy1s)
+                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock, m1s, dy1s, geos)
 #define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
 #if IS_BWD_Z3R
 #define IS_LAUNCH_LB_G(FE, NVB) do { if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, false); } while (0)
@@ -1013,6 +1045,8 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
 //     gradient; the coordinate-MLP half of the pass is skipped, z3s / Wc1 / wc2 are not read).
 //   m1s / dy1s [E, 64]: the first edge-MLP activation SiLU(z1) and SiLU'(z1) saved by is_egnn_layer_fwd -- read when the library
 //     was built with IS_LAYER_M1 = 1 (is_layer_saves_m1()), ignored otherwise.
+//   geos [E, 4]: (x_src - x_dst, |x_src - x_dst|^2) per edge slot saved by is_egnn_layer_fwd -- read when the library was built with
+//     IS_LAYER_GEO = 1 (is_layer_saves_geo()), ignored otherwise.
 //   wg_clock: NULL, or [grid][2] int64 -- every workgroup's start / end device wall clock (bench.py's in-situ launch timing).
 //   z3s == NULL with a coordinate gradient: the forward did not save z3; it is recomputed per tile as SiLU(z2) Wc1^T + bc1
 //     (bc1 = coord_mlp.0.bias, required then).
@@ -1024,10 +1058,11 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                                  const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
-                                 long long* wg_clock, const float* m1s, const float* dy1s, void* stream) {
+                                 long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream) {
   if (N <= 0) return 0;
   if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
-  if ((IS_LAYER_M1 != 0 && m1s == nullptr) || (IS_LAYER_M1 == 1 && dy1s == nullptr)) return -22;      // this build reads them
+  if ((IS_LAYER_M1 != 0 && m1s == nullptr) || (IS_LAYER_M1 == 1 && dy1s == nullptr) || (IS_LAYER_GEO && geos == nullptr))
+    return -22;      // this build reads them
   const bool gather = dZ1n != nullptr;
   const bool gx = gather || g_xout != nullptr;
   if (Fe < 0 || Fe > 8 || grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||
@@ -1042,10 +1077,13 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
   if (z3r)
     return is::launch_layer_bwd_z3r(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, bc1, g_xout, dZ1, dD, dPd, dx, partials,
-                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, st);
+                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
   return is::launch_layer_bwd(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, dx, partials,
-                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, st);
+                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
 }
+
+// 1: this library's is_egnn_layer_bwd reads the edge geometry from geos (filled by is_egnn_layer_fwd); 0: it recomputes it.
+extern "C" int is_layer_saves_geo(void) { return IS_LAYER_GEO; }
 
 // 1: this library's is_egnn_layer_bwd reads the first edge-MLP activation from m1s / dy1s (the caller lets is_egnn_layer_fwd save
 // them); 0: it recomputes it (m1s / dy1s ignored, the forward need not save them).  Build-time choice (Makefile M1=...).

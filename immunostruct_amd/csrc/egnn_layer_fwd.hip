@@ -73,7 +73,7 @@ struct FwdRows {     // prefetched operands of one tile
 };
 
 struct FwdBufs {
-  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3, m1, d1;
+  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3, m1, d1, geo;
 };
 
 __device__ __forceinline__ int tile_start(int cb, int e1) { return (cb + TE16 <= e1) ? cb : max(e1 - TE16, 0); }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     const float* __restrict__ h, int ld_h, const float* __restrict__ bn1, const float* __restrict__ bn2,
     const float* __restrict__ b0n, const float* __restrict__ b1n, const float* __restrict__ fpack,
     float* __restrict__ zn1, float* __restrict__ h_out, float* __restrict__ psd_next, long long* __restrict__ wg_clock,
-    float* __restrict__ m1s, float* __restrict__ dy1s) {
+    float* __restrict__ m1s, float* __restrict__ dy1s, float* __restrict__ geos) {
   __shared__ Fwd3Smem<FE_MAX> sm;
   wg_clock_start(wg_clock);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   B.ps = make_rsrc(ps); B.pd = make_rsrc(pd); B.x = make_rsrc(x); B.srcs = make_rsrc(srcs); B.dsts = make_rsrc(dsts);
   B.ea = make_rsrc(ea); B.hn = make_rsrc(h_neigh); B.z2 = make_rsrc(z2s); B.z3 = make_rsrc(z3s != nullptr ? z3s : z2s);
   B.m1 = make_rsrc(m1s != nullptr ? m1s : z2s); B.d1 = make_rsrc(dy1s != nullptr ? dy1s : z2s);
+  B.geo = make_rsrc(geos != nullptr ? geos : z2s);
+  const bool save_geo = SAVE && geos != nullptr;      // kernel-uniform: (x_src - x_dst, |.|^2) per edge slot, for the backward
   const int ld_p_bytes = ld_p * 4, ld_hn_bytes = ld_hn * 4;
 
   // first index / row loads are in flight while the weights are staged
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       const float d0 = r0.xs[0] - r0.xd[0], d1 = r0.xs[1] - r0.xd[1], d2 = r0.xs[2] - r0.xd[2];
       const float rad = radial3(d0, d1, d2);
       const float inv = 1.0f / (sqrtf(rad) + 1e-30f);
+      if (save_geo) buf_store4(f32x4{d0, d1, d2, rad}, B.geo, lane * 16, ts * 16);
       sm.e_rad[wave][lane] = rad;
       sm.e_xd[wave][0][lane] = d0 * inv;
       sm.e_xd[wave][1][lane] = d1 * inv;
@@ -485,7 +488,8 @@ extern "C" int is_debug_stamps3(long long* out) {
 // projection (b0n / b1n unused); b0n may be NULL.  wg_clock: NULL, or [nchunks / 4][2] int64 -- every workgroup's start / end
 // device wall clock (common.h wg_clock_start / _end; bench.py's in-situ launch timing).  m1s / dy1s [max(E,16), 64]: NULL, or out: the
 // first edge-MLP activation SiLU(z1) and SiLU'(z1) per edge slot -- or, with dy1s == NULL, the pre-activation z1 in m1s -- for a
-// backward built to read them (is_layer_saves_m1(): 1 = both arrays, 2 = z1 only).
+// backward built to read them (is_layer_saves_m1(): 1 = both arrays, 2 = z1 only).  geos [max(E,16), 4]: NULL, or out: (x_src - x_dst,
+// |x_src - x_dst|^2) per edge slot, for a backward built to read it (is_layer_saves_geo()).
 extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                  const int32_t* rowptr, const int32_t* srcs, const int32_t* dsts,
                                  const int32_t* chunk_ptr, int nchunks, const float* W1, int ldw, int din,
@@ -494,7 +498,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
                                  float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
                                  const float* bn2, const float* b0n, const float* b1n, const float* fpack,
                                  float* zn1, float* h_out, float* psd_next, long long* wg_clock, float* m1s, float* dy1s,
-                                 void* stream) {
+                                 float* geos, void* stream) {
   if (N <= 0) return 0;
   const bool coord = x_out != nullptr;
   const bool save = z2s != nullptr;
@@ -510,7 +514,7 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
 #define IS_LAUNCH_LF(FE, SV, CO, DI)                                                                                           \
   hipLaunchKernelGGL((is::egnn_layer_fwd_kernel<FE, SV, CO, DI>), grid, block, 0, st, ps, pd, ld_p, x, ea, rowptr, srcs, dsts, \
                      chunk_ptr, nchunks, W1, ldw, din, W2, b2, Wc1, bc1, wc2, h_neigh, ld_hn, x_out, z2s, z3s, E, Fe, h, ld_h, \
-                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next, wg_clock, m1s, dy1s)
+                     bn1, bn2, b0n, b1n, fpack, zn1, h_out, psd_next, wg_clock, m1s, dy1s, geos)
 #define IS_LAUNCH_LF_D(FE, SV, CO) do { if (din == 20) IS_LAUNCH_LF(FE, SV, CO, 20); else IS_LAUNCH_LF(FE, SV, CO, 64); } while (0)
 #define IS_LAUNCH_LF_C(FE, SV) do { if (coord) IS_LAUNCH_LF_D(FE, SV, true); else IS_LAUNCH_LF_D(FE, SV, false); } while (0)
   if (Fe <= 1) { if (save) IS_LAUNCH_LF_C(1, true); else IS_LAUNCH_LF_C(1, false); }

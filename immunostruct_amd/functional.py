@@ -490,6 +490,7 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
         save_m1 = int(lib.is_layer_saves_m1()) if need_grad else 0      # 1: SiLU(z1) + SiLU'(z1); 2: z1 only
         m1s = torch.empty(max(e, 16), HIDDEN, **f32) if save_m1 else None
         dy1s = torch.empty(max(e, 16), HIDDEN, **f32) if save_m1 == 1 else None
+        geos = torch.empty(max(e, 16), 4, **f32) if (need_grad and lib.is_layer_saves_geo()) else None
         zn1 = torch.empty(n, HIDDEN, **f32) if need_grad else None
         h_out = torch.empty(n, HIDDEN, **f32)
         emit = (not last) or head is not None
@@ -505,8 +506,8 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
             _lib.ptr(W1), ldw, din, _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2),
             _lib.ptr(h_neigh), HIDDEN, _lib.ptr(x_out), _lib.ptr(z2s), _lib.ptr(z3s), n, e, fe,
             _lib.ptr(h_in), ld_h, _lib.ptr(bn1), _lib.ptr(bn2), _lib.ptr(b0n), _lib.ptr(b1n), _lib.ptr(packs[i, 0]),
-            _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), _lib.ptr(clk), _lib.ptr(m1s), _lib.ptr(dy1s), st), "is_egnn_layer_fwd"))
-        layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, m1s=m1s, dy1s=dy1s, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
+            _lib.ptr(zn1), _lib.ptr(h_out), _lib.ptr(psd_next), _lib.ptr(clk), _lib.ptr(m1s), _lib.ptr(dy1s), _lib.ptr(geos), st), "is_egnn_layer_fwd"))
+        layers.append(dict(psd=psd, x=x, z2s=z2s, z3s=z3s, m1s=m1s, dy1s=dy1s, geos=geos, h_neigh=h_neigh, zn1=zn1, h_in=h_in, ld_h=ld_h, din=din,
                            h_out=h_out))
         psd, x, h_in, ld_h, din = psd_next, x_out, h_out, HIDDEN, HIDDEN
         if after is not None and after[0] == i:
@@ -648,7 +649,7 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.ptr(dZ1n), _lib.ptr(dDn), _lib.ptr(dxn), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
                     _lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["zn1"]), _lib.ptr(ctx.packs[i, 1]),
                     _lib.ptr(dh_total) if has_psd else None, _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), _lib.ptr(gxtot),
-                    _lib.ptr(clk), _lib.ptr(lay["m1s"]), _lib.ptr(lay["dy1s"]), st),
+                    _lib.ptr(clk), _lib.ptr(lay["m1s"]), _lib.ptr(lay["dy1s"]), _lib.ptr(lay["geos"]), st),
                 "is_egnn_layer_bwd"))
             pw = torch.empty(grid_w * wg_stride, **f32)
             keep.extend([dh_total, dzn1, g_psd_next, g_hd, pw, part_e, d_hn, above, gxtot])

@@ -102,7 +102,7 @@ int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, const float* x
                       float* z3s, int N, int E, int Fe, const float* h, int ld_h, const float* bn1,
                       const float* bn2, const float* b0n, const float* b1n, const float* fpack,
                       float* zn1, float* h_out, float* psd_next, long long* wg_clock, float* m1s, float* dy1s,
-                      void* stream);
+                      float* geos, void* stream);
 int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                       const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                       const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
@@ -111,12 +111,15 @@ int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x
                       const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                       const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                       const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
-                      long long* wg_clock, const float* m1s, const float* dy1s, void* stream);
+                      long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream);
 /* How this library's backward layer kernel gets the first edge-MLP activation (a build-time choice, csrc/Makefile M1=0|1|2):
  * 2 (default): it READS the pre-activation z1 from m1s [max(E,16), 64] -- pass the same array to is_egnn_layer_fwd, which fills
  * it (dy1s = NULL in both calls); 1: it reads m1 = SiLU(z1) from m1s and SiLU'(z1) from dy1s (both filled by the forward);
  * 0: it recomputes z1 from gathered rows (m1s / dy1s may be NULL).  The backward's windows are issue-bound, HBM is not.   */
 int is_layer_saves_m1(void);
+/* 1 (default build, csrc/Makefile GEO=0|1): the backward layer kernel READS the edge geometry (x_src - x_dst, |.|^2) from geos
+ * [max(E,16), 4], which is_egnn_layer_fwd fills (pass the same array to both); 0: it recomputes it from the coordinates.  */
+int is_layer_saves_geo(void);
 
 /* Node pre-projection on its own (any caller of a 128-wide two-bias projection of 64-wide rows: with W1 = [Wq | Wk]
  * it is the fused query/key projection of the node attention, models/layers.py:13-16,68) and its backward:
