@@ -57,6 +57,7 @@ struct Fwd3Smem {
   float e_xd[W3][3][TE16];
   float e_s[W3][TE16];
   float e_a[W3][FE_MAX][TE16];
+  float e_xdst[W3][3][TE16];      // the tile's destination coordinates (the coordinate update's base, read at the flush points)
 };
 
 template <int FE_MAX>
@@ -73,7 +74,7 @@ struct FwdRows {     // prefetched operands of one tile
 };
 
 struct FwdBufs {
-  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3, m1, d1, geo;
+  rsrc_t ps, pd, x, srcs, dsts, ea, hn, z2, z3, m1, d1, geo, xo;
 };
 
 __device__ __forceinline__ int tile_start(int cb, int e1) { return (cb + TE16 <= e1) ? cb : max(e1 - TE16, 0); }
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   B.ea = make_rsrc(ea); B.hn = make_rsrc(h_neigh); B.z2 = make_rsrc(z2s); B.z3 = make_rsrc(z3s != nullptr ? z3s : z2s);
   B.m1 = make_rsrc(m1s != nullptr ? m1s : z2s); B.d1 = make_rsrc(dy1s != nullptr ? dy1s : z2s);
   B.geo = make_rsrc(geos != nullptr ? geos : z2s);
+  B.xo = make_rsrc(x_out != nullptr ? x_out : h_neigh);
   const bool save_geo = SAVE && geos != nullptr;      // kernel-uniform: (x_src - x_dst, |.|^2) per edge slot, for the backward
   const int ld_p_bytes = ld_p * 4, ld_hn_bytes = ld_hn * 4;
 
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       const float inv = 1.0f / (sqrtf(rad) + 1e-30f);
       if (save_geo) buf_store4(f32x4{d0, d1, d2, rad}, B.geo, lane * 16, ts * 16);
       sm.e_rad[wave][lane] = rad;
+      if constexpr (COORD) { sm.e_xdst[wave][0][lane] = r0.xd[0]; sm.e_xdst[wave][1][lane] = r0.xd[1]; sm.e_xdst[wave][2][lane] = r0.xd[2]; }
       sm.e_xd[wave][0][lane] = d0 * inv;
       sm.e_xd[wave][1][lane] = d1 * inv;
       sm.e_xd[wave][2][lane] = d2 * inv;
@@ -344,10 +347,16 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
               if (COORD && lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
             }
             buf_store(acc_h, B.hn, lane * 4, v * ld_hn_bytes);
-            const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[0]), i));
-            const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[1]), i));
-            const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0.xd[2]), i));
-            if (COORD && lane < 3) x_out[v * 3 + lane] = (lane == 0 ? x0 : (lane == 1 ? x1 : x2)) + acc_x / (float)cnt;
+            if constexpr (COORD) {
+              // x' = x_dst + mean of the coordinate messages.  The flush code is unrolled 16 x and runs ~5 x per tile in an
+              // issue-bound loop: the mean as a product with the reciprocal of the (wave-uniform) count -- v_rcp + one Newton
+              // step, within 1 ulp of the quotient -- instead of a ten-instruction division, the base from LDS instead of
+              // three v_readlane + two selects, the store through a buffer view instead of 64-bit address arithmetic
+              const float c = (float)cnt;
+              float rc = rcp_f(c);
+              rc = __builtin_fmaf(__builtin_fmaf(-c, rc, 1.0f), rc, rc);
+              if (lane < 3) buf_store(sm.e_xdst[wave][lane][i] + acc_x * rc, B.xo, lane * 4, v * 12);
+            }
             acc_h = 0.0f; acc_x = 0.0f; cnt = 0;
             vnext = v + 1;
           }
