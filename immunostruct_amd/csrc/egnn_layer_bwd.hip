@@ -73,6 +73,7 @@ __device__ long long g_stamps_b[24];
 constexpr int WB16 = 4;
 constexpr int NV16 = 16;   // nodes per tile without a tile list
 constexpr int NVB_LISTED = 24;    // most nodes a listed tile may hold
+constexpr int RP_TILES = 8;       // tiles per workgroup whose rowptr slice is fetched ahead (B = 128: 3; the stress slice: 8)
 
 template <int FE_MAX, int NVB>
 struct Bwd16Smem {
@@ -82,6 +83,7 @@ struct Bwd16Smem {
   float bufB[WB16][TE16 * LD];
   float pdt[IS_LAYER_M1 ? 1 : NVB * H];   // Pd rows of this tile's destination nodes (z1 recompute only)
   int rp[NVB + 1];
+  int rp_tab[RP_TILES][NVB + 1];   // rowptr slices of this workgroup's first RP_TILES tiles (fetched once, in front of the edge loop)
   int e_dl[WB16][TE16];
   float e_ra[WB16][TE16 * (FE_MAX + 1)];   // per edge: [radial | edge features]: the B operand of the dw_r / dW_a outer product
   float wa[(FE_MAX > 1 && !IS_LAYER_M1) ? FE_MAX * H : 1];   // W_a columns, lane = channel (registers when FE_MAX == 1; z1 recompute only)
@@ -365,6 +367,17 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   // P3 reads the node phase's d_hn rows (written above by this workgroup, behind a barrier) through a restrict pointer:
   // without it every prefetch of the edge loop is ordered against every store of the loop
   const float* __restrict__ g_hn = nb.d_hn;
+  // the rowptr slices of this workgroup's tiles: every tile of the persistent loop is known now, so its slice is fetched here,
+  // under the weight staging, instead of at the tile's start (there it was a dependent load + two barriers per tile)
+  for (int idx = tid; idx < RP_TILES * (NVB + 1); idx += 256) {
+    const int k = idx / (NVB + 1), i = idx - k * (NVB + 1);
+    const int t = blockIdx.x + k * gridDim.x;
+    if (t < num_tiles) {
+      const int a0 = (tiles != nullptr) ? tiles[1 + t] : t * NV16;
+      const int cnt = (tiles != nullptr) ? min(NVB, tiles[2 + t] - a0) : min(NV16, N - a0);
+      sm.rp_tab[k][i] = rowptr[a0 + min(i, cnt)];
+    }
+  }
   load_matrix_lds_t(sm.w2t, W2, tid, 256);
   if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
 
@@ -419,8 +432,12 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     STAMPB(0);
     const int v0 = (tiles != nullptr) ? tiles[1 + tile] : tile * NV16;
     const int nv = (tiles != nullptr) ? min(NVB, tiles[2 + tile] - v0) : min(NV16, N - v0);
-    __syncthreads();
-    if (tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
+    const int tk = (tile - (int)blockIdx.x) / (int)gridDim.x;      // (wave-uniform) index of this tile in the workgroup's sequence
+    const int* rp = (tk < RP_TILES) ? sm.rp_tab[tk] : sm.rp;
+    // first tile: the tables and weight tiles are staged; later tiles need no barrier here (every window ends with one, and a
+    // tile's rowptr slice has its own table row) unless a slice is staged on the fly
+    if (tk == 0 || tk >= RP_TILES || !IS_LAYER_M1) __syncthreads();
+    if (tk >= RP_TILES && tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
 #if !IS_LAYER_M1
 #pragma unroll
     for (int i = 0; i < NVB / WB16; ++i) {
@@ -428,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       sm.pdt[nl * H + lane] = (nl < nv) ? buf_load(rs_pd, lane * 4, (v0 + nl) * ld_p_bytes) : 0.0f;
     }
 #endif
-    __syncthreads();
-    const int e_begin = __builtin_amdgcn_readfirstlane(sm.rp[0]), e_end = __builtin_amdgcn_readfirstlane(sm.rp[nv]);
+    if (tk >= RP_TILES || !IS_LAYER_M1) __syncthreads();      // (wave-uniform) a slice / Pd tile staged just now
+    const int e_begin = __builtin_amdgcn_readfirstlane(rp[0]), e_end = __builtin_amdgcn_readfirstlane(rp[nv]);
     // destination-side segment sums as MFMA products with the 0 / 1 incidence of the tile (exact products; fixed order):
     //   seg_h[m][t]: node 16 m + 4 q + t, column 16 wave + r        seg_x (wave XW only): same node, coordinate r < 3
     constexpr int MTN = (NVB + 15) / 16, XW = WB16 - 1;
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (sm.rp[mid] <= e) lo = mid; else hi = mid;
+            if (rp[mid] <= e) lo = mid; else hi = mid;
           }
           const int dl = valid ? lo : 0;
           const int v = v0 + dl;
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #endif
           float rr = sqrtf(rad);
           float inv = 1.0f / (rr + 1e-30f);
-          const float invdeg = 1.0f / (float)max(sm.rp[dl + 1] - sm.rp[dl], 1);
+          const float invdeg = 1.0f / (float)max(rp[dl + 1] - rp[dl], 1);
           float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
           if (!valid) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
           if (lane < TE16) {
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           int lo = 0, hi = nv;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (sm.rp[mid] <= e) lo = mid; else hi = mid;
+            if (rp[mid] <= e) lo = mid; else hi = mid;
           }
           dl_e = valid_e ? lo : 0;
           const int v = v0 + dl_e;
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           float rad = radial3(d0, d1, d2);
           float rr = sqrtf(rad);
           float inv = 1.0f / (rr + 1e-30f);
-          const float invdeg = 1.0f / (float)max(sm.rp[dl_e + 1] - sm.rp[dl_e], 1);
+          const float invdeg = 1.0f / (float)max(rp[dl_e + 1] - rp[dl_e], 1);
           float g0 = gx0 * invdeg, g1 = gx1 * invdeg, g2 = gx2 * invdeg;
           if (!valid_e) { d0 = d1 = d2 = rad = rr = inv = g0 = g1 = g2 = 0.0f; }
           if (lane < TE16) {
