@@ -59,15 +59,22 @@
 #include "common.h"
 #include "node16.h"
 
+#ifndef IS_GATHER_GB
+#define IS_GATHER_GB 4      // rows per round of the node phase's source gather
+#endif
+
 namespace is {
 
 #ifdef IS_STAGE_STAMPS
 __device__ long long g_stamps_b[24];
 #define STAMPB(k) do { if (blockIdx.x == 300 && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMPP(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+// stamp once every outstanding vector-memory access of the wave has returned (perturbs the schedule: diagnosis only)
+#define STAMPP_W(k) do { __builtin_amdgcn_s_waitcnt(0x0F70); STAMPP(k); } while (0)
 #else
 #define STAMPB(k) do { } while (0)
 #define STAMPP(k) do { } while (0)
+#define STAMPP_W(k) do { } while (0)
 #endif
 
 constexpr int WB16 = 4;
@@ -167,50 +174,49 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     float* ps_ = &sm.w2t[0];                  // [PROWS][LDP]  g_psd rows     (w2t | wc1t | bufA | bufB are contiguous)
     float* gs = ps_ + PROWS * LDP;            // [PROWS][LD]   dh
     float* zs = gs + PROWS * LD;              // [PROWS][LD]   dzn1
-    int* tv0 = &sm.e_dl[0][0];                // [TPP] first node of the pass's tiles | [TPP] their node counts
     const bool has_psd = nb.g_psd != nullptr;
     const int col = wave * 16 + r;
-    // transposed-weight operands of this wave's output columns (operand pack: coalesced 16-byte loads, L2)
-    float bp[32], ba[16], bx[2][16];
-    {
-      const f32x4* pk = reinterpret_cast<const f32x4*>(nb.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const f32x4 v = pk[g * 64];      // (unused without a projection; the pack slots exist either way)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bp[4 * g + j] = v[j];
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = pk[(8 + g) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ba[4 * g + j] = v[j];
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = pk[(12 + nt * 4 + g) * 64];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bx[nt][4 * g + j] = v[j];
-        }
-    }
+    // transposed-weight operands of this wave's output columns (operand pack: coalesced 16-byte loads, L2).  Fetched per
+    // pass, each part where its latency is covered and its registers are free: bp behind the first gather level, ba / bx
+    // behind the gather (they are first used two barriers later)
+    const f32x4* pk = reinterpret_cast<const f32x4*>(nb.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
+    STAMPP_W(20);
     for (int t0 = blockIdx.x; t0 < num_tiles; t0 += TPP * gridDim.x) {
       const int ntp = min(TPP, (num_tiles - t0 + (int)gridDim.x - 1) / (int)gridDim.x);     // tiles of this pass
       const int mt_used = ntp * (PITCH / 16);
-      if (tid < TPP) {
-        const int tl = t0 + tid * gridDim.x;
+      // first node / node count of the pass's tiles: workgroup-uniform, so they are scalar loads into scalar registers (they
+      // went through LDS behind a barrier, and every row_node() below was two LDS reads)
+      int ta0[TPP], tcnt[TPP];
+#pragma unroll
+      for (int k = 0; k < TPP; ++k) {
+        const int tl = t0 + k * (int)gridDim.x;
         int a0 = 0, cnt = 0;
-        if (tid < ntp) {
+        if (k < ntp) {
           a0 = (tiles != nullptr) ? tiles[1 + tl] : tl * NV16;
           cnt = (tiles != nullptr) ? min(NVB, tiles[2 + tl] - a0) : min(NV16, N - a0);
         }
-        tv0[tid] = a0;
-        tv0[TPP + tid] = cnt;
+        ta0[k] = __builtin_amdgcn_readfirstlane(a0);
+        tcnt[k] = __builtin_amdgcn_readfirstlane(cnt);
       }
-      __syncthreads();
       // node of pass row lr (or -1): tile k = lr / PITCH, i = lr % PITCH
-      auto row_node = [&](int lr) { const int k = lr / PITCH, i = lr % PITCH; return (i < tv0[TPP + k]) ? tv0[k] + i : -1; };
+      auto row_node = [&](int lr) {
+        const int k = lr / PITCH, i = lr % PITCH;
+        int a0 = ta0[0], cnt = tcnt[0];
+#pragma unroll
+        for (int kk = 1; kk < TPP; ++kk) { a0 = (k == kk) ? ta0[kk] : a0; cnt = (k == kk) ? tcnt[kk] : cnt; }
+        return (i < cnt) ? a0 + i : -1;
+      };
+      // the pass's front is a chain of dependent loads (the whole chip starts it at the same moment: ~1.2 us per level), so the
+      // order of issue is: first level of the gather, then everything independent of it, then the dependent levels
+      [[maybe_unused]] const int g_sub = tid & 3;       // gather role: 4 lanes per node, row g_lr of the pass
+      [[maybe_unused]] const int g_lr = tid >> 2;
+      [[maybe_unused]] int g_v = -1, g_lo = 0, g_hi = 0;
+      if constexpr (GATHER) {
+        g_v = (g_lr < mt_used * 16) ? row_node(g_lr) : -1;
+        const int vc = max(g_v, 0);
+        g_lo = nb.rowptr_src[vc];
+        g_hi = nb.rowptr_src[vc + 1];
+      }
       // epilogue inputs of this lane (rows mt*16 + 4q + t, column col): consumed two / three stages later
       float zpre[MT][4], gpre[MT][4];
       int vrow[MT][4];
@@ -224,51 +230,75 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           zpre[mt][t] = nb.zn1[(size_t)vc * H + col];
           gpre[mt][t] = (has_psd && nb.g_h != nullptr) ? nb.g_h[(size_t)vc * H + col] : 0.0f;
         }
+      float bp[32];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 v = pk[g * 64];      // (unused without a projection; the pack slots exist either way)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bp[4 * g + j] = v[j];
+      }
+      STAMPP_W(21);
       if constexpr (GATHER) {
-        // 4 lanes per node (16 floats of the 256-byte row per lane), all 64 rows of the pass at once: the three dependent
-        // latencies (rowptr -> slot ids -> rows) are paid once per pass; per-element summation order = is_gather_segment_sum's
-        const int sub = tid & 3;
-        const int lr = tid >> 2;
-        const int v = (lr < mt_used * 16) ? row_node(lr) : -1;
+        // lane `sub` holds columns 16 j + 4 sub .. + 3 (j = 0..3) of its node's row, so that each load instruction reads row
+        // segment j as ONE contiguous 64 bytes over the node's four lanes.  The slot ids of the first 8 out-edges are one level,
+        // their rows follow 4 at a time (a round's 16 row loads are in flight together; two rows per round and the ids inside
+        // the round made a node with seven out-edges eight dependent latencies, and the workgroup waits for its slowest lane).
+        // Ids / rows past the node's last edge are out-of-range buffer reads: no traffic, +0.0 -- the per-element summation
+        // order is is_gather_segment_sum's
+        const int sub = g_sub, lr = g_lr, v = g_v;
+        const int lo = g_lo, hi = (v >= 0) ? g_hi : g_lo;
+        constexpr int VIEW = 0x7fffe000;      // "everything below BUF_OOB" (the entry point bounds E accordingly)
+        const rsrc_t rs_z = make_rsrc_n(nb.dZ1n, VIEW), rs_d = make_rsrc_n(nb.dDn, VIEW), rs_p = make_rsrc_n(nb.pos_by_src, VIEW);
+        constexpr int GB = 4;
+        int e[2 * GB];
+#pragma unroll
+        for (int k = 0; k < 2 * GB; ++k) e[k] = buf_load_i(rs_p, (lo + k < hi) ? (lo + k) * 4 : BUF_OOB, 0);
         f32x4 acc[4], pdv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; pdv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < 4; ++j) {
+          acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          pdv[j] = *reinterpret_cast<const f32x4*>(nb.g_psd + (size_t)max(v, 0) * 128 + 64 + 16 * j + 4 * sub);
+        }
+        const float x_dst = (sub < 3) ? nb.dxn[max(v, 0) * 3 + sub] : 0.0f;
         float acc3 = 0.0f;
+        STAMPP_W(22);
+        auto round = [&](const int* ek, int p0) {      // rows p0 .. p0 + GB - 1 of the node's list
+          f32x4 a[GB][4];
+          float d[GB];
+#pragma unroll
+          for (int k = 0; k < GB; ++k) {
+            const bool on = p0 + k < hi;
+            const int zoff = on ? ek[k] * (H * 4) + sub * 16 : BUF_OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[k][j] = buf_load4(rs_z, zoff + 64 * j, 0);
+            d[k] = buf_load(rs_d, (on && sub < 3) ? ek[k] * 12 + sub * 4 : BUF_OOB, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < GB; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += a[k][j];
+            acc3 += d[k];
+          }
+        };
+        round(e, lo);
+        if (lo + GB < hi) round(e + GB, lo + GB);
+        for (int p = lo + 2 * GB; p < hi; p += GB) {
+          int e2[GB];
+#pragma unroll
+          for (int k = 0; k < GB; ++k) e2[k] = buf_load_i(rs_p, (p + k < hi) ? (p + k) * 4 : BUF_OOB, 0);
+          round(e2, p);
+        }
+        STAMPP_W(23);
         if (v >= 0) {
-          const int lo = nb.rowptr_src[v], hi = nb.rowptr_src[v + 1];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pdv[j] = *reinterpret_cast<const f32x4*>(nb.g_psd + (size_t)v * 128 + 64 + sub * 16 + 4 * j);
-          const float x_dst = (sub < 3) ? nb.dxn[v * 3 + sub] : 0.0f;
-          int p = lo;
-          for (; p + 2 <= hi; p += 2) {
-            const int e0 = nb.pos_by_src[p], e1 = nb.pos_by_src[p + 1];
-            f32x4 a0[4], a1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              a0[j] = *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e0 * H + sub * 16 + 4 * j);
-              a1[j] = *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e1 * H + sub * 16 + 4 * j);
-            }
-            float d0 = 0.0f, d1 = 0.0f;
-            if (sub < 3) { d0 = nb.dDn[(size_t)e0 * 3 + sub]; d1 = nb.dDn[(size_t)e1 * 3 + sub]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += a0[j]; acc[j] += a1[j]; }
-            acc3 += d0; acc3 += d1;
-          }
-          if (p < hi) {
-            const int e0 = nb.pos_by_src[p];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += *reinterpret_cast<const f32x4*>(nb.dZ1n + (size_t)e0 * H + sub * 16 + 4 * j);
-            if (sub < 3) acc3 += nb.dDn[(size_t)e0 * 3 + sub];
-          }
 #pragma unroll
           for (int j = 0; j < 4; ++j)      // Ps half, for the weight-gradient kernel
-            *reinterpret_cast<f32x4*>(nb.g_psd + (size_t)v * 128 + sub * 16 + 4 * j) = acc[j];
+            *reinterpret_cast<f32x4*>(nb.g_psd + (size_t)v * 128 + 16 * j + 4 * sub) = acc[j];
           if (sub < 3) nb.gxtot[v * 3 + sub] = x_dst + acc3;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + sub * 16 + 4 * j) = acc[j];
-          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 64 + sub * 16 + 4 * j) = pdv[j];
+          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 16 * j + 4 * sub) = acc[j];
+          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 64 + 16 * j + 4 * sub) = (v >= 0) ? pdv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       } else {
         // stage g_psd (or g_h) rows of the pass: all loads first, LDS stores afterwards
@@ -297,6 +327,21 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           }
         }
       }
+      float ba[16], bx[2][16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = pk[(8 + g) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ba[4 * g + j] = v[j];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = pk[(12 + nt * 4 + g) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bx[nt][4 * g + j] = v[j];
+        }
       __syncthreads();
       STAMPP(14);
       if (has_psd) {      // dh = g_h + g_psd W1sd
@@ -1078,6 +1123,8 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream) {
   if (N <= 0) return 0;
   if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
+  // (the gathered dZ1n / dDn rows of the layer above are addressed the same way: E * 256 bytes < 0x7fffe000 -- the layer that wrote
+  //  them, and this one's own z2 / dZ1 views, already required that of the same E)
   if ((IS_LAYER_M1 != 0 && m1s == nullptr) || (IS_LAYER_M1 == 1 && dy1s == nullptr) || (IS_LAYER_GEO && geos == nullptr))
     return -22;      // this build reads them
   const bool gather = dZ1n != nullptr;

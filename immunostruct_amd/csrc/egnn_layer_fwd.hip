@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     if (COORD && lane < 3) x_out[u * 3 + lane] = x[u * 3 + lane];
   }
   }   // va < vb
+  STAMP3(56);
 
   // ================= node half: the workgroup's own nodes =================
   using D = Node16Dims<DIN>;
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     }
   }
   __syncthreads();     // every wave's h_neigh rows are written (L2 / the CU's L1); weight tiles and act buffers are dead
+  STAMP3(57);
   float* xs = reinterpret_cast<float*>(&sm);           // [ROWS][LD1]   X = [h | h_neigh | 0]
   float* a1s = xs + ROWS * D::LD1;                     // [ROWS][LD]    SiLU(zn1)
   float* hps = xs;                                     // [ROWS][LD]    h' (over X, which is dead by then)
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       }
     }
     __syncthreads();
+    STAMP3(58);
     {     // zn1 = X Wn1^T + bn1 ; a1 = SiLU(zn1)
       f32x4 acc[MT];
       zero_acc4(acc);
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         }
     }
     __syncthreads();
+    STAMP3(59);
     {     // h' = a1 Wn2^T + bn2
       f32x4 acc[MT];
       zero_acc4(acc);
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         }
     }
     __syncthreads();
+    STAMP3(60);
     if (has_next) {     // next pre-projection: wave w produces psd columns [32w, 32w + 32)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     }
     if (row0 + ROWS < n1) __syncthreads();     // the next pass restages X over h'
   }
+  STAMP3(61);
   wg_clock_end(wg_clock);
 }
 

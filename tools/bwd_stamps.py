@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from immunostruct_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_dbg", "libimmunostruct_hip_dbg.so")
+_lib.LIB_PATH = os.environ.get("IMMUNOSTRUCT_DBG_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_dbg", "libimmunostruct_hip_dbg.so")
 from immunostruct_amd import synthetic
 from immunostruct_amd.graph import PackedGraphBatch
 from immunostruct_amd.nn import EGNNConv, egnn_stack_forward
@@ -32,5 +32,8 @@ for rep in range(4):
     t = list(buf)
     print(f"rep {rep}: backward of the stack {ev0.elapsed_time(ev1) * 1e3:.0f} us")
     print("  first tile:", " ".join(f"{bn[i]}:+{t[i] - t[i - 1]}" for i in range(1, 13)), " total", t[12] - t[0])
+    if t[20]:
+        print(f"  node phase front (debug waits): operand pack back +{t[20] - t[13]}, zn1 / g_h rows back +{t[21] - t[20]}, rowptr_src / g_psd / dx back"
+              f" +{t[22] - t[21]}, gather rounds +{t[23] - t[22]}, stores + LDS + barrier +{t[14] - t[23]}")
     print(f"  kernel: entry->gather+stage barrier +{t[14] - t[13]}, dh MFMA +{t[15] - t[14]}, da1/dzn1 +{t[16] - t[15]}, dX + end of node phase +{t[17] - t[16]},"
           f" weights staged -> first tile +{t[0] - t[17]}, all tiles +{t[18] - t[0]}, record +{t[19] - t[18]}; whole {t[19] - t[13]} ticks")

@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from immunostruct_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_dbg", "libimmunostruct_hip_dbg.so")
+_lib.LIB_PATH = os.environ.get("IMMUNOSTRUCT_DBG_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_dbg", "libimmunostruct_hip_dbg.so")
 from immunostruct_amd import synthetic
 from immunostruct_amd.graph import PackedGraphBatch
 from immunostruct_amd.nn import EGNNConv, egnn_stack_forward
@@ -22,6 +22,10 @@ for rep in range(3):
     buf = (ctypes.c_longlong * 64)()
     assert lib.is_debug_stamps3(ctypes.cast(buf, ctypes.c_void_p)) == 0
     t = list(buf)
-    n = max(i for i in range(64) if t[i] > 0) + 1
+    node = t[56:62]
+    t = t[:56]
+    n = max(i for i in range(56) if t[i] > 0) + 1
     print("fwd rep", rep, f"prologue (ids, rows, weights staged):+{t[1] - t[0]}",
-          " ".join(f"{lab[(i - 2) % 5]}:+{t[i] - t[i - 1]}" for i in range(2, n)), " total", t[n - 1] - t[0])
+          " ".join(f"{lab[(i - 2) % 5]}:+{t[i] - t[i - 1]}" for i in range(2, n)), " edge total", t[n - 1] - t[0],
+          "| node half: wait for the workgroup's waves:+%d stage X:+%d MM zn1:+%d MM h':+%d MM psd':+%d | kernel %d" % (
+              node[1] - node[0], node[2] - node[1], node[3] - node[2], node[4] - node[3], node[5] - node[4], node[5] - t[0]))
