@@ -406,6 +406,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       b1n_c[nt] = cc >= 64 ? b1n[cc - 64] : (b0n != nullptr ? b0n[cc] : 0.0f);
     }
   }
+  constexpr int RPW = ROWS / W3;                       // rows staged per wave and pass
+  // the first pass's rows of h do not depend on the edge half: requested before the barrier (the slowest wave of the workgroup
+  // is still in its edge loop), they are there when the h_neigh rows -- which do have to wait -- are asked for
+  float hv[RPW];
+  if (n0 < n1) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) hv[i] = h[(size_t)min(n0 + wave * RPW + i, n1 - 1) * ld_h + min(lane, DIN - 1)];
+  }
   __syncthreads();     // every wave's h_neigh rows are written (L2 / the CU's L1); weight tiles and act buffers are dead
   STAMP3(57);
   float* xs = reinterpret_cast<float*>(&sm);           // [ROWS][LD1]   X = [h | h_neigh | 0]
@@ -414,12 +422,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   for (int row0 = n0; row0 < n1; row0 += ROWS) {
     const int mt_used = min(MT, (n1 - row0 + 15) >> 4);     // 16-row tiles of this pass that hold nodes
     {
-      constexpr int RPW = ROWS / W3;                   // rows staged per wave: all loads first, then the LDS stores
-      float hv[RPW], nv[RPW];
+      float nv[RPW];                                   // all loads first, then the LDS stores
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
         const int row = min(row0 + wave * RPW + i, n1 - 1);
-        hv[i] = h[(size_t)row * ld_h + min(lane, DIN - 1)];
+        if (row0 != n0) hv[i] = h[(size_t)row * ld_h + min(lane, DIN - 1)];
         nv[i] = h_neigh[(size_t)row * ld_hn + lane];
       }
 #pragma unroll
