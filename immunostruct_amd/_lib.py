@@ -42,7 +42,7 @@ SIGNATURES = {
     "is_stack_prologue": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "is_egnn_node_wgrad_stride": [],
     "is_egnn_node_wgrad_proj_floats": [],
-    "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _P],
+    "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
     "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P, _I, _P],

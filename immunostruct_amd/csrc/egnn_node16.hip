@@ -245,42 +245,38 @@ __device__ __forceinline__ void egnn_node_wgrad16_node(WgradSmem& sm, const floa
   const int rr = lane >> 4, c4 = lane & 15;
   const bool h4 = DIN == 64 && (ld_h & 3) == 0 && (reinterpret_cast<uintptr_t>(h) & 15) == 0;      // h rows 16-byte aligned
   f32x4 s_g = f32x4{0.f, 0.f, 0.f, 0.f}, s_z = s_g;      // partial column sums of columns 4 c4 .. + 3 over rows == rr (mod 4)
-  f32x4 rg, rz, rzn, rxh, rxn;
-  auto fetch = [&](int c0) {
+  // The rows of a chunk travel global -> registers -> LDS.  TWO register sets: the loads of chunk c + 2 are issued when chunk c
+  // is computed and land during chunk c + 1 (83.0 -> 81.7 us; the ~2.9 us a 16-row chunk costs whatever the kind of workgroup
+  // is NOT this latency -- HISTORY.md, round 3)
+  struct Rows { f32x4 g, z, zn, xh, xn; };
+  Rows R0, R1;
+  auto fetch = [&](Rows& R, int c0) {
     const int row = c0 + wave * 4 + rr;
-    rg = buf_load4(rs_g, row * (H * 4) + c4 * 16, 0);
-    rz = buf_load4(rs_z, row * (H * 4) + c4 * 16, 0);
-    rzn = buf_load4(rs_zn, row * (H * 4) + c4 * 16, 0);
-    rxn = buf_load4(rs_hn, row * (ld_hn * 4) + c4 * 16, 0);
+    R.g = buf_load4(rs_g, row * (H * 4) + c4 * 16, 0);
+    R.z = buf_load4(rs_z, row * (H * 4) + c4 * 16, 0);
+    R.zn = buf_load4(rs_zn, row * (H * 4) + c4 * 16, 0);
+    R.xn = buf_load4(rs_hn, row * (ld_hn * 4) + c4 * 16, 0);
     if (h4) {
-      rxh = buf_load4(rs_h, row * (ld_h * 4) + c4 * 16, 0);
+      R.xh = buf_load4(rs_h, row * (ld_h * 4) + c4 * 16, 0);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) rxh[j] = (4 * c4 + j < DIN) ? buf_load(rs_h, row * (ld_h * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
+      for (int j = 0; j < 4; ++j) R.xh[j] = (4 * c4 + j < DIN) ? buf_load(rs_h, row * (ld_h * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
     }
   };
-  auto stage = [&](int buf) {      // registers -> LDS set `buf`
+  auto stage = [&](const Rows& R, int buf) {      // registers -> LDS set `buf`
     float *Xs = Xs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
     const int lr = wave * 4 + rr;
-    *reinterpret_cast<f32x4*>(Gs + lr * LD + 4 * c4) = rg;
-    *reinterpret_cast<f32x4*>(Zs + lr * LD + 4 * c4) = rz;
-    s_g += rg; s_z += rz;
+    *reinterpret_cast<f32x4*>(Gs + lr * LD + 4 * c4) = R.g;
+    *reinterpret_cast<f32x4*>(Zs + lr * LD + 4 * c4) = R.z;
+    s_g += R.g; s_z += R.z;
     f32x4 a;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = silu_f(rzn[j]);      // rows past N: SiLU(0) = 0
+    for (int j = 0; j < 4; ++j) a[j] = silu_f(R.zn[j]);      // rows past N: SiLU(0) = 0
     *reinterpret_cast<f32x4*>(As + lr * LD + 4 * c4) = a;
-    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 4 * c4) = rxh;
-    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 64 + 4 * c4) = rxn;
+    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 4 * c4) = R.xh;
+    *reinterpret_cast<f32x4*>(Xs + lr * LDP + 64 + 4 * c4) = R.xn;
   };
-  if (r_begin < r_end) {
-    fetch(r_begin);
-    stage(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int c0 = r_begin; c0 < r_end; c0 += 16, buf ^= 1) {
-    const bool more = c0 + 16 < r_end;
-    if (more) fetch(c0 + 16);        // in flight while this chunk's MFMAs run
+  auto products = [&](int buf) {
     const float *Xs = Xs2[buf], *Gs = Gs2[buf], *As = As2[buf], *Zs = Zs2[buf];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -296,9 +292,27 @@ __device__ __forceinline__ void egnn_node_wgrad16_node(WgradSmem& sm, const floa
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) dWn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bxv[nt], dWn[nt], 0, 0, 0);
     }
-    if (more) stage(buf ^ 1);
-    __syncthreads();      // the other set is complete, and every wave is done reading this one
+  };
+  if (r_begin < r_end) {
+    fetch(R0, r_begin);
+    fetch(R1, r_begin + 16);      // (rows past the slice are fetched but never staged; rows past N read as zero)
+    stage(R0, 0);
   }
+  __syncthreads();
+  // two chunks per trip, so that the register sets alternate without being copied (a copy waits for the loads it copies)
+  int c0 = r_begin;
+  for (; c0 + 16 < r_end; c0 += 32) {
+    // LDS set 0 holds chunk c0, R1 holds chunk c0 + 16; R0 receives chunk c0 + 32
+    fetch(R0, c0 + 32);
+    products(0);
+    stage(R1, 1);
+    __syncthreads();      // the other set is complete, and every wave is done reading this one
+    fetch(R1, c0 + 48);
+    products(1);
+    if (c0 + 32 < r_end) stage(R0, 0);
+    __syncthreads();
+  }
+  if (c0 < r_end) products(0);      // an odd last chunk: staged in set 0 by the trip before (or by the prologue)
   float* pn = part + WG_PROJ;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -340,35 +354,28 @@ __device__ __forceinline__ void egnn_node_wgrad16_proj(WgradSmem& sm, const floa
   const int rr = lane >> 4, c4 = lane & 15;      // staging role: row 4 wave + rr, columns 4 c4 .. + 3 (see the node kind)
   const bool h4 = dho == 64 && (ld_ho & 3) == 0 && (reinterpret_cast<uintptr_t>(h_out) & 15) == 0;
   f32x4 s_p0 = f32x4{0.f, 0.f, 0.f, 0.f}, s_p1 = s_p0;
-  f32x4 rp0, rp1, rho;
-  auto fetch = [&](int c0) {
+  struct Rows { f32x4 p0, p1, ho; };      // two register sets, prefetch distance 2 (see the node kind)
+  Rows R0, R1;
+  auto fetch = [&](Rows& R, int c0) {
     const int row = c0 + wave * 4 + rr;
-    rp0 = buf_load4(rs_p, row * 512 + c4 * 16, 0);
-    rp1 = buf_load4(rs_p, row * 512 + 256 + c4 * 16, 0);
+    R.p0 = buf_load4(rs_p, row * 512 + c4 * 16, 0);
+    R.p1 = buf_load4(rs_p, row * 512 + 256 + c4 * 16, 0);
     if (h4) {
-      rho = buf_load4(rs_ho, row * (ld_ho * 4) + c4 * 16, 0);
+      R.ho = buf_load4(rs_ho, row * (ld_ho * 4) + c4 * 16, 0);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) rho[j] = (4 * c4 + j < dho) ? buf_load(rs_ho, row * (ld_ho * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
+      for (int j = 0; j < 4; ++j) R.ho[j] = (4 * c4 + j < dho) ? buf_load(rs_ho, row * (ld_ho * 4) + (4 * c4 + j) * 4, 0) : 0.0f;
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](const Rows& R, int buf) {
     float *Ps = Ps2[buf], *Hs = Hs2[buf];
     const int lr = wave * 4 + rr;
-    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 4 * c4) = rp0;
-    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 64 + 4 * c4) = rp1;
-    s_p0 += rp0; s_p1 += rp1;
-    *reinterpret_cast<f32x4*>(Hs + lr * LD + 4 * c4) = rho;
+    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 4 * c4) = R.p0;
+    *reinterpret_cast<f32x4*>(Ps + lr * LDP + 64 + 4 * c4) = R.p1;
+    s_p0 += R.p0; s_p1 += R.p1;
+    *reinterpret_cast<f32x4*>(Hs + lr * LD + 4 * c4) = R.ho;
   };
-  if (r_begin < r_end) {
-    fetch(r_begin);
-    stage(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int c0 = r_begin; c0 < r_end; c0 += 16, buf ^= 1) {
-    const bool more = c0 + 16 < r_end;
-    if (more) fetch(c0 + 16);
+  auto products = [&](int buf) {
     const float *Ps = Ps2[buf], *Hs = Hs2[buf];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -383,9 +390,25 @@ __device__ __forceinline__ void egnn_node_wgrad16_proj(WgradSmem& sm, const floa
         dW1[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, bh[nt], dW1[1][nt], 0, 0, 0);
       }
     }
-    if (more) stage(buf ^ 1);
+  };
+  if (r_begin < r_end) {
+    fetch(R0, r_begin);
+    fetch(R1, r_begin + 16);
+    stage(R0, 0);
+  }
+  __syncthreads();
+  int c0 = r_begin;
+  for (; c0 + 16 < r_end; c0 += 32) {
+    fetch(R0, c0 + 32);
+    products(0);
+    stage(R1, 1);
+    __syncthreads();
+    fetch(R1, c0 + 48);
+    products(1);
+    if (c0 + 32 < r_end) stage(R0, 0);
     __syncthreads();
   }
+  if (c0 < r_end) products(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int lr = tile16_row(t, q);
@@ -422,17 +445,18 @@ struct WgradLayer {
 constexpr int WGRAD_MAX_LAYERS = 8;
 struct WgradBatch { WgradLayer layer[WGRAD_MAX_LAYERS]; };
 
-__global__ __launch_bounds__(256, 3) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int rows_per_wg) {
+__global__ __launch_bounds__(256, 3) void egnn_node_wgrad16_batched_kernel(WgradBatch batch, int N, int grid_node, int rows_node,
+                                                                           int grid_proj, int rows_proj) {
   __shared__ WgradSmem sm;
   const WgradLayer& L = batch.layer[blockIdx.y >> 1];
   float* part = L.partials + (size_t)blockIdx.x * WG_STRIDE;
   if ((blockIdx.y & 1) == 0) {
-    if (L.dzn1 == nullptr) return;      // a projection-only job (layer-0 pre-projection): NODE part left untouched
-    if (L.din == 20) egnn_node_wgrad16_node<20>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_per_wg);
-    else egnn_node_wgrad16_node<64>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_per_wg);
+    if (L.dzn1 == nullptr || (int)blockIdx.x >= grid_node) return;      // a projection-only job (layer-0 pre-projection): NODE part left untouched
+    if (L.din == 20) egnn_node_wgrad16_node<20>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_node);
+    else egnn_node_wgrad16_node<64>(sm, L.dh, L.zn1, L.dzn1, L.h, L.ld_h, L.h_neigh, L.ld_hn, part, N, rows_node);
   } else {
-    if (L.g_psd == nullptr) return;     // no next pre-projection: PROJ part left untouched
-    egnn_node_wgrad16_proj(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, part, N, rows_per_wg);
+    if (L.g_psd == nullptr || (int)blockIdx.x >= grid_proj) return;     // no next pre-projection: PROJ part left untouched
+    egnn_node_wgrad16_proj(sm, L.g_psd, L.h_out, L.ld_ho, L.dho, part, N, rows_proj);
   }
 }
 
@@ -470,11 +494,14 @@ extern "C" int is_egnn_node_wgrad_stride(void) { return is::WG_STRIDE; }
 extern "C" int is_egnn_node_wgrad_proj_floats(void) { return is::WG_PROJ; }
 
 // layers: host array of `nlayers` (<= 8) records {g_psd, h_out, dh, zn1, dzn1, h, h_neigh, partials, ld_h, din, ld_hn, ld_ho,
-// dho, pad} (pointers first, then six ints); every layer uses `grid` workgroups and the record layout of
-// is_egnn_node_wgrad.  A record with dzn1 == NULL is a projection-only job (PROJ part from g_psd and the first dho
-// columns of h_out, row stride ld_ho); a record with g_psd == NULL leaves the PROJ part untouched.
-extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream) {
-  if (N <= 0 || grid <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
+// dho, pad} (pointers first, then six ints); the NODE part of every layer is produced by `grid_node` workgroups (records 0 ..
+// grid_node - 1 of its partials), the PROJ part by `grid_proj` (records 0 .. grid_proj - 1), record layout and stride as
+// is_egnn_node_wgrad_stride / _proj_floats describe.  (The two kinds cost 12 and 8 MFMAs per 4-row step, but equal work per
+// workgroup -- grids 3 : 2 -- measured slower than equal grids: HISTORY.md, round 3.)
+// A record with dzn1 == NULL is a projection-only job (PROJ part from g_psd and the first dho columns of h_out, row stride
+// ld_ho); a record with g_psd == NULL leaves the PROJ part untouched.
+extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid_node, int grid_proj, int N, void* stream) {
+  if (N <= 0 || grid_node <= 0 || grid_proj <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
   if ((long long)N * 128 * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer row loads (4.1 M nodes)
   is::WgradBatch batch;
   const is::WgradLayer* src = static_cast<const is::WgradLayer*>(layers);
@@ -483,7 +510,8 @@ extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int g
     if ((src[i].din != 20 && src[i].din != 64) || src[i].dho < 0 || src[i].dho > 64) return -22;
     if (src[i].g_psd == nullptr && src[i].dzn1 == nullptr) return -22;
   }
-  const int rows = (((N + grid - 1) / grid) + 15) / 16 * 16;
-  hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(grid, 2 * nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), batch, N, rows);
+  auto rows_of = [N](int grid) { return (((N + grid - 1) / grid) + 15) / 16 * 16; };
+  hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(std::max(grid_node, grid_proj), 2 * nlayers), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), batch, N, grid_node, rows_of(grid_node), grid_proj, rows_of(grid_proj));
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -17,7 +17,11 @@ import os
 HIDDEN = 64
 _MAX_BWD_GRID = 256  # one persistent workgroup per CU (MI355X: 256 CUs)
 SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "1") == "1"      # 0: the backward recomputes z3 per tile instead of reading it back (measured: -37 MB per layer pair, +6 us per backward launch)
-WGRAD_GRID = 56      # workgroups per layer and kind of the batched node weight-gradient launch: 13 x 56 = 728 <= 3 x 256 resident
+# workgroups per layer of the batched node weight-gradient launch, by kind (node block: 12 MFMAs per 4-row step; next
+# pre-projection: 8).  13 x 56 = 728 <= 3 x 256 resident.  Equal work per workgroup (72 : 48) is SLOWER (82 -> 92 us): the launch
+# lasts as long as its longest workgroup, ~2.9 us per 16-row chunk whatever the kind (HISTORY.md, round 3)
+WGRAD_GRID_NODE = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID_NODE", "56"))
+WGRAD_GRID_PROJ = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID_PROJ", "56"))
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
 # Data-parallel mode of the two persistent layer kernels: their grids normally fill EVERY workgroup slot of the chip (2 per CU),
@@ -605,7 +609,8 @@ class EGNNStackFn(torch.autograd.Function):
         else:
             grid_e = max(1, min(layer_slots(), (n + 15) // 16))
         wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
-        grid_w = max(1, min(WGRAD_GRID, (n + 15) // 16))
+        grid_wn, grid_wp = max(1, min(WGRAD_GRID_NODE, (n + 15) // 16)), max(1, min(WGRAD_GRID_PROJ, (n + 15) // 16))
+        grid_w = max(grid_wn, grid_wp)      # records per partial buffer
         wjobs, rjobs = [], []     # weight-gradient layers / reduction jobs of the two batched launches at the end
         keep = []
         head = ctx.head
@@ -657,10 +662,10 @@ class EGNNStackFn(torch.autograd.Function):
                                          dh_total.data_ptr(), lay["zn1"].data_ptr(), dzn1.data_ptr(), lay["h_in"].data_ptr(),
                                          lay["h_neigh"].data_ptr(), pw.data_ptr(), lay["ld_h"], din, HIDDEN, HIDDEN, HIDDEN, 0))
             if is_head:
-                rjobs.append((pw, grid_w, wg_stride, wg_proj, None, head_flat))
+                rjobs.append((pw, grid_wp, wg_stride, wg_proj, None, head_flat))
             elif has_psd:
-                rjobs.append((pw, grid_w, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
-            rjobs.append((pw[wg_proj:], grid_w, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
+                rjobs.append((pw, grid_wp, wg_stride, wg_proj, plans[i + 1].proj_map, gflat[i + 1]))
+            rjobs.append((pw[wg_proj:], grid_wn, wg_stride, _NODE_STRIDE, plans[i].node_map, gflat[i]))
             rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
             above = (dZ1, dD, dx)
             g_hd, g_psd_next, g_xc = d_h, dpsd, dx
@@ -681,7 +686,7 @@ class EGNNStackFn(torch.autograd.Function):
             keep.append(pw0)
             wjobs.append(_lib.WgradLayer(g_psd_next.data_ptr(), lay0["h_in"].data_ptr(), None, None, None, None, None,
                                          pw0.data_ptr(), HIDDEN, HIDDEN, HIDDEN, lay0["ld_h"], lay0["din"], 0))
-            rjobs.append((pw0, grid_w, wg_stride, wg_proj, plans[0].proj_map, gflat[0]))
+            rjobs.append((pw0, grid_wp, wg_stride, wg_proj, plans[0].proj_map, gflat[0]))
         else:
             grid_n = max(1, min(_MAX_BWD_GRID, (n + 127) // 128))
             part_p = torch.empty(grid_n * _PROJ_STRIDE, **f32)
@@ -694,7 +699,7 @@ class EGNNStackFn(torch.autograd.Function):
         arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
         TailGate.mark()
         with KernelTimer.span("egnn_node_wgrad_batched"):
-            _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_w, n, st),
+            _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_wn, grid_wp, n, st),
                        "is_egnn_node_wgrad_batched")
         split = lib.is_reduce_partials_scratch_floats(1)
         big = torch.empty(sum(split * c for (_, _, _, c, _, _) in rjobs), **f32)

@@ -143,9 +143,10 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
  *     `layers` = host array of nlayers (<= 8) records
  *       { const float *g_psd, *h_out, *dh, *zn1, *dzn1, *h, *h_neigh; float* partials;
  *         int ld_h, din, ld_hn, ld_ho, dho, pad; }
- *     each processed by `grid` workgroups; partial record per workgroup = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out,
- *     is_egnn_node_wgrad_proj_floats floats) followed by [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2]; record stride
- *     is_egnn_node_wgrad_stride.  h_out has row stride ld_ho and dho (<= 64) valid columns; dzn1 == NULL marks a
+ *     partial record = [dW1sd 128x64 | db1 | db0] (g_psd^T h_out, is_egnn_node_wgrad_proj_floats floats: the PROJ part,
+ *     written by `grid_proj` workgroups = records 0 .. grid_proj - 1) followed by [dWn1 64x128 | dWn2 64x64 | dbn1 | dbn2] (the
+ *     NODE part, `grid_node` workgroups = records 0 .. grid_node - 1); record stride is_egnn_node_wgrad_stride; `partials`
+ *     holds max(grid_node, grid_proj) records.  h_out has row stride ld_ho and dho (<= 64) valid columns; dzn1 == NULL marks a
  *     projection-only job (only the dW1sd part, e.g. the layer-0 pre-projection of the raw node features), g_psd ==
  *     NULL a job without projection part.
  *   is_reduce_partials_batched: `jobs` = host array of njobs (<= 24) records
@@ -153,7 +154,7 @@ int is_reduce_partials(const float* partials, int nparts, int stride, int count,
  *     each processed exactly like is_reduce_partials (scratch: is_reduce_partials_scratch_floats(count) floats). */
 int is_egnn_node_wgrad_stride(void);
 int is_egnn_node_wgrad_proj_floats(void);
-int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid, int N, void* stream);
+int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid_node, int grid_proj, int N, void* stream);
 int is_reduce_partials_batched(const void* jobs, int njobs, void* stream);
 
 /* Latent block of the sequence VAE (models/hybrid_models.py:297-308,334-340): a1 [B,Hd] = vae_fc1(x) (pre-activation) ->
