@@ -8,20 +8,23 @@
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
+export TMPDIR=/tmp
+# HBM traffic first: bench.py reports roofline.traffic only from a file whose kernel-source digest matches the tree, so the
+# file of THIS build is put where bench.py looks for it (on the box; copy $out/pmc_traffic.json over the tracked one afterwards)
+for wl in iedb paired stress; do
+  bash tools/pmc_traffic.sh $wl $out/pmc_$wl.json
+done
+python tools/assemble_traffic.py $out $out/pmc_traffic.json
+cp $out/pmc_traffic.json $(python -c "import bench; print(bench.TRAFFIC_FILE)")
 for wl in iedb paired stress; do
   python bench.py --workload $wl --steps 30 --warmup 5 > $out/bench_$wl.json 2> $out/bench_$wl.err
   cut -c1-230 $out/bench_$wl.json
 done
-export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o rr -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-e2e > $out/prof.log 2> $out/prof.err
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/kernel_stats.txt 2>> $out/prof.err
 python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
-for wl in iedb paired stress; do
-  bash tools/pmc_traffic.sh $wl $out/pmc_$wl.json
-done
-python tools/assemble_traffic.py $out $out/pmc_traffic.json
 # config 2's second stage and the edge-density sweep
 python bench.py --stage finetune --steps 30 --warmup 5 > $out/bench_iedb_finetune.json 2> $out/bench_iedb_finetune.err
 bash tools/density_sweep.sh $out/sweep.json > /dev/null
