@@ -29,8 +29,19 @@ from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
-# the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer)
-FORK_AFTER_LAYER = int(os.environ.get("IMMUNOSTRUCT_FORK_AFTER_LAYER", "2"))
+# the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer).  "auto": its
+# forward (~100 us of side work) should end with the stack + node attention, not stretch more layer launches than it must -- the
+# longer a layer launch, the earlier the fork.  Measured on the round-3 kernels (same box, ms per step): B = 128 graphs / 72 k edges
+# after layer 1 / 2 / 3 / 4 = 1.104 / 1.104 / 1.090 / 1.121; 128 pairs / 145 k edges after 2 / 3 = 2.123 / 2.143
+_fork_env = os.environ.get("IMMUNOSTRUCT_FORK_AFTER_LAYER", "auto")
+FORK_AFTER_LAYER = None if _fork_env == "auto" else int(_fork_env)
+FORK_AUTO_EDGES = 100_000      # batches with at least this many edges fork one layer earlier
+
+
+def fork_after_layer(num_edges):
+    if FORK_AFTER_LAYER is not None:
+        return FORK_AFTER_LAYER
+    return 2 if num_edges >= FORK_AUTO_EDGES else 3
 MERGE_PAIRS = os.environ.get("IMMUNOSTRUCT_MERGE_PAIRS", "1") != "0"      # paired models: one encoder pass over [cancer; wild-type]
 if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
@@ -257,7 +268,7 @@ class MultimodalNet(nn.Module):
             side = _side_stream(seq.device)
             inp = self._graph_inputs(g)
             pro = (inp, egnn_stack_prelaunch(inp[3], g, inp[0], inp[1], inp[2], head=inp[4], final_coords=False,
-                                             fork_after=FORK_AFTER_LAYER))
+                                             fork_after=fork_after_layer(g.num_edges())))
             side.wait_event(pro[1].fork_event)
             with torch.cuda.stream(side):
                 HF.Stamps.mark("fwd seq-branch start")
