@@ -270,9 +270,19 @@ class CapturedTrainStep:
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
             self._forms[False] = (loss, self.reducer.sources())
         if not self.fused_optimizer:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
-                self.optimizer.step()
+            if self._split_update():
+                # one graph per gradient bucket: the first bucket's parameters (97 % of the bytes) are updated while the second,
+                # latency-bound all-reduce is still on the wire
+                self.graph_b = []
+                for i, b in enumerate(self.reducer.buckets):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, **({"pool": self.graph_b[0].pool()} if self.graph_b else {})):
+                        self.optimizer.step_subset(b["params"], first=i == 0)
+                    self.graph_b.append(graph)
+            else:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b):
+                    self.optimizer.step()
         if len(self._forms) == 2:
             self._choose_form(model, optimizer)
         else:
@@ -445,25 +455,56 @@ class CapturedTrainStep:
                 p.grad = g
         self._bnd = self._bnd_grads = None
 
-    def _body(self, eager=False):
-        if self._want_two_stage:
-            loss = self._stage1()
-            if self.two_stage:
-                work = self.reducer.reduce_bucket(0, async_op=True)
-                self._stage2()
-                self.reducer.reduce_bucket(1)
+    def _split_update(self):
+        """data-parallel forms with two gradient buckets: update bucket by bucket, each as soon as its all-reduce is done
+        (IMMUNOSTRUCT_DP_SPLIT_UPDATE=0: one update after both)"""
+        return (not self.fused_optimizer and len(self.reducer.buckets) == 2 and hasattr(self.optimizer, "step_subset")
+                and os.environ.get("IMMUNOSTRUCT_DP_SPLIT_UPDATE", "1") != "0")
+
+    def _reduce_and_update(self, stage2, update):
+        """the part of a data-parallel step behind the (first-stage) backward: all-reduce bucket by bucket, ``stage2()`` (the stack
+        backward of the two-stage form, or None) under the first bucket's all-reduce, ``update(i)`` = the optimizer step of bucket
+        i's parameters (i = None: of all parameters)"""
+        red = self.reducer
+        if not self._split_update():
+            if stage2 is not None:
+                work = red.reduce_bucket(0, async_op=True)
+                stage2()
+                red.reduce_bucket(1)
                 if work is not None:
                     work.wait()
             else:
-                self.reducer.all_reduce_mean()
+                red.all_reduce_mean()
+            update(None)
+            return
+        work0 = red.reduce_bucket(0, async_op=True)
+        if stage2 is not None:
+            stage2()
+        work1 = red.reduce_bucket(1, async_op=True)      # queued behind bucket 0 on the collective's stream
+        if work0 is not None:
+            work0.wait()
+        update(0)
+        if work1 is not None:
+            work1.wait()
+        update(1)
+
+    def _eager_update(self, i):
+        if i is None:
             self.optimizer.step()
+        else:
+            self.optimizer.step_subset(self.reducer.buckets[i]["params"], first=i == 0)
+
+    def _body(self, eager=False):
+        if self._want_two_stage:
+            loss = self._stage1()
+            self._reduce_and_update(self._stage2 if self.two_stage else None, self._eager_update)
             return loss
         loss = self._fwd_bwd()
-        self.reducer.all_reduce_mean()
         if self.fused_optimizer:
+            self.reducer.all_reduce_mean()
             self._optimizer_step()
         else:
-            self.optimizer.step()
+            self._reduce_and_update(None, self._eager_update)
         return loss
 
     def __call__(self, g, seq, prop, y):
@@ -475,17 +516,14 @@ class CapturedTrainStep:
         on-device batcher (``data.DeviceResidentDataset.gather_into``) writes them directly."""
         if hasattr(self.optimizer, "refresh"):
             self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
+        def update(i):
+            (self.graph_b if i is None else self.graph_b[i]).replay()
         if self.two_stage:
             self.graph_a1.replay()
-            work = self.reducer.reduce_bucket(0, async_op=True)    # in flight while graph A2 runs the stack backward
-            self.graph_a2.replay()
-            self.reducer.reduce_bucket(1)
-            if work is not None:
-                work.wait()
-            self.graph_b.replay()
+            # bucket 0 is in flight while graph A2 runs the stack backward
+            self._reduce_and_update(self.graph_a2.replay, update)
             return self.loss
         self.graph_a.replay()
         if self.graph_b is not None:
-            self.reducer.all_reduce_mean()
-            self.graph_b.replay()
+            self._reduce_and_update(None, update)
         return self.loss

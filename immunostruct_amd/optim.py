@@ -177,6 +177,30 @@ class Adam(torch.optim.Optimizer):
                 _lib.check(lib.is_adam_apply(_lib.ptr(tl), int(tl.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
                                              _lib.stream_ptr()), "is_adam_apply")
 
+    @torch.no_grad()
+    def step_subset(self, params, first):
+        """The update of :meth:`step` for the parameters in ``params`` only; ``first`` = this is the step's first part (the step
+        count advances and the bias corrections are formed once per step, by the first part; every other part of the same step
+        passes False).  The data-parallel engine updates the first gradient bucket's parameters while the second bucket's
+        all-reduce is still on the wire.  Same arithmetic as one :meth:`step` over all of them."""
+        lib = _lib.load()
+        capturing = torch.cuda.is_current_stream_capturing()
+        ids = set(id(p) for p in params)
+        for group in self.param_groups:
+            with_grad = [p for p in group["params"] if p.grad is not None]
+            if not with_grad:
+                continue
+            sub = [p for p in with_grad if id(p) in ids]
+            gs = self._group_state(group, with_grad)
+            table = self._table(group, sub, capturing)[1] if sub else None
+            if not capturing:
+                self.refresh_group(group, gs)
+            if first:
+                _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+            if table is not None:
+                _lib.check(lib.is_adam_apply(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+                                             _lib.stream_ptr()), "is_adam_apply")
+
     def refresh_group(self, group, gs):
         hh = self._hyper_host(group)
         if gs["hyper_host"] != hh:
