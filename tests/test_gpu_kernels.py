@@ -621,6 +621,65 @@ def test_hip_adam_matches_torch_optim(cuda_device, kind, wd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,wd", [("Adam", 1e-6), ("AdamW", 1e-2)])
+def test_hip_adam_in_parts_is_the_single_step(cuda_device, kind, wd):
+    """optim.Adam.step_subset (the data-parallel engine's update per gradient bucket: is_adam_prepare once, is_adam_apply per part)
+    leaves bit-for-bit the parameters and the state of one step() over all parameters, over several steps and a changing lr"""
+    from immunostruct_amd import optim
+    g = torch.Generator().manual_seed(12)
+    shapes = [(512, 700), (32,), (64, 130), (1,), (7, 3), (20000,)]
+    one_p = [torch.randn(*s, generator=g).to(cuda_device).requires_grad_(True) for s in shapes]
+    two_p = [p.detach().clone().requires_grad_(True) for p in one_p]
+    one = getattr(optim, kind)(one_p, lr=1e-2, weight_decay=wd)
+    two = getattr(optim, kind)(two_p, lr=1e-2, weight_decay=wd)
+    first, second = [two_p[0], two_p[2], two_p[5]], [two_p[1], two_p[3], two_p[4]]
+    for step in range(5):
+        for a, b in zip(one_p, two_p):
+            gr = torch.randn(a.shape, generator=g).to(cuda_device) * (1.0 + step)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if step == 2:
+            for o in (one, two):
+                o.param_groups[0]["lr"] = 3e-3
+        one.step()
+        two.step_subset(first, first=True)
+        two.step_subset(second, first=False)
+    for a, b in zip(one_p, two_p):
+        assert torch.equal(a.detach(), b.detach()), f"{kind} param {tuple(a.shape)}"
+        assert torch.equal(one.state[a]["exp_avg_sq"], two.state[b]["exp_avg_sq"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grids", [(72, 48), (40, 64), (7, 3)])
+def test_node_weight_gradients_do_not_depend_on_the_grids(cuda_device, grids):
+    """is_egnn_node_wgrad_batched with other numbers of workgroups per kind (the ABI's grid_node / grid_proj) gives the default grids'
+    weight gradients to fp32 round-off (another partition of the rows = another summation order), on a ragged batch"""
+    from immunostruct_amd import functional as HF
+    raw = synthetic.make_batch(6, seed=5, deg_extra=3, n_pad=37, n_real_choices=(30, 33, 37))
+    g = H.product_graph(raw, cuda_device)
+    torch.manual_seed(3)
+    layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(cuda_device) for i in range(3)]
+    h0 = g.ndata["x"][:, :20].contiguous(); x0 = g.ndata["x"][:, 20:].contiguous()
+
+    def grads():
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+        h, x = egnn_stack_forward(layers, g, h0, x0, g.edata["edge_attr"])
+        (h.square().mean() + 1e-3 * x.square().mean()).backward()
+        return [p.grad.clone() for l in layers for p in l.parameters() if p.grad is not None]
+
+    ref = grads()
+    saved = HF.WGRAD_GRID_NODE, HF.WGRAD_GRID_PROJ
+    HF.WGRAD_GRID_NODE, HF.WGRAD_GRID_PROJ = grids
+    try:
+        got = grads()
+    finally:
+        HF.WGRAD_GRID_NODE, HF.WGRAD_GRID_PROJ = saved
+    assert len(ref) == len(got)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        H.assert_close(b.cpu(), a.cpu(), 1e-5, f"gradient {i} with grids {grids}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [
     dict(b=128, inn=104, hid=32, out=1, act1=1, act2=0, drop=True, hgroup=0),     # classifier
     dict(b=37, inn=208, hid=32, out=1, act1=1, act2=0, drop=False, hgroup=0),     # paired classifier, ragged batch

@@ -132,3 +132,15 @@ def test_batch_concatenates_existing_csr_pieces():
         assert torch.equal(getattr(union._csr, k), getattr(want, k)), k
         assert getattr(union._csr, k).dtype == getattr(want, k).dtype, k
     assert torch.equal(union.edge_feat_csr(union.edata["edge_attr"]), union.edata["edge_attr"][want.eperm])
+
+
+def test_sequence_branch_fork_point_follows_the_batch_size(monkeypatch):
+    """models/_core.fork_after_layer: the forked sequence branch starts one EGNN layer earlier for batches whose layer launches are
+    long (>= FORK_AUTO_EDGES edges); IMMUNOSTRUCT_FORK_AFTER_LAYER pins it"""
+    from immunostruct_amd.models import _core
+    monkeypatch.setattr(_core, "FORK_AFTER_LAYER", None)
+    assert _core.fork_after_layer(72_313) == 3
+    assert _core.fork_after_layer(_core.FORK_AUTO_EDGES) == 2
+    assert _core.fork_after_layer(144_700) == 2
+    monkeypatch.setattr(_core, "FORK_AFTER_LAYER", 1)
+    assert _core.fork_after_layer(72_313) == 1 and _core.fork_after_layer(500_000) == 1
