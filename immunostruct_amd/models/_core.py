@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from .. import functional as HF
 from ..graph import PackedGraphBatch
 from ..graph import batch as graph_batch
-from ..nn import EGNNConv, egnn_stack_forward, egnn_stack_prelaunch
+from ..nn import EGNNConv, egnn_stack_forward, egnn_stack_prelaunch, stack_is_native
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
@@ -267,9 +267,12 @@ class MultimodalNet(nn.Module):
             main = torch.cuda.current_stream()
             side = _side_stream(seq.device)
             inp = self._graph_inputs(g)
-            pro = (inp, egnn_stack_prelaunch(inp[3], g, inp[0], inp[1], inp[2], head=inp[4], final_coords=False,
-                                             fork_after=fork_after_layer(g.num_edges())))
-            side.wait_event(pro[1].fork_event)
+            if stack_is_native(inp[3]):
+                pro = (inp, egnn_stack_prelaunch(inp[3], g, inp[0], inp[1], inp[2], head=inp[4], final_coords=False,
+                                                 fork_after=fork_after_layer(g.num_edges())))
+                side.wait_event(pro[1].fork_event)
+            else:
+                side.wait_stream(main)      # layer sizes outside the HIP kernels' build: torch-composed stack, nothing to prelaunch
             with torch.cuda.stream(side):
                 HF.Stamps.mark("fwd seq-branch start")
                 o.update(self._encode_sequence(seq, prop))

@@ -42,12 +42,12 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=
     dh = dm // heads
     x2 = x.reshape(b * n, dm)
     if qk is None:     # else: already produced by the EGNN stack's last node kernel (functional.egnn_stack head)
-        qk = HF.pair_linear(x2, wq, bq, wk, bk)
+        qk = HF.pair_linear(x2, wq, bq, wk, bk) if dm == 64 else torch.cat([F.linear(x2, wq, bq), F.linear(x2, wk, bk)], dim=1)
     if (heads == 1 and n <= 256 and dm == 64 and out_proj is not None and x.is_cuda
             and not need_weights):
         # scores -> softmax -> column mean -> ctx -> value projection -> w_concat: ONE forward launch
         return HF.attn_pooled_tail(qk, x2, wv, bv, out_proj.weight, out_proj.bias, b, n), None
-    if heads in (1, 8) and n <= 256:
+    if heads in (1, 8) and n <= 256 and dm == 64:
         ctx = HF.attn_colmean(qk, x2, b, n, heads)                             # (b, heads, dm)
         w = None
         if need_weights:

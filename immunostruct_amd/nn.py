@@ -31,12 +31,11 @@ from .graph import PackedGraphBatch
 class EGNNConv(nn.Module):
     def __init__(self, in_size, hidden_size, out_size, edge_feat_size=0):
         super().__init__()
-        if hidden_size != HF.HIDDEN:
-            raise NotImplementedError(
-                f"the HIP EGNN kernels are built for hidden_size={HF.HIDDEN} "
-                f"(reference gat_hidden_channels, models/hybrid_models.py:247); got {hidden_size}")
-        if edge_feat_size > 8:
-            raise NotImplementedError("edge_feat_size > 8 is not supported by the HIP EGNN kernels")
+        # the HIP layer kernels are built for the reference's sizes (hidden = out = 64 = gat_hidden_channels' default,
+        # models/hybrid_models.py:247; 20 or 64 input features; <= 8 edge features).  Any other size still runs -- on the device,
+        # composed from torch ops with the same fixed summation order (egnn_conv_composed below) -- so that every constructor
+        # argument of the reference's models is accepted; it is a slow path and cannot be captured by engine.CapturedTrainStep
+        self.native = hidden_size == HF.HIDDEN and out_size == HF.HIDDEN and in_size in (20, HF.HIDDEN) and edge_feat_size <= 8
         self.in_size, self.hidden_size = in_size, hidden_size
         self.out_size, self.edge_feat_size = out_size, edge_feat_size
         act = nn.SiLU()
@@ -77,13 +76,35 @@ def egnn_stack_prelaunch(layers, graph, node_feat, coord_feat, edge_feat=None, h
                                    head=head, final_coords=final_coords, fork_after=fork_after)
 
 
+def stack_is_native(layers):
+    """True when consecutive layers can run as the fused HIP stack (sizes the kernels are built for, one edge_feat_size)"""
+    fe = layers[0].edge_feat_size
+    return all(layer.native and layer.edge_feat_size == fe and (i == 0 or layer.in_size == HF.HIDDEN) for i, layer in enumerate(layers))
+
+
+def egnn_conv_composed(layer, csr, num_edges, h, x, ea_csr, want_coords=True):
+    """One EGNNConv layer from device-side torch ops, for sizes the HIP kernels are not built for: the arithmetic of
+    ``dgl.nn.EGNNConv`` (x_src - x_dst, squared distance, / (sqrt + 1e-30), [h_src, h_dst, radial, a], sum for h, mean for x) over
+    the destination-sorted edge slots, the two aggregations as segment sums over the CSR row pointer (fixed order, no atomics)."""
+    src, dst = csr.src_sorted[:num_edges].long(), csr.dst_sorted[:num_edges].long()
+    offsets = csr.rowptr_dst.long()
+    d = x[src] - x[dst]
+    radial = (d * d).sum(dim=1, keepdim=True)
+    feats = [h[src], h[dst], radial] + ([ea_csr[:num_edges]] if layer.edge_feat_size > 0 else [])
+    m = layer.edge_mlp(torch.cat(feats, dim=1))
+    h_neigh = torch.segment_reduce(m, "sum", offsets=offsets, axis=0)
+    h_out = layer.node_mlp(torch.cat([h, h_neigh], dim=1))
+    if not want_coords:
+        return h_out, None
+    msg_x = layer.coord_mlp(m) * (d / (radial.sqrt() + 1e-30))
+    deg = (offsets[1:] - offsets[:-1]).clamp(min=1).to(x.dtype).unsqueeze(1)
+    return h_out, x + torch.segment_reduce(msg_x, "sum", offsets=offsets, axis=0) / deg
+
+
 def _check_stack(layers, graph, edge_feat):
     if not isinstance(graph, PackedGraphBatch):
         raise TypeError("immunostruct_amd.nn.EGNNConv expects an immunostruct_amd.graph.PackedGraphBatch")
     fe = layers[0].edge_feat_size
-    for i, layer in enumerate(layers):
-        if layer.edge_feat_size != fe or layer.out_size != HF.HIDDEN or (i > 0 and layer.in_size != HF.HIDDEN):
-            raise NotImplementedError("fused EGNN stack needs out_size = 64 and a common edge_feat_size")
     if fe > 0 and edge_feat is None:
         raise ValueError("Edge features must be provided.")
     if edge_feat is not None and edge_feat.requires_grad:
@@ -99,6 +120,20 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, hea
     returned x may be None."""
     _check_stack(layers, graph, edge_feat)
     ea = graph.edge_feat_csr(edge_feat) if layers[0].edge_feat_size > 0 else None
+    if not stack_is_native(layers):
+        if getattr(graph, "edge_capacity", None) is not None:
+            raise NotImplementedError("EGNN layers of sizes the HIP kernels are not built for run from torch ops and cannot be "
+                                      "captured into a HIP graph (engine.CapturedTrainStep): train them with the eager loops")
+        HF._lib.require_device(node_feat, coord_feat)
+        h, x = node_feat, coord_feat
+        csr, e = graph.csr(), graph.num_edges()
+        for i, layer in enumerate(layers):
+            eai = graph.edge_feat_csr(edge_feat) if layer.edge_feat_size > 0 else None
+            h, x = egnn_conv_composed(layer, csr, e, h, x, eai, want_coords=final_coords or i + 1 < len(layers))
+        if head is not None:
+            wa, ba, wb, bb = head
+            return h, x, torch.cat([torch.nn.functional.linear(h, wa, ba), torch.nn.functional.linear(h, wb, bb)], dim=1)
+        return h, x
     return HF.egnn_stack(node_feat, coord_feat, ea, graph.csr(), [layer.native_parameters() for layer in layers], head=head,
                          final_coords=final_coords, prologue=prologue)
 
