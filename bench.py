@@ -56,7 +56,7 @@ TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")   # PMC-measured
 
 
 def layer_algorithmic(n_nodes, n_edges, din, fe):
-    """Algorithmic bytes / FLOP of one EGNN layer launch (DESIGN.md section 4, SURVEY.md section 8(d)).
+    """Algorithmic bytes / FLOP of one EGNN layer launch (DESIGN.md section 4.1, SURVEY.md section 8(d)).
 
     bytes: SURVEY's per-layer figure (it already holds the node rows: self rows for the node MLP / coordinate update and
     the writes).  FLOP: the dense work the launch performs -- edge half: the per-edge layers that remain after hoisting the

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void vae_latent_bwd_data_kernel(
 // 16 x 16 output tile, the contraction over the batch as v_mfma_f32_16x16x4_f32 steps in batch order (fixed), operands straight
 // from global memory (every load of a wave is independent).  Many one-wave workgroups of a few microseconds each: beside a
 // persistent layer kernel they slip into whatever slot frees up and are gone again, instead of holding slots for a whole
-// contraction loop.  The bias gradients are the column sums of the A operand of the first tile column.
+// contraction loop (HISTORY.md section 6).  The bias gradients are the column sums of the A operand of the first tile column.
 constexpr int WSTEPS = 32;       // MFMA steps (4 batch rows each) per batch of loads: B = 128 is ONE round trip
 __global__ __launch_bounds__(64) void vae_latent_bwd_wgrad_kernel(
     const float* __restrict__ a1, const float* __restrict__ dmu, const float* __restrict__ dlv,

@@ -1336,7 +1336,7 @@ class VaeLatentFn(torch.autograd.Function):
         if ctx.fc1:
             # the first layer inside this node (``a1`` is ignored): forward = the library GEMM; backward launches its weight
             # gradient BETWEEN this block's data path and weight pass -- the order the rest of the step's schedule wants
-            # (DESIGN.md section 3.6), which separate autograd nodes cannot express
+            # (DESIGN.md section 5.1), which separate autograd nodes cannot express
             a1 = _linear_forward(x, w1, b1)
             ctx.fc1_dest = getattr(w1, "_grad_dest", None)
             ctx.fc1_w, ctx.fc1_bias = w1, b1
@@ -1555,7 +1555,7 @@ class SpeculativeBackward:
     d loss / d recon for a unit seed), then the producing ``vae_fc4``'s input and weight gradients -- all on the stream ``recon``
     was produced on (the sequence branch's), where they depend on nothing the graph branch computes.  They run beside the EGNN
     forward layers (whose workgroups leave room for them) instead of beside the backward layers (whose do not: DESIGN.md
-    section 3.6).  The backward node of ``vae_fc4`` recognises the gradient it was speculated for by its buffer and hands the
+    section 5.1).  The backward node of ``vae_fc4`` recognises the gradient it was speculated for by its buffer and hands the
     stored results on; any other seed (a scaled loss) makes it launch normally -- the speculation is then wasted, not wrong."""
     enabled = False
     allowed = os.environ.get("IMMUNOSTRUCT_SPECULATIVE_BACKWARD", "1") != "0"

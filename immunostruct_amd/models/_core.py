@@ -263,7 +263,7 @@ class MultimodalNet(nn.Module):
             #  * the sequence branch (and, behind it on the same stream, the speculative backward of its reconstruction term)
             #    runs beside the second half of the stack and the attention / head / loss kernels (whose small grids leave
             #    half the CUs idle), and its backward entirely between the head's and the stack's backward -- not beside the
-            #    backward layer kernels, which own every wave slot (the fork point is a measured sweep).
+            #    backward layer kernels, which own every wave slot (HISTORY.md section 3; the fork point is a measured sweep).
             main = torch.cuda.current_stream()
             side = _side_stream(seq.device)
             inp = self._graph_inputs(g)

@@ -1,4 +1,4 @@
-"""How does the HIP graph executor run two independent branches of a captured graph?  
+"""How does the HIP graph executor run two independent branches of a captured graph?  (HISTORY.md section 6)
 
 Chains of dummy kernels with known durations are captured with different creation orders / stream roles and the replay
 time is compared with the serial sum and the ideal overlap.  python tools/graph_branch_probe.py"""
