@@ -231,59 +231,97 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
 
 // parameter gradients of the classifier, one workgroup: samples in ascending order (deterministic)
 __device__ __forceinline__ void ca_cls_wgrad(float* lds, const CaCls& cls, int T, int tid) {
-  constexpr int S = 8;                                   // samples per chunk
+  // samples per chunk.  This workgroup is a chain of B / S trips of (global loads -> barrier -> pre-activation gradients ->
+  // barrier -> products): with S = 8 its 16 trips at B = 128 outlasted the per-sample workgroups of the launch by ~ 15 us -- on
+  // the step's critical chain.  16 samples per trip (32 spill 250 registers into the per-sample path); every sum still runs over
+  // the samples in ascending order: same bits.
+  constexpr int S = 16;
+  static_assert(S * (CA_TMAX + 2 * CA_CLS_HID + 64) + 64 * CA_CLS_HID <= 5 * CA_HEADS * CA_TMAX + 4 * CA_THREADS, "chunk buffers + W2 must fit the shared block");
   float* zc = lds;                                       // [S][T]
   float* ghc = zc + S * CA_TMAX;                         // [S][hid]   d loss / d pre-activation 1
   float* hc = ghc + S * CA_CLS_HID;                      // [S][hid]   hid = a1 * mask
   float* g2c = hc + S * CA_CLS_HID;                      // [S][out]
+  float* w2s = g2c + S * 64;                             // [out][hid]  W2, staged once (it was re-read from global every trip)
   const int hid = cls.hid, out = cls.out;
   const int n1 = hid * T, n2 = out * hid;
+  const int hgroups = (hid + 3) / 4;                     // dW1 rows in groups of four
   constexpr int PER1 = (CA_CLS_HID * CA_TMAX + CA_THREADS - 1) / CA_THREADS;                    // dW1 entries per thread
+  static_assert(PER1 % 4 == 0, "dW1 entries are owned four rows at a time");
   constexpr int PER2 = (CA_CLS_HID + 64 * CA_CLS_HID + 64 + CA_THREADS - 1) / CA_THREADS;       // db1 | dW2 | db2 entries
+  constexpr int ZPT = (S * CA_TMAX + CA_THREADS - 1) / CA_THREADS;                              // z entries per thread and chunk
+  static_assert(S * 64 <= CA_THREADS && S * CA_CLS_HID <= CA_THREADS, "one g2 / a1 / mask entry per thread and chunk");
   float acc1[PER1], acc2[PER2];
 #pragma unroll
   for (int k = 0; k < PER1; ++k) acc1[k] = 0.0f;
 #pragma unroll
   for (int k = 0; k < PER2; ++k) acc2[k] = 0.0f;
+  for (int i = tid; i < n2; i += CA_THREADS) w2s[i] = cls.W2[i];
+  // the chunk's rows travel global -> registers -> LDS, the NEXT chunk's loads in flight while this one is reduced
+  float rz[ZPT], rg = 0.0f, ra = 0.0f, rm = 1.0f;
+  auto fetch = [&](int s0) {
+#pragma unroll
+    for (int u = 0; u < ZPT; ++u) {
+      const int i = tid + u * CA_THREADS, s = s0 + i / T;
+      rz[u] = (i < S * T && s < cls.B) ? cls.z_in[(size_t)s * T + i % T] : 0.0f;
+    }
+    rg = 0.0f;
+    if (tid < S * out) {
+      const int s = s0 + tid / out, o = tid % out;
+      if (s < cls.B) {
+        rg = cls.gy[(size_t)s * out + o];
+        if (cls.act2 == 1 && !(cls.y_in[(size_t)s * out + o] > 0.0f)) rg = 0.0f;
+      }
+    }
+    ra = 0.0f; rm = 1.0f;
+    if (tid < S * hid) {
+      const int s = s0 + tid / hid, h = tid % hid;
+      if (s < cls.B) {
+        ra = cls.a1_in[(size_t)s * hid + h];
+        if (cls.mask != nullptr) rm = cls.mask[(size_t)s * hid + h];
+      }
+    }
+  };
+  fetch(0);
   for (int s0 = 0; s0 < cls.B; s0 += S) {
-    __syncthreads();
-    for (int i = tid; i < S * T; i += CA_THREADS) {
-      const int s = s0 + i / T;
-      zc[(i / T) * CA_TMAX + i % T] = (s < cls.B) ? cls.z_in[(size_t)s * T + i % T] : 0.0f;
+    __syncthreads();      // the previous chunk's products are done with the buffers (first trip: w2s is staged)
+#pragma unroll
+    for (int u = 0; u < ZPT; ++u) {
+      const int i = tid + u * CA_THREADS;
+      if (i < S * T) zc[(i / T) * CA_TMAX + i % T] = rz[u];
     }
-    for (int i = tid; i < S * out; i += CA_THREADS) {
-      const int s = s0 + i / out, o = i % out;
+    if (tid < S * out) g2c[tid] = rg;
+    const float a_own = ra, m_own = rm;
+    __syncthreads();
+    if (s0 + S < cls.B) fetch(s0 + S);
+    if (tid < S * hid) {
+      const int sl = tid / hid, h = tid % hid;
       float g = 0.0f;
-      if (s < cls.B) {
-        g = cls.gy[(size_t)s * out + o];
-        if (cls.act2 == 1 && !(cls.y_in[(size_t)s * out + o] > 0.0f)) g = 0.0f;
+      if (s0 + sl < cls.B) {
+        for (int o = 0; o < out; ++o) g += g2c[sl * out + o] * w2s[o * hid + h];
+        g *= m_own;
+        if (!(a_own > 0.0f)) g = 0.0f;
       }
-      g2c[i] = g;
+      ghc[tid] = g;
+      hc[tid] = (s0 + sl < cls.B) ? a_own * m_own : 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < S * hid; i += CA_THREADS) {
-      const int sl = i / hid, h = i % hid, s = s0 + sl;
-      float a = 0.0f, m = 1.0f, g = 0.0f;
-      if (s < cls.B) {
-        a = cls.a1_in[(size_t)s * hid + h];
-        if (cls.mask != nullptr) m = cls.mask[(size_t)s * hid + h];
-        for (int o = 0; o < out; ++o) g += g2c[sl * out + o] * cls.W2[o * hid + h];
-        g *= m;
-        if (!(a > 0.0f)) g = 0.0f;
-      }
-      ghc[i] = g;
-      hc[i] = a * m;
-    }
-    __syncthreads();
+    // dW1[h][kk] += sum over the chunk of ghc[sl][h] * zc[sl][kk]: a thread owns column kk of FOUR consecutive rows h, so one
+    // read of zc feeds four products and the four ghc reads are the same address across the wave (one entry per thread and
+    // read pair made this phase -- 16 waves on one CU -- LDS-bandwidth bound: 2 us per trip)
 #pragma unroll
-    for (int k = 0; k < PER1; ++k) {
-      const int idx = tid + k * CA_THREADS;
-      if (idx < n1) {
-        const int h = idx / T, kk = idx % T;
-        float v = acc1[k];
-#pragma unroll
-        for (int sl = 0; sl < S; ++sl) v += ghc[sl * hid + h] * zc[sl * CA_TMAX + kk];
-        acc1[k] = v;
+    for (int k = 0; k < PER1 / 4; ++k) {
+      const int item = tid + k * CA_THREADS;      // (row group, column)
+      if (item < hgroups * T) {
+        const int h0 = 4 * (item / T), kk = item % T;
+        const int o1 = min(h0 + 1, hid - 1), o2 = min(h0 + 2, hid - 1), o3 = min(h0 + 3, hid - 1);
+        float a0 = acc1[4 * k], a1 = acc1[4 * k + 1], a2 = acc1[4 * k + 2], a3 = acc1[4 * k + 3];
+#pragma unroll 4
+        for (int sl = 0; sl < S; ++sl) {
+          const float zv = zc[sl * CA_TMAX + kk];
+          const float* gr = ghc + sl * hid;
+          a0 += gr[h0] * zv; a1 += gr[o1] * zv; a2 += gr[o2] * zv; a3 += gr[o3] * zv;
+        }
+        acc1[4 * k] = a0; acc1[4 * k + 1] = a1; acc1[4 * k + 2] = a2; acc1[4 * k + 3] = a3;
       }
     }
 #pragma unroll
@@ -305,9 +343,14 @@ __device__ __forceinline__ void ca_cls_wgrad(float* lds, const CaCls& cls, int T
     }
   }
 #pragma unroll
-  for (int k = 0; k < PER1; ++k) {
-    const int idx = tid + k * CA_THREADS;
-    if (idx < n1) cls.gcls[idx] = acc1[k];
+  for (int k = 0; k < PER1 / 4; ++k) {
+    const int item = tid + k * CA_THREADS;
+    if (item < hgroups * T) {
+      const int h0 = 4 * (item / T), kk = item % T;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (h0 + u < hid) cls.gcls[(h0 + u) * T + kk] = acc1[4 * k + u];
+    }
   }
 #pragma unroll
   for (int k = 0; k < PER2; ++k) {
