@@ -198,28 +198,42 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
   if constexpr (D == 64) {
     if (wv != nullptr) {
       // pooled tail of a single head (models/layers.py:74-77 on the mean-pooled vector): hid = W_v ctx + b_v,
-      // y = W_c hid + b_c, the arithmetic of csrc/mlp_head.hip (k ascending from the bias) on LDS-staged transposed
-      // weights; the Q / K tiles are dead by now and lend their space
-      constexpr int LDW = 65;
-      float* wvt = sm.qs;                       // [k][d]
-      float* wct = sm.qs + 64 * LDW;            // [h][o]
-      __syncthreads();
-      for (int i = tid; i < 64 * 64; i += 64 * NT) {
-        wvt[(i & 63) * LDW + (i >> 6)] = wv[i];
-        wct[(i & 63) * LDW + (i >> 6)] = wc[i];
+      // y = W_c hid + b_c, the arithmetic of csrc/mlp_head.hip (k ascending from the bias).  Both 64 x 64 matrices go to LDS
+      // row-major with a pitch of 65 (lane d then reads row d conflict-free) where the dead Q / K tiles were: ALL their loads
+      // are issued first -- coalesced 16-byte loads, one round trip for the whole workgroup -- and stored after the barrier.
+      // (One element per thread and trip -- 11 dependent load / store trips -- made this tail 18 of the launch's 37 us.)
+      constexpr int LDW = 65, NTH = 64 * NT, PER = (1024 + NTH - 1) / NTH;
+      float* wvl = sm.qs;                       // [d][k]
+      float* wcl = sm.qs + 64 * LDW;            // [o][h]
+      f32x4 rv[PER], rc[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int idx = min(tid + u * NTH, 1023);
+        rv[u] = reinterpret_cast<const f32x4*>(wv)[idx];
+        rc[u] = reinterpret_cast<const f32x4*>(wc)[idx];
+      }
+      __syncthreads();      // every wave is done with the Q / K tiles
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int idx = tid + u * NTH;
+        if (idx < 1024) {
+          const int row = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wvl[row * LDW + c4 + j] = rv[u][j]; wcl[row * LDW + c4 + j] = rc[u][j]; }
+        }
       }
       __syncthreads();
-      if (tid < 64) {
+      if (tid < 64) {      // one wave: its LDS accesses are in order
         float acc = bv[tid];
-        for (int k = 0; k < 64; ++k) acc += wvt[k * LDW + tid] * sm.cpart[0][k];
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) acc += wvl[tid * LDW + k] * sm.cpart[0][k];
         if (a1_out != nullptr) a1_out[(size_t)b * 64 + tid] = acc;
         sm.dab[tid] = acc;
-      }
-      __syncthreads();
-      if (tid < 64) {
-        float acc = bc[tid];
-        for (int h = 0; h < 64; ++h) acc += wct[h * LDW + tid] * sm.dab[h];
-        y_out[(size_t)b * 64 + tid] = acc;
+        __builtin_amdgcn_wave_barrier();
+        float y = bc[tid];
+#pragma unroll 16
+        for (int h = 0; h < 64; ++h) y += wcl[tid * LDW + h] * sm.dab[h];
+        y_out[(size_t)b * 64 + tid] = y;
       }
     }
   }
