@@ -48,20 +48,20 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
   using D = Node16Dims<DIN>;
   const int r = lane & 15, q = lane >> 4;
   const int col = wave * 16 + r;
-  f32x4* fp = reinterpret_cast<f32x4*>(J.fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
-  f32x4* bp = reinterpret_cast<f32x4*>(J.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
-  // every slot is gathered into registers first and stored afterwards: the 160 scattered loads of a lane are then in
-  // flight together (interleaved with the stores they would be serialised by possible aliasing)
+  f32x4* __restrict__ fp = reinterpret_cast<f32x4*>(J.fpack) + (size_t)wave * NODE_FWD_SLOTS * 64 + lane;
+  f32x4* __restrict__ bp = reinterpret_cast<f32x4*>(J.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
+  // the slots of a pack are gathered into registers first and stored afterwards: the ~ 80 scattered loads of a lane are then in
+  // flight together (interleaved with the stores they would be serialised by possible aliasing).  Forward pack, then backward
+  // pack: both at once need 160 registers, and this kernel's register count is what lets the projection workgroups of the
+  // same launch fit four to a CU (the whole launch in one round: 14 -> 7 us)
   const float* __restrict__ Wn1 = J.Wn1;
   const float* __restrict__ Wn2 = J.Wn2;
   const float* __restrict__ W1n = J.W1n;
   const float* __restrict__ W1nb = J.W1nb;
   const int ldw_n = J.ldw_n;
-  f32x4 fv[NODE_FWD_SLOTS], bv[NODE_BWD_SLOTS];
+  f32x4 fv[NODE_FWD_SLOTS];
 #pragma unroll
   for (int i = 0; i < NODE_FWD_SLOTS; ++i) fv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < NODE_BWD_SLOTS; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // ---- forward ----
   constexpr int G1 = D::KQ1 / 4;
 #pragma unroll
@@ -83,7 +83,13 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
         for (int j = 0; j < 4; ++j) fv[G1 + 4 + nt * 4 + g][j] = row[q * 16 + 4 * g + j];
     }
   }
+  constexpr int NF = G1 + 4 + 8;      // forward slots in use (the rest of the 20 stay unwritten, as before)
+#pragma unroll
+  for (int i = 0; i < NF; ++i) fp[i * 64] = fv[i];
   // ---- backward (transposed operands) ----
+  f32x4 bv[NODE_BWD_SLOTS];
+#pragma unroll
+  for (int i = 0; i < NODE_BWD_SLOTS; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (W1n != nullptr) {
 #pragma unroll
     for (int g = 0; g < 8; ++g)
@@ -105,9 +111,6 @@ __device__ __forceinline__ void node_pack_body(const NodePackJob& J, int wave, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) bv[12 + nt * 4 + g][j] = (xc < D::KV) ? Wn1[(size_t)(q * 16 + 4 * g + j) * D::KV + xc] : 0.0f;
   }
-  constexpr int NF = G1 + 4 + 8;      // forward slots in use (the rest of the 20 stay unwritten, as before)
-#pragma unroll
-  for (int i = 0; i < NF; ++i) fp[i * 64] = fv[i];
 #pragma unroll
   for (int i = 0; i < NODE_BWD_SLOTS; ++i) bp[i * 64] = bv[i];
 }
@@ -125,6 +128,20 @@ __device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int
   // straight from global memory touches 64 cache lines per load), row stride odd => conflict-free column reads
   constexpr int LDWL = 2 * DIN + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // a wave walks nodes n = (block * 4 + wave) + i * stride in groups of G: the group's feature rows are in flight together, and
+  // the FIRST group's (usually the only one) are requested before the weights are staged: one round trip instead of two
+  constexpr int G = 6;
+  const int stride = nblocks * 4;
+  float hv[G], xv[G];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int n = n0 + g * stride;
+      hv[g] = (n < N && lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
+      xv[g] = (x_dst != nullptr && n < N && lane < 3) ? x_src[(size_t)n * ld_x + lane] : 0.0f;
+    }
+  };
+  fetch(block * 4 + wave);
   {
     constexpr int CNT = 64 * 2 * DIN, PER = (CNT + 255) / 256;
     float v[PER];
@@ -148,17 +165,8 @@ __device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int
     ws[k] = wl[lane * LDWL + k];
     wd[k] = wl[lane * LDWL + DIN + k];
   }
-  // a wave walks nodes n = (block * 4 + wave) + i * stride in groups of G: the group's feature rows are in flight together
-  constexpr int G = 6;
-  const int stride = nblocks * 4;
   for (int n0 = block * 4 + wave; n0 < N; n0 += G * stride) {
-    float hv[G], xv[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int n = n0 + g * stride;
-      hv[g] = (n < N && lane < DIN) ? h[(size_t)n * ld_h + lane] : 0.0f;
-      xv[g] = (x_dst != nullptr && n < N && lane < 3) ? x_src[(size_t)n * ld_x + lane] : 0.0f;
-    }
+    if (n0 != block * 4 + wave) fetch(n0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int n = n0 + g * stride;
@@ -166,7 +174,8 @@ __device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int
         float as = bias0, ad = bias;
 #pragma unroll
         for (int k = 0; k < DIN; ++k) {
-          const float hk = __shfl(hv[g], k, 64);
+          // feature k of the node lives in lane k: a scalar broadcast (v_readlane), not a trip through the LDS crossbar
+          const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv[g]), k));
           as += hk * ws[k];
           ad += hk * wd[k];
         }
@@ -178,23 +187,26 @@ __device__ __forceinline__ void stack_proj_body(const float* __restrict__ h, int
   }
 }
 
-// blocks [0, njobs) write the operand packs (first: their 160 scattered loads per lane are the longest chain of the launch),
+// blocks [0, 4 njobs) write the operand packs (first: their scattered loads are the longest chain of the launch),
 // the remaining proj_blocks compute the layer-0 pre-projection
-__global__ __launch_bounds__(256) void stack_prologue_kernel(NodePackBatch batch, int njobs, int proj_blocks, const float* __restrict__ h,
-                                                             int ld_h, int din, const float* __restrict__ W1, int ldw,
+template <int PDIN>      // the projection's input width: the 64-wide form keeps 128 weight registers per lane (two workgroups per CU)
+__global__ __launch_bounds__(256, PDIN == 20 ? 4 : 2) void stack_prologue_kernel(NodePackBatch batch, int njobs, int proj_blocks, const float* __restrict__ h,
+                                                             int ld_h, const float* __restrict__ W1, int ldw,
                                                              const float* __restrict__ b0, const float* __restrict__ b1,
                                                              float* __restrict__ psd, const float* __restrict__ x_src, int ld_x,
                                                              float* __restrict__ x_dst, int N) {
   __shared__ float wl[64 * 129];
-  if ((int)blockIdx.x >= njobs) {
-    const int blk = blockIdx.x - njobs;
-    if (din == 20) stack_proj_body<20>(h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N, blk, proj_blocks, wl);
-    else stack_proj_body<64>(h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N, blk, proj_blocks, wl);
+  if ((int)blockIdx.x >= 4 * njobs) {
+    const int blk = blockIdx.x - 4 * njobs;
+    stack_proj_body<PDIN>(h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N, blk, proj_blocks, wl);
     return;
   }
-  const NodePackJob& J = batch.job[blockIdx.x];
-  if (J.din == 20) node_pack_body<20>(J, threadIdx.x >> 6, threadIdx.x & 63);
-  else node_pack_body<64>(J, threadIdx.x >> 6, threadIdx.x & 63);
+  // a pack is written by four workgroups of ONE wave each (wave w's quarter): a wave's scattered loads touch 64 cache lines per
+  // instruction, and four such waves on one CU queue behind its single texture addresser
+  if (threadIdx.x >= 64) return;
+  const NodePackJob& J = batch.job[blockIdx.x >> 2];
+  if (J.din == 20) node_pack_body<20>(J, blockIdx.x & 3, threadIdx.x);
+  else node_pack_body<64>(J, blockIdx.x & 3, threadIdx.x);
 }
 
 // Streaming weight-gradient kernel of one layer's node block (outer products over the N rows):
@@ -485,8 +497,12 @@ extern "C" int is_stack_prologue(const void* jobs, int njobs, const float* h, in
     if ((src[i].din != 20 && src[i].din != 64) || ((src[i].W1n == nullptr) != (src[i].W1nb == nullptr))) return -22;
   }
   const int proj_blocks = std::min((N + 23) / 24, 1024);
-  hipLaunchKernelGGL(is::stack_prologue_kernel, dim3(proj_blocks + njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
-                     njobs, proj_blocks, h, ld_h, din, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N);
+  if (din == 20)
+    hipLaunchKernelGGL(is::stack_prologue_kernel<20>, dim3(proj_blocks + 4 * njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
+                       njobs, proj_blocks, h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N);
+  else
+    hipLaunchKernelGGL(is::stack_prologue_kernel<64>, dim3(proj_blocks + 4 * njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
+                       njobs, proj_blocks, h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
