@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void node_proj_fwd_kernel(const float* __restr
     float as = bias0, ad = bias;
 #pragma unroll
     for (int k = 0; k < DIN; ++k) {
-      const float hk = __shfl(hv, k, 64);
+      const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), k));
       as += hk * ws[k];
       ad += hk * wd[k];
     }

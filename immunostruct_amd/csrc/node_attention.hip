@@ -260,7 +260,8 @@ __device__ __forceinline__ float attn_tail_matvec_t(const float* __restrict__ w,
 #pragma unroll
     for (int u = 0; u < 16; ++u) wr[u] = w[(o0 + u) * 64 + lane];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += wr[u] * __shfl(v, o0 + u, 64);
+    for (int u = 0; u < 16; ++u)      // component o0 + u lives in that lane: a scalar broadcast, not a trip through the LDS crossbar
+      acc += wr[u] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), o0 + u));
   }
   return acc;
 }
