@@ -65,6 +65,7 @@ SIGNATURES = {
     "is_mlp2_bwd_record_floats": [_I, _I, _I],
     "is_debug_timestamp": [_P, _P],
     "is_debug_emulated_collective": [_P, _LL, _I, _I, _LL, _P, _P],
+    "is_debug_stream_copy": [_P, _P, _LL, _I, _P],
     "is_gather_segment_sum": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "is_segment_pool_fwd": [_P, _I, _P, _P, _P, _I, _I, _P],
     "is_segment_pool_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],

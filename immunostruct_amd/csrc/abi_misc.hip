@@ -100,3 +100,26 @@ extern "C" int is_debug_emulated_collective(float* buf, long long n, int grid, i
                      elapsed);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+
+// Measurement aid (bench.py `roofline.hbm_view.measured_peak`, SURVEY.md section 8(d): "also report against a measured
+// hipMemcpy / triad ceiling"): dst[0, n) = src[0, n) as a grid-stride loop of 16-byte non-temporal accesses, four loads in
+// flight per thread.  n = number of 16-byte words.  Bytes moved = 32 n (read + write).
+namespace is {
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = (long long)blockIdx.x * 256 * 4 + threadIdx.x; i < n; i += stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * 256 < n) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * 256 < n) __builtin_nontemporal_store(v[u], dst + i + u * 256);
+  }
+}
+}
+extern "C" int is_debug_stream_copy(const void* src, void* dst, long long n16, int grid, void* stream) {
+  if (grid <= 0 || n16 < 0 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return -22;
+  hipLaunchKernelGGL(is::stream_copy_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const is::f32x4*>(src), static_cast<is::f32x4*>(dst), n16);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

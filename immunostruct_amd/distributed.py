@@ -18,24 +18,35 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's env; returns (rank, local_rank, world)."""
+    """Initialise the default process group from torchrun's env; returns (rank, local_rank, world).
+
+    ``IMMUNOSTRUCT_FORCE_COLLECTIVE=1`` with one rank creates a ONE-RANK RCCL group (the whole launch path of the data-parallel
+    step -- ``init_process_group("nccl")``, asynchronous ``all_reduce`` on RCCL's stream, ``work.wait()`` between captured
+    graphs -- on the single GPU of a test box).  ``IMMUNOSTRUCT_DIST_MAX_NCHANNELS=k`` bounds RCCL's channel count (one
+    persistent workgroup per channel) -- opt-in: the only measurement behind a bound is the single-GPU emulation
+    (tools/dp_overlap_emulation.py), and on a real xGMI node fewer channels can cost all-reduce bandwidth."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    forced = world == 1 and os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1"
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             # IMMUNOSTRUCT_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a single GPU
             backend = os.environ.get("IMMUNOSTRUCT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            # RCCL runs one persistent workgroup per channel; the overlapped (two-stage) step leaves the slots of
-            # functional.RESERVED_CUS compute units free for them, so the channel count is bounded to what fits there
-            # (25 MB buckets over 7 xGMI links do not need more).  Respected only when the user has not set it.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+            torch.cuda.set_device(int(os.environ.get("IMMUNOSTRUCT_FORCE_DEVICE", local_rank)))
+            cap = os.environ.get("IMMUNOSTRUCT_DIST_MAX_NCHANNELS")
+            if cap:
+                os.environ["NCCL_MAX_NCHANNELS"] = str(int(cap))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def collectives_forced():
+    """one rank, but the collectives are issued all the same (IMMUNOSTRUCT_FORCE_COLLECTIVE=1 under an initialised group)"""
+    return os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
 
 
 class FlatGradReducer:
@@ -58,9 +69,9 @@ class FlatGradReducer:
             raise ValueError("no trainable parameters")
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.always_pack = always_pack
-        self._packing = self.world > 1 or always_pack
-        # debugging aid: issue the collectives even in a one-rank process group (exercises the RCCL launch path on one GPU)
-        self._collective = self.world > 1 or (os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1" and dist.is_initialized())
+        # issue the collectives even in a one-rank process group (the RCCL launch path on the one GPU of a test box)
+        self._collective = self.world > 1 or collectives_forced()
+        self._packing = self.world > 1 or always_pack or self._collective
         self.buckets = []
         # True: reduce_bucket divides by the world size (its own pass over the bucket); the engine switches it off when
         # the optimizer applies 1 / world itself (immunostruct_amd.optim: ``grad_scale``)
@@ -162,8 +173,9 @@ class FlatGradReducer:
 
 def time_all_reduce(reducer, repeats=10):
     """standalone duration (ms, max over ranks) of the all-reduce of every gradient bucket -- nothing beside it on the GPU; what a
-    data-parallel bench line needs to explain its own efficiency.  None without a process group."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1) or not reducer.buckets:
+    data-parallel bench line needs to explain its own efficiency.  None when the reducer issues no collectives (one rank
+    without IMMUNOSTRUCT_FORCE_COLLECTIVE)."""
+    if not (dist.is_initialized() and getattr(reducer, "_collective", False)) or not reducer.buckets:
         return None
     import time
     out = []
@@ -184,7 +196,7 @@ def time_all_reduce(reducer, repeats=10):
 
 def broadcast_parameters(module, src=0):
     """Make all ranks start from rank ``src``'s weights (also after ``load_trained(new_head=True)``)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not collectives_forced()):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):

@@ -204,6 +204,7 @@ class CapturedTrainStep:
         # None: not classified yet; False: no overlapped optimizer step; list: the EGNN stack's own parameters
         # (IMMUNOSTRUCT_ADAM_OVERLAP=1: measured, no gain -- the tail is bandwidth-bound, HISTORY.md -- hence off by default)
         self._tail_late = None if os.environ.get("IMMUNOSTRUCT_ADAM_OVERLAP", "0") == "1" else False
+        self._split = None
         snap = _snapshot(model, optimizer) if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -222,6 +223,9 @@ class CapturedTrainStep:
         # "auto" times every candidate and keeps the fastest
         default_res = "0,16" if getattr(reducer, "_collective", False) else "0"
         self._reserved_candidates = sorted({max(0, int(v)) for v in os.environ.get("IMMUNOSTRUCT_DP_RESERVED_CUS", default_res).split(",") if v.strip() != ""}) or [0]
+        if mode != "auto":
+            # nothing is timed: only the first candidate would ever be replayed
+            self._reserved_candidates = self._reserved_candidates[:1]
         self._a2 = {}
         self.reserved = self._reserved_candidates[0]
         if self.two_stage:
@@ -232,7 +236,7 @@ class CapturedTrainStep:
                 HF.RESERVED_CUS = res
                 try:
                     for sg in (self.sgraph if self.paired else (self.sgraph,)):
-                        HF.prepare_layer_partitions(sg._csr, fe)
+                        HF.prepare_layer_partitions(sg._csr, fe, forward=False)   # (the forward's: built by the warm-up steps)
                 finally:
                     HF.RESERVED_CUS = saved
             self.graph_a1 = torch.cuda.CUDAGraph()
@@ -458,8 +462,10 @@ class CapturedTrainStep:
     def _split_update(self):
         """data-parallel forms with two gradient buckets: update bucket by bucket, each as soon as its all-reduce is done
         (IMMUNOSTRUCT_DP_SPLIT_UPDATE=0: one update after both)"""
-        return (not self.fused_optimizer and len(self.reducer.buckets) == 2 and hasattr(self.optimizer, "step_subset")
-                and os.environ.get("IMMUNOSTRUCT_DP_SPLIT_UPDATE", "1") != "0")
+        if self._split is None:
+            self._split = os.environ.get("IMMUNOSTRUCT_DP_SPLIT_UPDATE", "1") != "0"      # read once: not per replay
+        return (self._split and not self.fused_optimizer and len(self.reducer.buckets) == 2
+                and hasattr(self.optimizer, "step_subset"))
 
     def _reduce_and_update(self, stage2, update):
         """the part of a data-parallel step behind the (first-stage) backward: all-reduce bucket by bucket, ``stage2()`` (the stack

@@ -47,10 +47,13 @@ def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
 
-def prepare_layer_partitions(csr, fe):
+def prepare_layer_partitions(csr, fe, forward=True):
     """build (and cache in ``csr``) the work partitions the two layer kernels will ask for under the CURRENT ``RESERVED_CUS`` --
-    to be called outside a stream capture: a partition built while capturing lives in the capture's memory pool"""
-    csr.chunks(fwd_chunk_count(csr.num_edges))
+    to be called outside a stream capture: a partition built while capturing lives in the capture's memory pool.
+    ``forward=False``: only the backward kernel's tiles (the reserved-CU candidates of the data-parallel step's stack backward:
+    the forward is always captured on the full grid, and every cached chunk partition is refreshed per batch)"""
+    if forward:
+        csr.chunks(fwd_chunk_count(csr.num_edges))
     if use_bwd_tiles(csr.num_nodes, csr.num_edges, layer_slots(), fe):
         csr.tiles(64, 24)
 

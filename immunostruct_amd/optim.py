@@ -44,7 +44,7 @@ class Adam(torch.optim.Optimizer):
         dev = params[0].device
         gs = self._groups.get(id(group))
         if gs is None:
-            gs = dict(tables={}, hyper_host=None, captured={}, pending=[], spares={},
+            gs = dict(tables={}, hyper_host=None, captured={}, pending=[], spares={}, prepared=False, updated=set(),
                       state=torch.zeros(3, dtype=torch.float32, device=dev), hyper=torch.zeros(8, dtype=torch.float32, device=dev))
             self._groups[id(group)] = gs
         return gs
@@ -90,7 +90,9 @@ class Adam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         gs = self._group_state(group, params)
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in params)
+        # the rows hold the moment buffers' addresses too: a table is only valid for the state tensors it was built from
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                     p.numel()) for p in params)
         if capturing:
             # gradients produced inside a capture live at fixed addresses of the graph's memory pool.  The step being
             # captured gets a chunk table of its OWN, kept alive with the optimizer: eager steps before or after never
@@ -197,9 +199,70 @@ class Adam(torch.optim.Optimizer):
                 self.refresh_group(group, gs)
             if first:
                 _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+                gs["prepared"] = True
+                gs["updated"] = set()
+            elif not gs["prepared"] or any(id(p) in gs["updated"] for p in sub):
+                # a later part without a first part would silently reuse the PREVIOUS step's step size and bias corrections
+                raise RuntimeError("step_subset(first=False) without a step_subset(first=True) of the same step in front of it "
+                                   "(none yet, or these parameters were already updated since the last one): every step's "
+                                   "first part advances the step count and forms the bias corrections")
+            gs["updated"].update(id(p) for p in sub)
             if table is not None:
                 _lib.check(lib.is_adam_apply(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
                                              _lib.stream_ptr()), "is_adam_apply")
+
+    # ---- checkpointing ---------------------------------------------------------
+    def state_dict(self):
+        """torch's layout; every parameter's state also carries ``step`` (torch.optim.Adam's key) read from the device-side counter
+        of its group, so that a checkpoint resumes with the right bias corrections -- here or under ``torch.optim.Adam``"""
+        for group in self.param_groups:
+            gs = self._groups.get(id(group))
+            if gs is None:
+                continue
+            step = torch.tensor(float(gs["state"][0].item()))
+            for p in group["params"]:
+                if self.state.get(p):
+                    self.state[p]["step"] = step.clone()
+        return super().state_dict()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """values are copied INTO the existing moment buffers where they exist (chunk tables and captured steps hold their
+        addresses); otherwise the loaded tensors are adopted and every cached table of the group is dropped.  The device-side
+        step counter is restored from the ``step`` entries."""
+        old = {p: dict(st) for p, st in self.state.items()}
+        old_groups = {i: self._groups.get(id(g)) for i, g in enumerate(self.param_groups)}
+        super().load_state_dict(state_dict)
+        self._groups = {id(g): old_groups[i] for i, g in enumerate(self.param_groups) if old_groups.get(i) is not None}
+        for group in self.param_groups:
+            gs = self._groups.get(id(group))
+            adopted, step = False, None
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                if "step" in st:
+                    step = float(st.pop("step"))
+                for k in ("exp_avg", "exp_avg_sq"):
+                    new = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+                    have = old.get(p, {}).get(k)
+                    if have is not None and have.shape == new.shape:
+                        have.copy_(new)
+                        st[k] = have
+                    else:
+                        st[k] = new
+                        adopted = True
+            if gs is None and step is not None:
+                with_state = [p for p in group["params"] if self.state.get(p)]
+                gs = self._group_state(group, with_state) if with_state else None
+            if gs is not None:
+                if adopted:
+                    if gs["captured"]:
+                        raise RuntimeError("load_state_dict would replace moment buffers a captured step holds the addresses of")
+                    gs["tables"].clear()
+                if step is not None:
+                    gs["state"][0] = step
+                gs["prepared"] = False
 
     def refresh_group(self, group, gs):
         hh = self._hyper_host(group)

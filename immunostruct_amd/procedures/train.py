@@ -169,7 +169,7 @@ def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_
     train_index = torch.as_tensor(train_index, dtype=torch.int64, device=device)
     val_index = torch.as_tensor(val_index, dtype=torch.int64, device=device)
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
-    if world > 1:
+    if dist.is_initialized():      # (world 1 only under IMMUNOSTRUCT_FORCE_COLLECTIVE=1: the collectives are issued all the same)
         broadcast_parameters(model)
         # identical seeds on every rank would make the ranks draw the same noise / dropout masks for their (different) samples
         torch.cuda.manual_seed(int(seed) + 7919 * (rank + 1))

@@ -100,7 +100,7 @@ def main(argv=None):
     device = torch.device("cuda", local_rank) if world > 1 else torch.device("cuda")
 
     def sync():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()      # rank 0 has written the checkpoint every rank loads next
     seed_everything(config.seed)
     gen = torch.Generator().manual_seed(config.seed)

@@ -139,14 +139,14 @@ def main(argv=None):
     opt = optim.Adam(model.parameters(), lr=config.learning_rate_pretrain)
     fit(splits, tr, va, opt, losses.regression_loss_SSL if ssl else losses.regression_loss, "pretrain")
     print("DONE PRE-TRAINING")
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()      # rank 0 has written the checkpoint every rank loads next
     model.load_trained(config.model_save_path_pretrain, new_head=True)
     ds, splits, tr, va, te = loaders(binary=True)
     opt = optim.Adam(model.parameters(), lr=config.learning_rate_finetune, weight_decay=1e-6)
     fit(splits, tr, va, opt, losses.BCE_loss_SSL if ssl else losses.BCE_loss, "finetune")
     print("DONE FINE TUNING")
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     model.load_trained(config.model_save_path_finetune, new_head=False)
     # metrics as the reference reports them (train_IEDB_wFT.py:117-129): the Youden threshold of the TRAIN set is applied to the test set

@@ -273,6 +273,10 @@ int is_debug_timestamp(long long* slot, void* stream);
 int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, long long* elapsed,
                                  void* stream);
 
+/* Measurement aid (bench.py: the copy-bandwidth ceiling HBM fractions are also quoted against):
+ * dst[0, n16) = src[0, n16) in 16-byte words, `grid` workgroups of 256 threads, non-temporal accesses; moves 32 * n16 bytes. */
+int is_debug_stream_copy(const void* src, void* dst, long long n16, int grid, void* stream);
+
 /* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
  * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
  * bytes a multiple of 4.                                                                                   */

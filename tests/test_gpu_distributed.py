@@ -1,5 +1,6 @@
 """Multi-rank paths on the one GPU of the test box: two processes (torch.distributed.run, gloo backend) share cuda:0.
-The RCCL backend needs one GPU per rank and is exercised by the driver's multi-GPU bench only."""
+RCCL needs one GPU per rank, so the ``nccl`` backend itself is exercised as a ONE-RANK group (the ``*_rccl_*`` tests below:
+init, asynchronous all-reduce between captured graphs, wait, timing, form selection); more ranks are the driver's 8-GPU run."""
 import os
 import subprocess
 import sys
@@ -92,6 +93,68 @@ def test_bench_launches_its_own_ranks(cuda_device):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["global_batch"] == 256
+
+
+def _rccl_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "IMMUNOSTRUCT_DIST_BACKEND",
+                                                             "IMMUNOSTRUCT_FORCE_DEVICE", "IMMUNOSTRUCT_DP_OVERLAP")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def _bench_line(env, *flags):
+    import json
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-e2e",
+                          "--no-kernel-timers", "--no-copy-ceiling"] + list(flags), cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_under_a_one_rank_rccl_group(cuda_device):
+    """``IMMUNOSTRUCT_FORCE_COLLECTIVE=1 python bench.py --gpus 1 --force-pack``: the data-parallel step (gradient buckets,
+    RCCL all-reduce per bucket between the captured graphs, 1/world inside Adam) in a fresh child under a real ``nccl`` process
+    group; the same seeded steps without the group end at the same loss."""
+    port = "29571"
+    line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT=port), "--force-pack")
+    cfg = line["config"]
+    assert cfg["dist_backend"] == "nccl" and cfg["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    ar = cfg["grad_allreduce"]
+    assert ar["form"] in ("serial", "two-stage backward, bucket 0 overlapped")
+    assert ar["tuned_ms"] is not None and ar["tuned_ms"]["serial_ms"] > 0            # auto: every candidate was replayed with the collectives
+    assert ar["standalone_allreduce"] and all(b["ms"] > 0 for b in ar["standalone_allreduce"])      # time_all_reduce under nccl
+    assert sum(ar["buckets"]) == sum(b["floats"] for b in ar["standalone_allreduce"])
+    plain = _bench_line(_rccl_env())
+    assert plain["config"]["dist_backend"] is None and plain["config"]["grad_allreduce"] is None
+    a, b = line["config"]["final_loss"], plain["config"]["final_loss"]
+    assert abs(a - b) <= 1e-6 * abs(b) + 1e-5, (a, b)      # (the line rounds the loss to 5 decimals)
+
+
+@pytest.mark.gpu
+def test_captured_data_parallel_forms_under_a_one_rank_rccl_group(cuda_device):
+    """tools/dp_rccl1_check.py: the two-stage captured step (asynchronous all-reduce of bucket 0 under the stack backward,
+    ``work.wait()`` honoured in front of the per-bucket update), the serial one and the auto-selected one under a 1-rank
+    ``nccl`` group == the eager unpacked step after 3 Adam steps; collectives and waits per step counted; ``time_all_reduce``
+    runs under nccl."""
+    res = subprocess.run([sys.executable, os.path.join("tools", "dp_rccl1_check.py")], cwd=ROOT,
+                         env=_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29572"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-4000:]
+    assert "RCCL 1-RANK CHECK OK" in res.stdout
+    assert res.stdout.count("form two-stage") >= 1 and res.stdout.count("form serial") >= 1
+
+
+@pytest.mark.gpu
+def test_training_loop_under_a_one_rank_rccl_group(cuda_device, tmp_path):
+    """the entry script's device loop (procedures.train_model_device: broadcast of the weights, captured data-parallel step,
+    eager trailing batch, rank-0 checkpoint, barrier) with every collective going through RCCL"""
+    res = subprocess.run([sys.executable, "-m", "immunostruct_amd.train_IEDB_wFT", "--model", "HybridModelv2", "--full-sequence",
+                          "--sequence-loss", "--num-epochs", "1", "--learning-rate-pretrain", "1e-4", "--batch-size", "16", "--synthetic", "100",
+                          "--device-dataset", "--seed", "3", "--model-save-dir", str(tmp_path)], cwd=ROOT,
+                         env=_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29573"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("DONE FINE TUNING") == 1 and len(list(tmp_path.glob("*.pt"))) == 2
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -649,6 +649,75 @@ def test_hip_adam_in_parts_is_the_single_step(cuda_device, kind, wd):
 
 
 @pytest.mark.gpu
+def test_hip_adam_subset_update_needs_its_first_part(cuda_device):
+    """a later part of a step without the step's first part would reuse the previous step's step size / bias corrections:
+    step_subset refuses it (no first part yet; the same parameters twice since the last first part)"""
+    from immunostruct_amd import optim
+    ps = [torch.randn(40, 3, device=cuda_device).requires_grad_(True), torch.randn(9, device=cuda_device).requires_grad_(True)]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    o = optim.Adam(ps, lr=1e-2)
+    with pytest.raises(RuntimeError, match="first=True"):
+        o.step_subset([ps[1]], first=False)
+    o.step_subset([ps[0]], first=True)
+    o.step_subset([ps[1]], first=False)
+    with pytest.raises(RuntimeError, match="first=True"):      # the next step began without its first part
+        o.step_subset([ps[1]], first=False)
+    o.step_subset([ps[0]], first=True)
+    o.step_subset([ps[1]], first=False)
+    torch.cuda.synchronize()
+    assert float(o._groups[id(o.param_groups[0])]["state"][0]) == 2.0
+
+
+@pytest.mark.gpu
+def test_hip_adam_checkpoint_round_trip(cuda_device):
+    """state_dict / load_state_dict: a resumed optimizer (fresh object, and the SAME object with live chunk tables) continues
+    bit-identically -- moments copied into the existing buffers, the device-side step counter restored -- and the
+    checkpoint loads into torch.optim.Adam (it carries torch's ``step`` entry)."""
+    from immunostruct_amd import optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(300, 70), (33,), (20000,)]
+    mk = lambda: [torch.randn(*s, generator=torch.Generator().manual_seed(1 + i)).to(cuda_device).requires_grad_(True)
+                  for i, s in enumerate(shapes)]
+    grads = [[torch.randn(*s, generator=g).to(cuda_device) for s in shapes] for _ in range(6)]
+
+    def run(o, ps, steps):
+        for k in steps:
+            for p, gr in zip(ps, grads[k]):
+                p.grad = gr.clone()
+            o.step()
+    a_p = mk(); a = optim.Adam(a_p, lr=1e-2, weight_decay=1e-6)
+    run(a, a_p, range(6))
+    b_p = mk(); b = optim.Adam(b_p, lr=1e-2, weight_decay=1e-6)
+    run(b, b_p, range(3))
+    ck = b.state_dict()
+    ck_params = [p.detach().clone() for p in b_p]
+    assert float(ck["state"][0]["step"]) == 3.0
+    # fresh object
+    c_p = [p.clone().requires_grad_(True) for p in ck_params]
+    c = optim.Adam(c_p, lr=1e-2, weight_decay=1e-6)
+    c.load_state_dict(ck)
+    run(c, c_p, range(3, 6))
+    # the same object, after it moved on (tables cached for its state tensors)
+    run(b, b_p, range(3, 5))
+    with torch.no_grad():
+        for p, v in zip(b_p, ck_params):
+            p.copy_(v)
+    bufs = [b.state[p]["exp_avg"].data_ptr() for p in b_p]
+    b.load_state_dict(ck)
+    assert bufs == [b.state[p]["exp_avg"].data_ptr() for p in b_p]
+    run(b, b_p, range(3, 6))
+    # torch's optimizer reads the same checkpoint
+    t_p = [p.clone().requires_grad_(True) for p in ck_params]
+    t = torch.optim.Adam(t_p, lr=1e-2, weight_decay=1e-6)
+    t.load_state_dict(ck)
+    run(t, t_p, range(3, 6))
+    for x, y, z, w in zip(a_p, c_p, b_p, t_p):
+        assert torch.equal(x.detach(), y.detach()) and torch.equal(x.detach(), z.detach())
+        H.assert_close(w.detach().cpu(), x.detach().cpu(), 2e-6, "torch.optim.Adam resumed from the HIP optimizer's checkpoint")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("grids", [(72, 48), (40, 64), (7, 3)])
 def test_node_weight_gradients_do_not_depend_on_the_grids(cuda_device, grids):
     """is_egnn_node_wgrad_batched with other numbers of workgroups per kind (the ABI's grid_node / grid_proj) gives the default grids'
