@@ -597,7 +597,7 @@ class StressWorkload:
             self.graphs = []
             for i in range(len(self.pool)):
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):      # (a process group's watchdog thread polls events)
                     self._body(i)
                 self.reducer.bind_sources()
                 self.graphs.append((gr, self.reducer.sources()))
@@ -780,7 +780,8 @@ def main():
     # untimed: keep replaying until the step time is stable (clocks / caches / allocator of a cold box), at most ~0.5 s;
     # every rank runs the same number of blocks (the stop decision is rank 0's)
     settle, prev = [], None
-    for blk in range(40):
+    fixed_blocks = os.environ.get("IMMUNOSTRUCT_BENCH_SETTLE_BLOCKS")      # tests: a run-to-run identical number of steps
+    for blk in range(40 if fixed_blocks is None else int(fixed_blocks)):
         fence()
         s0 = time.perf_counter()
         for i in range(5):
@@ -788,7 +789,7 @@ def main():
         fence()
         cur = (time.perf_counter() - s0) / 5
         settle.append(round(cur * 1e3, 3))
-        stop = (prev is not None and abs(cur - prev) <= 0.02 * prev and blk >= 2) or sum(settle) * 5e-3 > 0.5
+        stop = fixed_blocks is None and ((prev is not None and abs(cur - prev) <= 0.02 * prev and blk >= 2) or sum(settle) * 5e-3 > 0.5)
         if world > 1:
             flag = torch.tensor([1 if stop else 0], device=dev)
             torch.distributed.broadcast(flag, src=0)
@@ -895,7 +896,7 @@ def main():
         ddp = torch.distributed.is_initialized()
         config = dict(workload=wl.describe(), global_batch=wl.graphs_per_step * world, nodes_per_batch=wl.n_nodes,
                       edges_per_batch=int(wl.n_edges), parallelism=f"dp{world}",
-                      final_loss=None if final_loss is None else round(final_loss, 5),
+                      final_loss=None if final_loss is None else round(final_loss, 7),
                       rccl_ranks=torch.distributed.get_world_size() if ddp else 1,
                       dist_backend=torch.distributed.get_backend() if ddp else None)
         config.update(extra_config)

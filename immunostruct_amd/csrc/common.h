@@ -34,6 +34,11 @@ constexpr int WAVES = 4;
 __device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v); }
 
 // SiLU and its derivative.  sigma = 1 / (1 + exp(-z)).
+// (IS_ABL_* switches: TIMING-ONLY ablation builds, results wrong on purpose -- HISTORY.md "issue-bound model, ablations")
+#ifdef IS_ABL_SILU
+__device__ __forceinline__ float silu_f(float z) { return z * 0.5f; }
+__device__ __forceinline__ void silu_fg(float z, float& y, float& dy) { y = z * 0.5f; dy = 0.5f; }
+#else
 __device__ __forceinline__ float silu_f(float z) {
   const float s = rcp_f(1.0f + __expf(-z));
   return z * s;
@@ -43,6 +48,7 @@ __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
   y = z * s;
   dy = s * (1.0f + z * (1.0f - s));
 }
+#endif
 
 // |d|^2 with a FIXED contraction (the compiler otherwise picks fma chains or packed multiplies per call site,
 // and the forward / backward / v2 / v3 kernels would disagree in the last bit).

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     // behind the gather (they are first used two barriers later)
     const f32x4* pk = reinterpret_cast<const f32x4*>(nb.bpack) + (size_t)wave * NODE_BWD_SLOTS * 64 + lane;
     STAMPP_W(20);
+#ifdef IS_ABL_NONODE
+    for (int t0 = num_tiles; t0 < num_tiles; t0 += TPP * gridDim.x) {
+#else
     for (int t0 = blockIdx.x; t0 < num_tiles; t0 += TPP * gridDim.x) {
+#endif
       const int ntp = min(TPP, (num_tiles - t0 + (int)gridDim.x - 1) / (int)gridDim.x);     // tiles of this pass
       const int mt_used = ntp * (PITCH / 16);
       // first node / node count of the pass's tiles: workgroup-uniform, so they are scalar loads into scalar registers (they
@@ -800,14 +804,25 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
         // ---- WG1: dWc1[16w.., :] += sum over the window's edge tiles of dz3^T mh ----
 #pragma unroll
         for (int wt = 0; wt < WB16; ++wt)
+#ifdef IS_ABL_NOMFMA
+          if (win + wt * TE16 < e_end) dWc1[0][0] += sm.bufA[wt][lane] * sm.bufB[wt][lane];
+#else
           if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.bufA[wt], sm.bufB[wt], wave, lane);
+#endif
       }
 
       if (nvalid > 0) {
         // ---- MM3: dmh = dz3 Wc1 + g_hn[dst] ; dz2 = dmh * SiLU'(z2) ----
         f32x4 acc[4];
         zero_acc4(acc);
+#ifdef IS_ABL_NOMFMA
+        if constexpr (GX) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(bufA + r * LD + 4 * q + 16 * nt);
+        }
+#else
         if constexpr (GX) mm16_rows<4, H>(acc, bufA, sm.wc1t, lane);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -887,13 +902,22 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       // ---- WG2: dW2[16w.., :] += sum over edge tiles of dz2^T m1 ----
 #pragma unroll
       for (int wt = 0; wt < WB16; ++wt)
+#ifdef IS_ABL_NOMFMA
+        if (win + wt * TE16 < e_end) dW2[0][0] += sm.bufA[wt][lane] * sm.bufB[wt][lane];
+#else
         if (win + wt * TE16 < e_end) mm16_outer_rows(dW2, sm.bufA[wt], sm.bufB[wt], wave, lane);
+#endif
 
       if (nvalid > 0) {
         // ---- MM4: dm1 = dz2 W2 ; dz1 = dm1 * SiLU'(z1) ----
         f32x4 acc[4];
         zero_acc4(acc);
+#ifdef IS_ABL_NOMFMA
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(bufA + r * LD + 4 * q + 16 * nt);
+#else
         mm16_rows<4, H>(acc, bufA, sm.w2t, lane);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int row = tile16_row(t, q);
@@ -901,7 +925,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             const float dz1 = acc[nt][t] * dy[t][nt];      // rows past nvalid: 0 (dz2 = 0)
+#ifndef IS_ABL_STORES
             buf_store(dz1, rdz1, vt + (t * H + nt * 16) * 4, 0);      // (rows past nvalid: dropped)
+#endif
             dy[t][nt] = dz1;
             part += dz1 * wr_t[nt];
           }
@@ -938,7 +964,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
             q1 = u1 * inv - d1 * k + d1 * dr2;
             q2 = u2 * inv - d2 * k + d2 * dr2;
             const size_t e = (size_t)(cb + lane);
+#ifndef IS_ABL_STORES
             dD[e * 3 + 0] = q0; dD[e * 3 + 1] = q1; dD[e * 3 + 2] = q2;
+#endif
           }
           sm.e_gx[wave][0][lane] = q0; sm.e_gx[wave][1][lane] = q1; sm.e_gx[wave][2][lane] = q2;
         }
@@ -961,6 +989,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       //      [edges x columns] products with the incidence matrix built from e_dl (rows past a tile's end: dz1 = dL/dd = 0).
       //      Wave w owns columns [16 w, 16 w + 16); the coordinate columns ride on the last wave (the one whose edge tile
       //      is empty in most windows).  Replaces a per-node loop over LDS rows (dependent reads: 4 k cycles per window).
+#ifndef IS_ABL_SEG
 #pragma unroll
       for (int wt = 0; wt < WB16; ++wt)
         if (win + wt * TE16 < e_end) {
@@ -979,6 +1008,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
             }
           }
         }
+#else
+      seg_h[0][0] += sm.bufA[0][lane]; seg_x[0][0] += sm.e_gx[0][0][r];
+#endif
       __syncthreads();
     }
 

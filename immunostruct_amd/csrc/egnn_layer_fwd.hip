@@ -142,10 +142,15 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 #ifdef IS_STAGE_STAMPS
   int stamp_k = 2;
 #endif
-  const bool save3 = SAVE && COORD && z3s != nullptr;      // kernel-uniform: z3 is saved only for a backward that does not recompute it
+#ifdef IS_ABL_STORES
+  constexpr bool ABL_SAVE = false;
+#else
+  constexpr bool ABL_SAVE = true;
+#endif
+  const bool save3 = ABL_SAVE && SAVE && COORD && z3s != nullptr;      // kernel-uniform: z3 is saved only for a backward that does not recompute it
   // kernel-uniform: the first edge-MLP activation m1 = SiLU(z1) and its derivative are saved for a backward that reads them
   // back instead of recomputing z1 from gathered rows (the backward's windows are issue-bound: HBM has room, the SIMDs do not)
-  const bool save1 = SAVE && m1s != nullptr;
+  const bool save1 = ABL_SAVE && SAVE && m1s != nullptr;
 
   // ---- chunk of this wave ----
   const int c = blockIdx.x * W3 + wave;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   B.m1 = make_rsrc(m1s != nullptr ? m1s : z2s); B.d1 = make_rsrc(dy1s != nullptr ? dy1s : z2s);
   B.geo = make_rsrc(geos != nullptr ? geos : z2s);
   B.xo = make_rsrc(x_out != nullptr ? x_out : h_neigh);
-  const bool save_geo = SAVE && geos != nullptr;      // kernel-uniform: (x_src - x_dst, |.|^2) per edge slot, for the backward
+  const bool save_geo = ABL_SAVE && SAVE && geos != nullptr;      // kernel-uniform: (x_src - x_dst, |.|^2) per edge slot, for the backward
   const int ld_p_bytes = ld_p * 4, ld_hn_bytes = ld_hn * 4;
 
   // first index / row loads are in flight while the weights are staged
@@ -258,10 +263,15 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
           for (int k = 0; k < 4; ++k) z[i4 + k] += av[k] * wa_c[f];
         }
       float ex[TE16];
+#ifdef IS_ABL_SILU
+#pragma unroll
+      for (int i = 0; i < TE16; ++i) ex[i] = 0.5f;
+#else
 #pragma unroll
       for (int i = 0; i < TE16; ++i) ex[i] = __expf(-z[i]);
 #pragma unroll
       for (int i = 0; i < TE16; ++i) ex[i] = rcp_f(1.0f + ex[i]);
+#endif
       if (save1) {
         // rows in slot order, lane = channel: one coalesced 256-byte row per store.  dy1s != NULL: m1 = SiLU(z1) and
         // SiLU'(z1) = sigma + m1 (1 - sigma) (two arrays, nothing left to evaluate in the backward); dy1s == NULL: z1 itself
@@ -290,13 +300,18 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     {
       f32x4 acc[4];
       zero_acc4(acc);
+#ifdef IS_ABL_NOMFMA
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(act + r * LD + 4 * q + 16 * nt);
+#else
       mm16_rows<4, H>(acc, act, sm.w.w2, lane);
+#endif
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float z2 = acc[nt][t] + b2_c[nt];
-          if (SAVE) buf_store(z2, B.z2, tile_off + (t * H + nt * 16) * 4, tile_base);
+          if (SAVE && ABL_SAVE) buf_store(z2, B.z2, tile_off + (t * H + nt * 16) * 4, tile_base);
           act[tile16_row(t, q) * LD + nt * 16 + r] = silu_f(z2);
         }
     }
@@ -307,7 +322,12 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     if constexpr (COORD) {
       f32x4 acc[4];
       zero_acc4(acc);
+#ifdef IS_ABL_NOMFMA
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(act + r * LD + 4 * q + 16 * nt);
+#else
       mm16_rows<4, H>(acc, act, sm.w.wc1, lane);
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float part = 0.0f;
@@ -325,6 +345,9 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     STAMP3N();
 
     // ---- SEG: running segment sums by destination; flush points are wave-uniform ----
+#ifdef IS_ABL_SEG
+    if (cb + TE16 >= e1) { buf_store(act[lane], B.hn, lane * 4, va * ld_hn_bytes); vnext = vb; }      // (keeps the tile's results alive)
+#else
     {
       const unsigned long long fm = __ballot(id0.flush != 0);
       float hv[TE16], cs[TE16], cd[TE16];
@@ -363,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         }
       }
     }
+#endif
     __builtin_amdgcn_wave_barrier();
     STAMP3N();
     r0 = r1;
@@ -419,7 +443,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   float* xs = reinterpret_cast<float*>(&sm);           // [ROWS][LD1]   X = [h | h_neigh | 0]
   float* a1s = xs + ROWS * D::LD1;                     // [ROWS][LD]    SiLU(zn1)
   float* hps = xs;                                     // [ROWS][LD]    h' (over X, which is dead by then)
+#ifdef IS_ABL_NONODE
+  for (int row0 = n0; row0 < n0; row0 += ROWS) {
+#else
   for (int row0 = n0; row0 < n1; row0 += ROWS) {
+#endif
     const int mt_used = min(MT, (n1 - row0 + 15) >> 4);     // 16-row tiles of this pass that hold nodes
     {
       float nv[RPW];                                   // all loads first, then the LDS stores

@@ -27,6 +27,12 @@ import torch
 from .graph import CSRIndex, PackedGraphBatch
 
 
+# Captures are thread-local: under a process group, ProcessGroupNCCL's watchdog thread polls the events of outstanding collectives
+# (hipEventQuery) at any time -- in the default "global" mode such a call from ANOTHER thread invalidates the capture in progress
+# ("operation not permitted when stream is capturing", first met under a one-rank RCCL group in round 4)
+_CAPTURE = {"capture_error_mode": "thread_local"}
+
+
 class StaticGraphBatch(PackedGraphBatch):
     """Fixed-capacity device buffers with the PackedGraphBatch surface."""
 
@@ -240,7 +246,7 @@ class CapturedTrainStep:
                 finally:
                     HF.RESERVED_CUS = saved
             self.graph_a1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a1):
+            with torch.cuda.graph(self.graph_a1, **_CAPTURE):
                 loss = self._stage1()
             # a graph always writes the gradient buffers it allocated while capturing: pack from those
             self.reducer.bind_sources(0)
@@ -252,7 +258,7 @@ class CapturedTrainStep:
                 saved = HF.RESERVED_CUS
                 HF.RESERVED_CUS = res
                 try:
-                    with torch.cuda.graph(graph, pool=self.graph_a1.pool()):
+                    with torch.cuda.graph(graph, pool=self.graph_a1.pool(), **_CAPTURE):
                         self._stage2(retain=res != self._reserved_candidates[-1])
                 finally:
                     HF.RESERVED_CUS = saved
@@ -263,7 +269,7 @@ class CapturedTrainStep:
             self._forms[True] = (loss, sources)
         if not self.two_stage or mode == "auto":
             self.graph_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, **_CAPTURE):
                 loss = self._fwd_bwd()
                 if self.fused_optimizer:
                     self._optimizer_step()
@@ -280,12 +286,12 @@ class CapturedTrainStep:
                 self.graph_b = []
                 for i, b in enumerate(self.reducer.buckets):
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, **({"pool": self.graph_b[0].pool()} if self.graph_b else {})):
+                    with torch.cuda.graph(graph, **({"pool": self.graph_b[0].pool()} if self.graph_b else {}), **_CAPTURE):
                         self.optimizer.step_subset(b["params"], first=i == 0)
                     self.graph_b.append(graph)
             else:
                 self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b):
+                with torch.cuda.graph(self.graph_b, **_CAPTURE):
                     self.optimizer.step()
         if len(self._forms) == 2:
             self._choose_form(model, optimizer)

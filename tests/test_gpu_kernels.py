@@ -690,7 +690,8 @@ def test_hip_adam_checkpoint_round_trip(cuda_device):
     run(a, a_p, range(6))
     b_p = mk(); b = optim.Adam(b_p, lr=1e-2, weight_decay=1e-6)
     run(b, b_p, range(3))
-    ck = b.state_dict()
+    import copy
+    ck = copy.deepcopy(b.state_dict())      # (what torch.save would write: state_dict() itself references the live moment buffers)
     ck_params = [p.detach().clone() for p in b_p]
     assert float(ck["state"][0]["step"]) == 3.0
     # fresh object
