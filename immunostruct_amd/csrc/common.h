@@ -39,12 +39,35 @@ __device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v
 __device__ __forceinline__ float silu_f(float z) { return z * 0.5f; }
 __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) { y = z * 0.5f; dy = 0.5f; }
 #else
+// sigma(z) to ~1 ulp.  __expf(-z) = v_exp_f32(-z * log2 e) rounds the PRODUCT (relative 2^-24 of an exponent of size |z| log2 e: an
+// error of ~|z| ulp in the result) and v_rcp_f32 adds 1 ulp; summed over 10^5 edges that cancel, this per-term error was the
+// worst gradient tensor's distance from the fp64 oracle (round 3: 2.6 x the element-wise bound where torch's CPU SiLU is at 0.5 x).
+// Here the product's rounding error is recovered with one fma and folded back (2^(t + lo) = 2^t (1 + lo ln 2)), and the
+// reciprocal takes one Newton step: 6 more full-rate instructions per SiLU, which the ablation of round 4 shows to be hidden
+// (the SiLU pairs are not on the layer kernels' critical path: replacing them by ONE multiply moved the launches by < 3 %).
+// IS_SILU_FAST restores the two-instruction form (A/B builds).
+__device__ __forceinline__ float sigmoid_f(float z) {
+#ifdef IS_SILU_FAST
+  return rcp_f(1.0f + __expf(-z));
+#else
+  constexpr float L2E = 1.44269504088896340736f;          // log2(e) rounded to fp32
+  constexpr float L2E_LO = 1.92596299112661746e-8f;       // log2(e) - L2E
+  const float nz = -z;
+  const float t = nz * L2E;
+  const float lo = __builtin_fmaf(nz, L2E_LO, __builtin_fmaf(nz, L2E, -t));     // exact product error + the constant's tail
+  float e = __builtin_amdgcn_exp2f(__builtin_fminf(t, 126.0f));                 // (z < -87: sigma < 2^-126 either way; no inf below)
+  e = __builtin_fmaf(e, lo * 0.693147180559945309f, e);
+  const float d = 1.0f + e;
+  float s = rcp_f(d);
+  s = __builtin_fmaf(__builtin_fmaf(-d, s, 1.0f), s, s);  // one Newton step
+  return s;
+#endif
+}
 __device__ __forceinline__ float silu_f(float z) {
-  const float s = rcp_f(1.0f + __expf(-z));
-  return z * s;
+  return z * sigmoid_f(z);
 }
 __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) {
-  const float s = rcp_f(1.0f + __expf(-z));
+  const float s = sigmoid_f(z);
   y = z * s;
   dy = s * (1.0f + z * (1.0f - s));
 }

@@ -268,9 +268,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       for (int i = 0; i < TE16; ++i) ex[i] = 0.5f;
 #else
 #pragma unroll
-      for (int i = 0; i < TE16; ++i) ex[i] = __expf(-z[i]);
-#pragma unroll
-      for (int i = 0; i < TE16; ++i) ex[i] = rcp_f(1.0f + ex[i]);
+      for (int i = 0; i < TE16; ++i) ex[i] = sigmoid_f(z[i]);
 #endif
       if (save1) {
         // rows in slot order, lane = channel: one coalesced 256-byte row per store.  dy1s != NULL: m1 = SiLU(z1) and

@@ -417,25 +417,44 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
       }
     }
     // this wave's query-block tiles (keys on the lanes); issued AFTER the x rows: vector loads return in order, the
-    // reduction above must not wait behind these 24 KB
-    float pq[NT][16];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
-    STAMPA(2);
-    __syncthreads();
-    STAMPA(3);
-    // ---- pass A: query block `wave`.  t_i = sum_j P_ij dabar_j (keys on the lanes -> lane reduction) ----
+    // reduction above must not wait behind these 24 KB.  They are only needed for t_i here -- held in registers across the
+    // (not unrolled) dQ loop below the array was indexed dynamically and lived in SCRATCH (400 bytes per lane: global ->
+    // registers -> scratch -> registers); the dQ loop now re-reads its tiles one ahead of their use, as pass B does (L2 hits)
+    float tpart[16];
     {
-      float tpart[16];
+      constexpr int G = NT > 6 ? NT / 2 : NT;      // tiles held at once (n = 256: two rounds of four -- eight would spill)
+      float pq[G][16];
+#pragma unroll
+      for (int nt = 0; nt < G; ++nt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
+      STAMPA(2);
+      __syncthreads();
+      STAMPA(3);
+      // ---- pass A: query block `wave`.  t_i = sum_j P_ij dabar_j (keys on the lanes -> lane reduction) ----
 #pragma unroll
       for (int t = 0; t < 16; ++t) tpart[t] = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float dj = sm.dab[nt * 32 + r];
+      for (int g0 = 0; g0 < NT; g0 += G) {
+        if (g0 > 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) tpart[t] += pq[nt][t] * dj;
+          for (int nt = 0; nt < G; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + g0 + nt) * 16 + t) * 64 + lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < G; ++nt) {
+          const float dj = sm.dab[(g0 + nt) * 32 + r];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) tpart[t] += pq[nt][t] * dj;
+        }
+      }
+    }
+    {
+      float pk[16], pn[16];
+      if (mine) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pk[t] = pbase[((wave * NT + 0) * 16 + t) * 64 + lane];
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -452,8 +471,11 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
       float* tr = sm.tr[wave];
 #pragma unroll 1
       for (int nt = 0; nt < (mine ? NT : 0); ++nt) {
+        const int nn = min(nt + 1, NT - 1);                    // next tile in flight during this tile's transposition + MFMAs
 #pragma unroll
-        for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pq[nt][t];      // [query row][key col]
+        for (int t = 0; t < 16; ++t) pn[t] = pbase[((wave * NT + nn) * 16 + t) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pk[t];      // [query row][key col]
         __builtin_amdgcn_wave_barrier();
         // all LDS operands of the tile first, then the MFMAs back to back (an LDS read in front of every MFMA
         // exposes its latency 16 times per tile when one wave has the SIMD to itself)
@@ -475,6 +497,8 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
           for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[t], kv[t][ct], dq[ct], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pk[t] = pn[t];
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
