@@ -326,7 +326,8 @@ class IedbWorkload(TrainStepWorkload):
         else:
             self.opt = optim.Adam(self.model.parameters(), lr=1e-3)
         self.losses = Losses(VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
-        self.pool = [device_batch(synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + i, deg_extra=args.deg_extra), dev,
+        self.pool = [device_batch(synthetic.make_batch(args.batch, seed=1000 * (rank + 1) + i, deg_extra=args.deg_extra,
+                                                       symmetric=args.symmetric_edges), dev,
                                   "y_bin" if self.finetune else "y_reg") for i in range(4)]
         self.graphs_per_step = args.batch
         self.n_nodes = self.pool[0]["raw"].num_nodes
@@ -350,19 +351,20 @@ class IedbWorkload(TrainStepWorkload):
                     f"(pos_weight 81/19), Adam lr 1e-4 weight decay 1e-6; B={a.batch} graphs/GPU x 190 padded nodes, "
                     f"E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}), Fe=1")
         return (f"IEDB pretrain step (BASELINE config 2): {a.model}, full-sequence + sequence-loss, regression loss, Adam; "
-                f"B={a.batch} graphs/GPU x 190 padded nodes, E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}), Fe=1")
+                f"B={a.batch} graphs/GPU x 190 padded nodes, E~{int(self.n_edges)} edges/batch (deg_extra={a.deg_extra}"
+                f"{', every edge in both directions' if a.symmetric_edges else ''}), Fe=1")
 
     def roofline(self, timers, insitu=None):
         # the timed launches are the five full ones per step (layer 0: Din = 20, layers 1-4: Din = 64); the last layer's
         # launch skips the coordinate MLP (its output is unused by the model) and is timed under its own name
-        key = "iedb_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
+        key = "iedb_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2 and not self.args.symmetric_edges) else None
         return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu)
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import functional_ref as FR
         from oracle import graph_ref
         a = self.args
-        raw = synthetic.make_batch(a.batch, seed=1, deg_extra=a.deg_extra)
+        raw = synthetic.make_batch(a.batch, seed=1, deg_extra=a.deg_extra, symmetric=a.symmetric_edges)
         shapes = {k: tuple(v.shape) for k, v in model_map["HybridModelv2"](vae_input_dim=VAE_IN, device="cpu").state_dict().items()}
         sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synthetic.det_state_dict(shapes, seed=3).items()}
         fine = self.finetune
@@ -739,6 +741,7 @@ def main():
                     help="iedb: regression stage (Adam 1e-3) or the BCE finetune stage (Adam 1e-4, weight decay 1e-6)")
     ap.add_argument("--batch", type=int, default=None, help="graphs (paired: pairs) per GPU per step; default 128 (stress: 256)")
     ap.add_argument("--deg-extra", type=int, default=2, help="iedb / paired: random contact edges per residue (E/N - 1)")
+    ap.add_argument("--symmetric-edges", action="store_true", help="iedb: every chain link / contact in both directions (2 x the edges)")
     ap.add_argument("--model", default="HybridModelv2", help="iedb: the model class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="iedb, one GPU: skip the batcher-inclusive epoch over 27 000 resident graphs")

@@ -11,14 +11,21 @@
 // flow through it to the embeddings: the backward returns d loss / d emb_c and d loss / d emb_w only.
 // BatchNorm's running statistics are not maintained (nothing ever reads them: the module stays in train mode).
 //
-//   contr_side_fwd  (grid 2, one workgroup of 16 waves per side): y1 = emb W1^T -> batch statistics -> a1 -> z0 = a1 W2^T
-//                   -> centre -> per-column std -> hinge.  Intermediates live in a global scratch that stays in L1/L2
-//                   (the whole problem is ~0.5 MB); phases are separated by workgroup barriers.
+//   contr_side_fwd  y1 = emb W1^T -> batch statistics -> a1 -> z0 = a1 W2^T -> centre -> per-column std -> hinge.  BatchNorm's
+//                   statistics, the centring and the std are PER OUTPUT COLUMN, so the side pass is cut by 32-column blocks:
+//                   contr_side_fwd_a (grid 2 sides x 4 blocks: y1, statistics, a1 of the block's columns) and
+//                   contr_side_fwd_b (same grid: z0 = a1 W2^T needs every column of a1 -- hence the launch boundary --
+//                   then centre / std of the block's columns).  Round 3 ran each side as ONE workgroup of 16 waves
+//                   (67 us forward, 60 us backward on 2 of 256 CUs, on the chain the attention backward waits for); the
+//                   row-stripe / combine order of every column reduction is unchanged, so the values are bit-identical.
+//                   Intermediates live in a global scratch that stays in L2 (the whole problem is ~0.5 MB).
 //   contr_pair_fwd  pair = zc zw^T / Z and corr = zc^T zw / B tile by tile (32 x 32 per wave) + the weighted squared
 //                   deviations -> one partial per tile;   contr_finish sums the partials in tile order.
 //   contr_pair_bwd  dzc = dPair zw / Z + zw dCorr^T / B,  dzw = dPair^T zc / Z + zc dCorr / B   (tiles of B x Z)
-//   contr_side_bwd  (grid 2): hinge + centring backward -> da1 = dz0 W2 -> ReLU / BatchNorm backward (batch statistics)
-//                   -> d emb = dy1 W1.
+//   contr_side_bwd  hinge + centring backward -> da1 = dz0 W2 -> ReLU / BatchNorm backward (batch statistics) -> d emb = dy1 W1,
+//                   cut the same way: contr_side_bwd_a (2 x 4 blocks of da1 / dy1 columns; every workgroup forms the column
+//                   means of ALL of dz0 for itself -- 2 x 64 KB from L2 -- and centres on the fly) and contr_side_bwd_b
+//                   (2 x ceil(E / 32) column blocks of d emb).
 // All matrix products run on v_mfma_f32_32x32x2_f32 with operands read straight from global memory (L1 hits), every
 // reduction has a fixed order -> bitwise reproducible.  B <= 256 pairs, E <= 256, Z = 128.
 #include "common.h"
@@ -68,7 +75,7 @@ __device__ __forceinline__ f32x16 zero16() {
 constexpr int SLAB = 32, SLD = SLAB + 1, SLAB_ROWS = 256, SLAB_COLS = 128;
 struct SlabSmem { float a[SLAB_ROWS * SLD]; float w[SLAB_COLS * SLD]; };
 
-template <bool WKC, typename FA, typename FW, typename FOUT>
+template <bool WKC, int NW = C_WAVES, typename FA, typename FW, typename FOUT>
 __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
   const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
   const int row_tiles = (B + 31) / 32, col_tiles = (N + 31) / 32, ntiles = row_tiles * col_tiles;
@@ -76,11 +83,11 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
   for (int k0 = 0; k0 < K; k0 += SLAB) {
     __syncthreads();
     // A slab: rows x 32 k (k fastest: 128-byte row segments)
-    for (int idx = tid; idx < row_tiles * 32 * SLAB; idx += 64 * C_WAVES) {
+    for (int idx = tid; idx < row_tiles * 32 * SLAB; idx += 64 * NW) {
       const int i = idx / SLAB, kk = idx % SLAB;
       sm.a[i * SLD + kk] = (i < B && k0 + kk < K) ? a_elem(i, k0 + kk) : 0.0f;
     }
-    for (int idx = tid; idx < col_tiles * 32 * SLAB; idx += 64 * C_WAVES) {
+    for (int idx = tid; idx < col_tiles * 32 * SLAB; idx += 64 * NW) {
       int c, kk;
       if (WKC) { c = idx / SLAB; kk = idx % SLAB; } else { kk = idx / (col_tiles * 32); c = idx % (col_tiles * 32); }
       sm.w[c * SLD + kk] = (c < N && k0 + kk < K) ? w_elem(k0 + kk, c) : 0.0f;
@@ -88,7 +95,7 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
     __syncthreads();
 #pragma unroll
     for (int own = 0; own < 2; ++own) {
-      const int tl = wave + own * C_WAVES;
+      const int tl = wave + own * NW;
       if (tl < ntiles) {
         const float* ap = sm.a + ((tl / col_tiles) * 32 + r) * SLD;
         const float* wp = sm.w + ((tl % col_tiles) * 32 + r) * SLD;
@@ -100,7 +107,7 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
   }
 #pragma unroll
   for (int own = 0; own < 2; ++own) {
-    const int tl = wave + own * C_WAVES;
+    const int tl = wave + own * NW;
     if (tl < ntiles) {
       const int i0 = (tl / col_tiles) * 32, j0 = (tl % col_tiles) * 32;
 #pragma unroll
@@ -116,82 +123,98 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
 // scratch layout per side (floats): Y [B][Z] | A1 [B][Z] | Zc [B][Z] | stats: mu[Z] inv[Z] colmean[Z] std[Z]
 __host__ __device__ inline long long side_floats(int B) { return 3LL * B * CZ + 4 * CZ; }
 
-__global__ __launch_bounds__(64 * C_WAVES) void contr_side_fwd_kernel(
+constexpr int SB_COLS = 32;                 // columns per side-pass workgroup
+constexpr int SB_BLOCKS = CZ / SB_COLS;     // 4
+constexpr int SB_WAVES = 4;
+constexpr int SB_GROUPS = C_GROUPS;         // row stripes of a column reduction: the 16-wave kernel's 8 (same sums, same order)
+static_assert(SB_GROUPS * SB_COLS == 64 * SB_WAVES, "one thread per (row stripe, column)");
+
+__device__ __forceinline__ float block_group_sum(const float (*part)[SB_COLS], int c) {
+  float t = part[0][c];
+#pragma unroll
+  for (int g = 1; g < SB_GROUPS; ++g) t += part[g][c];
+  return t;
+}
+
+// grid (SB_BLOCKS, 2 sides): columns [32 blk, 32 blk + 32) of y1 = emb W1^T, their batch statistics (biased variance),
+// xhat and a1 = relu(gamma xhat + beta)
+__global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_a_kernel(
     const float* __restrict__ emb_c, const float* __restrict__ emb_w, int ld_e, int E,
     const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ W2, float* __restrict__ scratch, float* __restrict__ hinge, int B) {
-  const int side = blockIdx.x;
+    float* __restrict__ scratch, int B) {
+  const int side = blockIdx.y, c0 = blockIdx.x * SB_COLS;
   const float* emb = side == 0 ? emb_c : emb_w;
   float* S = scratch + (size_t)side * side_floats(B);
-  float* Y = S; float* A1 = Y + (size_t)B * CZ; float* Zc = A1 + (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
-  __shared__ float red[CZ];
+  float* Y = S; float* A1 = Y + (size_t)B * CZ; float* st = A1 + 2 * (size_t)B * CZ;
+  __shared__ float red[SB_COLS], rinv[SB_COLS];
   __shared__ SlabSmem slab;
-  __shared__ float part[C_GROUPS][CZ];      // column passes: C_GROUPS row stripes per column, combined in a fixed order
+  __shared__ float part[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
-  const int col = tid & (CZ - 1), grp = tid / CZ;
-  // ---- y1 = emb W1^T ----
-  gemm_slabs<true>(slab, B, CZ, E, [&](int i, int k) { return emb[(size_t)i * ld_e + k]; },
-                   [&](int k, int c) { return W1[(size_t)c * E + k]; },
-                   [&](int i, int c, float v) { Y[(size_t)i * CZ + c] = v; }, tid);
-  // ---- batch statistics of every column (biased variance), a1 = relu(gamma xhat + beta) ----
+  const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
+  gemm_slabs<true, SB_WAVES>(slab, B, SB_COLS, E, [&](int i, int k) { return emb[(size_t)i * ld_e + k]; },
+                             [&](int k, int c) { return W1[(size_t)(c0 + c) * E + k]; },
+                             [&](int i, int c, float v) { Y[(size_t)i * CZ + c0 + c] = v; }, tid);
   {
     float s = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) s += Y[(size_t)b * CZ + col];
+    for (int b = grp; b < B; b += SB_GROUPS) s += Y[(size_t)b * CZ + c0 + col];
     part[grp][col] = s;
     __syncthreads();
-    if (tid < CZ) red[tid] = group_sum(part, tid) / (float)B;
+    if (tid < SB_COLS) red[tid] = block_group_sum(part, tid) / (float)B;
     __syncthreads();
     const float mu = red[col];
     float v = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) { const float d = Y[(size_t)b * CZ + col] - mu; v += d * d; }
+    for (int b = grp; b < B; b += SB_GROUPS) { const float d = Y[(size_t)b * CZ + c0 + col] - mu; v += d * d; }
     part[grp][col] = v;
     __syncthreads();
-    if (tid < CZ) {
-      st[tid] = red[tid];
-      st[CZ + tid] = 1.0f / sqrtf(group_sum(part, tid) / (float)B + BN_EPS);
+    if (tid < SB_COLS) {
+      const float inv = 1.0f / sqrtf(block_group_sum(part, tid) / (float)B + BN_EPS);
+      st[c0 + tid] = red[tid];
+      st[CZ + c0 + tid] = inv;
+      rinv[tid] = inv;
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
-    const int k = idx % CZ;
-    const float xh = (Y[idx] - st[k]) * st[CZ + k];
-    Y[idx] = xh;                                     // Y now holds xhat (needed by the backward)
-    A1[idx] = fmaxf(gamma[k] * xh + beta[k], 0.0f);
+  for (int idx = tid; idx < B * SB_COLS; idx += 64 * SB_WAVES) {
+    const int k = idx % SB_COLS;
+    const size_t at = (size_t)(idx / SB_COLS) * CZ + c0 + k;
+    const float xh = (Y[at] - red[k]) * rinv[k];
+    Y[at] = xh;                                      // Y now holds xhat (needed by the backward)
+    A1[at] = fmaxf(gamma[c0 + k] * xh + beta[c0 + k], 0.0f);
   }
+}
+
+// grid (SB_BLOCKS, 2 sides): columns [32 blk, 32 blk + 32) of z0 = a1 W2^T, centred over the batch; their unbiased std
+// (the hinge term is formed from the stds by contr_finish, in column order)
+__global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_b_kernel(const float* __restrict__ W2, float* __restrict__ scratch, int B) {
+  const int side = blockIdx.y, c0 = blockIdx.x * SB_COLS;
+  float* S = scratch + (size_t)side * side_floats(B);
+  const float* A1 = S + (size_t)B * CZ; float* Zc = S + 2 * (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
+  __shared__ float red[SB_COLS];
+  __shared__ SlabSmem slab;
+  __shared__ float part[SB_GROUPS][SB_COLS];
+  const int tid = threadIdx.x;
+  const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
+  gemm_slabs<true, SB_WAVES>(slab, B, SB_COLS, CZ, [&](int i, int k) { return A1[(size_t)i * CZ + k]; },
+                             [&](int k, int c) { return W2[(size_t)(c0 + c) * CZ + k]; },
+                             [&](int i, int c, float v) { Zc[(size_t)i * CZ + c0 + c] = v; }, tid);
+  float s = 0.0f;
+  for (int b = grp; b < B; b += SB_GROUPS) s += Zc[(size_t)b * CZ + c0 + col];
+  part[grp][col] = s;
   __syncthreads();
-  // ---- z0 = a1 W2^T ----
-  gemm_slabs<true>(slab, B, CZ, CZ, [&](int i, int k) { return A1[(size_t)i * CZ + k]; },
-                   [&](int k, int c) { return W2[(size_t)c * CZ + k]; },
-                   [&](int i, int c, float v) { Zc[(size_t)i * CZ + c] = v; }, tid);
-  // ---- centre, unbiased variance, hinge ----
-  {
-    float s = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) s += Zc[(size_t)b * CZ + col];
-    part[grp][col] = s;
-    __syncthreads();
-    if (tid < CZ) red[tid] = group_sum(part, tid) / (float)B;
-    __syncthreads();
-    const float m = red[col];
-    float v = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) {
-      const float d = Zc[(size_t)b * CZ + col] - m;
-      Zc[(size_t)b * CZ + col] = d;
-      v += d * d;
-    }
-    part[grp][col] = v;
-    __syncthreads();
-    if (tid < CZ) {
-      const float sd = sqrtf(group_sum(part, tid) / (float)(B - 1) + 1e-4f);
-      st[2 * CZ + tid] = red[tid];
-      st[3 * CZ + tid] = sd;
-      red[tid] = fmaxf(1.0f - sd, 0.0f);
-    }
+  if (tid < SB_COLS) red[tid] = block_group_sum(part, tid) / (float)B;
+  __syncthreads();
+  const float m = red[col];
+  float v = 0.0f;
+  for (int b = grp; b < B; b += SB_GROUPS) {
+    const float d = Zc[(size_t)b * CZ + c0 + col] - m;
+    Zc[(size_t)b * CZ + c0 + col] = d;
+    v += d * d;
   }
+  part[grp][col] = v;
   __syncthreads();
-  if (tid == 0) {
-    float s = 0.0f;
-    for (int k = 0; k < CZ; ++k) s += red[k];
-    hinge[side] = s / (float)CZ;
+  if (tid < SB_COLS) {
+    st[2 * CZ + c0 + tid] = red[tid];
+    st[3 * CZ + c0 + tid] = sqrtf(block_group_sum(part, tid) / (float)(B - 1) + 1e-4f);
   }
 }
 
@@ -247,11 +270,19 @@ __global__ __launch_bounds__(256) void contr_pair_fwd_kernel(
 
 // loss = scale * gate * (pair / correlation terms + hinge): `scale` is the caller's loss coefficient, `gate` (device, may be NULL)
 // the reference's early-out as a 0 / 1 factor -- both folded in here instead of two multiply launches behind the loss
-__global__ void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ hinge,
+// (hinge term of a side = mean_k relu(1 - std_k), summed in column order from the stds the side pass left in `scratch`)
+__global__ void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ scratch, int B,
                                     float* __restrict__ loss, const float* __restrict__ gate, float scale) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.0f;
     for (int i = 0; i < nparts; ++i) s += partials[i];
+    float hinge[2];
+    for (int side = 0; side < 2; ++side) {
+      const float* sd = scratch + (size_t)side * side_floats(B) + 3 * (size_t)B * CZ + 3 * CZ;
+      float h = 0.0f;
+      for (int k = 0; k < CZ; ++k) h += fmaxf(1.0f - sd[k], 0.0f);
+      hinge[side] = h / (float)CZ;
+    }
     loss[0] = (s + 0.5f * (hinge[0] + hinge[1])) * (gate != nullptr ? gate[0] * scale : scale);
   }
 }
@@ -331,53 +362,50 @@ __global__ __launch_bounds__(256) void contr_pair_bwd_kernel(
   }
 }
 
-__global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
-    const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ W2,
-    const float* __restrict__ scratch, float* __restrict__ DZ, float* __restrict__ work, const float* __restrict__ g_loss,
-    const float* __restrict__ gate, float scale, float* __restrict__ demb_c, float* __restrict__ demb_w, int ld_d, int E, int B) {
-  const int side = blockIdx.x;
+// grid (SB_BLOCKS, 2 sides): hinge gradient + centring backward of ALL columns of dz0 (the contraction below needs them all:
+// every workgroup forms the 128 column means for itself, the values go into the product's A operand on the fly), then columns
+// [32 blk, 32 blk + 32) of da1 = dz0 W2 and their ReLU / BatchNorm backward (batch statistics) -> dy1 (`work`)
+__global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_a_kernel(
+    const float* __restrict__ gamma, const float* __restrict__ W2, const float* __restrict__ scratch,
+    const float* __restrict__ DZ, float* __restrict__ work, int B) {
+  const int side = blockIdx.y, c0 = blockIdx.x * SB_COLS;
   const float* S = scratch + (size_t)side * side_floats(B);
   const float* XH = S; const float* A1 = XH + (size_t)B * CZ; const float* Zc = A1 + (size_t)B * CZ;
   const float* st = Zc + (size_t)B * CZ;
-  float* dz = DZ + (size_t)side * B * CZ;
-  float* wk = work + (size_t)side * B * CZ;                  // da1, then dy1
-  float* demb = side == 0 ? demb_c : demb_w;
-  __shared__ float s1[CZ], s2[CZ];
+  const float* dz = DZ + (size_t)side * B * CZ;
+  float* wk = work + (size_t)side * B * CZ;                  // dy1
+  __shared__ float coef_s[CZ], mean_s[CZ];
+  __shared__ float s1[SB_COLS], s2[SB_COLS];
   __shared__ SlabSmem slab;
-  __shared__ float part[C_GROUPS][CZ], part2[C_GROUPS][CZ];
+  __shared__ float part[SB_GROUPS][SB_COLS], part2[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
-  const int col = tid & (CZ - 1), grp = tid / CZ;
-  const float g = g_loss[0] * (gate != nullptr ? gate[0] * scale : scale);
-  // ---- hinge gradient + centring backward (per column) ----
-  {
-    const float sd = st[3 * CZ + col];
+  const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
+  // ---- hinge gradient + centring backward, per column, all 128 columns (four rounds of 32; the 16-wave kernel's row
+  //      stripes and combine order) ----
+  for (int cb = 0; cb < CZ; cb += SB_COLS) {
+    const int k = cb + col;
+    const float sd = st[3 * CZ + k];
     // d hinge / d var_k = -(1/2) * (1/Z) * [sd < 1] / (2 sd);  d var_k / d z_bk = 2 z_bk / (B - 1)
     const float dv = (sd < 1.0f) ? -0.5f / (float)CZ / (2.0f * sd) : 0.0f;
     const float coef = dv * 2.0f / (float)(B - 1);
     float s = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) {
-      const float v = dz[(size_t)b * CZ + col] + coef * Zc[(size_t)b * CZ + col];
-      dz[(size_t)b * CZ + col] = v;
-      s += v;
-    }
+    for (int b = grp; b < B; b += SB_GROUPS) s += dz[(size_t)b * CZ + k] + coef * Zc[(size_t)b * CZ + k];
     part[grp][col] = s;
     __syncthreads();
-    if (tid < CZ) s1[tid] = group_sum(part, tid) / (float)B;
+    if (tid < SB_COLS) { mean_s[cb + tid] = block_group_sum(part, tid) / (float)B; coef_s[cb + tid] = coef; }
     __syncthreads();
-    const float m = s1[col];
-    for (int b = grp; b < B; b += C_GROUPS) dz[(size_t)b * CZ + col] -= m;
   }
-  __syncthreads();
-  // ---- da1 = dz0 W2 ----
-  gemm_slabs<false>(slab, B, CZ, CZ, [&](int i, int k) { return dz[(size_t)i * CZ + k]; },
-                    [&](int k, int c) { return W2[(size_t)k * CZ + c]; },
-                    [&](int i, int c, float v) { wk[(size_t)i * CZ + c] = v; }, tid);
+  // ---- da1 = dz0 W2 (this block's columns); A operand = the centred gradient ----
+  gemm_slabs<false, SB_WAVES>(slab, B, SB_COLS, CZ,
+                              [&](int i, int k) { return (dz[(size_t)i * CZ + k] + coef_s[k] * Zc[(size_t)i * CZ + k]) - mean_s[k]; },
+                              [&](int k, int c) { return W2[(size_t)k * CZ + c0 + c]; },
+                              [&](int i, int c, float v) { wk[(size_t)i * CZ + c0 + c] = v; }, tid);
   // ---- ReLU backward, BatchNorm backward on batch statistics ----
   {
-    const float gm = gamma[col];
+    const float gm = gamma[c0 + col];
     float a = 0.0f, c = 0.0f;
-    for (int b = grp; b < B; b += C_GROUPS) {
-      const size_t idx = (size_t)b * CZ + col;
+    for (int b = grp; b < B; b += SB_GROUPS) {
+      const size_t idx = (size_t)b * CZ + c0 + col;
       const float dxh = (A1[idx] > 0.0f) ? wk[idx] * gm : 0.0f;
       wk[idx] = dxh;
       a += dxh;
@@ -385,19 +413,29 @@ __global__ __launch_bounds__(64 * C_WAVES) void contr_side_bwd_kernel(
     }
     part[grp][col] = a; part2[grp][col] = c;
     __syncthreads();
-    if (tid < CZ) { s1[tid] = group_sum(part, tid); s2[tid] = group_sum(part2, tid); }
+    if (tid < SB_COLS) { s1[tid] = block_group_sum(part, tid); s2[tid] = block_group_sum(part2, tid); }
   }
   __syncthreads();
-  for (int idx = tid; idx < B * CZ; idx += 64 * C_WAVES) {
-    const int k = idx % CZ;
-    wk[idx] = st[CZ + k] / (float)B * ((float)B * wk[idx] - s1[k] - XH[idx] * s2[k]);     // dy1
+  for (int idx = tid; idx < B * SB_COLS; idx += 64 * SB_WAVES) {
+    const int k = idx % SB_COLS;
+    const size_t at = (size_t)(idx / SB_COLS) * CZ + c0 + k;
+    wk[at] = st[CZ + c0 + k] / (float)B * ((float)B * wk[at] - s1[k] - XH[at] * s2[k]);     // dy1
   }
-  __syncthreads();
-  // ---- d emb = dy1 W1, scaled by the upstream gradient ----
-  for (int c0 = 0; c0 < E; c0 += SLAB_COLS)       // E <= 256: at most two column blocks of the slab width
-    gemm_slabs<false>(slab, B, min(SLAB_COLS, E - c0), CZ, [&](int i, int k) { return wk[(size_t)i * CZ + k]; },
-                      [&](int k, int c) { return W1[(size_t)k * E + c0 + c]; },
-                      [&](int i, int c, float v) { demb[(size_t)i * ld_d + c0 + c] = v * g; }, tid);
+}
+
+// grid (ceil(E / 32), 2 sides): columns [32 blk, ...) of d emb = dy1 W1, scaled by the upstream gradient
+__global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_b_kernel(
+    const float* __restrict__ W1, const float* __restrict__ work, const float* __restrict__ g_loss,
+    const float* __restrict__ gate, float scale, float* __restrict__ demb_c, float* __restrict__ demb_w, int ld_d, int E, int B) {
+  const int side = blockIdx.y, c0 = blockIdx.x * SB_COLS;
+  const float* wk = work + (size_t)side * B * CZ;
+  float* demb = side == 0 ? demb_c : demb_w;
+  __shared__ SlabSmem slab;
+  const int tid = threadIdx.x;
+  const float g = g_loss[0] * (gate != nullptr ? gate[0] * scale : scale);
+  gemm_slabs<false, SB_WAVES>(slab, B, min(SB_COLS, E - c0), CZ, [&](int i, int k) { return wk[(size_t)i * CZ + k]; },
+                              [&](int k, int c) { return W1[(size_t)k * E + c0 + c]; },
+                              [&](int i, int c, float v) { demb[(size_t)i * ld_d + c0 + c] = v * g; }, tid);
 }
 
 }  // namespace is
@@ -420,13 +458,13 @@ extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld
   const long long sides = 2 * is::side_floats(B);
   float* PAIR = scratch + sides;
   float* CORR = PAIR + (long long)B * B;
-  float* hinge = CORR + is::CZ * is::CZ;
-  float* partials = hinge + 2;
+  float* partials = CORR + is::CZ * is::CZ + 2;
   const int rt = (B + 31) / 32, ntiles = rt * rt + 16, nblocks = (ntiles + 3) / 4;
-  hipLaunchKernelGGL(is::contr_side_fwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, emb_c, emb_w, ld_e, E, W1, gamma, beta, W2,
-                     scratch, hinge, B);
+  const dim3 sgrid(is::SB_BLOCKS, 2), sblock(64 * is::SB_WAVES);
+  hipLaunchKernelGGL(is::contr_side_fwd_a_kernel, sgrid, sblock, 0, st, emb_c, emb_w, ld_e, E, W1, gamma, beta, scratch, B);
+  hipLaunchKernelGGL(is::contr_side_fwd_b_kernel, sgrid, sblock, 0, st, W2, scratch, B);
   hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
-  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, hinge, loss, gate, scale);
+  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, scratch, B, loss, gate, scale);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -453,7 +491,9 @@ extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float
   float* wk = work + 2LL * B * is::CZ;
   const int rt = (B + 31) / 32, ntiles = 2 * rt * 4;
   hipLaunchKernelGGL(is::contr_pair_bwd_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, DZ, B);
-  hipLaunchKernelGGL(is::contr_side_bwd_kernel, dim3(2), dim3(64 * is::C_WAVES), 0, st, W1, gamma, W2, scratch, DZ, wk, g_loss,
-                     gate, scale, demb_c, demb_w, ld_d, E, B);
+  const dim3 sblock(64 * is::SB_WAVES);
+  hipLaunchKernelGGL(is::contr_side_bwd_a_kernel, dim3(is::SB_BLOCKS, 2), sblock, 0, st, gamma, W2, scratch, DZ, wk, B);
+  hipLaunchKernelGGL(is::contr_side_bwd_b_kernel, dim3((E + is::SB_COLS - 1) / is::SB_COLS, 2), sblock, 0, st, W1, wk, g_loss, gate,
+                     scale, demb_c, demb_w, ld_d, E, B);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const long long* __re
 // chunk_ptr [k + 1][2] = (b_j, rowptr[b_j]) with b_0 = 0, b_k = N, b_j = first node whose first in-edge index is >= j * E / k:
 // the node-aligned, edge-balanced partition of graph.py `balanced_node_chunks`, straight from the rowptr in device memory
 // shares != 0: the chunks of the first / second half of the workgroups get (P + 1) / 2 : (P - 1) / 2 parts of the edges when
-// P = ceil(edges per wave pair / 16) is odd and the node-aligned chunks have slack (graph.py chunk_shares: same integer rule)
+// P = ceil(edges per wave pair / 16) is odd, the node-aligned chunks have slack and the larger workgroups need no extra pass of
+// the node half (graph.py chunk_shares: same integer rule)
 __global__ __launch_bounds__(256) void chunk_partition_kernel(const int* __restrict__ rowptr, int N, int k, int shares, int* __restrict__ out) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j > k) return;
@@ -267,7 +268,12 @@ __global__ __launch_bounds__(256) void chunk_partition_kernel(const int* __restr
   long long wa = 1, wb = 1;
   if (shares) {
     const long long p = (2 * E + 16LL * k - 1) / (16LL * k);
-    if ((p % 2 == 1) && p >= 3 && (p * 16 * k - 2 * E >= 6LL * k)) { wa = (p + 1) / 2; wb = (p - 1) / 2; }
+    if ((p % 2 == 1) && p >= 3 && (p * 16 * k - 2 * E >= 6LL * k)) {
+      // ... and the larger workgroups' nodes (average + a margin of 4) must not need one more 64-row pass of the forward kernel's
+      // node half than equal shares would
+      const long long big = (8LL * N * ((p + 1) / 2) + p * k - 1) / (p * k), flat = (4LL * N + k - 1) / k;
+      if ((big + 4 + 63) / 64 == (flat + 4 + 63) / 64) { wa = (p + 1) / 2; wb = (p - 1) / 2; }
+    }
   }
   const long long half = k / 2;
   const long long wj = wa * min((long long)j, half) + wb * max((long long)j - half, 0LL);

@@ -47,21 +47,31 @@ def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
 
+FWD_NODES_PER_WG = 56      # nodes a forward workgroup should own at most on average: one 64-row pass of its node half, with a margin
+
+
 def prepare_layer_partitions(csr, fe, forward=True):
     """build (and cache in ``csr``) the work partitions the two layer kernels will ask for under the CURRENT ``RESERVED_CUS`` --
     to be called outside a stream capture: a partition built while capturing lives in the capture's memory pool.
     ``forward=False``: only the backward kernel's tiles (the reserved-CU candidates of the data-parallel step's stack backward:
     the forward is always captured on the full grid, and every cached chunk partition is refreshed per batch)"""
     if forward:
-        csr.chunks(fwd_chunk_count(csr.num_edges))
+        csr.chunks(fwd_chunk_count(csr.num_edges, csr.num_nodes))
     if use_bwd_tiles(csr.num_nodes, csr.num_edges, layer_slots(), fe):
         csr.tiles(64, 24)
 
 
-def fwd_chunk_count(num_edges):
-    """number of wave-chunks of the forward layer kernel: ~FWD_CHUNK_EDGES edges per wave, at most FWD_CHUNKS_MAX waves,
-    a multiple of the 4 waves of a workgroup"""
-    k = max(4, min(FWD_CHUNKS_MAX, 4 * layer_slots(), (num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES))
+def fwd_chunk_count(num_edges, num_nodes=0):
+    """number of wave-chunks of the forward layer kernel: ~FWD_CHUNK_EDGES edges per wave and at most FWD_NODES_PER_WG nodes per
+    workgroup of 4 waves (its node half runs 64 rows per pass: at E / N = 2, 32 edges per wave are 64.5 nodes per workgroup and
+    half of the workgroups ran a second pass -- round 3's sweep: 51 us at 48 k edges against 46 us at 72 k), at most
+    FWD_CHUNKS_MAX waves, a multiple of the 4 waves of a workgroup.  A count between one and two workgroups per CU is rounded up
+    to the full grid: with 377 workgroups on 256 CUs the launch lasts as long as the CUs that hold two."""
+    full = min(FWD_CHUNKS_MAX, 4 * layer_slots())
+    k = max((num_edges + FWD_CHUNK_EDGES - 1) // FWD_CHUNK_EDGES, (4 * num_nodes + FWD_NODES_PER_WG - 1) // FWD_NODES_PER_WG)
+    if 2 * k > full:
+        k = full
+    k = max(4, min(full, k))
     return (k + 3) // 4 * 4
 
 
@@ -476,7 +486,7 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
     st = _lib.stream_ptr()
     f32 = dict(dtype=torch.float32, device=x.device)
     layers = []
-    kf = fwd_chunk_count(e)
+    kf = fwd_chunk_count(e, n)
     chunks = csr.chunks(kf)
     h_in, ld_h, din = h0, ld_h0, din0
     for i in range(n_layers):

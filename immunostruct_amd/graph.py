@@ -111,14 +111,25 @@ FULL_GRID_CHUNKS = 2048
 CHUNK_SHARES = __import__("os").environ.get("IMMUNOSTRUCT_FWD_SHARES", "auto")      # "auto" | "flat"
 
 
-def chunk_shares(e, k):
-    """(wa, wb): weight of a chunk of the first / second half of the workgroups; ``e`` a 0-d / 1-element integer tensor (no sync).
+NODE_PASS_ROWS = 64      # rows of one pass of the forward kernel's node half (csrc/egnn_layer_fwd.hip ROWS)
+
+
+def chunk_shares(e, k, n=None):
+    """(wa, wb): weight of a chunk of the first / second half of the workgroups; ``e`` a 0-d / 1-element integer tensor (no sync),
+    ``n`` the number of nodes.  Uneven shares (P + 1) / 2 : (P - 1) / 2 when P = ceil(edges per wave pair / 16) is odd and the
+    node-aligned chunks have slack -- and only while the LARGER workgroups' nodes do not need one more 64-row pass of the node
+    half than equal shares would (average nodes per workgroup + a margin of 4: a 2 : 1 split of 47.5 nodes per workgroup puts
+    63 on the first half of the workgroups, and half of those then run a second node pass).
     The device kernel (csrc/segment_ops.hip ``chunk_partition_kernel``) evaluates the same integer rule."""
     one = torch.ones_like(e)
     if CHUNK_SHARES != "auto" or k != FULL_GRID_CHUNKS:
         return one, one
     p = (2 * e + 16 * k - 1) // (16 * k)
     use = (p % 2 == 1) & (p >= 3) & (p * 16 * k - 2 * e >= 6 * k)
+    if n is not None:
+        big = (8 * int(n) * ((p + 1) // 2) + p * k - 1) // (p * k)          # ceil of the larger workgroups' average node count
+        flat = (4 * int(n) + k - 1) // k
+        use = use & ((big + 4 + NODE_PASS_ROWS - 1) // NODE_PASS_ROWS == (flat + 4 + NODE_PASS_ROWS - 1) // NODE_PASS_ROWS)
     return torch.where(use, (p + 1) // 2, one), torch.where(use, (p - 1) // 2, one)
 
 
@@ -130,7 +141,7 @@ def balanced_node_chunks(rowptr, k):
     n = rowptr.numel() - 1
     rp = rowptr.long()
     e = rp[-1:]                                                   # stays on the device: no sync
-    wa, wb = chunk_shares(e, k)
+    wa, wb = chunk_shares(e, k, n)
     half = k // 2
     j = torch.arange(k + 1, device=rowptr.device, dtype=torch.int64)
     wj = wa * torch.clamp(j, max=half) + wb * torch.clamp(j - half, min=0)

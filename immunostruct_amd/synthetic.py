@@ -11,7 +11,9 @@ synthetic batches with the *shape* of the real ones (``SURVEY.md`` section 8d):
 * node feature = 20-d amino-acid one-hot || 3-d C-alpha coordinate
   (``data/preprocess.py:40-41``); coordinates are a 3.8 Angstrom random walk;
 * edges = directed chain i->i+1 plus ``deg_extra`` random directed contacts per
-  real node (never touching padded nodes, never self loops);
+  real node (never touching padded nodes, never self loops); ``symmetric=True``
+  lists every chain link and contact in BOTH directions, as ``from_networkx`` does
+  for the undirected residue graphs Graphein builds (twice the edges);
 * edge feature = ones(E, 1) (``data/utils.py:60``) or U(0,1) features when
   ``edge_feats`` > 1 (BASELINE config 5);
 * sequence = 283 tokens over 21 symbols, trailing peptide pad symbol index 20
@@ -67,7 +69,7 @@ class RawBatch:
         return out
 
 
-def _one_graph(rng, n_pad, n_real, deg_extra, edge_feats):
+def _one_graph(rng, n_pad, n_real, deg_extra, edge_feats, symmetric=False):
     x = np.zeros((n_pad, NODE_FEATS), dtype=np.float32)
     aa = rng.randint(0, AA, size=n_real)
     x[np.arange(n_real), aa] = 1.0
@@ -81,6 +83,8 @@ def _one_graph(rng, n_pad, n_real, deg_extra, edge_feats):
     extra_src = (extra_dst + 1 + rng.randint(0, n_real - 1, size=extra_dst.shape[0])) % n_real
     src = np.concatenate([chain_src, extra_src]).astype(np.int64)
     dst = np.concatenate([chain_dst, extra_dst]).astype(np.int64)
+    if symmetric:
+        src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
     order = rng.permutation(src.shape[0])  # edge order is arbitrary in the real data
     src, dst = src[order], dst[order]
     if edge_feats == 1:
@@ -91,7 +95,7 @@ def _one_graph(rng, n_pad, n_real, deg_extra, edge_feats):
 
 
 def make_batch(num_graphs, seed=1, n_pad=190, deg_extra=2, edge_feats=1, n_real_choices=(188, 189, 190),
-               n_real_probs=(0.49, 0.29, 0.22)) -> RawBatch:
+               n_real_probs=(0.49, 0.29, 0.22), symmetric=False) -> RawBatch:
     """Draw one batch.  ``seed`` fully determines it (numpy legacy RandomState)."""
     rng = np.random.RandomState(seed)
     xs, srcs, dsts, eas = [], [], [], []
@@ -99,7 +103,7 @@ def make_batch(num_graphs, seed=1, n_pad=190, deg_extra=2, edge_feats=1, n_real_
     for g in range(num_graphs):
         n_real = int(rng.choice(n_real_choices, p=n_real_probs))
         n_real = min(n_real, n_pad)
-        x, s, d, ea = _one_graph(rng, n_pad, n_real, deg_extra, edge_feats)
+        x, s, d, ea = _one_graph(rng, n_pad, n_real, deg_extra, edge_feats, symmetric)
         xs.append(x)
         srcs.append(s + g * n_pad)
         dsts.append(d + g * n_pad)

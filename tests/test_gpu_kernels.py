@@ -543,6 +543,7 @@ def test_layer_forward_does_not_depend_on_the_chunking(cuda_device, monkeypatch,
     out = {}
     for chunk_edges in (4, 32, 1000):
         monkeypatch.setattr(HF, "FWD_CHUNK_EDGES", chunk_edges)
+        monkeypatch.setattr(HF, "FWD_NODES_PER_WG", 10 ** 9)      # (the chunk count follows the edges alone here)
         torch.manual_seed(3)
         layers = [EGNNConv(20 if i == 0 else 64, 64, 64, fe).to(cuda_device) for i in range(2)]
         g = H.product_graph(raw, cuda_device)

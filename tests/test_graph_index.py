@@ -102,6 +102,12 @@ def test_balanced_node_chunks_cover_all_nodes():
         assert (int(wa), int(wb)) == exp, (e, p, int(wa), int(wb))
         assert tuple(int(v) for v in chunk_shares(torch.tensor([e]), 1024)) == (1, 1)
     assert tuple(int(v) for v in chunk_shares(torch.tensor([72313]), 2048)) == (3, 2)
+    # ... and only while the larger workgroups' nodes fit one pass of the forward kernel's node half: B = 128 x 190 nodes keeps 3 : 2
+    # at E / N = 3, but not 2 : 1 at E / N = 2 (63 nodes per workgroup of the first half on average: a second node pass)
+    assert tuple(int(v) for v in chunk_shares(torch.tensor([72313]), 2048, 24320)) == (3, 2)      # 57 nodes: still one pass
+    assert tuple(int(v) for v in chunk_shares(torch.tensor([43000]), 2048)) == (2, 1)
+    assert tuple(int(v) for v in chunk_shares(torch.tensor([43000]), 2048, 24320)) == (1, 1)      # 64 + 4 nodes: a second pass
+    assert tuple(int(v) for v in chunk_shares(torch.tensor([43000]), 2048, 40000)) == (2, 1)      # 105 + 4 against 79 + 4 nodes: two passes either way
     reg = torch.arange(0, 35 * 2049, 35, dtype=torch.int32)        # 2048 nodes of in-degree 35: one node per flat chunk
     t = balanced_node_chunks(reg, 2048)
     edges = (t[1:, 1] - t[:-1, 1]).tolist()
