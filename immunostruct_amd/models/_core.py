@@ -29,6 +29,7 @@ from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
+EARLY_JOIN = os.environ.get("IMMUNOSTRUCT_EARLY_JOIN", "0") == "1"
 # the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer).  "auto": its
 # forward (~100 us of side work) should end with the stack + node attention, not stretch more layer launches than it must -- the
 # longer a layer launch, the earlier the fork.  Measured on the round-3 kernels (same box, ms per step): B = 128 graphs / 72 k edges
@@ -230,6 +231,7 @@ class MultimodalNet(nn.Module):
                 mu, logvar, z, h3 = HF.vae_latent(a1, self.vae_fc21.weight, self.vae_fc21.bias, self.vae_fc22.weight,
                                                   self.vae_fc22.bias, eps, p, self.vae_fc3.weight, self.vae_fc3.bias,
                                                   fc1=(x, self.vae_fc1.weight, self.vae_fc1.bias) if fuse1 else None)
+                self._latent_done(o, prop)
                 recon = HF.linear_small_batch(h3, self.vae_fc4.weight, self.vae_fc4.bias)
             else:
                 h1 = F.relu(a1)
@@ -237,13 +239,25 @@ class MultimodalNet(nn.Module):
                 z = self.reparameterize(mu, logvar)
                 if p is not None:
                     z = torch.cat([z, p], dim=1)
+                self._latent_done(o, prop)
                 recon = self.decode_vae(z)
             o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=recon)
-        if not sp.ssl and prop.is_cuda:
-            # the classifier's dropout mask, drawn here -- on the sequence branch's stream, long before the head needs it
+        else:
+            self._latent_done(o, prop)
+        return o
+
+    def _latent_done(self, o, prop):
+        """everything the fusion head needs from the sequence branch exists (latent + property embedding): draw the classifier's
+        dropout mask -- on the sequence branch's stream, long before the head needs it; the decoder draws nothing, so the
+        order of the random draws is the reference's -- and mark the point: the head may start here, it does not need the
+        reconstruction (``_encode``: IMMUNOSTRUCT_EARLY_JOIN)"""
+        if not self.SPEC.ssl and prop.is_cuda:
             rows = prop.shape[0] // 2 if self._pair_rows else prop.shape[0]
             o["_cls_mask"] = (HF.sequential_dropout_mask(self.classifier, rows, prop.device),)
-        return o
+        if prop.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            o["_latent_ready"] = ev
 
     def _encode(self, g, seq, prop, need_attention=False):
         """Graph branch and sequence branch are independent until the fusion head: the sequence branch is
@@ -284,13 +298,22 @@ class MultimodalNet(nn.Module):
             HF.Stamps.mark("fwd graph-branch end")
             HF.Stamps.hook(o["x_gat_node"], "bwd graph-branch start (d x_gat)")
         if overlap:
-            main.wait_stream(side)
+            # the head needs the latent, not the reconstruction: when the loss consumes the reconstruction on the sequence branch's
+            # own stream (functional.SpeculativeBackward: the engine's steps) the main stream joins at the latent -- an event long
+            # passed when the node attention ends -- instead of behind the decoder's GEMM (a cross-queue wait of ~15 us in the
+            # replayed step's timeline, round 3)
+            ev = o.pop("_latent_ready", None)
+            if EARLY_JOIN and HF.SpeculativeBackward.enabled and ev is not None and torch.is_grad_enabled():
+                main.wait_event(ev)
+            else:
+                main.wait_stream(side)
             for t in o.values():
                 for u in (t if isinstance(t, tuple) else (t,)):
                     if torch.is_tensor(u):
                         u.record_stream(main)
         else:
             o.update(self._encode_sequence(seq, prop))
+            o.pop("_latent_ready", None)
         return o
 
     def _head(self, pieces, cls_mask=None):
