@@ -39,15 +39,14 @@ __device__ __forceinline__ float rcp_f(float v) { return __builtin_amdgcn_rcpf(v
 __device__ __forceinline__ float silu_f(float z) { return z * 0.5f; }
 __device__ __forceinline__ void silu_fg(float z, float& y, float& dy) { y = z * 0.5f; dy = 0.5f; }
 #else
-// sigma(z) to ~1 ulp.  __expf(-z) = v_exp_f32(-z * log2 e) rounds the PRODUCT (relative 2^-24 of an exponent of size |z| log2 e: an
-// error of ~|z| ulp in the result) and v_rcp_f32 adds 1 ulp; summed over 10^5 edges that cancel, this per-term error was the
-// worst gradient tensor's distance from the fp64 oracle (round 3: 2.6 x the element-wise bound where torch's CPU SiLU is at 0.5 x).
-// Here the product's rounding error is recovered with one fma and folded back (2^(t + lo) = 2^t (1 + lo ln 2)), and the
-// reciprocal takes one Newton step: 6 more full-rate instructions per SiLU, which the ablation of round 4 shows to be hidden
-// (the SiLU pairs are not on the layer kernels' critical path: replacing them by ONE multiply moved the launches by < 3 %).
-// IS_SILU_FAST restores the two-instruction form (A/B builds).
+// sigma(z) = 1 / (1 + exp(-z)) as v_exp_f32 of the scaled argument + v_rcp_f32 (~|z| + 1 ulp).  IS_SILU_ACCURATE builds a ~1 ulp
+// form (the rounding error of the product -z log2 e recovered with one fma and folded back, 2^(t + lo) = 2^t (1 + lo ln 2); one
+// Newton step on the reciprocal; 7 more full-rate instructions).  Round 4 measured both: the accurate form does NOT move the
+// full-size gradients' distance from the fp64 oracle (worst tensor 8.93 x the element-wise bound against 9.09 x: the per-term
+// SiLU error is not what separates the HIP path from torch's fp32 there -- HISTORY.md), and costs the iedb step nothing measurable,
+// the paired step 2.3 %, the stress stack 3.4 %.  Hence opt-in.
 __device__ __forceinline__ float sigmoid_f(float z) {
-#ifdef IS_SILU_FAST
+#ifndef IS_SILU_ACCURATE
   return rcp_f(1.0f + __expf(-z));
 #else
   constexpr float L2E = 1.44269504088896340736f;          // log2(e) rounded to fp32

@@ -120,6 +120,68 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
   __syncthreads();
 }
 
+// The same product for ONE 32-column block of the output (N <= 32), four waves: every thread issues ALL of a slab's loads (32 of
+// the A slab, 4 of the W slab) before its first LDS store -- one memory round trip per 32-wide K slab.  (Staged element by
+// element, as gemm_slabs does with its 16 waves, four waves paid 16 dependent round trips per slab: 35 us per launch.)  Wave w
+// owns the row tiles w and w + 4.  Same k order and MFMA mapping as gemm_slabs: same bits.
+template <bool WKC, typename FA, typename FW, typename FOUT>
+__device__ __forceinline__ void gemm_block(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
+  constexpr int NT = 256, PA = SLAB_ROWS * SLAB / NT, PW = 32 * SLAB / NT;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+  const int row_tiles = (B + 31) / 32;
+  f32x16 acc[2] = {zero16(), zero16()};
+  for (int k0 = 0; k0 < K; k0 += SLAB) {
+    float av[PA], wv[PW];
+#pragma unroll
+    for (int u = 0; u < PA; ++u) {
+      const int idx = tid + u * NT, i = idx / SLAB, kk = idx % SLAB;
+      av[u] = (i < B && k0 + kk < K) ? a_elem(i, k0 + kk) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+      const int idx = tid + u * NT;
+      const int c = WKC ? idx / SLAB : idx % 32, kk = WKC ? idx % SLAB : idx / 32;
+      wv[u] = (c < N && k0 + kk < K) ? w_elem(k0 + kk, c) : 0.0f;
+    }
+    __syncthreads();      // the previous slab's products are done
+#pragma unroll
+    for (int u = 0; u < PA; ++u) {
+      const int idx = tid + u * NT, i = idx / SLAB, kk = idx % SLAB;
+      if (i < row_tiles * 32) sm.a[i * SLD + kk] = av[u];
+    }
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+      const int idx = tid + u * NT;
+      const int c = WKC ? idx / SLAB : idx % 32, kk = WKC ? idx % SLAB : idx / 32;
+      sm.w[c * SLD + kk] = wv[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int own = 0; own < 2; ++own) {
+      const int tl = wave + own * 4;
+      if (tl < row_tiles) {
+        const float* ap = sm.a + (tl * 32 + r) * SLD;
+        const float* wp = sm.w + r * SLD;
+#pragma unroll
+        for (int kk = 0; kk < SLAB; kk += 2)
+          acc[own] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk + hf], wp[kk + hf], acc[own], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int own = 0; own < 2; ++own) {
+    const int tl = wave + own * 4;
+    if (tl < row_tiles) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = tl * 32 + tile_row(t, hf);
+        if (i < B && r < N) out(i, r, acc[own][t]);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // scratch layout per side (floats): Y [B][Z] | A1 [B][Z] | Zc [B][Z] | stats: mu[Z] inv[Z] colmean[Z] std[Z]
 __host__ __device__ inline long long side_floats(int B) { return 3LL * B * CZ + 4 * CZ; }
 
@@ -138,6 +200,8 @@ __device__ __forceinline__ float block_group_sum(const float (*part)[SB_COLS], i
 
 // grid (SB_BLOCKS, 2 sides): columns [32 blk, 32 blk + 32) of y1 = emb W1^T, their batch statistics (biased variance),
 // xhat and a1 = relu(gamma xhat + beta)
+constexpr int BLD = SB_COLS + 1;      // the block's [B][32] output tile stays in LDS between the product and the column passes
+
 __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_a_kernel(
     const float* __restrict__ emb_c, const float* __restrict__ emb_w, int ld_e, int E,
     const float* __restrict__ W1, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -148,22 +212,23 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_a_kernel(
   float* Y = S; float* A1 = Y + (size_t)B * CZ; float* st = A1 + 2 * (size_t)B * CZ;
   __shared__ float red[SB_COLS], rinv[SB_COLS];
   __shared__ SlabSmem slab;
+  __shared__ float blk[SLAB_ROWS * BLD];
   __shared__ float part[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
   const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
-  gemm_slabs<true, SB_WAVES>(slab, B, SB_COLS, E, [&](int i, int k) { return emb[(size_t)i * ld_e + k]; },
-                             [&](int k, int c) { return W1[(size_t)(c0 + c) * E + k]; },
-                             [&](int i, int c, float v) { Y[(size_t)i * CZ + c0 + c] = v; }, tid);
+  gemm_block<true>(slab, B, SB_COLS, E, [&](int i, int k) { return emb[(size_t)i * ld_e + k]; },
+                   [&](int k, int c) { return W1[(size_t)(c0 + c) * E + k]; },
+                   [&](int i, int c, float v) { blk[i * BLD + c] = v; }, tid);
   {
     float s = 0.0f;
-    for (int b = grp; b < B; b += SB_GROUPS) s += Y[(size_t)b * CZ + c0 + col];
+    for (int b = grp; b < B; b += SB_GROUPS) s += blk[b * BLD + col];
     part[grp][col] = s;
     __syncthreads();
     if (tid < SB_COLS) red[tid] = block_group_sum(part, tid) / (float)B;
     __syncthreads();
     const float mu = red[col];
     float v = 0.0f;
-    for (int b = grp; b < B; b += SB_GROUPS) { const float d = Y[(size_t)b * CZ + c0 + col] - mu; v += d * d; }
+    for (int b = grp; b < B; b += SB_GROUPS) { const float d = blk[b * BLD + col] - mu; v += d * d; }
     part[grp][col] = v;
     __syncthreads();
     if (tid < SB_COLS) {
@@ -174,12 +239,12 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_a_kernel(
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < B * SB_COLS; idx += 64 * SB_WAVES) {
-    const int k = idx % SB_COLS;
-    const size_t at = (size_t)(idx / SB_COLS) * CZ + c0 + k;
-    const float xh = (Y[at] - red[k]) * rinv[k];
-    Y[at] = xh;                                      // Y now holds xhat (needed by the backward)
-    A1[at] = fmaxf(gamma[c0 + k] * xh + beta[c0 + k], 0.0f);
+  const float gm = gamma[c0 + col], bt = beta[c0 + col];
+  for (int b = grp; b < B; b += SB_GROUPS) {
+    const size_t at = (size_t)b * CZ + c0 + col;
+    const float xh = (blk[b * BLD + col] - red[col]) * rinv[col];
+    Y[at] = xh;                                      // Y holds xhat (needed by the backward)
+    A1[at] = fmaxf(gm * xh + bt, 0.0f);
   }
 }
 
@@ -191,14 +256,15 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_b_kernel(const f
   const float* A1 = S + (size_t)B * CZ; float* Zc = S + 2 * (size_t)B * CZ; float* st = Zc + (size_t)B * CZ;
   __shared__ float red[SB_COLS];
   __shared__ SlabSmem slab;
+  __shared__ float blk[SLAB_ROWS * BLD];
   __shared__ float part[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
   const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
-  gemm_slabs<true, SB_WAVES>(slab, B, SB_COLS, CZ, [&](int i, int k) { return A1[(size_t)i * CZ + k]; },
-                             [&](int k, int c) { return W2[(size_t)(c0 + c) * CZ + k]; },
-                             [&](int i, int c, float v) { Zc[(size_t)i * CZ + c0 + c] = v; }, tid);
+  gemm_block<true>(slab, B, SB_COLS, CZ, [&](int i, int k) { return A1[(size_t)i * CZ + k]; },
+                   [&](int k, int c) { return W2[(size_t)(c0 + c) * CZ + k]; },
+                   [&](int i, int c, float v) { blk[i * BLD + c] = v; }, tid);
   float s = 0.0f;
-  for (int b = grp; b < B; b += SB_GROUPS) s += Zc[(size_t)b * CZ + c0 + col];
+  for (int b = grp; b < B; b += SB_GROUPS) s += blk[b * BLD + col];
   part[grp][col] = s;
   __syncthreads();
   if (tid < SB_COLS) red[tid] = block_group_sum(part, tid) / (float)B;
@@ -206,7 +272,7 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_fwd_b_kernel(const f
   const float m = red[col];
   float v = 0.0f;
   for (int b = grp; b < B; b += SB_GROUPS) {
-    const float d = Zc[(size_t)b * CZ + c0 + col] - m;
+    const float d = blk[b * BLD + col] - m;
     Zc[(size_t)b * CZ + c0 + col] = d;
     v += d * d;
   }
@@ -377,49 +443,71 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_a_kernel(
   __shared__ float coef_s[CZ], mean_s[CZ];
   __shared__ float s1[SB_COLS], s2[SB_COLS];
   __shared__ SlabSmem slab;
+  __shared__ float blk[SLAB_ROWS * BLD];
   __shared__ float part[SB_GROUPS][SB_COLS], part2[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
   const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
-  // ---- hinge gradient + centring backward, per column, all 128 columns (four rounds of 32; the 16-wave kernel's row
-  //      stripes and combine order) ----
+  // ---- hinge gradient + centring backward, per column, all 128 columns (four rounds of 32 columns: a thread's rows of a round
+  //      are loaded together; the 16-wave kernel's row stripes and combine order) ----
+  constexpr int RMAX = SLAB_ROWS / SB_GROUPS;      // rows of a stripe (B <= 256)
   for (int cb = 0; cb < CZ; cb += SB_COLS) {
     const int k = cb + col;
     const float sd = st[3 * CZ + k];
     // d hinge / d var_k = -(1/2) * (1/Z) * [sd < 1] / (2 sd);  d var_k / d z_bk = 2 z_bk / (B - 1)
     const float dv = (sd < 1.0f) ? -0.5f / (float)CZ / (2.0f * sd) : 0.0f;
     const float coef = dv * 2.0f / (float)(B - 1);
+    float dzv[RMAX], zcv[RMAX];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int b = grp + u * SB_GROUPS;
+      dzv[u] = (b < B) ? dz[(size_t)b * CZ + k] : 0.0f;
+      zcv[u] = (b < B) ? Zc[(size_t)b * CZ + k] : 0.0f;
+    }
     float s = 0.0f;
-    for (int b = grp; b < B; b += SB_GROUPS) s += dz[(size_t)b * CZ + k] + coef * Zc[(size_t)b * CZ + k];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u)
+      if (grp + u * SB_GROUPS < B) s += dzv[u] + coef * zcv[u];
     part[grp][col] = s;
     __syncthreads();
     if (tid < SB_COLS) { mean_s[cb + tid] = block_group_sum(part, tid) / (float)B; coef_s[cb + tid] = coef; }
     __syncthreads();
   }
   // ---- da1 = dz0 W2 (this block's columns); A operand = the centred gradient ----
-  gemm_slabs<false, SB_WAVES>(slab, B, SB_COLS, CZ,
-                              [&](int i, int k) { return (dz[(size_t)i * CZ + k] + coef_s[k] * Zc[(size_t)i * CZ + k]) - mean_s[k]; },
-                              [&](int k, int c) { return W2[(size_t)k * CZ + c0 + c]; },
-                              [&](int i, int c, float v) { wk[(size_t)i * CZ + c0 + c] = v; }, tid);
+  gemm_block<false>(slab, B, SB_COLS, CZ,
+                    [&](int i, int k) { return (dz[(size_t)i * CZ + k] + coef_s[k] * Zc[(size_t)i * CZ + k]) - mean_s[k]; },
+                    [&](int k, int c) { return W2[(size_t)k * CZ + c0 + c]; },
+                    [&](int i, int c, float v) { blk[i * BLD + c] = v; }, tid);
   // ---- ReLU backward, BatchNorm backward on batch statistics ----
+  const float gm = gamma[c0 + col];
+  float a1v[RMAX], xhv[RMAX];
+#pragma unroll
+  for (int u = 0; u < RMAX; ++u) {
+    const int b = grp + u * SB_GROUPS;
+    a1v[u] = (b < B) ? A1[(size_t)b * CZ + c0 + col] : 0.0f;
+    xhv[u] = (b < B) ? XH[(size_t)b * CZ + c0 + col] : 0.0f;
+  }
   {
-    const float gm = gamma[c0 + col];
     float a = 0.0f, c = 0.0f;
-    for (int b = grp; b < B; b += SB_GROUPS) {
-      const size_t idx = (size_t)b * CZ + c0 + col;
-      const float dxh = (A1[idx] > 0.0f) ? wk[idx] * gm : 0.0f;
-      wk[idx] = dxh;
-      a += dxh;
-      c += dxh * XH[idx];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int b = grp + u * SB_GROUPS;
+      if (b < B) {
+        const float dxh = (a1v[u] > 0.0f) ? blk[b * BLD + col] * gm : 0.0f;
+        blk[b * BLD + col] = dxh;
+        a += dxh;
+        c += dxh * xhv[u];
+      }
     }
     part[grp][col] = a; part2[grp][col] = c;
     __syncthreads();
     if (tid < SB_COLS) { s1[tid] = block_group_sum(part, tid); s2[tid] = block_group_sum(part2, tid); }
   }
   __syncthreads();
-  for (int idx = tid; idx < B * SB_COLS; idx += 64 * SB_WAVES) {
-    const int k = idx % SB_COLS;
-    const size_t at = (size_t)(idx / SB_COLS) * CZ + c0 + k;
-    wk[at] = st[CZ + c0 + k] / (float)B * ((float)B * wk[at] - s1[k] - XH[at] * s2[k]);     // dy1
+  const float scale = st[CZ + c0 + col] / (float)B;
+#pragma unroll
+  for (int u = 0; u < RMAX; ++u) {
+    const int b = grp + u * SB_GROUPS;
+    if (b < B) wk[(size_t)b * CZ + c0 + col] = scale * ((float)B * blk[b * BLD + col] - s1[col] - xhv[u] * s2[col]);     // dy1
   }
 }
 
@@ -433,9 +521,9 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_b_kernel(
   __shared__ SlabSmem slab;
   const int tid = threadIdx.x;
   const float g = g_loss[0] * (gate != nullptr ? gate[0] * scale : scale);
-  gemm_slabs<false, SB_WAVES>(slab, B, min(SB_COLS, E - c0), CZ, [&](int i, int k) { return wk[(size_t)i * CZ + k]; },
-                              [&](int k, int c) { return W1[(size_t)k * E + c0 + c]; },
-                              [&](int i, int c, float v) { demb[(size_t)i * ld_d + c0 + c] = v * g; }, tid);
+  gemm_block<false>(slab, B, min(SB_COLS, E - c0), CZ, [&](int i, int k) { return wk[(size_t)i * CZ + k]; },
+                    [&](int k, int c) { return W1[(size_t)k * E + c0 + c]; },
+                    [&](int i, int c, float v) { demb[(size_t)i * ld_d + c0 + c] = v * g; }, tid);
 }
 
 }  // namespace is

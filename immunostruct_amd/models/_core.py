@@ -29,7 +29,7 @@ from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
-EARLY_JOIN = os.environ.get("IMMUNOSTRUCT_EARLY_JOIN", "0") == "1"
+EARLY_JOIN = os.environ.get("IMMUNOSTRUCT_EARLY_JOIN", "1") != "0"
 # the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer).  "auto": its
 # forward (~100 us of side work) should end with the stack + node attention, not stretch more layer launches than it must -- the
 # longer a layer launch, the earlier the fork.  Measured on the round-3 kernels (same box, ms per step): B = 128 graphs / 72 k edges
