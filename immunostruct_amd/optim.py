@@ -250,7 +250,9 @@ class Adam(torch.optim.Optimizer):
                         have.copy_(new)
                         st[k] = have
                     else:
-                        st[k] = new
+                        # (torch's load_state_dict hands tensors that already sit on the right device through WITHOUT a copy:
+                        #  adopted as they are, the checkpoint's own tensors would be updated in place by the next step)
+                        st[k] = new.clone()
                         adopted = True
             if gs is None and step is not None:
                 with_state = [p for p in group["params"] if self.state.get(p)]

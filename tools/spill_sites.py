@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 src, key = sys.argv[1], sys.argv[2]
-asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-gline-tables-only", "-S", "-DIS_LAYER_M1=2", "-DIS_LAYER_GEO=1", "-Wno-unused-function",
+asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-gline-tables-only", "-S", "-DIS_LAYER_M1=2", "-DIS_LAYER_GEO=1", "-Wno-unused-function"] + sys.argv[3:] + [
                       "--cuda-device-only", src, "-o", "-"], capture_output=True, text=True).stdout.split("\n")
 starts = [i for i, l in enumerate(asm) if re.match(r"_Z\S+:", l)]
 for a, b in zip(starts, starts[1:] + [len(asm)]):
