@@ -465,6 +465,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   // raw-buffer views: scalar bases, one lane-constant byte offset per access pattern, range-checked where rows past a
   // tile's end must read as zero / must not be written (no per-element predication, no 64-bit vector address math)
   const int voff_tile = (4 * q * H + r) * 4;            // element (row 4q [+ t], column r [+ 16 nt]) of a [16][64] tile
+  // the saved pre-activation arrays (z1, z2, z3) keep channel 16 nt + r at position 4 r + nt of its row (is_egnn_layer_fwd): a
+  // lane's four channels of a row are 16 contiguous bytes
+  const int voff_tile4 = (4 * q * H + 4 * r) * 4;
 #if !IS_LAYER_M1
   const int ld_p_bytes = ld_p * 4;
   const rsrc_t rs_ps = make_rsrc(ps), rs_pd = make_rsrc(pd);
@@ -508,6 +511,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       const int nvalid = __builtin_amdgcn_readfirstlane(max(0, min(TE16, e_end - cb)));
       int vt = voff_tile;      // opaque per window: the constant parts of the 48 tile accesses then stay instruction offsets
       asm volatile("" : "+v"(vt));      // (hoisted out of the loop they would be 16 more live registers)
+      int vt4 = voff_tile4;
+      asm volatile("" : "+v"(vt4));
       STAMPB(1);
       float dy[4][4];   // SiLU'(z2), later SiLU'(z1), tile layout
       float up[4][4];   // dL/dh_neigh[dst] for this tile (prefetched)
@@ -530,12 +535,16 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       const rsrc_t rz3 = make_rsrc_n((GX && !Z3R) ? z3s + (size_t)cb * H : z2s, (GX && !Z3R) ? nvalid * H * 4 : 0);
       const rsrc_t rdz1 = make_rsrc_n(dZ1 + (size_t)cb * H, nvalid * H * 4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (GX && !Z3R) {
+          const f32x4 v3 = buf_load4(rz3, vt4 + t * (H * 4), 0);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if constexpr (GX && !Z3R) z3v[t][nt] = buf_load(rz3, vt + (t * H + nt * 16) * 4, 0);
-          z2v[t][nt] = buf_load(rz2, vt + (t * H + nt * 16) * 4, 0);
+          for (int nt = 0; nt < 4; ++nt) z3v[t][nt] = v3[nt];
         }
+        const f32x4 v2 = buf_load4(rz2, vt4 + t * (H * 4), 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) z2v[t][nt] = v2[nt];
+      }
       [[maybe_unused]] int src_lane = 0;      // S0: source node of edge (lane & 15), kept for the gathers of the z1 recompute
       if (nvalid > 0) {
         // Two forms of the window's first half, selected by the PREPROCESSOR (see the top of the file): the plain form of rounds
@@ -781,14 +790,16 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #if IS_LAYER_M1
         // prefetch the saved first activation (tile layout, rows past nvalid read as 0): in flight during WG1 + MM3
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 v1 = buf_load4(rm1, vt4 + t * (H * 4), 0);
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            m1v[t][nt] = buf_load(rm1, vt + (t * H + nt * 16) * 4, 0);
+          for (int nt = 0; nt < 4; ++nt) m1v[t][nt] = v1[nt];
 #if IS_LAYER_M1 == 1
-            d1v[t][nt] = buf_load(rd1, vt + (t * H + nt * 16) * 4, 0);
+          const f32x4 vd = buf_load4(rd1, vt4 + t * (H * 4), 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) d1v[t][nt] = vd[nt];
 #endif
-          }
+        }
 #else
         // prefetch the gathers of the z1 recompute (SA): in flight during WG1 + MM3
 #pragma unroll

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
   float acc_h = 0.0f, acc_x = 0.0f;
   int cnt = 0;         // edges accumulated for the open node
   int vnext = va;      // first node of the chunk that has not been written yet
-  const int tile_off = (4 * q * H + r) * 4;     // byte offset of D-layout element (t = 0, nt = 0); (t, nt): + (t*H + nt*16)*4
+  const int tile_off4 = (4 * q * H + 4 * r) * 4;     // byte offset of this lane's 16 bytes in row 4 q of a saved tile; row 4 q + t: + t * 256
 
   for (int cb = e0; cb < e1; cb += TE16) {
     const int ts = tile_start(cb, e1);
@@ -274,17 +274,22 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         // rows in slot order, lane = channel: one coalesced 256-byte row per store.  dy1s != NULL: m1 = SiLU(z1) and
         // SiLU'(z1) = sigma + m1 (1 - sigma) (two arrays, nothing left to evaluate in the backward); dy1s == NULL: z1 itself
         // (one array: the backward evaluates the SiLU pair but no longer gathers / recomputes z1)
+        // (column order of the three saved pre-activation arrays: channel c = 16 nt + r sits at position 4 r + nt of its row, so
+        //  that the MFMA accumulator layout -- lane (r, q) holds channels r, 16 + r, 32 + r, 48 + r of rows 4 q + t -- stores and
+        //  loads 16 contiguous bytes per lane and row: 4 full 256-byte rows per instruction instead of 16 half cache lines.  The
+        //  arrays are private to is_egnn_layer_fwd / _bwd.)
         const int row_base = ts * (H * 4);
+        const int pl = (4 * (lane & 15) + (lane >> 4)) * 4;      // byte position of channel `lane` in a saved row
         if (dy1s != nullptr) {
 #pragma unroll
           for (int i = 0; i < TE16; ++i) {
             const float y = z[i] * ex[i];
-            buf_store(y, B.m1, lane * 4, row_base + i * (H * 4));
-            buf_store(__builtin_fmaf(y, 1.0f - ex[i], ex[i]), B.d1, lane * 4, row_base + i * (H * 4));
+            buf_store(y, B.m1, pl, row_base + i * (H * 4));
+            buf_store(__builtin_fmaf(y, 1.0f - ex[i], ex[i]), B.d1, pl, row_base + i * (H * 4));
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < TE16; ++i) buf_store(z[i], B.m1, lane * 4, row_base + i * (H * 4));
+          for (int i = 0; i < TE16; ++i) buf_store(z[i], B.m1, pl, row_base + i * (H * 4));
         }
       }
 #pragma unroll
@@ -305,13 +310,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       mm16_rows<4, H>(acc, act, sm.w.w2, lane);
 #endif
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int t = 0; t < 4; ++t) {
+        f32x4 zr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float z2 = acc[nt][t] + b2_c[nt];
-          if (SAVE && ABL_SAVE) buf_store(z2, B.z2, tile_off + (t * H + nt * 16) * 4, tile_base);
-          act[tile16_row(t, q) * LD + nt * 16 + r] = silu_f(z2);
-        }
+        for (int nt = 0; nt < 4; ++nt) zr[nt] = acc[nt][t] + b2_c[nt];
+        if (SAVE && ABL_SAVE) buf_store4(zr, B.z2, tile_off4 + t * (H * 4), tile_base);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) act[tile16_row(t, q) * LD + nt * 16 + r] = silu_f(zr[nt]);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     STAMP3N();
@@ -329,12 +335,12 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float part = 0.0f;
+        f32x4 zr;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float z3 = acc[nt][t] + bc1_c[nt];
-          if (save3) buf_store(z3, B.z3, tile_off + (t * H + nt * 16) * 4, tile_base);
-          part += silu_f(z3) * wc2_c[nt];
-        }
+        for (int nt = 0; nt < 4; ++nt) zr[nt] = acc[nt][t] + bc1_c[nt];
+        if (save3) buf_store4(zr, B.z3, tile_off4 + t * (H * 4), tile_base);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) part += silu_f(zr[nt]) * wc2_c[nt];
         part = sum_over_r16(part);
         if (r == 0) sm.e_s[wave][tile16_row(t, q)] = part;
       }

@@ -67,7 +67,9 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *     W1 [64, ldw]       NATIVE edge_mlp.0.weight, ldw = 2*din + 1 + Fe; only the radial / edge-feature columns are read
  *     W2,b2 = edge_mlp.2 ; Wc1,bc1 = coord_mlp.0 ; wc2 [64] = coord_mlp.2.weight
  *     h [N, ld_h]        the layer's input node features (din = 20 | 64 columns); fpack = its forward operand pack
- *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward (z2s == NULL: none saved;
+ *     z2s, z3s [max(E,16), 64], zn1 [N,64]   out: pre-activations saved for the backward, opaque to the caller (z2s, z3s and
+ *                        m1s keep channel 16 nt + r at column 4 r + nt of a row: the MFMA accumulator layout then moves 16
+ *                        contiguous bytes per lane; only is_egnn_layer_bwd reads them) (z2s == NULL: none saved;
  *                        z3s == NULL: z3 is not saved -- is_egnn_layer_bwd then recomputes it from z2, the default)
  *     wg_clock           NULL, or [nchunks / 4][2] int64: every workgroup's start / end device wall clock (100 MHz)
  *     x_out == NULL      the coordinate branch is not evaluated (last layer of a stack whose coordinates are unused,
