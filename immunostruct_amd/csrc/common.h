@@ -319,8 +319,13 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
-__device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t rs, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff, soff, 0);
+// 16-byte store.  NO scalar offset: a buffer store of more than 8 bytes WITH an SGPR offset reads its data registers late, and
+// this toolchain leaves only one instruction between such a store and the next VALU write of those registers -- measured on
+// gfx950 (round 4): z2 / z3 rows stored as `buffer_store_dwordx4 v[18:21], v108, s[52:55], s51 offen` followed two instructions
+// later by `v_pk_add_f32 v[18:19], ...` came out corrupted at full residency (nondeterministic gradients at B = 128, identical
+// ones at B = 32).  The hazard does not exist for stores without an SGPR offset: callers fold their scalar part into `voff`.
+__device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t rs, int voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff, 0, 0);
 }
 __device__ __forceinline__ void buf_store(float v, rsrc_t rs, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);

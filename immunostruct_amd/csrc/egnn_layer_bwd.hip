@@ -166,6 +166,14 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
   const float* __restrict__ gxsrc = GATHER ? nb.gxtot : g_xout;
 
+#ifdef IS_BWD_DELAY
+  // experiment (HISTORY.md round 4): the second half of the grid (workgroup i + grid / 2 shares its CU with workgroup i) starts
+  // IS_BWD_DELAY x 0.1 us late, so that the two workgroups of a CU do not walk the same phases at the same time
+  if (2 * (int)blockIdx.x >= (int)gridDim.x) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < 10LL * IS_BWD_DELAY) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   STAMPP(13);
   // ================= P1 + P2: source gather and node data path of ALL tiles of this workgroup =================
   // (before the persistent edge loop: its weight-gradient accumulators do not exist yet, so the 80 operand registers
@@ -537,11 +545,19 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if constexpr (GX && !Z3R) {
+#ifdef IS_ZP_BWD_DW
+          f32x4 v3; for (int nt = 0; nt < 4; ++nt) v3[nt] = buf_load(rz3, vt4 + nt * 4 + t * (H * 4), 0);
+#else
           const f32x4 v3 = buf_load4(rz3, vt4 + t * (H * 4), 0);
+#endif
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) z3v[t][nt] = v3[nt];
         }
+#ifdef IS_ZP_BWD_DW
+        f32x4 v2; for (int nt = 0; nt < 4; ++nt) v2[nt] = buf_load(rz2, vt4 + nt * 4 + t * (H * 4), 0);
+#else
         const f32x4 v2 = buf_load4(rz2, vt4 + t * (H * 4), 0);
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) z2v[t][nt] = v2[nt];
       }
@@ -791,7 +807,11 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
         // prefetch the saved first activation (tile layout, rows past nvalid read as 0): in flight during WG1 + MM3
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+#ifdef IS_ZP_BWD_DW
+          f32x4 v1; for (int nt = 0; nt < 4; ++nt) v1[nt] = buf_load(rm1, vt4 + nt * 4 + t * (H * 4), 0);
+#else
           const f32x4 v1 = buf_load4(rm1, vt4 + t * (H * 4), 0);
+#endif
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) m1v[t][nt] = v1[nt];
 #if IS_LAYER_M1 == 1

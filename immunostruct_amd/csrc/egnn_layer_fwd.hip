@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
       const float d0 = r0.xs[0] - r0.xd[0], d1 = r0.xs[1] - r0.xd[1], d2 = r0.xs[2] - r0.xd[2];
       const float rad = radial3(d0, d1, d2);
       const float inv = 1.0f / (sqrtf(rad) + 1e-30f);
-      if (save_geo) buf_store4(f32x4{d0, d1, d2, rad}, B.geo, lane * 16, ts * 16);
+      if (save_geo) buf_store4(f32x4{d0, d1, d2, rad}, B.geo, lane * 16 + ts * 16);
       sm.e_rad[wave][lane] = rad;
       if constexpr (COORD) { sm.e_xdst[wave][0][lane] = r0.xd[0]; sm.e_xdst[wave][1][lane] = r0.xd[1]; sm.e_xdst[wave][2][lane] = r0.xd[2]; }
       sm.e_xd[wave][0][lane] = d0 * inv;
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     STAMP3N();
 
     const int tile_base = ts * (H * 4);      // scalar byte offset of the tile inside z2s / z3s
+    const int tile_voff4 = tile_off4 + tile_base;      // (16-byte stores take no scalar offset: common.h buf_store4)
     // ---- MM1: z2 = m1 W2^T + b2 ; mh = SiLU(z2) ----
     {
       f32x4 acc[4];
@@ -314,7 +315,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         f32x4 zr;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) zr[nt] = acc[nt][t] + b2_c[nt];
-        if (SAVE && ABL_SAVE) buf_store4(zr, B.z2, tile_off4 + t * (H * 4), tile_base);
+#ifdef IS_ZP_FWD_DW
+        if (SAVE && ABL_SAVE) { for (int nt = 0; nt < 4; ++nt) buf_store(zr[nt], B.z2, tile_off4 + nt * 4 + t * (H * 4), tile_base); }
+#else
+        if (SAVE && ABL_SAVE) buf_store4(zr, B.z2, tile_voff4 + t * (H * 4));
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) act[tile16_row(t, q) * LD + nt * 16 + r] = silu_f(zr[nt]);
       }
@@ -338,7 +343,11 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
         f32x4 zr;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) zr[nt] = acc[nt][t] + bc1_c[nt];
-        if (save3) buf_store4(zr, B.z3, tile_off4 + t * (H * 4), tile_base);
+#ifdef IS_ZP_FWD_DW
+        if (save3) { for (int nt = 0; nt < 4; ++nt) buf_store(zr[nt], B.z3, tile_off4 + nt * 4 + t * (H * 4), tile_base); }
+#else
+        if (save3) buf_store4(zr, B.z3, tile_voff4 + t * (H * 4));
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) part += silu_f(zr[nt]) * wc2_c[nt];
         part = sum_over_r16(part);
