@@ -166,14 +166,6 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
   const float* __restrict__ gxsrc = GATHER ? nb.gxtot : g_xout;
 
-#ifdef IS_BWD_DELAY
-  // experiment (HISTORY.md round 4): the second half of the grid (workgroup i + grid / 2 shares its CU with workgroup i) starts
-  // IS_BWD_DELAY x 0.1 us late, so that the two workgroups of a CU do not walk the same phases at the same time
-  if (2 * (int)blockIdx.x >= (int)gridDim.x) {
-    const long long t0 = (long long)wall_clock64();
-    while ((long long)wall_clock64() - t0 < 10LL * IS_BWD_DELAY) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   STAMPP(13);
   // ================= P1 + P2: source gather and node data path of ALL tiles of this workgroup =================
   // (before the persistent edge loop: its weight-gradient accumulators do not exist yet, so the 80 operand registers

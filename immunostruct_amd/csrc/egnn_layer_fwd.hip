@@ -299,9 +299,14 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
     STAMP3N();
 
     const int tile_base = ts * (H * 4);      // scalar byte offset of the tile inside z2s / z3s
-    const int tile_voff4 = tile_off4 + tile_base;      // (16-byte stores take no scalar offset: common.h buf_store4)
+    // (16-byte stores take no scalar offset -- common.h buf_store4 -- so the tile's base joins the lane offset: formed where it
+    //  is used, from an opaque copy, so that the sum is not one more register live across both matrix stages: the Fe = 8
+    //  instantiation sits at 256)
     // ---- MM1: z2 = m1 W2^T + b2 ; mh = SiLU(z2) ----
     {
+      int tile_voff4 = tile_off4;
+      asm volatile("" : "+v"(tile_voff4));
+      tile_voff4 += tile_base;
       f32x4 acc[4];
       zero_acc4(acc);
 #ifdef IS_ABL_NOMFMA
@@ -329,6 +334,9 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 
     // ---- MM2: z3 = mh Wc1^T + bc1 ; s = SiLU(z3) . wc2 ----
     if constexpr (COORD) {
+      int tile_voff4 = tile_off4;
+      asm volatile("" : "+v"(tile_voff4));
+      tile_voff4 += tile_base;
       f32x4 acc[4];
       zero_acc4(acc);
 #ifdef IS_ABL_NOMFMA
