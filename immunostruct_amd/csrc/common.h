@@ -353,11 +353,22 @@ __device__ __forceinline__ void wg_sum_store_64x64(const f32x16 (&acc)[2][2], fl
   __syncthreads();
 }
 
-// sum of v over the 32 lanes that share hf (lanes differ in r = lane & 31).
+// sum / maximum of v over the 32 lanes that share hf (lanes differ in r = lane & 31): the 16 lanes of a DPP row by four DPP
+// operations, the two rows of the half by ONE ds_swizzle (lane ^ 16).  (As a loop of five __shfl_xor this was five ds_bpermute
+// trips through the LDS crossbar, each with its address arithmetic: 166 of them per wave and head in the node attention forward.)
+__device__ __forceinline__ float swap_rows16(float v) {      // value of lane ^ 16
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
 __device__ __forceinline__ float sum_over_r(float v) {
-#pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v = sum_over_r16(v);
+  return v + swap_rows16(v);
+}
+__device__ __forceinline__ float max_over_r(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  return fmaxf(v, swap_rows16(v));
 }
 
 // copy a row-major [rows x 64] fp32 matrix from global into an LD-strided LDS tile.

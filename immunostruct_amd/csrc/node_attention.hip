@@ -135,8 +135,7 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_fwd_kernel(
           acc[nt][t] = s;
           m = fmaxf(m, s);
         }
-#pragma unroll
-        for (int mk = 16; mk >= 1; mk >>= 1) m = fmaxf(m, __shfl_xor(m, mk, 64));
+        m = max_over_r(m);
         float l = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -345,7 +344,7 @@ __device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t
   else if (tid < 2 * TAIL_ROWS) dbv[r0 + tid - TAIL_ROWS] = bsum;
 }
 
-constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop
+constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop (32: one round trip for n = 190, but 116 spilled registers)
 
 // HALVES = 2 (experimental, see attn_bwd_split): TWO workgroups per graph (blockIdx.x = 2 * graph + half; adjacent ids land on
 // different CUs).  A graph's
@@ -405,10 +404,13 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
 #pragma unroll
         for (int u = 0; u < DAB_ROWS; ++u) {
           const int j = j0 + u * NT;
-          float d = sum_over_r16(xv[u] * g);          // 16-lane rows by DPP, then the four rows
-          d += __shfl_xor(d, 16, 64);
-          d += __shfl_xor(d, 32, 64);
-          if (j < NT * 32 && lane == 0) sm.dab[j] = d;
+          // 16-lane rows by DPP (every lane of a row then holds the row's sum), then the four rows by two broadcast adds
+          // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lanes 48..63 hold the wave's sum) -- no trip
+          // through the LDS crossbar
+          float d = sum_over_r16(xv[u] * g);
+          d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142, 0xA, 0xF, false));
+          d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143, 0xC, 0xF, false));
+          if (j < NT * 32 && lane == 63) sm.dab[j] = d;
           if (j < n && (j / (NT * 32 / HALVES)) == half) {      // (the direct term's rows: this half's only)
             float* dst = dx + (size_t)(b * n + j) * 64 + lane;
             *dst = (hd == 0 ? 0.0f : *dst) + ab[u] * g;
