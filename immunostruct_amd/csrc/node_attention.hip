@@ -49,10 +49,22 @@ struct AttnSmem {
   float cpart[NT][64];
 };
 
+// DUAL: K and Q rows resident together (the two matrix passes run side by side, see attn_colmean_bwd_kernel)
+template <int NT, int D>
+constexpr bool attn_bwd_dual() {      // (at most 12 waves = 170 registers per wave)
+#ifdef IS_ATTN_DUAL
+  return NT <= 6 && sizeof(float) * (2 * NT * 32 * (D + 4) + NT * 32 * 33 + 3 * NT * 32) <= 150 * 1024;
+#else
+  return false;      // measured slower (HISTORY.md round 4): kept as a build switch
+#endif
+}
+
 template <int NT, int D>
 struct AttnBwdSmem {
   static constexpr int LDQ = D + 4;
-  float kq[NT * 32 * LDQ];    // K rows during pass A, then Q rows during pass B
+  static constexpr bool DUAL = attn_bwd_dual<NT, D>();
+  float kq[NT * 32 * LDQ];    // K rows (pass A); without DUAL: then the Q rows (pass B)
+  float qs[DUAL ? NT * 32 * LDQ : 1];      // DUAL: Q rows
   float abar[NT * 32];
   float dab[NT * 32];         // d abar_j
   float tvec[NT * 32];        // t_i
@@ -346,64 +358,74 @@ __device__ __forceinline__ void attn_tail_wgrad(float* lds, const AttnTailBwd& t
 
 constexpr int DAB_ROWS = 16;      // x rows in flight per wave in the d abar / direct-term loop (32: one round trip for n = 190, but 116 spilled registers)
 
-// HALVES = 2 (experimental, see attn_bwd_split): TWO workgroups per graph (blockIdx.x = 2 * graph + half; adjacent ids land on
-// different CUs).  A graph's
-// backward is 2 * NT matrix passes of 192 MFMAs (32x32x2: 12 k cycles each); with one workgroup per graph NT = 6 waves sit on 4
-// SIMDs, two of which carry two passes' worth -- and half of the chip's CUs idle (128 graphs, 256 CUs).  Here every workgroup
-// still stages K / Q, forms dabar and the t_i of ALL query blocks (cheap, and pass B needs them all), but runs the dQ / dK matrix
-// passes -- and stores the direct term -- only for ITS half of the query / key blocks: one pass per SIMD.  The outputs of the two
-// halves are disjoint rows of dqk / dx: no reduction, bit-identical to the one-workgroup form.
-template <int NT, int D, int HALVES>
-__global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
+// One workgroup per graph.  The backward is two matrix passes per 32-row block -- dQ = dS K for the block's queries (pass A, from
+// its probability tiles transposed through LDS) and dK = dS^T Q for its keys (pass B) -- of 192 MFMAs (32x32x2: 12 k cycles) each.
+// Round 3 ran them one after the other on NT waves: with NT = 6 waves on 4 SIMDs two SIMDs carry two waves, and each pass lasted
+// 2 x 12 k cycles + its LDS latencies (31 k + 34 k of the launch's 100 k cycles, tools/attn_stamps.py).  DUAL (K and Q rows fit
+// the LDS together: every shape of the models' defaults): 2 NT waves, waves [0, NT) run pass A and waves [NT, 2 NT) pass B AT THE
+// SAME TIME -- three waves per SIMD, 12 x 12 k / 4 = 37 k cycles of matrix work for both passes; the d abar / direct-term rows
+// are spread over all 2 NT waves (one round of 16 row loads per wave for n = 190).  Outputs are disjoint rows: bit-identical to
+// the sequential form, which remains for shapes whose K + Q rows exceed the LDS (n > 192 with one head).
+// (Round 3 also tried TWO workgroups per graph: measured slower -- duplicated staging and t_i work -- and removed in round 4.)
+template <int NT, int D>
+__global__ __launch_bounds__((attn_bwd_dual<NT, D>() ? 128 : 64) * NT) void attn_colmean_bwd_kernel(
     const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
     const float* __restrict__ probs, const float* __restrict__ g_ctx, float* __restrict__ dqk,
     float* __restrict__ dx, int n, int heads, AttnTailBwd tail) {
   constexpr int LDQ = AttnBwdSmem<NT, D>::LDQ;
   constexpr int CT = (D + 31) / 32;
-  static_assert(HALVES == 1 || (HALVES == 2 && NT % 2 == 0), "two halves need an even number of 32-row blocks");
+  constexpr bool DUAL = AttnBwdSmem<NT, D>::DUAL;
+  constexpr int NW = DUAL ? 2 * NT : NT, NTHREADS = 64 * NW;
   __shared__ AttnBwdSmem<NT, D> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / HALVES, half = blockIdx.x % HALVES;
-  const bool mine = (wave / (NT / HALVES)) == half;      // this wave's query / key block belongs to this workgroup's half
+  const int b0 = blockIdx.x;
+  const bool do_a = !DUAL || wave < NT, do_b = !DUAL || wave >= NT;      // (wave-uniform) this wave's passes
+  const int blk = (DUAL && wave >= NT) ? wave - NT : wave;              // its 32-row block
   if constexpr (D == 64) {
-    if (tail.gy != nullptr && b >= tail.B) {      // the extra workgroups: parameter gradients of the pooled tail
-      if (half == 0) attn_tail_wgrad<64 * NT>(sm.kq, tail, b - tail.B, tid);
+    if (tail.gy != nullptr && b0 >= tail.B) {      // the extra workgroups: parameter gradients of the pooled tail
+      attn_tail_wgrad<NTHREADS>(sm.kq, tail, b0 - tail.B, tid);
       return;
     }
   }
   const int r = lane & 31, hf = lane >> 5;
   const float scale = rsqrtf((float)D);
   const float coef = scale / (float)n;
-  // direct term dx_j[c] = sum_h abar_h[j] g_ctx_h[c]: thread (wave, lane = c) owns rows j = wave, wave+NT, ...
+  // direct term dx_j[c] = sum_h abar_h[j] g_ctx_h[c]: thread (wave, lane = c) owns rows j = wave, wave + NW, ...
   // and accumulates over the heads in global memory (same thread, same address: no race)
 
   STAMPA(0);
   float g_tail = 0.0f;
   if constexpr (D == 64) {
-    if (tail.gy != nullptr) g_tail = attn_tail_gctx(tail, b, lane);
+    if (tail.gy != nullptr) g_tail = attn_tail_gctx(tail, b0, lane);
     __builtin_amdgcn_sched_barrier(0);      // keep the two mat-vecs' loads out of the register-heavy passes below
   }
+  float* qrows = DUAL ? sm.qs : sm.kq;      // where pass B finds the Q rows
   for (int hd = 0; hd < heads; ++hd) {
+    // (opaque per head: every row address below would otherwise be formed once in front of the loop -- some sixty 64-bit values
+    //  that do not fit 170 registers and came back from scratch inside the staging and row loops: 150 k instead of 100 k cycles)
+    int b = b0;
+    asm volatile("" : "+s"(b));
     __syncthreads();
-    attn_stage_half<NT, D>(sm.kq, qk, 1, b, n, hd, tid, 64 * NT);       // K rows
+    attn_stage_half<NT, D>(sm.kq, qk, 1, b, n, hd, tid, NTHREADS);       // K rows
+    if constexpr (DUAL) attn_stage_half<NT, D>(sm.qs, qk, 0, b, n, hd, tid, NTHREADS);       // Q rows
     STAMPA(1);
     const float* gc = g_ctx != nullptr ? g_ctx + (size_t)(b * heads + hd) * 64 : nullptr;
     const float* pbase = probs + (size_t)(b * heads + hd) * NT * NT * 1024;
-    // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NT, ... with
-    // lane = channel (one coalesced 256-byte row per load, 8 rows in flight)
+    // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NW, ... with
+    // lane = channel (one coalesced 256-byte row per load, 16 rows in flight)
     {
       const float g = (gc != nullptr) ? gc[lane] : g_tail;
-      for (int j0 = wave; j0 < NT * 32; j0 += DAB_ROWS * NT) {
+      for (int j0 = wave; j0 < NT * 32; j0 += DAB_ROWS * NW) {
         float xv[DAB_ROWS], ab[DAB_ROWS];
 #pragma unroll
         for (int u = 0; u < DAB_ROWS; ++u) {
-          const int j = j0 + u * NT;
+          const int j = j0 + u * NW;
           xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
           ab[u] = (j < n) ? abar_in[(size_t)(b * heads + hd) * n + j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < DAB_ROWS; ++u) {
-          const int j = j0 + u * NT;
+          const int j = j0 + u * NW;
           // 16-lane rows by DPP (every lane of a row then holds the row's sum), then the four rows by two broadcast adds
           // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lanes 48..63 hold the wave's sum) -- no trip
           // through the LDS crossbar
@@ -411,165 +433,176 @@ __global__ __launch_bounds__(64 * NT) void attn_colmean_bwd_kernel(
           d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142, 0xA, 0xF, false));
           d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143, 0xC, 0xF, false));
           if (j < NT * 32 && lane == 63) sm.dab[j] = d;
-          if (j < n && (j / (NT * 32 / HALVES)) == half) {      // (the direct term's rows: this half's only)
+          if (j < n) {
             float* dst = dx + (size_t)(b * n + j) * 64 + lane;
             *dst = (hd == 0 ? 0.0f : *dst) + ab[u] * g;
           }
         }
       }
     }
-    // this wave's query-block tiles (keys on the lanes); issued AFTER the x rows: vector loads return in order, the
-    // reduction above must not wait behind these 24 KB.  They are only needed for t_i here -- held in registers across the
-    // (not unrolled) dQ loop below the array was indexed dynamically and lived in SCRATCH (400 bytes per lane: global ->
-    // registers -> scratch -> registers); the dQ loop now re-reads its tiles one ahead of their use, as pass B does (L2 hits)
+    // pass A's query-block tiles (keys on the lanes); issued AFTER the x rows: vector loads return in order, the reduction
+    // above must not wait behind these 24 KB.  They are only needed for t_i here -- held in registers across the (not unrolled)
+    // dQ loop below the array was indexed dynamically and lived in SCRATCH (round 3: 400 bytes per lane); the dQ loop re-reads
+    // its tiles one ahead of their use, as pass B does (L2 hits)
     float tpart[16];
     {
-      constexpr int G = NT > 6 ? NT / 2 : NT;      // tiles held at once (n = 256: two rounds of four -- eight would spill)
+      constexpr int G = (DUAL || NT > 6) ? NT / 2 : NT;      // tiles held at once (170 registers per wave with 2 NT waves)
       float pq[G][16];
+      if (do_a) {
 #pragma unroll
-      for (int nt = 0; nt < G; ++nt)
+        for (int nt = 0; nt < G; ++nt)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + nt) * 16 + t) * 64 + lane];
+          for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((blk * NT + nt) * 16 + t) * 64 + lane];
+      }
       STAMPA(2);
       __syncthreads();
       STAMPA(3);
-      // ---- pass A: query block `wave`.  t_i = sum_j P_ij dabar_j (keys on the lanes -> lane reduction) ----
+      // ---- t_i = sum_j P_ij dabar_j for query block `blk` (keys on the lanes -> lane reduction) ----
+      if (do_a) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) tpart[t] = 0.f;
+        for (int t = 0; t < 16; ++t) tpart[t] = 0.f;
 #pragma unroll
-      for (int g0 = 0; g0 < NT; g0 += G) {
-        if (g0 > 0) {
+        for (int g0 = 0; g0 < NT; g0 += G) {
+          if (g0 > 0) {
 #pragma unroll
-          for (int nt = 0; nt < G; ++nt)
+            for (int nt = 0; nt < G; ++nt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((wave * NT + g0 + nt) * 16 + t) * 64 + lane];
-        }
+              for (int t = 0; t < 16; ++t) pq[nt][t] = pbase[((blk * NT + g0 + nt) * 16 + t) * 64 + lane];
+          }
 #pragma unroll
-        for (int nt = 0; nt < G; ++nt) {
-          const float dj = sm.dab[(g0 + nt) * 32 + r];
+          for (int nt = 0; nt < G; ++nt) {
+            const float dj = sm.dab[(g0 + nt) * 32 + r];
 #pragma unroll
-          for (int t = 0; t < 16; ++t) tpart[t] += pq[nt][t] * dj;
+            for (int t = 0; t < 16; ++t) tpart[t] += pq[nt][t] * dj;
+          }
         }
       }
     }
-    {
-      float pk[16], pn[16];
-      if (mine) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) pk[t] = pbase[((wave * NT + 0) * 16 + t) * 64 + lane];
-      }
+    if (do_a) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const float ti = sum_over_r(tpart[t]);
-        if (r == 0) sm.tvec[wave * 32 + tile_row(t, hf)] = ti;
+        if (r == 0) sm.tvec[blk * 32 + tile_row(t, hf)] = ti;
       }
+    }
+    if constexpr (DUAL) __syncthreads();      // t_i of every query block is in LDS (pass B reads them all); Q and K rows are staged
+    STAMPA(4);
+    // ---- pass A: dQ[i][c] = sum_j dS[i][j] K[j][c] for query block `blk`: transpose each P tile (wave-private LDS) so that
+    //      the queries sit on the lanes; the dS registers are then the MFMA A operand ----
+    if (do_a) {
       __builtin_amdgcn_wave_barrier();
-      const float ti = sm.tvec[wave * 32 + r];       // query i = wave*32 + r on the lanes from here on
-      STAMPA(4);
-      // dQ[i][c] = sum_j dS[i][j] K[j][c]: transpose each P tile (wave-private LDS) so that the queries sit on the
-      // lanes; the dS registers are then the MFMA A operand
+      const float ti = sm.tvec[blk * 32 + r];       // query i = blk*32 + r on the lanes from here on
       f32x16 dq[CT];
       zero_acc(dq);
-      float* tr = sm.tr[wave];
-#pragma unroll 1
-      for (int nt = 0; nt < (mine ? NT : 0); ++nt) {
-        const int nn = min(nt + 1, NT - 1);                    // next tile in flight during this tile's transposition + MFMAs
+      float* tr = sm.tr[blk];
+      // tiles are fetched TWO ahead of their use (a tile's transposition + 32 MFMAs last about as long as one L2 / MALL round
+      // trip: one tile ahead left part of it exposed)
+      float pk[16], pn[16], p2[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pn[t] = pbase[((wave * NT + nn) * 16 + t) * 64 + lane];
+      for (int t = 0; t < 16; ++t) {
+        pk[t] = pbase[((blk * NT + 0) * 16 + t) * 64 + lane];
+        pn[t] = pbase[((blk * NT + min(1, NT - 1)) * 16 + t) * 64 + lane];
+      }
+#pragma unroll 1
+      for (int nt = 0; nt < NT; ++nt) {
+        const int nn = min(nt + 2, NT - 1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) p2[t] = pbase[((blk * NT + nn) * 16 + t) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 16; ++t) tr[tile_row(t, hf) * 33 + r] = pk[t];      // [query row][key col]
         __builtin_amdgcn_wave_barrier();
-        // all LDS operands of the tile first, then the MFMAs back to back (an LDS read in front of every MFMA
-        // exposes its latency 16 times per tile when one wave has the SIMD to itself)
-        float ds[16], kv[16][CT];
+        // the LDS operands of TB k-steps first, then their MFMAs back to back (an LDS read in front of every MFMA exposes its
+        // latency 16 times per tile; all sixteen steps' operands at once are 48 registers -- too many at three waves per SIMD)
+        constexpr int TB = DUAL ? 8 : 16;      // k-steps whose operands are fetched together
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int jl = tile_row(t, hf), j = nt * 32 + jl;
-          ds[t] = tr[r * 33 + jl] * (sm.dab[j] - ti) * coef;                          // P[i = lane][j] -> dS
+        for (int t0 = 0; t0 < 16; t0 += TB) {
+          float ds[TB], kv[TB][CT];
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const int c = ct * 32 + r;
-            kv[t][ct] = (c < D) ? sm.kq[j * LDQ + c] : 0.f;
+          for (int u = 0; u < TB; ++u) {
+            const int jl = tile_row(t0 + u, hf), j = nt * 32 + jl;
+            ds[u] = tr[r * 33 + jl] * (sm.dab[j] - ti) * coef;                          // P[i = lane][j] -> dS
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const int c = ct * 32 + r;
+              kv[u][ct] = (c < D) ? sm.kq[j * LDQ + c] : 0.f;
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads above, the MFMAs below (the scheduler re-interleaves them)
+#pragma unroll
+          for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[u], kv[u][ct], dq[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads above, the MFMAs below (the scheduler re-interleaves them)
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[t], kv[t][ct], dq[ct], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pk[t] = pn[t];
+        for (int t = 0; t < 16; ++t) { pk[t] = pn[t]; pn[t] = p2[t]; }
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const int ii = wave * 32 + tile_row(t, hf), c = ct * 32 + r;
-          if (mine && ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
+          const int ii = blk * 32 + tile_row(t, hf), c = ct * 32 + r;
+          if (ii < n && c < D) dqk[(size_t)(b * n + ii) * 128 + hd * D + c] = dq[ct][t];
         }
     }
     STAMPA(5);
-    __syncthreads();   // t_i of every query block is in LDS; every wave is done with the K rows
-    STAMPA(6);
-    attn_stage_half<NT, D>(sm.kq, qk, 0, b, n, hd, tid, 64 * NT);       // Q rows
-    __syncthreads();
-    STAMPA(7);
-    // ---- pass B: key block `wave` (keys on the lanes, queries on the registers): dK[j][c] = sum_i dS[i][j] Q[i][c] ----
-    if (mine) {      // (wave-uniform)
+    if constexpr (!DUAL) {
+      __syncthreads();   // t_i of every query block is in LDS; every wave is done with the K rows
+      STAMPA(6);
+      attn_stage_half<NT, D>(sm.kq, qk, 0, b, n, hd, tid, NTHREADS);       // Q rows
+      __syncthreads();
+      STAMPA(7);
+    }
+    // ---- pass B: key block `blk` (keys on the lanes, queries on the registers): dK[j][c] = sum_i dS[i][j] Q[i][c] ----
+    if (do_b) {      // (wave-uniform)
       f32x16 dk[CT];
       zero_acc(dk);
-      const float dabj = sm.dab[wave * 32 + r];
-      float pk[16], pn[16];
+      const float dabj = sm.dab[blk * 32 + r];
+      float pk[16], pn[16], p2[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) pk[t] = pbase[((0 * NT + wave) * 16 + t) * 64 + lane];
+      for (int t = 0; t < 16; ++t) {
+        pk[t] = pbase[((0 * NT + blk) * 16 + t) * 64 + lane];
+        pn[t] = pbase[((min(1, NT - 1) * NT + blk) * 16 + t) * 64 + lane];
+      }
 #pragma unroll 1
       for (int mt = 0; mt < NT; ++mt) {
-        const int mn = min(mt + 1, NT - 1);                    // next tile in flight during this tile's MFMAs
+        const int mn = min(mt + 2, NT - 1);                    // two tiles ahead
 #pragma unroll
-        for (int t = 0; t < 16; ++t) pn[t] = pbase[((mn * NT + wave) * 16 + t) * 64 + lane];
-        float ds[16], qv[16][CT];
+        for (int t = 0; t < 16; ++t) p2[t] = pbase[((mn * NT + blk) * 16 + t) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int i = mt * 32 + tile_row(t, hf);
-          ds[t] = pk[t] * (dabj - sm.tvec[i]) * coef;
+        for (int t0 = 0; t0 < 16; t0 += 8) {
+          float ds[8], qv[8][CT];
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const int c = ct * 32 + r;
-            qv[t][ct] = (c < D) ? sm.kq[i * LDQ + c] : 0.f;
+          for (int u = 0; u < 8; ++u) {
+            const int i = mt * 32 + tile_row(t0 + u, hf);
+            ds[u] = pk[t0 + u] * (dabj - sm.tvec[i]) * coef;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const int c = ct * 32 + r;
+              qv[u][ct] = (c < D) ? qrows[i * LDQ + c] : 0.f;
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[u], qv[u][ct], dk[ct], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[t], qv[t][ct], dk[ct], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) pk[t] = pn[t];
+        for (int t = 0; t < 16; ++t) { pk[t] = pn[t]; pn[t] = p2[t]; }
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const int jj = wave * 32 + tile_row(t, hf), c = ct * 32 + r;
+          const int jj = blk * 32 + tile_row(t, hf), c = ct * 32 + r;
           if (jj < n && c < D) dqk[(size_t)(b * n + jj) * 128 + 64 + hd * D + c] = dk[ct][t];
         }
     }
     STAMPA(8);
   }
-}
-
-// Two workgroups per graph: OFF unless IMMUNOSTRUCT_ATTN_SPLIT=1.  Measured at B = 128 (HISTORY.md): the launch got slower, 55 -> ~66
-// us -- a wave's dQ pass is its OWN serial chain (per key tile: transposition through LDS, 48 LDS reads, then 32 MFMAs: 5.4 k cycles
-// of which 2 k are MFMA issue), which two waves sharing a SIMD already overlapped completely, so giving every pass a SIMD of its
-// own bought nothing in pass A (32.8 k vs 31.4 k cycles) and 10 k cycles in pass B, less than the duplicated staging, dabar and
-// t_i work and the second XCD's reads of the same Q / K / P rows cost.  The form stays (bit-identical, tested) for experiments.
-inline bool attn_bwd_split(int graphs) {
-  (void)graphs;
-  const char* e = getenv("IMMUNOSTRUCT_ATTN_SPLIT");      // (read per call: the tests flip it)
-  return e != nullptr && e[0] != '\0' && atoi(e) != 0;
 }
 
 }  // namespace is
@@ -597,27 +630,25 @@ extern "C" int is_debug_stamps_attn(long long* out) {
     }                                                                                                                \
   } while (0)
 
-// the backward: one or two workgroups per graph (HV); grid = HV * (graphs + extra workgroups)
-#define ATTN_DISPATCH_BWD_HV(HV, ...)                                                                                        \
-  do {                                                                                                                       \
-    const int nt = (n + 31) / 32;                                                                                            \
-    hipStream_t st = static_cast<hipStream_t>(stream);                                                                       \
-    if (heads == 1) {                                                                                                        \
-      if (nt <= 2) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<2, 64, HV>), dim3(HV * B), dim3(128), 0, st, __VA_ARGS__);      \
-      else if (nt <= 4) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<4, 64, HV>), dim3(HV * B), dim3(256), 0, st, __VA_ARGS__); \
-      else if (nt <= 6) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<6, 64, HV>), dim3(HV * B), dim3(384), 0, st, __VA_ARGS__); \
-      else hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<8, 64, HV>), dim3(HV * B), dim3(512), 0, st, __VA_ARGS__);              \
-    } else {                                                                                                                 \
-      if (nt <= 2) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<2, 8, HV>), dim3(HV * B), dim3(128), 0, st, __VA_ARGS__);       \
-      else if (nt <= 4) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<4, 8, HV>), dim3(HV * B), dim3(256), 0, st, __VA_ARGS__);  \
-      else if (nt <= 6) hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<6, 8, HV>), dim3(HV * B), dim3(384), 0, st, __VA_ARGS__);  \
-      else hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<8, 8, HV>), dim3(HV * B), dim3(512), 0, st, __VA_ARGS__);               \
-    }                                                                                                                        \
-  } while (0)
-// one workgroup per graph unless IMMUNOSTRUCT_ATTN_SPLIT=1 (see attn_bwd_split)
-#define ATTN_DISPATCH_BWD(GRAPHS, ...)                                                                    \
-  do {                                                                                                    \
-    if (is::attn_bwd_split(GRAPHS)) ATTN_DISPATCH_BWD_HV(2, __VA_ARGS__); else ATTN_DISPATCH_BWD_HV(1, __VA_ARGS__); \
+// the backward: one workgroup per graph, 2 NT waves when K and Q rows fit the LDS together (attn_bwd_dual), else NT
+#define ATTN_BWD_LAUNCH(NTV, DV, ...)                                                                                           \
+  hipLaunchKernelGGL((is::attn_colmean_bwd_kernel<NTV, DV>), dim3(B), dim3((is::attn_bwd_dual<NTV, DV>() ? 128 : 64) * NTV), 0, st, \
+                     __VA_ARGS__)
+#define ATTN_DISPATCH_BWD(GRAPHS, ...)                                                       \
+  do {                                                                                       \
+    const int nt = (n + 31) / 32;                                                            \
+    hipStream_t st = static_cast<hipStream_t>(stream);                                       \
+    if (heads == 1) {                                                                        \
+      if (nt <= 2) ATTN_BWD_LAUNCH(2, 64, __VA_ARGS__);                                      \
+      else if (nt <= 4) ATTN_BWD_LAUNCH(4, 64, __VA_ARGS__);                                 \
+      else if (nt <= 6) ATTN_BWD_LAUNCH(6, 64, __VA_ARGS__);                                 \
+      else ATTN_BWD_LAUNCH(8, 64, __VA_ARGS__);                                              \
+    } else {                                                                                 \
+      if (nt <= 2) ATTN_BWD_LAUNCH(2, 8, __VA_ARGS__);                                       \
+      else if (nt <= 4) ATTN_BWD_LAUNCH(4, 8, __VA_ARGS__);                                  \
+      else if (nt <= 6) ATTN_BWD_LAUNCH(6, 8, __VA_ARGS__);                                  \
+      else ATTN_BWD_LAUNCH(8, 8, __VA_ARGS__);                                               \
+    }                                                                                        \
   } while (0)
 
 // qk [B*n, 128] = [Q | K], x [B*n, 64]; heads in {1, 8}; n <= 256 nodes per graph (all graphs equal, padded).
