@@ -14,6 +14,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 BATCH = 16
 OUT_TOL, GRAD_TOL = 1e-5, 1e-4      # element-wise (tests/helpers.py): SURVEY 8c / BASELINE.md: 1e-5 rel on outputs, 1e-4 on gradients
+FULL_SIZE_FACTOR = 6.0      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
 
 
 def _with_eps(fn, eps_list, device):
@@ -199,15 +200,18 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
     if b >= 64:
         # full size: sums over ~150 k edges in fp32 differ between two correct implementations by more than the small-batch
         # tolerance (dw_r sums products with squared distances up to 1e4); the yardstick is then the fp64 oracle -- the HIP
-        # gradient must meet the element-wise bound against it, or be within 8x of the fp32 reference arithmetic's own distance
-        # from it.  That distance is itself one draw of a round-off realisation, so it is taken as the larger of TWO
-        # realisations of the fp32 oracle: the batch as given, and the same batch with its edge list permuted (every
-        # scatter-add then runs in another order; the two differ by 2 - 4x on the worst tensors).  Why 8 and not 1: the worst
-        # tensor, coord_mlp.2.weight of layer 4, is a sum over 146 k edges of ds * SiLU(z3) that cancels to ~1e-3 of its terms, so
-        # its error is the PER-TERM error times sqrt(N) -- and the kernels evaluate SiLU with the hardware's v_exp_f32 / v_rcp_f32
-        # (1 ulp each + the scaled argument, ~3e-7 relative) where torch's CPU path is ~1e-7.  Measured: HIP 2.6x the bound (3e-4
-        # of the largest entry), fp32 oracle 0.5x; forming the 512 workgroup records' sum in fp64 did not move it (2.6176 ->
-        # 2.6189: the error is in the terms, not in the summation), earlier builds landed at 4.0x - 5.1x of one oracle draw.
+        # gradient must meet the element-wise bound against it, or be within FULL_SIZE_FACTOR x of the fp32 reference
+        # arithmetic's own distance from it.  That distance is itself one draw of a round-off realisation, so it is taken as the
+        # larger of TWO realisations of the fp32 oracle: the batch as given, and the same batch with its edge list permuted
+        # (every scatter-add then runs in another order; the two differ by up to 1.6 x on the worst tensors).
+        # Measured (round 4, printed by this test with -s): eight tensors exceed the element-wise bound, all on the coordinate
+        # path (coord_mlp.* of layers 2 - 4, edge_mlp.* of layer 2: sums over 146 k edges that cancel to ~1e-3 of their terms);
+        # the worst, GCN_layers.3.coord_mlp.2.weight, is 8.9 x the bound where the fp32 oracle is 3.0 x, and over the eight the
+        # HIP path sits at 2.0 - 4.0 x the fp32 oracle's distance.  What that systematic factor is NOT (each measured): the
+        # kernels' v_exp_f32 / v_rcp_f32 SiLU (a ~1 ulp sigmoid, -DIS_SILU_ACCURATE, moved the worst tensor from 9.09 x to
+        # 8.93 x), the MFMA pipe (bit-equal to an ascending fp32 FMA chain: tools/ubench/mfma_exact.hip), the order of the 512
+        # workgroup records' sum (formed in fp64: unchanged).  Round 3 allowed 8 x; the factor is now the measured 4.0 + the
+        # spread of the CPU oracle's own realisation.
         sd_64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
         it64 = FR.forward("HybridModelv2", sd_64, H.oracle_graph(raw, torch.float64), seq.double(), prop.double(), eps=eps.double())
         FR.regression_loss(it64["recon_x"], seq.double(), it64["mu"], it64["logvar"], it64["final_output"], y.double(), H.VAE_IN).backward()
@@ -244,7 +248,7 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
             if r_hip > 1.0:
                 print("  above the element-wise bound: %-40s HIP %.3f x, fp32 oracle %.3f x (other edge order %.3f x)" % (
                     name, r_hip, H.worst_ratio(ref_grad, sd_64[name].grad, GRAD_TOL), H.worst_ratio(sd_p[name].grad, sd_64[name].grad, GRAD_TOL)))
-            assert r_hip <= max(1.0, 8.0 * r_ref), (f"grad {name}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
+            assert r_hip <= max(1.0, FULL_SIZE_FACTOR * r_ref), (f"grad {name}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
                                                     f"gradient, the fp32 oracle (worse of two summation orders) {r_ref:.2f} x")
             err = H.rel_err(p.grad.cpu(), sd_64[name].grad)
         else:
@@ -647,11 +651,11 @@ def test_paired_product_route_at_full_size_vs_oracle(cuda_device, capturable):
             continue
         r_hip = H.worst_ratio(p.grad.cpu(), sd64[name].grad, GRAD_TOL)
         r_ref = max(H.worst_ratio(ref, sd64[name].grad, GRAD_TOL), H.worst_ratio(sdp[name].grad, sd64[name].grad, GRAD_TOL))
-        assert r_hip <= max(1.0, 8.0 * r_ref), (f"grad {name}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 gradient, "
+        assert r_hip <= max(1.0, FULL_SIZE_FACTOR * r_ref), (f"grad {name}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 gradient, "
                                                 f"the fp32 oracle (worse of two summation orders) {r_ref:.2f} x")
         if r_hip > worst[1]:
-            worst = (name, r_hip)
-    print("paired route, worst gradient (x bound vs fp64):", worst)
+            worst = (name, r_hip, r_ref)
+    print("paired route, worst gradient (x bound vs fp64; fp32 oracle):", worst)
 
 
 def test_paired_training_trajectory_matches_oracle(cuda_device):
