@@ -52,7 +52,7 @@ VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 H = 64
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
 def layer_algorithmic(n_nodes, n_edges, din, fe):
