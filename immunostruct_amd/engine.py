@@ -31,6 +31,7 @@ from .graph import CSRIndex, PackedGraphBatch
 # (hipEventQuery) at any time -- in the default "global" mode such a call from ANOTHER thread invalidates the capture in progress
 # ("operation not permitted when stream is capturing", first met under a one-rank RCCL group in round 4)
 _CAPTURE = {"capture_error_mode": "thread_local"}
+_EARLY_PREPARE = os.environ.get("IMMUNOSTRUCT_ADAM_EARLY_PREPARE", "0") == "1"
 
 
 class StaticGraphBatch(PackedGraphBatch):
@@ -354,6 +355,7 @@ class CapturedTrainStep:
         from .functional import Stamps
         Stamps.mark("step start")
         self.reducer.zero()
+        self._early_prepare()
         from .functional import SpeculativeBackward, unit_gradient
         overlap = self.fused_optimizer and self._tail_late is not False and hasattr(self.optimizer, "step_overlapped")
         if overlap and self._tail_late is None:
@@ -377,12 +379,30 @@ class CapturedTrainStep:
         Stamps.mark("backward done (main stream)")
         return loss.detach()
 
+    def _early_prepare(self):
+        """single-GPU step, IMMUNOSTRUCT_ADAM_EARLY_PREPARE=1: the optimizer's one-thread launch (step count, bias corrections) goes
+        to the models' side stream at the TOP of the step -- it depends on nothing but the previous step's update -- instead of
+        sitting, with a queue hand-over, in front of the update on the critical chain"""
+        if not (self.fused_optimizer and _EARLY_PREPARE and hasattr(self.optimizer, "prepare") and getattr(self.optimizer, "_groups", None)):
+            return
+        from .models import _core
+        main = torch.cuda.current_stream()
+        side = _core._side_stream(self.y.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.optimizer.prepare()
+        self._prepared_on = side
+
     def _optimizer_step(self):
         """single-GPU step: the update of everything but the EGNN stack's own parameters runs on the models' side stream beside the
         stack backward's tail (functional.TailGate) when IMMUNOSTRUCT_ADAM_OVERLAP=1; default: one launch at the end"""
         from . import functional as HF
         gate = HF.TailGate.event
         HF.TailGate.event = None
+        side = getattr(self, "_prepared_on", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._prepared_on = None
         if self._tail_late and gate is not None:
             from .models import _core
             self.optimizer.step_overlapped(self._tail_late, gate, _core._side_stream(self.y.device))
