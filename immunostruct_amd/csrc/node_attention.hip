@@ -605,6 +605,383 @@ __global__ __launch_bounds__((attn_bwd_dual<NT, D>() ? 128 : 64) * NT) void attn
   }
 }
 
+// =====================================================================================================================
+// 16-row blocks (round 4): single head (D = 64), n <= 192.  One WAVE per 16-row block on v_mfma_f32_16x16x4_f32 -- NB = 4 / 8 /
+// 12 waves per graph, for n = 190 three per SIMD on all four SIMDs where the 32-row kernels above put six waves on four SIMDs
+// (two SIMDs carried two waves: every matrix phase lasted twice its share).  A block's operands are small (16 accumulator
+// registers per output tile row, 4 registers per stored probability tile), so twelve waves fit their 170 registers; the phases
+// in front of the matrix passes (staging, d abar rows, t_i) spread over twice the waves.
+//   probs layout: [b][query block][key block][register t (4)][lane (64)] -- tile (qb, kb) in the 16x16x4 accumulator layout
+//   (lane (r, q), register t = P[16 qb + 4 q + t][16 kb + r]): 256-byte rows, same total size as the 32-row layout.
+//   backward: K (pass A) and Q (pass B) are staged TRANSPOSED and split by key / query quarter,
+//       T[(j % 16) / 4][c][4 (j / 16) + j % 4]   (row j, column c; plane stride a multiple of 64 floats, row stride 52),
+//   so that the B operand of four k-steps is ONE conflict-free ds_read_b128 per output tile (the k-slots of step s are the rows
+//   4 q + s of the 16-row tile), as are the A operand (from the wave's transposition tile) and the d abar / t_i values.
+constexpr int A16_LDQ = 68;
+
+template <int NB>
+struct Attn16FwdSmem {
+  float qs[NB * 16 * A16_LDQ];
+  float ks[NB * 16 * A16_LDQ];
+  float wpart[NB][NB * 16];
+  float abar[NB * 16];
+  float cpart[NB][64];
+  float hid[64];
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * NB) void attn16_fwd_kernel(
+    const float* __restrict__ qk, const float* __restrict__ x, float* __restrict__ ctx, float* __restrict__ abar_out,
+    float* __restrict__ probs, int n, const float* __restrict__ wv, const float* __restrict__ bv,
+    const float* __restrict__ wc, const float* __restrict__ bc, float* __restrict__ a1_out, float* __restrict__ y_out) {
+  static_assert(NB % 4 == 0, "column tiles are walked four at a time");
+  constexpr int LDQ = A16_LDQ, NTH = 64 * NB;
+  __shared__ Attn16FwdSmem<NB> sm;
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const float scale = 0.125f;      // 1 / sqrt(64)
+  // ---- stage Q and K rows (all loads of a thread's batch first) ----
+  for (int idx0 = tid; idx0 < NB * 16 * 16; idx0 += 4 * NTH) {      // 16 float4 per row
+    f32x4 qv[4], kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * NTH, lr = idx >> 4, c4 = idx & 15;
+      const bool ok = idx < NB * 16 * 16 && lr < n;
+      const float* src = qk + (size_t)(b * n + (ok ? lr : 0)) * 128 + c4 * 4;
+      qv[u] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      kv[u] = ok ? *reinterpret_cast<const f32x4*>(src + 64) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * NTH, lr = idx >> 4, c4 = idx & 15;
+      if (idx < NB * 16 * 16) {
+        *reinterpret_cast<f32x4*>(sm.qs + lr * LDQ + c4 * 4) = qv[u];
+        *reinterpret_cast<f32x4*>(sm.ks + lr * LDQ + c4 * 4) = kv[u];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // ---- S = Q_blk K^T, 16 x (16 NB), four column tiles at a time; softmax over the row; column sums ----
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cg = 0; cg < NB / 4; ++cg) {
+      f32x4 a4[4];
+      zero_acc4(a4);
+      mm16_rows<4, 64, LDQ, LDQ>(a4, sm.qs + blk * 16 * LDQ, sm.ks + cg * 64 * LDQ, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[cg * 4 + j] = a4[j];
+    }
+    float* ptile = probs != nullptr ? probs + ((size_t)b * NB + blk) * NB * 256 : nullptr;
+    float colsum[NB];
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt) colsum[nt] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = blk * 16 + 4 * q + t;
+      float m = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) {
+        const float sv = (nt * 16 + r < n) ? acc[nt][t] * scale : -INFINITY;
+        acc[nt][t] = sv;
+        m = fmaxf(m, sv);
+      }
+      m = fmaxf(m, dpp_move<0xB1>(m));
+      m = fmaxf(m, dpp_move<0x4E>(m));
+      m = fmaxf(m, dpp_move<0x141>(m));
+      m = fmaxf(m, dpp_move<0x140>(m));
+      float l = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) {
+        const float e = __expf(acc[nt][t] - m);   // exp(-inf) = 0 for masked columns
+        acc[nt][t] = e;
+        l += e;
+      }
+      l = sum_over_r16(l);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) {
+        const float pv = (i < n) ? acc[nt][t] * inv : 0.0f;      // rows of padded queries are stored as zeros
+        colsum[nt] += pv;
+        if (ptile != nullptr) ptile[(nt * 4 + t) * 64 + lane] = pv;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt) {      // the four row quarters of a column: lanes r, r + 16, r + 32, r + 48
+      float v = colsum[nt];
+      v += swap_rows16(v);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) sm.wpart[blk][nt * 16 + r] = v;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < NB * 16; j += NTH) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NB; ++w) v += sm.wpart[w][j];
+    v /= (float)n;
+    sm.abar[j] = v;
+    if (j < n && abar_out != nullptr) abar_out[(size_t)b * n + j] = v;
+  }
+  __syncthreads();
+  {
+    float a = 0.f;
+    for (int j0 = blk; j0 < n; j0 += 8 * NB) {     // a fixed order per wave, 8 row loads in flight
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * NB;
+        xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * NB;
+        if (j < n) a += sm.abar[j] * xv[u];
+      }
+    }
+    sm.cpart[blk][lane] = a;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NB; ++w) v += sm.cpart[w][tid];
+    ctx[(size_t)b * 64 + tid] = v;
+    sm.cpart[0][tid] = v;      // (own column: read above by this thread only)
+  }
+  if (wv != nullptr) {
+    // pooled tail of the single head (models/layers.py:74-77 on the mean-pooled vector): hid = W_v ctx + b_v, y = W_c hid + b_c
+    // (see attn_colmean_fwd_kernel): both matrices row-major with a pitch of 65 where the dead Q tile was, all loads first
+    constexpr int LDW = 65, PER = (1024 + NTH - 1) / NTH;
+    float* wvl = sm.qs;
+    float* wcl = sm.qs + 64 * LDW;
+    f32x4 rv[PER], rc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = min(tid + u * NTH, 1023);
+      rv[u] = reinterpret_cast<const f32x4*>(wv)[idx];
+      rc[u] = reinterpret_cast<const f32x4*>(wc)[idx];
+    }
+    __syncthreads();      // every wave is done with the Q / K tiles (and cpart[0] is complete)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + u * NTH;
+      if (idx < 1024) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wvl[row * LDW + c4 + j] = rv[u][j]; wcl[row * LDW + c4 + j] = rc[u][j]; }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {      // one wave: its LDS accesses are in order
+      float acc1 = bv[tid];
+#pragma unroll 16
+      for (int k = 0; k < 64; ++k) acc1 += wvl[tid * LDW + k] * sm.cpart[0][k];
+      if (a1_out != nullptr) a1_out[(size_t)b * 64 + tid] = acc1;
+      sm.hid[tid] = acc1;
+      __builtin_amdgcn_wave_barrier();
+      float y = bc[tid];
+#pragma unroll 16
+      for (int h = 0; h < 64; ++h) y += wcl[tid * LDW + h] * sm.hid[h];
+      y_out[(size_t)b * 64 + tid] = y;
+    }
+  }
+}
+
+constexpr int A16_TLD = 52;      // floats per column of a quarter plane (NB <= 12 tiles x 4 + pad; 13 slots: odd)
+template <int NB>
+struct Attn16BwdSmem {
+  static constexpr int PLANE = 64 * A16_TLD;      // 3328 floats = 52 x 64
+  float kqT[4 * PLANE];       // K rows (pass A), then Q rows (pass B), transposed and split by row quarter
+  float dab[NB * 16];
+  float tvec[NB * 16];
+  float tr[NB][16 * 20];      // wave-private transposition tile
+};
+
+// stage Q (which = 0) or K (1) transposed: element (row j, column c) -> T[(j % 16) / 4][c][4 (j / 16) + j % 4]
+template <int NB>
+__device__ __forceinline__ void attn16_stage_T(float* dst, const float* __restrict__ qk, int which, int b, int n, int tid) {
+  constexpr int NTH = 64 * NB, PLANE = Attn16BwdSmem<NB>::PLANE;
+  for (int idx0 = tid; idx0 < NB * 16 * 16; idx0 += 4 * NTH) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * NTH, lr = idx >> 4, c4 = idx & 15;
+      const bool ok = idx < NB * 16 * 16 && lr < n;
+      v[u] = ok ? *reinterpret_cast<const f32x4*>(qk + (size_t)(b * n + (ok ? lr : 0)) * 128 + which * 64 + c4 * 4)
+                : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * NTH, lr = idx >> 4, c4 = idx & 15;
+      if (idx < NB * 16 * 16) {
+        float* base = dst + ((lr & 15) >> 2) * PLANE + 4 * (lr >> 4) + (lr & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base[(c4 * 4 + j) * A16_TLD] = v[u][j];
+      }
+    }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64 * NB) void attn16_bwd_kernel(
+    const float* __restrict__ qk, const float* __restrict__ x, const float* __restrict__ abar_in,
+    const float* __restrict__ probs, const float* __restrict__ g_ctx, float* __restrict__ dqk,
+    float* __restrict__ dx, int n, AttnTailBwd tail) {
+  constexpr int NTH = 64 * NB, PLANE = Attn16BwdSmem<NB>::PLANE;
+  __shared__ Attn16BwdSmem<NB> sm;
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tail.gy != nullptr && b >= tail.B) {      // the extra workgroups: parameter gradients of the pooled tail
+    attn_tail_wgrad<NTH>(sm.kqT, tail, b - tail.B, tid);
+    return;
+  }
+  const int r = lane & 15, q = lane >> 4;
+  const float coef = 0.125f / (float)n;
+  STAMPA(0);
+  float g_tail = 0.0f;
+  if (tail.gy != nullptr) g_tail = attn_tail_gctx(tail, b, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  attn16_stage_T<NB>(sm.kqT, qk, 1, b, n, tid);       // K rows
+  STAMPA(1);
+  const float* pbase = probs + (size_t)b * NB * NB * 256;
+  // dabar_j = g_ctx . x_j and the direct term dx_j = abar_j g_ctx: wave w owns rows j = w, w + NB, ... (lane = channel)
+  {
+    const float g = (g_ctx != nullptr) ? g_ctx[(size_t)b * 64 + lane] : g_tail;
+    for (int j0 = blk; j0 < NB * 16; j0 += DAB_ROWS * NB) {
+      float xv[DAB_ROWS], ab[DAB_ROWS];
+#pragma unroll
+      for (int u = 0; u < DAB_ROWS; ++u) {
+        const int j = j0 + u * NB;
+        xv[u] = (j < n) ? x[(size_t)(b * n + j) * 64 + lane] : 0.f;
+        ab[u] = (j < n) ? abar_in[(size_t)b * n + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < DAB_ROWS; ++u) {
+        const int j = j0 + u * NB;
+        float d = sum_over_r16(xv[u] * g);
+        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x142, 0xA, 0xF, false));
+        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x143, 0xC, 0xF, false));
+        if (j < NB * 16 && lane == 63) sm.dab[j] = d;
+        if (j < n) dx[(size_t)(b * n + j) * 64 + lane] = ab[u] * g;
+      }
+    }
+  }
+  // ---- t_i = sum_j P_ij dabar_j for the block's 16 queries: its NB probability tiles, keys on the lanes ----
+  float tpart[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    f32x4 pq[NB];
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pq[nt][t] = pbase[((blk * NB + nt) * 4 + t) * 64 + lane];
+    STAMPA(2);
+    __syncthreads();      // d abar of every row is in LDS; the K rows are staged
+    STAMPA(3);
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt) {
+      const float dj = sm.dab[nt * 16 + r];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tpart[t] += pq[nt][t] * dj;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float ti = sum_over_r16(tpart[t]);
+    if (r == 0) sm.tvec[blk * 16 + 4 * q + t] = ti;
+  }
+  __builtin_amdgcn_wave_barrier();
+  STAMPA(4);
+  {
+    // ---- pass A: dQ[i][c] = sum_j dS[i][j] K[j][c] for the block's queries.  Each P tile is transposed through the wave's LDS
+    //      tile so that the queries sit on the lanes; k-slot q of step s is key 4 q + s of the tile ----
+    const float ti = sm.tvec[blk * 16 + r];
+    f32x4 dq[4];
+    zero_acc4(dq);
+    float* tr = sm.tr[blk];
+    f32x4 pk, pn, p2;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pk[t] = pbase[((blk * NB + 0) * 4 + t) * 64 + lane];
+      pn[t] = pbase[((blk * NB + 1) * 4 + t) * 64 + lane];
+    }
+#pragma unroll 1
+    for (int kt = 0; kt < NB; ++kt) {
+      const int nn = min(kt + 2, NB - 1);      // tiles are fetched two ahead of their use
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p2[t] = pbase[((blk * NB + nn) * 4 + t) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tr[(4 * q + t) * 20 + r] = pk[t];      // [query row][key col]
+      __builtin_amdgcn_wave_barrier();
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(tr + r * 20 + 4 * q);      // P[i = r][keys 4 q .. 4 q + 3]
+      const f32x4 dj = *reinterpret_cast<const f32x4*>(sm.dab + kt * 16 + 4 * q);
+      f32x4 kb[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) kb[nt] = *reinterpret_cast<const f32x4*>(sm.kqT + q * PLANE + (nt * 16 + r) * A16_TLD + kt * 4);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const float ds = pa[sidx] * (dj[sidx] - ti) * coef;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kb[nt][sidx], dq[nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      pk = pn; pn = p2;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ii = blk * 16 + 4 * q + t;
+        if (ii < n) dqk[(size_t)(b * n + ii) * 128 + nt * 16 + r] = dq[nt][t];
+      }
+  }
+  STAMPA(5);
+  __syncthreads();   // t_i of every block is in LDS; every wave is done with the K rows
+  STAMPA(6);
+  attn16_stage_T<NB>(sm.kqT, qk, 0, b, n, tid);       // Q rows
+  __syncthreads();
+  STAMPA(7);
+  {
+    // ---- pass B: dK[j][c] = sum_i dS[i][j] Q[i][c] for the block's keys (keys on the lanes): the tile registers ARE the A
+    //      operand (k-slot q of step t is query 4 q + t of the tile) ----
+    f32x4 dk[4];
+    zero_acc4(dk);
+    const float dabj = sm.dab[blk * 16 + r];
+    f32x4 pk, pn, p2;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pk[t] = pbase[((0 * NB + blk) * 4 + t) * 64 + lane];
+      pn[t] = pbase[((1 * NB + blk) * 4 + t) * 64 + lane];
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < NB; ++qt) {
+      const int nn = min(qt + 2, NB - 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p2[t] = pbase[((nn * NB + blk) * 4 + t) * 64 + lane];
+      const f32x4 tv = *reinterpret_cast<const f32x4*>(sm.tvec + qt * 16 + 4 * q);
+      f32x4 qb[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) qb[nt] = *reinterpret_cast<const f32x4*>(sm.kqT + q * PLANE + (nt * 16 + r) * A16_TLD + qt * 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float ds = pk[t] * (dabj - tv[t]) * coef;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dk[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qb[nt][t], dk[nt], 0, 0, 0);
+      }
+      pk = pn; pn = p2;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int jj = blk * 16 + 4 * q + t;
+        if (jj < n) dqk[(size_t)(b * n + jj) * 128 + 64 + nt * 16 + r] = dk[nt][t];
+      }
+  }
+  STAMPA(8);
+}
+
 }  // namespace is
 
 #ifdef IS_STAGE_STAMPS
@@ -659,12 +1036,38 @@ extern "C" long long is_attn_colmean_probs_floats(int B, int n, int heads) {
   return (long long)B * heads * nt * nt * 1024;
 }
 
+// single head, n <= 192: the 16-row-block kernels (NB = 4 / 8 / 12 waves per graph)
+#define ATTN16_FWD(...)                                                                                                     \
+  do {                                                                                                                      \
+    hipStream_t st = static_cast<hipStream_t>(stream);                                                                      \
+    if (n <= 64) hipLaunchKernelGGL((is::attn16_fwd_kernel<4>), dim3(B), dim3(256), 0, st, __VA_ARGS__);                     \
+    else if (n <= 128) hipLaunchKernelGGL((is::attn16_fwd_kernel<8>), dim3(B), dim3(512), 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((is::attn16_fwd_kernel<12>), dim3(B), dim3(768), 0, st, __VA_ARGS__);                            \
+  } while (0)
+#define ATTN16_BWD(...)                                                                                                     \
+  do {                                                                                                                      \
+    hipStream_t st = static_cast<hipStream_t>(stream);                                                                      \
+    if (n <= 64) hipLaunchKernelGGL((is::attn16_bwd_kernel<4>), dim3(B), dim3(256), 0, st, __VA_ARGS__);                     \
+    else if (n <= 128) hipLaunchKernelGGL((is::attn16_bwd_kernel<8>), dim3(B), dim3(512), 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((is::attn16_bwd_kernel<12>), dim3(B), dim3(768), 0, st, __VA_ARGS__);                            \
+  } while (0)
+namespace is {
+inline bool attn16_applies(int n, int heads) {
+  const char* e = getenv("IMMUNOSTRUCT_ATTN_TILES");      // "32": the 32-row-block kernels everywhere (A/B, tests)
+  return heads == 1 && n <= 192 && !(e != nullptr && atoi(e) == 32);
+}
+}
+
 extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,
                                    int heads, void* stream) {
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
   const float* none = nullptr;
   float* nout = nullptr;
+  if (is::attn16_applies(n, heads)) {
+    ATTN16_FWD(qk, x, ctx, abar, probs, n, none, none, none, none, nout, nout);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, none, none, none, none, nout, nout);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -678,6 +1081,10 @@ extern "C" int is_attn_colmean_fwd_tail(const float* qk, const float* x, float* 
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || wv == nullptr || bv == nullptr || wc == nullptr || bc == nullptr || y_out == nullptr) return -22;
   const int heads = 1;
+  if (is::attn16_applies(n, heads)) {
+    ATTN16_FWD(qk, x, ctx, abar, probs, n, wv, bv, wc, bc, a1_out, y_out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, wv, bv, wc, bc, a1_out, y_out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -688,6 +1095,10 @@ extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float*
   if (B <= 0) return 0;
   if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
   const is::AttnTailBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (is::attn16_applies(n, heads)) {
+    ATTN16_BWD(qk, x, abar, probs, g_ctx, dqk, dx, n, none);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   ATTN_DISPATCH_BWD(B, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, none);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -705,6 +1116,10 @@ extern "C" int is_attn_colmean_bwd_tail(const float* qk, const float* x, const f
   const float* g_ctx = nullptr;
   const is::AttnTailBwd tail{gy, wv, wc, pooled, a1, gtail, B_};
   const int B = B_ + is::TAIL_SLABS;      // grid: the graphs + the parameter-gradient workgroups
+  if (is::attn16_applies(n, heads)) {
+    ATTN16_BWD(qk, x, abar, probs, g_ctx, dqk, dx, n, tail);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
   ATTN_DISPATCH_BWD(B_, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -456,9 +456,13 @@ def test_combined_attention_with_classifier_is_the_chain(cuda_device, feat, toke
         assert torch.equal(HF.combined_attention_classifier(pieces, mha, cls), HF.sequential_mlp2(cls, HF.combined_attention_mean(pieces, mha)))
 
 
-@pytest.mark.parametrize("heads,n", [(1, 190), (8, 190), (1, 45), (8, 9), (1, 256), (8, 70)])
-def test_node_attention_pooled_mean(cuda_device, heads, n):
-    """fused Q/K projection + scores/softmax/column-mean kernel == mean over nodes of the reference attention block."""
+@pytest.mark.parametrize("need_weights", [True, False])
+@pytest.mark.parametrize("heads,n", [(1, 190), (8, 190), (1, 45), (8, 9), (1, 256), (8, 70), (1, 100), (1, 64), (1, 192)])
+def test_node_attention_pooled_mean(cuda_device, heads, n, need_weights):
+    """fused Q/K projection + scores/softmax/column-mean kernel == mean over nodes of the reference attention block.
+    ``need_weights=False`` with one head takes the launch that also holds the pooled tail (value projection + w_concat), the one
+    the models run; random inputs give the attention matrix structure -- the models' golden batches have near-uniform attention,
+    which a wrong column sum survives (round 4)."""
     from immunostruct_amd.models.layers import MultiHeadAttention
     rng = np.random.RandomState(heads * 1000 + n)
     b = 3
@@ -474,10 +478,11 @@ def test_node_attention_pooled_mean(cuda_device, heads, n):
     mha = MultiHeadAttention(64, heads).to(cuda_device)
     mha.load_state_dict({k[2:]: v for k, v in sd.items()})
     xd = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
-    pooled, w = mha.pooled_mean(xd, need_weights=True)
+    pooled, w = mha.pooled_mean(xd, need_weights=need_weights)
     (pooled * torch.from_numpy(gup).to(cuda_device)).sum().backward()
     H.assert_close(pooled.detach().cpu(), ref.detach(), 5e-6, "pooled attention")
-    H.assert_close(w.cpu(), w_ref.detach(), 5e-6, "attention weights")
+    if need_weights:
+        H.assert_close(w.cpu(), w_ref.detach(), 5e-6, "attention weights")
     H.assert_close(xd.grad.cpu(), x64.grad, 5e-5, "d pooled / d x")
     gmax = max(float(v.grad.abs().max()) for v in sd64.values())
     for name, p in mha.named_parameters():
