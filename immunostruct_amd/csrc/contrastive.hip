@@ -45,19 +45,21 @@ __device__ __forceinline__ float group_sum(const float (*part)[CZ], int c) {
 }
 
 // acc (32 x 32) += sum_k a(row r, k) * b(k, col r); K rounded up to even, accessors return 0 past the end.
+// The operands come straight from global memory (L1 / L2 hits): the loads of 32 k are issued together before their 16 MFMAs
+// (eight k at a time left 16 dependent round trips per 128-deep product: contr_pair_bwd 40 us for 4 us of matrix work).
 template <typename FA, typename FB>
 __device__ __forceinline__ void tile32(f32x16& acc, int K, FA a, FB b, int lane) {
   const int r = lane & 31, hf = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    float av[4], bv[4];
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    float av[16], bv[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int k = k0 + 2 * u + hf;
       av[u] = (k < K) ? a(r, k) : 0.0f;
       bv[u] = (k < K) ? b(k, r) : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
 }
 
@@ -121,49 +123,51 @@ __device__ __forceinline__ void gemm_slabs(SlabSmem& sm, int B, int N, int K, FA
 }
 
 // The same product for ONE 32-column block of the output (N <= 32), four waves: every thread issues ALL of a slab's loads (32 of
-// the A slab, 4 of the W slab) before its first LDS store -- one memory round trip per 32-wide K slab.  (Staged element by
-// element, as gemm_slabs does with its 16 waves, four waves paid 16 dependent round trips per slab: 35 us per launch.)  Wave w
-// owns the row tiles w and w + 4.  Same k order and MFMA mapping as gemm_slabs: same bits.
-template <bool WKC, typename FA, typename FW, typename FOUT>
-__device__ __forceinline__ void gemm_block(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
-  constexpr int NT = 256, PA = SLAB_ROWS * SLAB / NT, PW = 32 * SLAB / NT;
+// the A slab, DEPTH / 8 of the W slab) before its first LDS store -- one memory round trip per K slab.  (Staged element by
+// element, as gemm_slabs does with its 16 waves, four waves paid 16 dependent round trips per slab: 35 us per launch.)  The slab is
+// DEPTH = 32 k deep for up to 256 rows and 64 deep for up to 128 rows (same LDS, half the round trips).  Wave w owns the row
+// tiles w and w + 4.  Same k order and MFMA mapping as gemm_slabs: same bits.
+template <bool WKC, int DEPTH, typename FA, typename FW, typename FOUT>
+__device__ __forceinline__ void gemm_block_d(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
+  constexpr int NT = 256, LDD = DEPTH + 1, ROWS = SLAB_ROWS * SLAB / DEPTH, PA = ROWS * DEPTH / NT, PW = 32 * DEPTH / NT;
+  static_assert(ROWS * LDD <= SLAB_ROWS * SLD && 32 * LDD <= SLAB_COLS * SLD, "the deeper slab must fit the same LDS");
   const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
   const int row_tiles = (B + 31) / 32;
   f32x16 acc[2] = {zero16(), zero16()};
-  for (int k0 = 0; k0 < K; k0 += SLAB) {
+  for (int k0 = 0; k0 < K; k0 += DEPTH) {
     float av[PA], wv[PW];
 #pragma unroll
     for (int u = 0; u < PA; ++u) {
-      const int idx = tid + u * NT, i = idx / SLAB, kk = idx % SLAB;
+      const int idx = tid + u * NT, i = idx / DEPTH, kk = idx % DEPTH;
       av[u] = (i < B && k0 + kk < K) ? a_elem(i, k0 + kk) : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < PW; ++u) {
       const int idx = tid + u * NT;
-      const int c = WKC ? idx / SLAB : idx % 32, kk = WKC ? idx % SLAB : idx / 32;
+      const int c = WKC ? idx / DEPTH : idx % 32, kk = WKC ? idx % DEPTH : idx / 32;
       wv[u] = (c < N && k0 + kk < K) ? w_elem(k0 + kk, c) : 0.0f;
     }
     __syncthreads();      // the previous slab's products are done
 #pragma unroll
     for (int u = 0; u < PA; ++u) {
-      const int idx = tid + u * NT, i = idx / SLAB, kk = idx % SLAB;
-      if (i < row_tiles * 32) sm.a[i * SLD + kk] = av[u];
+      const int idx = tid + u * NT, i = idx / DEPTH, kk = idx % DEPTH;
+      if (i < row_tiles * 32) sm.a[i * LDD + kk] = av[u];
     }
 #pragma unroll
     for (int u = 0; u < PW; ++u) {
       const int idx = tid + u * NT;
-      const int c = WKC ? idx / SLAB : idx % 32, kk = WKC ? idx % SLAB : idx / 32;
-      sm.w[c * SLD + kk] = wv[u];
+      const int c = WKC ? idx / DEPTH : idx % 32, kk = WKC ? idx % DEPTH : idx / 32;
+      sm.w[c * LDD + kk] = wv[u];
     }
     __syncthreads();
 #pragma unroll
     for (int own = 0; own < 2; ++own) {
       const int tl = wave + own * 4;
       if (tl < row_tiles) {
-        const float* ap = sm.a + (tl * 32 + r) * SLD;
-        const float* wp = sm.w + r * SLD;
+        const float* ap = sm.a + (tl * 32 + r) * LDD;
+        const float* wp = sm.w + r * LDD;
 #pragma unroll
-        for (int kk = 0; kk < SLAB; kk += 2)
+        for (int kk = 0; kk < DEPTH; kk += 2)
           acc[own] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk + hf], wp[kk + hf], acc[own], 0, 0, 0);
       }
     }
@@ -180,6 +184,12 @@ __device__ __forceinline__ void gemm_block(SlabSmem& sm, int B, int N, int K, FA
     }
   }
   __syncthreads();
+}
+
+template <bool WKC, typename FA, typename FW, typename FOUT>
+__device__ __forceinline__ void gemm_block(SlabSmem& sm, int B, int N, int K, FA a_elem, FW w_elem, FOUT out, int tid) {
+  if (B <= 128) gemm_block_d<WKC, 64>(sm, B, N, K, a_elem, w_elem, out, tid);      // (kernel-uniform)
+  else gemm_block_d<WKC, 32>(sm, B, N, K, a_elem, w_elem, out, tid);
 }
 
 // scratch layout per side (floats): Y [B][Z] | A1 [B][Z] | Zc [B][Z] | stats: mu[Z] inv[Z] colmean[Z] std[Z]
@@ -337,16 +347,26 @@ __global__ __launch_bounds__(256) void contr_pair_fwd_kernel(
 // loss = scale * gate * (pair / correlation terms + hinge): `scale` is the caller's loss coefficient, `gate` (device, may be NULL)
 // the reference's early-out as a 0 / 1 factor -- both folded in here instead of two multiply launches behind the loss
 // (hinge term of a side = mean_k relu(1 - std_k), summed in column order from the stds the side pass left in `scratch`)
-__global__ void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ scratch, int B,
-                                    float* __restrict__ loss, const float* __restrict__ gate, float scale) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ __launch_bounds__(256) void contr_finish_kernel(const float* __restrict__ partials, int nparts, const float* __restrict__ scratch, int B,
+                                                           float* __restrict__ loss, const float* __restrict__ gate, float scale) {
+  // (all loads in parallel, the sums by one thread in index order from LDS: one thread walking 8 + 256 global values itself
+  //  took 8 us)
+  __shared__ float hs[2][CZ];
+  __shared__ float ps[256];
+  const int tid = threadIdx.x;
+  {
+    const int side = tid / CZ, k = tid % CZ;
+    hs[side][k] = fmaxf(1.0f - scratch[(size_t)side * side_floats(B) + 3 * (size_t)B * CZ + 3 * CZ + k], 0.0f);
+  }
+  for (int i = tid; i < nparts; i += 256) ps[i] = partials[i];      // nparts <= (8 * 8 + 16 + 3) / 4 * 4 = 84
+  __syncthreads();
+  if (tid == 0) {
     float s = 0.0f;
-    for (int i = 0; i < nparts; ++i) s += partials[i];
+    for (int i = 0; i < nparts; ++i) s += ps[i];
     float hinge[2];
     for (int side = 0; side < 2; ++side) {
-      const float* sd = scratch + (size_t)side * side_floats(B) + 3 * (size_t)B * CZ + 3 * CZ;
       float h = 0.0f;
-      for (int k = 0; k < CZ; ++k) h += fmaxf(1.0f - sd[k], 0.0f);
+      for (int k = 0; k < CZ; ++k) h += hs[side][k];
       hinge[side] = h / (float)CZ;
     }
     loss[0] = (s + 0.5f * (hinge[0] + hinge[1])) * (gate != nullptr ? gate[0] * scale : scale);
@@ -447,15 +467,20 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_a_kernel(
   __shared__ float part[SB_GROUPS][SB_COLS], part2[SB_GROUPS][SB_COLS];
   const int tid = threadIdx.x;
   const int col = tid & (SB_COLS - 1), grp = tid / SB_COLS;
-  // ---- hinge gradient + centring backward, per column, all 128 columns (four rounds of 32 columns: a thread's rows of a round
-  //      are loaded together; the 16-wave kernel's row stripes and combine order) ----
+  // ---- hinge gradient + centring backward, per column, all 128 columns: four rounds of 32 columns (a thread's rows of a round
+  //      are loaded together; the 16-wave kernel's row stripes and combine order), their partial sums parked in LDS, ONE barrier
+  //      pair for all four rounds ----
   constexpr int RMAX = SLAB_ROWS / SB_GROUPS;      // rows of a stripe (B <= 256)
-  for (int cb = 0; cb < CZ; cb += SB_COLS) {
-    const int k = cb + col;
+  float (*part4)[SB_GROUPS][SB_COLS] = reinterpret_cast<float (*)[SB_GROUPS][SB_COLS]>(blk);      // [4][8][32]: the block tile is free
+  float coef_r[CZ / SB_COLS];
+#pragma unroll
+  for (int cbi = 0; cbi < CZ / SB_COLS; ++cbi) {
+    const int k = cbi * SB_COLS + col;
     const float sd = st[3 * CZ + k];
     // d hinge / d var_k = -(1/2) * (1/Z) * [sd < 1] / (2 sd);  d var_k / d z_bk = 2 z_bk / (B - 1)
     const float dv = (sd < 1.0f) ? -0.5f / (float)CZ / (2.0f * sd) : 0.0f;
     const float coef = dv * 2.0f / (float)(B - 1);
+    coef_r[cbi] = coef;
     float dzv[RMAX], zcv[RMAX];
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
@@ -467,11 +492,21 @@ __global__ __launch_bounds__(64 * SB_WAVES) void contr_side_bwd_a_kernel(
 #pragma unroll
     for (int u = 0; u < RMAX; ++u)
       if (grp + u * SB_GROUPS < B) s += dzv[u] + coef * zcv[u];
-    part[grp][col] = s;
-    __syncthreads();
-    if (tid < SB_COLS) { mean_s[cb + tid] = block_group_sum(part, tid) / (float)B; coef_s[cb + tid] = coef; }
-    __syncthreads();
+    part4[cbi][grp][col] = s;
   }
+  __syncthreads();
+  if (tid < CZ) {
+    const int cbi = tid / SB_COLS, c = tid % SB_COLS;
+    float t = part4[cbi][0][c];
+#pragma unroll
+    for (int g = 1; g < SB_GROUPS; ++g) t += part4[cbi][g][c];
+    mean_s[tid] = t / (float)B;
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int cbi = 0; cbi < CZ / SB_COLS; ++cbi) coef_s[cbi * SB_COLS + col] = coef_r[cbi];
+  }
+  __syncthreads();
   // ---- da1 = dz0 W2 (this block's columns); A operand = the centred gradient ----
   gemm_block<false>(slab, B, SB_COLS, CZ,
                     [&](int i, int k) { return (dz[(size_t)i * CZ + k] + coef_s[k] * Zc[(size_t)i * CZ + k]) - mean_s[k]; },
@@ -552,7 +587,7 @@ extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld
   hipLaunchKernelGGL(is::contr_side_fwd_a_kernel, sgrid, sblock, 0, st, emb_c, emb_w, ld_e, E, W1, gamma, beta, scratch, B);
   hipLaunchKernelGGL(is::contr_side_fwd_b_kernel, sgrid, sblock, 0, st, W2, scratch, B);
   hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
-  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(64), 0, st, partials, nblocks * 4, scratch, B, loss, gate, scale);
+  hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(256), 0, st, partials, nblocks * 4, scratch, B, loss, gate, scale);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

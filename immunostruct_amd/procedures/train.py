@@ -82,12 +82,16 @@ def _contrastive_beside(contrastive, emb, target, coeff, loss):
     main = torch.cuda.current_stream()
     side = _core._side_stream(loss.device)
     ready = getattr(emb[0], "_ready_event", None)      # recorded by the model right behind the embeddings
+    pre = None
+    if ready is not None and hasattr(contrastive, "prepare_targets"):
+        with torch.cuda.stream(side):      # positive mask + two-class gate: they need the targets only, not the embeddings
+            pre = contrastive.prepare_targets(target)
     if ready is not None:
         side.wait_event(ready)       # not the fusion head / the other loss terms enqueued since: they run beside this loss
     else:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        c = contrastive(emb[0], emb[1], target, scale=coeff)
+        c = contrastive(emb[0], emb[1], target, scale=coeff, **({"targets": pre} if pre is not None else {}))
     main.wait_stream(side)
     if torch.is_tensor(c):
         c.record_stream(main)

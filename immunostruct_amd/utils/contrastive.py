@@ -45,13 +45,25 @@ class PairedContrastiveLoss(nn.Module):
         self.projector.to(device)
         self.capturable = False      # True: no host-side early-out (engine.CapturedTrainStep on paired batches)
 
-    def forward(self, embedding_cancer, embedding_wt, is_immunogenic, scale=1.0):
+    def prepare_targets(self, is_immunogenic):
+        """capturable mode: (positive mask, two-class gate) of a target batch -- they depend on the targets alone, so a loop can
+        issue this launch long before the embeddings exist (``procedures.train._contrastive_beside``) and hand the result to
+        :meth:`forward` as ``targets``; None when not applicable"""
+        if self.capturable and is_immunogenic.is_cuda:
+            from .. import functional as HF
+            return HF.contrastive_targets(is_immunogenic)
+        return None
+
+    def forward(self, embedding_cancer, embedding_wt, is_immunogenic, scale=1.0, targets=None):
         """the reference's signature plus ``scale``: returns scale * loss with the factor applied inside the HIP launches (the
-        train loops pass their ``coeff_contrastive`` here instead of multiplying the result)"""
+        train loops pass their ``coeff_contrastive`` here instead of multiplying the result); ``targets``: the result of
+        :meth:`prepare_targets` for the same ``is_immunogenic``"""
         from .. import _lib
         _lib.require_device(embedding_cancer, embedding_wt)      # no CPU path, as everywhere in this package
         gate = pos = None
-        if self.capturable and is_immunogenic.is_cuda:
+        if targets is not None:
+            pos, gate = targets
+        elif self.capturable and is_immunogenic.is_cuda:
             # same rule without a host decision (a captured HIP graph cannot branch on data): the loss is always
             # evaluated -- it is finite for any target -- and multiplied by [the target holds exactly two distinct
             # values], computed on the device (one launch, csrc/contrastive.hip is_contrastive_targets, together with the
