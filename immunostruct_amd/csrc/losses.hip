@@ -44,51 +44,61 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // stage 2 (one workgroup of 1024 threads: the kernel is a latency chain on the step's critical path, so the three loops are
-// kept to at most four trips): finish MSE, KLD + grads, prediction term + grads, total
+// kept to at most four trips): finish MSE, KLD + grads, prediction term + grads, total.
+// PARTS selects the terms of ONE launch (bit 0: reconstruction MSE from stage 1's partials + the total, bit 1: KLD + its gradients,
+// bit 2: prediction term + its gradient).  7 is the fused launch.  The split forms let a caller evaluate the prediction term where
+// the logit is produced and the sequence terms where the reconstruction is, with no wait between the two (functional.vae_loss,
+// deferred total): 4 and 2 leave their raw sums in sums[2] / sums[1], 1 reads them there and writes out[] / total.  Every sum is
+// formed by the same threads in the same order in all forms: the split launches reproduce the fused one bit for bit.
 constexpr int FIN_BLOCK = 1024, FIN_WAVES = FIN_BLOCK / 64;
+constexpr int PART_MSE = 1, PART_KLD = 2, PART_PRED = 4;
+template <int PARTS>
 __global__ __launch_bounds__(FIN_BLOCK) void loss_finish_kernel(
     const float* __restrict__ partials, int nparts, long long recon_total,
     const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ d_mu,
     float* __restrict__ d_logvar, int latent_total,
     const float* __restrict__ logit, const float* __restrict__ y, float* __restrict__ d_logit, int batch,
-    int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ out, float* __restrict__ total) {
+    int mode, float pos_weight, float c_pred, float c_mse, float c_kld, float* __restrict__ sums, float* __restrict__ out,
+    float* __restrict__ total) {
   __shared__ float red[3][FIN_WAVES];
   const int tid = threadIdx.x;
   // the three per-thread partial sums first (their loads are independent: all in flight together), then ONE pass of
   // wave reductions and one barrier for all three; fixed order throughout
   float acc_m = 0.0f, acc_k = 0.0f, acc_p = 0.0f;
-  if (recon_total > 0)
+  if ((PARTS & PART_MSE) && recon_total > 0)
     for (int i = tid; i < nparts; i += FIN_BLOCK) acc_m += partials[i];
   const float inv = latent_total > 0 ? 1.0f / (float)latent_total : 0.0f;
-  for (int i = tid; i < latent_total; i += FIN_BLOCK) {
-    // exp(lv) - 1 through expm1f: for a freshly initialised model logvar is close to 0 and (1 - exp(lv)) formed from a fast exp
-    // loses most of its digits (the bias gradients of vae_fc22 are sums of these terms)
-    const float m = mu[i], lv = logvar[i], em1 = expm1f(lv);
-    acc_k += lv - m * m - em1;
-    d_mu[i] = c_kld * m * inv;
-    d_logvar[i] = c_kld * 0.5f * em1 * inv;
-  }
-  const float invb = 1.0f / (float)batch;
-  for (int i = tid; i < batch; i += FIN_BLOCK) {
-    const float z = logit[i], t = y[i];
-    if (mode == 0) {
-      const float d = z - t;
-      acc_p += d * d;
-      d_logit[i] = c_pred * 2.0f * d * invb;
-    } else {
-      // -[pw*t*log(sig(z)) + (1-t)*log(1-sig(z))], stable form
-      const float lw = 1.0f + (pos_weight - 1.0f) * t;
-      const float sp = log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.0f);  // softplus(-z)
-      acc_p += (1.0f - t) * z + lw * sp;
-      const float sg = 1.0f / (1.0f + __expf(-z));
-      d_logit[i] = c_pred * ((1.0f - t) * sg - pos_weight * t * (1.0f - sg)) * invb;
+  if (PARTS & PART_KLD)
+    for (int i = tid; i < latent_total; i += FIN_BLOCK) {
+      // exp(lv) - 1 through expm1f: for a freshly initialised model logvar is close to 0 and (1 - exp(lv)) formed from a fast exp
+      // loses most of its digits (the bias gradients of vae_fc22 are sums of these terms)
+      const float m = mu[i], lv = logvar[i], em1 = expm1f(lv);
+      acc_k += lv - m * m - em1;
+      d_mu[i] = c_kld * m * inv;
+      d_logvar[i] = c_kld * 0.5f * em1 * inv;
     }
-  }
+  const float invb = 1.0f / (float)batch;
+  if (PARTS & PART_PRED)
+    for (int i = tid; i < batch; i += FIN_BLOCK) {
+      const float z = logit[i], t = y[i];
+      if (mode == 0) {
+        const float d = z - t;
+        acc_p += d * d;
+        d_logit[i] = c_pred * 2.0f * d * invb;
+      } else {
+        // -[pw*t*log(sig(z)) + (1-t)*log(1-sig(z))], stable form
+        const float lw = 1.0f + (pos_weight - 1.0f) * t;
+        const float sp = log1pf(__expf(-fabsf(z))) + fmaxf(-z, 0.0f);  // softplus(-z)
+        acc_p += (1.0f - t) * z + lw * sp;
+        const float sg = 1.0f / (1.0f + __expf(-z));
+        d_logit[i] = c_pred * ((1.0f - t) * sg - pos_weight * t * (1.0f - sg)) * invb;
+      }
+    }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
-    acc_m += __shfl_xor(acc_m, m, 64);
-    acc_k += __shfl_xor(acc_k, m, 64);
-    acc_p += __shfl_xor(acc_p, m, 64);
+    if (PARTS & PART_MSE) acc_m += __shfl_xor(acc_m, m, 64);
+    if (PARTS & PART_KLD) acc_k += __shfl_xor(acc_k, m, 64);
+    if (PARTS & PART_PRED) acc_p += __shfl_xor(acc_p, m, 64);
   }
   if ((tid & 63) == 0) { red[0][tid >> 6] = acc_m; red[1][tid >> 6] = acc_k; red[2][tid >> 6] = acc_p; }
   __syncthreads();
@@ -100,6 +110,13 @@ __global__ __launch_bounds__(FIN_BLOCK) void loss_finish_kernel(
 #pragma unroll
       for (int w = 0; w < FIN_WAVES; ++w) v += red[k][w];
       s[k] = v;
+    }
+    if (PARTS != 7) {
+      if (PARTS & PART_KLD) sums[1] = s[1];
+      if (PARTS & PART_PRED) sums[2] = s[2];
+      if (!(PARTS & PART_MSE)) return;
+      s[1] = sums[1];
+      s[2] = sums[2];
     }
     const float mse = recon_total > 0 ? s[0] / (float)recon_total : 0.0f;
     const float kld = latent_total > 0 ? -0.5f * s[1] * inv : 0.0f;
@@ -148,8 +165,38 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
       hipLaunchKernelGGL(is::recon_mse_kernel, dim3(nparts), dim3(is::LOSS_BLOCK), 0, st, recon, x, d_recon, partials,
                          recon_total, c_mse * 2.0f / (float)recon_total);
   }
-  hipLaunchKernelGGL(is::loss_finish_kernel, dim3(1), dim3(is::FIN_BLOCK), 0, st, partials, nparts, recon_total, mu,
+  hipLaunchKernelGGL(is::loss_finish_kernel<7>, dim3(1), dim3(is::FIN_BLOCK), 0, st, partials, nparts, recon_total, mu,
                      logvar, d_mu, d_logvar, latent_total, logit, y, d_logit, batch, mode, pos_weight, c_pred, c_mse,
-                     c_kld, out, total);
+                     c_kld, (float*)nullptr, out, total);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// The three terms of is_vae_loss as separate launches (same sums, same bits): the prediction term on the stream the logit is
+// produced on, the KLD term where mu / logvar are, and the total -- stage 2 of the reconstruction term (partials[] from
+// is_recon_mse) plus the two raw sums the other launches left in sums[1] (KLD) / sums[2] (prediction) -- wherever both are
+// complete.  sums: 4 floats of device memory shared by the three.
+extern "C" int is_loss_pred_term(const float* logit, const float* y, float* d_logit, int batch, int mode, float pos_weight,
+                                 float c_pred, float* sums, void* stream) {
+  if (batch <= 0 || logit == nullptr || y == nullptr || d_logit == nullptr || sums == nullptr) return -22;
+  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_PRED>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     (const float*)nullptr, 0, 0LL, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     0, logit, y, d_logit, batch, mode, pos_weight, c_pred, 0.0f, 0.0f, sums, (float*)nullptr, (float*)nullptr);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int is_loss_kld_term(const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total, float c_kld,
+                                float* sums, void* stream) {
+  if (latent_total <= 0 || mu == nullptr || logvar == nullptr || d_mu == nullptr || d_logvar == nullptr || sums == nullptr) return -22;
+  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_KLD>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     (const float*)nullptr, 0, 0LL, mu, logvar, d_mu, d_logvar, latent_total, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, 1, 0, 1.0f, 0.0f, 0.0f, c_kld, sums, (float*)nullptr, (float*)nullptr);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int is_loss_total(const float* partials, long long recon_total, int latent_total, int batch, float c_pred, float c_mse,
+                             float c_kld, float* sums, float* out, float* total, void* stream) {
+  if (batch <= 0 || recon_total <= 0 || partials == nullptr || sums == nullptr || out == nullptr) return -22;
+  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_MSE>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     partials, recon_parts(recon_total), recon_total, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, latent_total, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, batch, 0, 1.0f,
+                     c_pred, c_mse, c_kld, sums, out, total);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -270,12 +270,17 @@ class CapturedTrainStep:
             self._forms[True] = (loss, sources)
         if not self.two_stage or mode == "auto":
             self.graph_a = torch.cuda.CUDAGraph()
+            dump = os.environ.get("IMMUNOSTRUCT_GRAPH_DUMP")       # debugging aid: the captured step as a dot file (tools/graph_edges.py)
+            if dump:
+                self.graph_a.enable_debug_mode()
             with torch.cuda.graph(self.graph_a, **_CAPTURE):
                 loss = self._fwd_bwd()
                 if self.fused_optimizer:
                     self._optimizer_step()
                     from .functional import Stamps
                     Stamps.mark("optimizer done")
+            if dump:
+                self.graph_a.debug_dump(dump)
             if not self.fused_optimizer:
                 self.reducer.bind_sources()
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)

@@ -1572,18 +1572,16 @@ class SpeculativeBackward:
     stored results on; any other seed (a scaled loss) makes it launch normally -- the speculation is then wasted, not wrong."""
     enabled = False
     allowed = os.environ.get("IMMUNOSTRUCT_SPECULATIVE_BACKWARD", "1") != "0"
-
-    def __enter__(self):
-        self._saved, SpeculativeBackward.enabled = SpeculativeBackward.enabled, SpeculativeBackward.allowed
-        return self
-
-    def __exit__(self, *exc):
-        SpeculativeBackward.enabled = self._saved
-        return False
+    # the sequence terms of the loss evaluated on the sequence branch's stream, the prediction term on the head's, the total
+    # formed in the backward (SeqTermsFn / vae_loss) instead of the one-launch loss on the head's stream;
+    # measured: the head's stream loses two cross-queue hops and 4 us of loss launch (comb_attn_fwd -> comb_attn_bwd 22.8 -> 7 us),
+    # and the step does not get shorter (HISTORY.md 7.7): off unless IMMUNOSTRUCT_DEFER_LOSS=1
+    defer = os.environ.get("IMMUNOSTRUCT_DEFER_LOSS", "0") == "1"
 
 
-def _speculate_recon_backward(recon, x, c_mse):
-    """-> (d_recon, partials) with stage 1 and the producer's backward launched on the producer's stream, or None"""
+def _speculate_recon_backward(recon, x, c_mse, join=True):
+    """-> (d_recon, partials) with stage 1 and the producer's backward launched on the producer's stream, or None
+    (``join=False``: the caller's stream does not wait for stage 1 -- nothing on it reads the partial sums)"""
     node = recon.grad_fn if torch.is_tensor(recon) else None
     if (not SpeculativeBackward.enabled or node is None or type(node).__name__ != "LinearSmallBatchFnBackward" or not recon.is_cuda
             or recon.dtype != torch.float32 or not recon.is_contiguous() or getattr(node, "fwd_stream", None) is None
@@ -1604,15 +1602,140 @@ def _speculate_recon_backward(recon, x, c_mse):
             gx, dw, db = LinearSmallBatchFn.launch_backward(node, d_recon, node.needs_input_grad[0])
     node.spec = (d_recon, gx, dw, db)
     if side != main:
-        main.wait_event(ready)
+        if join:
+            main.wait_event(ready)
         for t in (d_recon, partials, gx, dw, db, xs):
             if t is not None:
                 t.record_stream(main)
     return d_recon, partials
 
 
+class SeqTermsSlot:
+    """what :func:`vae_loss` leaves for :class:`SeqTermsFn`'s backward: the sequence terms' gradients and the total's operands"""
+    __slots__ = ("stream", "grads", "total_args", "scale")
+
+    def __init__(self, stream):
+        self.stream, self.grads, self.total_args, self.scale = stream, None, None, None
+
+
+def _launch_loss_total(slot):
+    lib = _lib.load()
+    partials, rt, lt, b, c_pred, c_mse, c_kld, sums, out, total = slot.total_args
+    slot.total_args = None
+    _lib.check(lib.is_loss_total(_lib.ptr(partials), rt, lt, b, float(c_pred), float(c_mse), float(c_kld), _lib.ptr(sums), _lib.ptr(out),
+                                 _lib.ptr(total), _lib.stream_ptr()), "is_loss_total")
+
+
+class SeqTermsFn(torch.autograd.Function):
+    """Identity on the latent ``z`` on its way to the fusion head, applied on the sequence branch's stream once the reconstruction
+    is enqueued (``models/_core.py``).  It exists for its backward: the loss terms that depend on the sequence branch only --
+    reconstruction MSE, KLD -- reach ``recon`` / ``mu`` / ``logvar`` from HERE, a node of the sequence branch's own stream that runs
+    when the head's gradient of ``z`` arrives, instead of from the loss node on the head's stream.  With the gradients computed
+    ahead by :func:`vae_loss` on this stream, the head's stream neither waits for the reconstruction in the forward nor hands
+    anything to this stream at the start of the backward: two cross-queue hops and the one-workgroup loss launch (~ 22 us) leave
+    the step's critical chain.  The total -- the last thing that needs both streams' terms -- is formed by this backward too."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar, recon, slot):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, gz):
+        slot = ctx.slot
+        if slot.grads is None:          # no loss asked for the sequence terms
+            return gz, None, None, None, None
+        d_recon, d_mu, d_lv = slot.grads
+        _launch_loss_total(slot)
+        if slot.scale is not None:      # a seed other than unit_gradient(): DeferredLossFn's backward (which ran first) left it here
+            d_mu, d_lv = torch._foreach_mul([d_mu, d_lv], slot.scale)
+            d_recon = d_recon * slot.scale      # (a new buffer: vae_fc4's backward then launches normally)
+        slot.grads = None
+        return gz, d_mu, d_lv, d_recon, None
+
+
+class DeferredLossFn(torch.autograd.Function):
+    """The loss node of the deferred form: the prediction term's launch on the logit's stream; ``total`` and ``terms`` are written
+    by :class:`SeqTermsFn`'s backward (valid once the backward has run -- the engine's steps read them after the step)"""
+
+    @staticmethod
+    def forward(ctx, logit, y, mode, pos_weight, c_pred, sums, slot, out, total):
+        lib = _lib.load()
+        logit_c = _lib.f32c(logit.reshape(-1))
+        y_c = _lib.f32c(y.reshape(-1).to(torch.float32))
+        b = int(logit_c.numel())
+        if y_c.numel() != b:
+            raise ValueError(f"target has {y_c.numel()} elements, prediction {b}")
+        d_logit = torch.empty(b, dtype=torch.float32, device=logit.device)
+        _lib.check(lib.is_loss_pred_term(_lib.ptr(logit_c), _lib.ptr(y_c), _lib.ptr(d_logit), b, int(mode), float(pos_weight), float(c_pred),
+                                         _lib.ptr(sums), _lib.stream_ptr()), "is_loss_pred_term")
+        ctx.slot, ctx.logit_shape = slot, logit.shape
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(d_logit)
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        (d_logit,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 9
+        if g is not _unit_gradients.get((g.device.type, g.device.index)):
+            ctx.slot.scale = g
+            d_logit = d_logit * g
+        return d_logit.reshape(ctx.logit_shape), None, None, None, None, None, None, None, None
+
+
+def attach_sequence_terms(z, mu, logvar, recon):
+    """-> z for the fusion head, with the sequence terms' gradients routed through :class:`SeqTermsFn` (call on the sequence
+    branch's stream); None when the deferred loss does not apply (then nothing changes)"""
+    if not (SpeculativeBackward.enabled and SpeculativeBackward.defer and torch.is_grad_enabled() and torch.is_tensor(recon)
+            and recon.is_cuda and z.requires_grad and recon.requires_grad):
+        return None
+    slot = SeqTermsSlot(torch.cuda.current_stream(z.device))
+    out = SeqTermsFn.apply(z, mu, logvar, recon, slot)
+    mu._seq_slot = slot
+    return out
+
+
+def _vae_loss_deferred(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, slot):
+    """prediction term on the caller's stream, reconstruction + KLD terms on the sequence branch's (``slot.stream``), no wait
+    between them; -> (total, terms) or None when the speculation does not apply"""
+    if float(c_mse) == 0.0 or mu.dtype != torch.float32 or logvar.dtype != torch.float32 or not (mu.is_contiguous() and logvar.is_contiguous()):
+        return None
+    if type(getattr(recon, "grad_fn", None)).__name__ != "LinearSmallBatchFnBackward" or getattr(recon.grad_fn, "fwd_stream", None) != slot.stream:
+        return None
+    pre = _speculate_recon_backward(recon, x, c_mse, join=False)
+    if pre is None:
+        return None
+    lib = _lib.load()
+    dev = logit.device
+    main = torch.cuda.current_stream(dev)
+    sums = torch.empty(4, dtype=torch.float32, device=dev)      # [1] KLD, [2] prediction: each written by its launch before the total reads it
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    total = torch.empty((), dtype=torch.float32, device=dev)
+    with torch.cuda.stream(slot.stream):
+        d_mu, d_lv = torch.empty_like(mu), torch.empty_like(logvar)
+        _lib.check(lib.is_loss_kld_term(_lib.ptr(mu), _lib.ptr(logvar), _lib.ptr(d_mu), _lib.ptr(d_lv), int(mu.numel()), float(c_kld),
+                                        _lib.ptr(sums), _lib.stream_ptr()), "is_loss_kld_term")
+    for t in (sums, out, total):
+        t.record_stream(slot.stream)
+    for t in (d_mu, d_lv):
+        t.record_stream(main)
+    slot.grads = (pre[0], d_mu, d_lv)
+    slot.total_args = (pre[1], int(recon.numel()), int(mu.numel()), int(logit.numel()), c_pred, c_mse, c_kld, sums, out, total)
+    slot.scale = None
+    return DeferredLossFn.apply(logit, y, mode, pos_weight, c_pred, sums, slot, out, total)
+
+
 def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):
     """Returns (total, terms[4] = {total, prediction, recon MSE, KLD})."""
+    slot = getattr(mu, "_seq_slot", None) if torch.is_tensor(mu) else None
+    if slot is not None and slot.grads is None and SpeculativeBackward.enabled and torch.is_grad_enabled() and recon is not None:
+        res = _vae_loss_deferred(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, slot)
+        if res is not None:
+            return res
     pre = _speculate_recon_backward(recon, x, c_mse) if recon is not None else None
     return VaeLossFn.apply(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, pre)
 

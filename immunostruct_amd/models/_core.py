@@ -241,6 +241,11 @@ class MultimodalNet(nn.Module):
                     z = torch.cat([z, p], dim=1)
                 self._latent_done(o, prop)
                 recon = self.decode_vae(z)
+            if not self._pair_rows and sp.graph:
+                # the loss's sequence terms reach recon / mu / logvar through a node of THIS stream (functional.SeqTermsFn): the
+                # head's stream then never waits for the reconstruction (engine steps only; None: nothing changes)
+                zt = HF.attach_sequence_terms(z, mu, logvar, recon)
+                z = z if zt is None else zt
             o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=recon)
         else:
             self._latent_done(o, prop)

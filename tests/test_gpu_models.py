@@ -134,11 +134,15 @@ def test_comparative_train_step_matches_reference_golden(cuda_device, name, wt):
     print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
 
 
+@pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("seed_kind", ["unit", "scaled", "plain"])
-def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, seed_kind):
+def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, seed_kind, defer, monkeypatch):
     """functional.SpeculativeBackward (the engine's steps): the reconstruction term's backward launched from the loss gives,
     bit for bit, the gradients of the ordinary backward when the backward is seeded with ``unit_gradient()``; with any other
-    seed (a scaled loss, a plain ``backward()``) the speculated results are dropped and the ordinary path runs."""
+    seed (a scaled loss, a plain ``backward()``) the speculated results are dropped and the ordinary path runs.
+    ``defer``: the loss in three launches (prediction term on the head's stream, KLD beside the reconstruction term on the
+    sequence branch's, total formed by ``SeqTermsFn``'s backward) -- same value, same gradients, bit for bit; the value is read
+    after the backward, as the engine does."""
     from immunostruct_amd import functional as HF
     dev = cuda_device
     raw = synthetic.make_batch(6, seed=71, deg_extra=2)
@@ -146,6 +150,8 @@ def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, 
     eps = H.make_eps(4, 6)
     seq, prop, y = torch.from_numpy(raw.one_hot_sequence()).to(dev), torch.from_numpy(raw.prop).to(dev), torch.from_numpy(raw.y_reg).to(dev)
     losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+
+    monkeypatch.setattr(HF.SpeculativeBackward, "defer", defer)
 
     def run(speculate):
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
@@ -158,6 +164,7 @@ def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, 
             loss = losses.regression_loss(res[0], seq, res[1], res[2], res[3], y)
         node = res[0].grad_fn
         assert (getattr(node, "spec", None) is not None) == speculate      # launched ahead only when asked to
+        assert (type(loss.grad_fn).__name__ == "DeferredLossFnBackward") == (speculate and defer)
         if seed_kind == "unit":
             loss.backward(HF.unit_gradient(dev))
         elif seed_kind == "scaled":
