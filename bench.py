@@ -52,6 +52,10 @@ VAE_IN = synthetic.SEQ_LEN * synthetic.SEQ_ALPHABET
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 H = 64
+# where the captured step's dropout masks / reparameterisation noise come from (engine.CapturedTrainStep step_random):
+# "device" = one launch of the library's generator inside the step; IMMUNOSTRUCT_STEP_RANDOM=torch: torch's generator inside the
+# step (rounds 1 - 3: two generator-state fills in front of every replay), =prefetch: torch's generator one step ahead
+STEP_RANDOM = {"torch": None}.get(os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"), os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"))
 TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
@@ -265,7 +269,7 @@ class TrainStepWorkload:
         if not args.eager:
             from immunostruct_amd.engine import CapturedTrainStep
             self.captured = CapturedTrainStep(self.model, self.opt, self.reducer, self.forward_loss, template,
-                                              edge_capacity=edge_capacity)
+                                              edge_capacity=edge_capacity, step_random=STEP_RANDOM)
 
     def step(self, i):
         if self.captured is None:
@@ -439,7 +443,7 @@ class IedbWorkload(TrainStepWorkload):
         perm = torch.randperm(num_graphs, generator=torch.Generator().manual_seed(5)).to(dev)
         dds.gather_into(perm[:a.batch], *buf)
         eng = CapturedTrainStep(self.model, self.opt, D.FlatGradReducer(self.model.parameters(), world=1), self.forward_loss, buf,
-                                edge_capacity=a.batch * dds.max_edges, warmup=1)
+                                edge_capacity=a.batch * dds.max_edges, warmup=1, step_random=STEP_RANDOM)
         steps = num_graphs // a.batch
 
         def epoch():

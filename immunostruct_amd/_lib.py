@@ -45,6 +45,7 @@ SIGNATURES = {
     "is_egnn_node_wgrad_batched": [_P, _I, _I, _I, _I, _P],
     "is_reduce_partials_batched": [_P, _I, _P],
     "is_multi_copy": [_P, _I, _P],
+    "is_step_random": [_P, _I, _P, _P],
     "is_batch_gather": [_P, _I, _I, _I, _I] + [_P] * 15 + [_P, _I, _P],
     "is_chunk_partition": [_P, _I, _I, _I, _P, _P],
     "is_adam_step": [_P, _I, _P, _P, _P],
@@ -123,6 +124,11 @@ class ReduceJob(ctypes.Structure):
 class CaPart(ctypes.Structure):
     """one piece of the combined attention's token row (mirrors `CaPart` in csrc/combined_attention.hip)"""
     _fields_ = [("x", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("width", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class RandJob(ctypes.Structure):
+    """one job of is_step_random"""
+    _fields_ = [("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("kind", ctypes.c_int), ("p", ctypes.c_float)]
 
 
 class CopyJob(ctypes.Structure):

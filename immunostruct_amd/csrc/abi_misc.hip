@@ -123,3 +123,89 @@ extern "C" int is_debug_stream_copy(const void* src, void* dst, long long n16, i
                      static_cast<const is::f32x4*>(src), static_cast<is::f32x4*>(dst), n16);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// The random tensors of one train step -- scaled dropout keep-masks (nn.Dropout in training mode: reference
+// models/hybrid_models.py:277-295) and the reparameterisation noise (torch.randn_like, hybrid_models.py:301-304) -- as ONE launch
+// from a device-resident generator state, for the captured step: no host-side generator, so no seed / offset fill launches in
+// front of every graph replay, and one launch instead of three.  Philox4x32-10 (Salmon et al., SC'11: the generator behind
+// torch's and cuRAND's default streams) keyed by the seed, counter = (element quad, job, step): every value is a function of
+// (seed, step, job, element) alone -- independent of the grid.  state: [0] seed, [1] step counter (advanced by the launch's last
+// workgroup), [2] ticket.
+namespace is {
+struct RandJob { float* out; long long n; int kind; float p; };      // kind 0: N(0, 1); 1: keep-mask of Dropout(p), scaled by 1 / (1 - p)
+constexpr int RAND_MAX_JOBS = 8;
+struct RandBatch { RandJob job[RAND_MAX_JOBS]; };
+
+__device__ inline void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void step_random_kernel(RandBatch batch, unsigned long long* __restrict__ state) {
+  const RandJob& J = batch.job[blockIdx.y];
+  const unsigned long long seed = state[0], step = state[1];
+  const long long quads = (J.n + 3) >> 2;
+  const float keep = J.p < 1.0f ? 1.0f / (1.0f - J.p) : 0.0f;
+  for (long long qd = (long long)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += (long long)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)qd, (unsigned)(qd >> 32) ^ ((unsigned)blockIdx.y << 24), (unsigned)step, (unsigned)(step >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    float u[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = ((float)(r[i] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1), 24 bits
+    if (J.kind == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {      // Box-Muller
+        const float rad = sqrtf(-2.0f * logf(u[i]));
+        float sn, cs;
+        sincosf(6.283185307179586f * u[i + 1], &sn, &cs);
+        v[i] = rad * cs;
+        v[i + 1] = rad * sn;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = u[i] >= J.p ? keep : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * qd + i < J.n) J.out[4 * qd + i] = v[i];
+  }
+  // every thread has read the step counter (above); the last workgroup to get here advances it for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+    if (atomicAdd(&state[2], 1ULL) == total - 1) {
+      state[1] = step + 1;
+      state[2] = 0;
+      __threadfence();
+    }
+  }
+}
+}  // namespace is
+
+// jobs: host array of njobs (<= 8) records { float* out; long long n; int kind; float p; }; state: 3 x uint64 of device memory
+extern "C" int is_step_random(const void* jobs, int njobs, unsigned long long* state, void* stream) {
+  if (njobs <= 0 || njobs > is::RAND_MAX_JOBS || state == nullptr) return -22;
+  is::RandBatch batch;
+  const is::RandJob* src = static_cast<const is::RandJob*>(jobs);
+  long long maxn = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (src[i].n <= 0 || src[i].out == nullptr || src[i].kind < 0 || src[i].kind > 1 || !(src[i].p >= 0.0f && src[i].p <= 1.0f)) return -22;
+    batch.job[i] = src[i];
+    maxn = src[i].n > maxn ? src[i].n : maxn;
+  }
+  int blocks = (int)((maxn / 4 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  hipLaunchKernelGGL(is::step_random_kernel, dim3(blocks, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch, state);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

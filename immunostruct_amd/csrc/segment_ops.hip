@@ -152,7 +152,7 @@ extern "C" int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_
 // target) as ONE launch instead of ten hipMemcpyAsync calls.
 namespace is {
 struct CopyJob { const void* src; void* dst; long long bytes; };
-constexpr int COPY_MAX_JOBS = 16;
+constexpr int COPY_MAX_JOBS = 24;
 struct CopyBatch { CopyJob job[COPY_MAX_JOBS]; };
 
 __global__ __launch_bounds__(256) void multi_copy_kernel(CopyBatch batch) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(CopyBatch batch) {
 }
 }  // namespace is
 
-// jobs: host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; }, bytes % 4 == 0
+// jobs: host array of njobs (<= 24) records { const void* src; void* dst; long long bytes; }, bytes % 4 == 0
 extern "C" int is_multi_copy(const void* jobs, int njobs, void* stream) {
   if (njobs <= 0 || njobs > is::COPY_MAX_JOBS) return -22;
   is::CopyBatch batch;

@@ -122,8 +122,8 @@ def multi_copy(pairs):
         if nbytes:
             jobs.append(_lib.CopyJob(s_.data_ptr(), d_.data_ptr(), nbytes))
     lib = _lib.load()
-    for at in range(0, len(jobs), 16):
-        chunk = jobs[at:at + 16]
+    for at in range(0, len(jobs), 24):
+        chunk = jobs[at:at + 24]
         arr = (_lib.CopyJob * len(chunk))(*chunk)
         _lib.check(lib.is_multi_copy(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _lib.stream_ptr()), "is_multi_copy")
 
@@ -167,7 +167,8 @@ class CapturedTrainStep:
     eager train steps on the template batch (they update the model like any other step), then captures.
     """
 
-    def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3, preserve_state=False):
+    def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3, preserve_state=False,
+                 step_random=None):
         if warmup < 1:
             raise ValueError("warmup must be >= 1: optimizer state and BLAS handles have to be created by an eager "
                              "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
@@ -185,6 +186,14 @@ class CapturedTrainStep:
             self.sgraph = StaticGraphBatch(g, edge_capacity)
             self.seq, self.prop = torch.zeros_like(seq), torch.zeros_like(prop)
         self.y = torch.zeros_like(y)
+        # step_random (functional.StepRandom): where the step's dropout masks and reparameterisation noise come from.  None: the
+        # models draw them inside the step with torch's generator (every replay of a graph that does launches two generator-state
+        # fills in front of it).  "device": one launch of the library's own generator inside the step (is_step_random).
+        # "prefetch": torch's generator, one step ahead, outside the captured step, handed over with the batch (same values as
+        # eager steps draw; measured slower: the helper stream's launches disturb the persistent layer kernels).  Off by
+        # default: a ``forward_loss`` that patches the draws (tests with fixed noise) would be bypassed
+        from .functional import StepRandom
+        self._rand = StepRandom(self.y.device, step_random) if step_random else None
         self._load(*template)
         self.fused_optimizer = not reducer.packing   # single rank: optimizer inside the same graph
         if getattr(reducer, "_collective", False) and hasattr(optimizer, "grad_scale") and reducer.divide:
@@ -347,13 +356,21 @@ class CapturedTrainStep:
             self._use_form(False)
 
     def _load(self, g, seq, prop, y):
+        rand = self._rand.pairs() if self._rand is not None else []      # the prefetched random tensors ride on the same launch
         if self.paired:
             pairs = [(y, self.y)]
             for sg, gi, si, ss, pi, ps in zip(self.sgraph, g, seq, self.seq, prop, self.prop):
                 pairs += sg.copy_pairs(gi) + [(si, ss), (pi, ps)]
-            multi_copy(pairs)
+            multi_copy(pairs + rand)
         else:
-            multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
+            multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)] + rand)
+
+    def _refresh_random(self):
+        """hand the prefetched random tensors over when ``_load`` did not (replay() on buffers the on-device batcher filled)"""
+        if self._rand is not None:
+            rand = self._rand.pairs()
+            if rand:
+                multi_copy(rand)
 
     def _fwd_bwd(self):
         from . import functional as HF
@@ -366,7 +383,7 @@ class CapturedTrainStep:
         if overlap and self._tail_late is None:
             HF.StackBoundary.begin()
         try:
-            with SpeculativeBackward():      # the backward below is seeded with the unit gradient
+            with SpeculativeBackward(), HF.StepRandom.use(self._rand):      # the backward below is seeded with the unit gradient
                 loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         finally:
             bnd = HF.StackBoundary.end() if (overlap and self._tail_late is None) else None
@@ -465,7 +482,7 @@ class CapturedTrainStep:
         self.reducer.zero()
         HF.StackBoundary.begin()
         try:
-            with HF.SpeculativeBackward():
+            with HF.SpeculativeBackward(), HF.StepRandom.use(self._rand):
                 loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         finally:
             bnd = HF.StackBoundary.end()
@@ -532,6 +549,12 @@ class CapturedTrainStep:
             self.optimizer.step_subset(self.reducer.buckets[i]["params"], first=i == 0)
 
     def _body(self, eager=False):
+        if eager and self._rand is not None:
+            self._refresh_random()
+            try:
+                return self._body()
+            finally:
+                self._rand.prefetch()
         if self._want_two_stage:
             loss = self._stage1()
             self._reduce_and_update(self._stage2 if self.two_stage else None, self._eager_update)
@@ -553,14 +576,17 @@ class CapturedTrainStep:
         on-device batcher (``data.DeviceResidentDataset.gather_into``) writes them directly."""
         if hasattr(self.optimizer, "refresh"):
             self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
+        self._refresh_random()
         def update(i):
             (self.graph_b if i is None else self.graph_b[i]).replay()
         if self.two_stage:
             self.graph_a1.replay()
             # bucket 0 is in flight while graph A2 runs the stack backward
             self._reduce_and_update(self.graph_a2.replay, update)
-            return self.loss
-        self.graph_a.replay()
-        if self.graph_b is not None:
-            self._reduce_and_update(None, update)
+        else:
+            self.graph_a.replay()
+            if self.graph_b is not None:
+                self._reduce_and_update(None, update)
+        if self._rand is not None:
+            self._rand.prefetch()      # the next step's draws, on the helper stream, beside this step
         return self.loss

@@ -1156,11 +1156,123 @@ def mlp2(x, w1, b1, w2, b2, mask=None, act1=0, act2=0, hgroup=0):
 _ones_cache = {}
 
 
+class StepRandom:
+    """The random tensors of a train step -- dropout keep-masks, the reparameterisation noise -- drawn OUTSIDE the captured step,
+    one step ahead, with the very calls the models make (``F.dropout`` of a ones tensor, ``torch.randn_like``: torch's generator,
+    same order, same values as an eager step would draw).
+
+    Why: a captured graph that uses torch's generator makes every ``CUDAGraph.replay()`` launch two fill kernels (the generator's
+    seed and offset) in front of the graph -- 10.6 us on the step's critical chain -- and the three draws are launch-bound torch
+    kernels inside the step.  With a provider active (``StepRandom.use``) the models get static buffers instead of drawing; the
+    engine draws the next step's values on a helper stream while the current step runs (:meth:`prefetch`) and hands them over
+    with the batch (:meth:`pairs`, the same ``is_multi_copy`` launch)."""
+    active = None
+
+    def __init__(self, device, mode="prefetch"):
+        """``mode`` "prefetch": as above.  "device": the step's tensors come from ONE launch of the library's own generator
+        (``is_step_random``: Philox4x32-10 on a device-resident state seeded from ``torch.cuda.initial_seed()``) issued inside the step at
+        its first draw -- no helper stream, nothing outside the captured graph, one launch instead of three; the values are not
+        torch's streams (same distributions; reproducible for a given seed)."""
+        if mode not in ("prefetch", "device"):
+            raise ValueError("StepRandom mode must be 'prefetch' or 'device'")
+        self.mode = mode
+        self.slots, self.cursor = [], 0
+        self.pending = self.ready = self._keep = None
+        if mode == "device":
+            self.state = torch.tensor([torch.cuda.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+        else:
+            self.stream = torch.cuda.Stream(device=device)
+
+    def _launch(self, slots):
+        import ctypes
+        jobs = [_lib.RandJob(s["buf"].data_ptr(), s["buf"].numel(), 0 if s["kind"] == "randn" else 1, float(s["p"])) for s in slots]
+        arr = (_lib.RandJob * len(jobs))(*jobs)
+        _lib.check(_lib.load().is_step_random(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _lib.ptr(self.state), _lib.stream_ptr()),
+                   "is_step_random")
+
+    class _Use:
+        def __init__(self, provider):
+            self.provider = provider
+
+        def __enter__(self):
+            self.saved, StepRandom.active = StepRandom.active, self.provider
+            if self.provider is not None:
+                self.provider.cursor = 0
+            return self.provider
+
+        def __exit__(self, *exc):
+            StepRandom.active = self.saved
+            return False
+
+    @classmethod
+    def use(cls, provider):
+        """the models' draws inside this context come from ``provider`` (None: they draw themselves)"""
+        return cls._Use(provider)
+
+    @staticmethod
+    def _sample(kind, like, p):
+        if kind == "randn":
+            return torch.randn_like(like)
+        return torch.nn.functional.dropout(like, p=p, training=True)
+
+    def draw(self, kind, like, p=0.0):
+        i, self.cursor = self.cursor, self.cursor + 1
+        if i == len(self.slots):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("StepRandom: a draw the eager warm-up step did not make appeared during capture")
+            if self.mode == "device":      # the first (eager) step learns the step's draws one by one: a launch each
+                if like.dtype != torch.float32:
+                    raise RuntimeError("StepRandom: float32 draws only")
+                self.slots.append({"kind": kind, "p": p, "buf": torch.empty(like.shape, dtype=torch.float32, device=like.device)})
+                self._launch(self.slots[-1:])
+                return self.slots[-1]["buf"]
+            buf = self._sample(kind, like, p)      # the first (eager) step: drawn in place, like any eager step
+            self.slots.append({"kind": kind, "like": like if kind == "dropout" else torch.empty_like(like), "p": p, "buf": buf})
+            return buf
+        s = self.slots[i]
+        if s["kind"] != kind or s["buf"].shape != like.shape or s["p"] != p:
+            raise RuntimeError(f"StepRandom: draw {i} was {s['kind']} {tuple(s['buf'].shape)} p={s['p']}, now {kind} {tuple(like.shape)} p={p}")
+        if i == 0 and self.mode == "device":
+            self._launch(self.slots)      # every tensor of the step, on the stream of the step's first draw (the others follow it)
+        return s["buf"]
+
+    def prefetch(self):
+        """draw the next step's values (slot order = the models' draw order) on the helper stream"""
+        if not self.slots or self.mode != "prefetch":
+            return
+        with torch.cuda.stream(self.stream):
+            self.pending = [self._sample(s["kind"], s["like"], s["p"]) for s in self.slots]
+            self.ready = torch.cuda.Event()
+            self.ready.record()
+
+    def pairs(self):
+        """(source, destination) copies that hand the prefetched values to the step's static buffers; the current stream waits for
+        the draws.  [] when nothing is pending (the values in the buffers have not been consumed yet)"""
+        if self.pending is None:
+            return []
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready)
+        pend, self.pending = self.pending, None
+        for t in pend:
+            t.record_stream(cur)
+        self._keep = pend
+        return [(t, s["buf"]) for t, s in zip(pend, self.slots)]
+
+
+def randn_like(t):
+    """``torch.randn_like(t)``, or the engine's prefetched draw (:class:`StepRandom`)"""
+    prov = StepRandom.active
+    return torch.randn_like(t) if prov is None else prov.draw("randn", t)
+
+
 def dropout_mask(rows, cols, p, device):
     """scaled keep-mask of nn.Dropout(p) in training mode (torch's generator: capturable), as an explicit tensor"""
     key = (rows, cols, str(device))
     if key not in _ones_cache:
         _ones_cache[key] = torch.ones(rows, cols, dtype=torch.float32, device=device)
+    prov = StepRandom.active
+    if prov is not None:
+        return prov.draw("dropout", _ones_cache[key], p)
     return torch.nn.functional.dropout(_ones_cache[key], p=p, training=True)
 
 
@@ -1577,6 +1689,14 @@ class SpeculativeBackward:
     # measured: the head's stream loses two cross-queue hops and 4 us of loss launch (comb_attn_fwd -> comb_attn_bwd 22.8 -> 7 us),
     # and the step does not get shorter (HISTORY.md 7.7): off unless IMMUNOSTRUCT_DEFER_LOSS=1
     defer = os.environ.get("IMMUNOSTRUCT_DEFER_LOSS", "0") == "1"
+
+    def __enter__(self):
+        self._saved, SpeculativeBackward.enabled = SpeculativeBackward.enabled, SpeculativeBackward.allowed
+        return self
+
+    def __exit__(self, *exc):
+        SpeculativeBackward.enabled = self._saved
+        return False
 
 
 def _speculate_recon_backward(recon, x, c_mse, join=True):

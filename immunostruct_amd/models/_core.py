@@ -152,9 +152,9 @@ class MultimodalNet(nn.Module):
         if self._pair_rows:
             # merged (cancer; wild-type) batch: two draws in the reference's order (cancer first), one per member
             b = self._pair_rows
-            eps = torch.cat([torch.randn_like(mu[:b]), torch.randn_like(mu[b:])], dim=0)
+            eps = torch.cat([HF.randn_like(mu[:b]), HF.randn_like(mu[b:])], dim=0)
         else:
-            eps = torch.randn_like(mu)
+            eps = HF.randn_like(mu)
         return mu + eps * torch.exp(0.5 * logvar)
 
     def decode_vae(self, z):
@@ -225,9 +225,9 @@ class MultimodalNet(nn.Module):
                 like = x.new_empty(x.shape[0], self.vae_latent_dim)
                 if self._pair_rows:
                     b = self._pair_rows
-                    eps = torch.cat([torch.randn_like(like[:b]), torch.randn_like(like[b:])], dim=0)
+                    eps = torch.cat([HF.randn_like(like[:b]), HF.randn_like(like[b:])], dim=0)
                 else:
-                    eps = torch.randn_like(like)
+                    eps = HF.randn_like(like)
                 mu, logvar, z, h3 = HF.vae_latent(a1, self.vae_fc21.weight, self.vae_fc21.bias, self.vae_fc22.weight,
                                                   self.vae_fc22.bias, eps, p, self.vae_fc3.weight, self.vae_fc3.bias,
                                                   fc1=(x, self.vae_fc1.weight, self.vae_fc1.bias) if fuse1 else None)

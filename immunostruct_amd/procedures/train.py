@@ -185,8 +185,10 @@ def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_
         model.train()
         first = assemble(train_index[rank:rank + bsz * world:world][:bsz], buf, True)
         # the engine's construction runs one eager warm-up step on this batch and then restores model + optimizer
+        # (step_random: the captured step's dropout masks / noise from the library's generator, seeded from the device seed set
+        #  above -- config.step_random = None keeps torch's generator inside the step)
         captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, first, edge_capacity=edge_capacity(bsz),
-                                     warmup=1, preserve_state=True)
+                                     warmup=1, preserve_state=True, step_random=getattr(config, "step_random", "device"))
     tails = {}
 
     def eager_batch(idx, train):

@@ -280,9 +280,17 @@ int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, 
 int is_debug_stream_copy(const void* src, void* dst, long long n16, int grid, void* stream);
 
 /* Batched device-to-device copy (hand-over of a device-resident batch into the static buffers of a captured
- * graph): `jobs` = host array of njobs (<= 16) records { const void* src; void* dst; long long bytes; },
+ * graph): `jobs` = host array of njobs (<= 24) records { const void* src; void* dst; long long bytes; },
  * bytes a multiple of 4.                                                                                   */
 int is_multi_copy(const void* jobs, int njobs, void* stream);
+
+/* The random tensors of one train step in ONE launch from a device-resident generator state (captured steps: no host-side
+ * generator, hence no seed / offset fills in front of every graph replay): scaled keep-masks of nn.Dropout(p) in training mode
+ * (reference models/hybrid_models.py:277-295) and N(0, 1) noise for the reparameterisation (hybrid_models.py:301-304).
+ * `jobs` = host array of njobs (<= 8) records { float* out; long long n; int kind; float p; } (kind 0: normal, 1: keep-mask
+ * scaled by 1 / (1 - p)); state = 3 x uint64 of device memory { seed, step counter, ticket }: Philox4x32-10, every value a
+ * function of (seed, step, job, element); the launch advances the step counter.                                              */
+int is_step_random(const void* jobs, int njobs, unsigned long long* state, void* stream);
 
 /* On-device batcher (reference data/utils.py:160-176: `collate` -> dgl.batch): assemble the block-diagonal batch of the
  * B graphs idx[0..B) (int64, device) from a device-resident dataset of per-graph CSR pieces, all graphs padded to n

@@ -139,3 +139,37 @@ def _row_worst(b, diff, tol):
     ratio = diff / (ATOL_FRACTION * tol * rs + tol * b.abs())
     live = (rs > 1e-6 * float(b.abs().max())).expand_as(ratio)
     return float(ratio[live].max()) if live.any() else 0.0
+
+
+# ---- Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), numpy: the checker of
+# csrc/abi_misc.hip step_random_kernel (pinned to the Random123 known-answer vectors in tests/test_step_contexts.py) ----
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32, key: (2,) uint32 -> (..., 4) uint32"""
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    m0, m1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = m0 * c[0], m1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack([x.astype(np.uint32) for x in c], axis=-1)
+
+
+def step_random_expected(n, kind, p, seed, step, job):
+    """what is_step_random writes for a job of n elements: float64 values (normals) / exact float32 values (masks)"""
+    quads = (n + 3) // 4
+    ctr = np.zeros((quads, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(quads, dtype=np.uint64) & 0xFFFFFFFF
+    ctr[:, 1] = np.uint32(job << 24)
+    ctr[:, 2], ctr[:, 3] = np.uint32(step & 0xFFFFFFFF), np.uint32(step >> 32)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    u = ((r >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    if kind == 0:
+        u = u.astype(np.float64)
+        rad = np.sqrt(-2.0 * np.log(u[:, 0::2]))
+        ang = 2.0 * np.pi * u[:, 1::2].astype(np.float32).astype(np.float64)
+        out = np.stack([rad[:, 0] * np.cos(ang[:, 0]), rad[:, 0] * np.sin(ang[:, 0]), rad[:, 1] * np.cos(ang[:, 1]), rad[:, 1] * np.sin(ang[:, 1])], axis=1)
+    else:
+        out = np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
+    return out.reshape(-1)[:n]

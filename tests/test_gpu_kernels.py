@@ -939,3 +939,47 @@ def test_vae_latent_block_matches_torch(cuda_device, b, hd, pw):
     for name, h, r in zip(("a1", "W21", "b21", "W22", "b22", "p", "W3", "b3"), grads_h, grads_r):
         if r is not None:
             H.assert_close(h, r, GRAD_TOL, "grad " + name)
+
+
+@pytest.mark.gpu
+def test_step_random_launch_matches_the_philox_checker_and_its_distributions(cuda_device):
+    """``is_step_random`` (csrc/abi_misc.hip): every value is Philox4x32-10 of (seed, step, job, element) -- compared with the numpy
+    checker (tests/helpers.py, pinned to the Random123 known answers): keep-masks exactly, normals to float32 round-off of
+    Box-Muller; the launch advances the step; a value does not depend on the size of its job; moments of 2^20 normals."""
+    from immunostruct_amd import functional as HF
+    dev = cuda_device
+    seed = 0x1234567_89ABCDE
+    torch.manual_seed(seed)
+    prov = HF.StepRandom(dev, "device")
+    assert int(prov.state[0]) == seed and int(prov.state[1]) == 0
+    like_n, ones = torch.empty(37, 11, device=dev), torch.ones(128, 32, device=dev)
+    with HF.StepRandom.use(prov):      # the first step: one launch per draw (steps 0, 1, 2 of the generator)
+        a = HF.randn_like(like_n).clone()
+        b = HF.dropout_mask(128, 32, 0.1, dev).clone()
+        c = HF.randn_like(like_n[:5]).clone()
+    assert int(prov.state[1]) == 3 and int(prov.state[2]) == 0
+    np.testing.assert_allclose(a.cpu().numpy().reshape(-1), H.step_random_expected(37 * 11, 0, 0.0, seed, 0, 0), atol=2e-5, rtol=0)
+    assert np.array_equal(b.cpu().numpy().reshape(-1), H.step_random_expected(128 * 32, 1, 0.1, seed, 1, 0))
+    np.testing.assert_allclose(c.cpu().numpy().reshape(-1), H.step_random_expected(55, 0, 0.0, seed, 2, 0), atol=2e-5, rtol=0)
+    with HF.StepRandom.use(prov):      # later steps: ONE launch for the three tensors, at the first draw (generator step 3: jobs 0, 1, 2)
+        a2 = HF.randn_like(like_n)
+        assert int(prov.state[1]) == 4
+        b2 = HF.dropout_mask(128, 32, 0.1, dev)
+        c2 = HF.randn_like(like_n[:5])
+        assert int(prov.state[1]) == 4
+    np.testing.assert_allclose(a2.cpu().numpy().reshape(-1), H.step_random_expected(37 * 11, 0, 0.0, seed, 3, 0), atol=2e-5, rtol=0)
+    assert np.array_equal(b2.cpu().numpy().reshape(-1), H.step_random_expected(128 * 32, 1, 0.1, seed, 3, 1))
+    np.testing.assert_allclose(c2.cpu().numpy().reshape(-1), H.step_random_expected(55, 0, 0.0, seed, 3, 2), atol=2e-5, rtol=0)
+    # (a job's values do not depend on its length: c2 is the head of what a longer job 2 of step 3 would hold)
+    np.testing.assert_allclose(c2.cpu().numpy().reshape(-1), H.step_random_expected(4000, 0, 0.0, seed, 3, 2)[:55], atol=2e-5, rtol=0)
+    with pytest.raises(RuntimeError):
+        with HF.StepRandom.use(prov):
+            HF.dropout_mask(128, 32, 0.1, dev)      # not the draw the first step made here
+    big = HF.StepRandom(dev, "device")
+    with HF.StepRandom.use(big):
+        z = HF.randn_like(torch.empty(1 << 20, device=dev)).double()
+        m = HF.dropout_mask(4096, 256, 0.3, dev)
+    assert abs(float(z.mean())) < 4e-3 and abs(float(z.var()) - 1.0) < 6e-3
+    assert abs(float((z ** 3).mean())) < 2e-2 and abs(float((z ** 4).mean()) - 3.0) < 5e-2 and float(z.abs().max()) < 6.0
+    keep = float((m > 0).double().mean())
+    assert abs(keep - 0.7) < 2e-3 and set(torch.unique(m).tolist()) == {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))}

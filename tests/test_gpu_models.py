@@ -439,6 +439,96 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 3 captured steps")
 
 
+@pytest.mark.parametrize("always_pack", [False, True])
+def test_prefetched_random_tensors_reproduce_eager_training(cuda_device, always_pack, monkeypatch):
+    """``CapturedTrainStep(step_random="prefetch")``: dropout masks and the reparameterisation noise are drawn one step ahead,
+    outside the captured step, with the calls the models make -- a model in TRAINING mode (both dropouts active, noise from
+    torch's generator) then takes the steps an eager loop with the same seed takes: same draws, in the same order."""
+    from immunostruct_amd import functional as HF
+    from immunostruct_amd.distributed import FlatGradReducer
+    from immunostruct_amd.engine import CapturedTrainStep
+    from immunostruct_amd import optim
+    dev = cuda_device
+    monkeypatch.setenv("IMMUNOSTRUCT_DP_OVERLAP", "1")
+    raws = [synthetic.make_batch(6, seed=s, deg_extra=d) for s, d in ((61, 2), (62, 3), (63, 1), (64, 2))]
+    batches = [(H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev),
+                torch.from_numpy(r.prop).to(dev), torch.from_numpy(r.y_reg).to(dev)) for r in raws]
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+
+    def forward_loss(m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return losses.regression_loss(recon, seq, mu, logvar, final, y)
+
+    def run(captured):
+        model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
+        model.train()
+        red = FlatGradReducer(model.parameters(), world=1, always_pack=always_pack)
+        opt = optim.Adam(model.parameters(), lr=1e-4)
+        torch.manual_seed(4321)
+        out = []
+        if captured:
+            eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1,
+                                    step_random="prefetch")
+            assert len(eng._rand.slots) == 3 and [s["kind"] for s in eng._rand.slots] == ["dropout", "randn", "dropout"]
+            for b in batches:
+                out.append(float(eng(*b)))
+        else:
+            for b in [batches[0]] + batches:
+                red.zero()
+                loss = forward_loss(model, *b)
+                loss.backward()
+                red.all_reduce_mean()
+                opt.step()
+                out.append(float(loss.detach()))
+        return out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    l_e, sd_e = run(False)
+    l_c, sd_c = run(True)
+    l_e = l_e[1:]   # drop the warm-up step's loss
+    assert len(set(l_e)) == len(l_e)
+    for a, b in zip(l_e, l_c):
+        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
+    for k in sd_e:
+        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 4 captured steps with prefetched random tensors")
+    assert HF.StepRandom.active is None
+
+
+def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
+    """``CapturedTrainStep(step_random="device")``: a model in TRAINING mode draws its dropout masks and noise from the library's
+    generator inside the captured step (one launch per step, no torch generator in the graph): the same seed gives the same
+    trajectory, another seed another one (the distributions themselves: ``test_step_random_launch_...`` in test_gpu_kernels.py)."""
+    from immunostruct_amd.distributed import FlatGradReducer
+    from immunostruct_amd.engine import CapturedTrainStep
+    from immunostruct_amd import optim
+    dev = cuda_device
+    raws = [synthetic.make_batch(6, seed=s, deg_extra=d) for s, d in ((61, 2), (62, 3), (63, 1), (64, 2))]
+    batches = [(H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev),
+                torch.from_numpy(r.prop).to(dev), torch.from_numpy(r.y_reg).to(dev)) for r in raws]
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+
+    def forward_loss(m, g, seq, prop, y):
+        recon, mu, logvar, final = m(g, seq, prop)
+        return losses.regression_loss(recon, seq, mu, logvar, final, y)
+
+    def run(seed, mode):
+        model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
+        model.train()
+        torch.manual_seed(seed)
+        eng = CapturedTrainStep(model, optim.Adam(model.parameters(), lr=1e-4), FlatGradReducer(model.parameters(), world=1), forward_loss,
+                                batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1, step_random=mode)
+        if mode == "device":
+            assert [s["kind"] for s in eng._rand.slots] == ["dropout", "randn", "dropout"]
+        out = [float(eng(*b)) for b in batches + batches]
+        if mode == "device":
+            assert int(eng._rand.state[1]) == 3 + 8      # three single launches of the eager step, then one per step
+        return out
+
+    a, b, c = run(5, "device"), run(5, "device"), run(6, "device")
+    assert a == b and a != c and len(set(a)) == len(a) and all(np.isfinite(a))
+
+
 @pytest.mark.parametrize("form", ["two_pass", "merged"])
 def test_captured_paired_step_matches_eager(cuda_device, form, monkeypatch):
     """The paired (cancer, wild-type) train step -- encoder on both members, fused head, BCE + reconstruction terms, paired

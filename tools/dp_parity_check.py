@@ -106,7 +106,8 @@ def check_tail(rank, world, dev):
     ref = copy.deepcopy(model)
     tmp = tempfile.mkdtemp()
     cfg = SimpleNamespace(batch_size=bsz, num_epochs=2, model_save_path_pretrain=os.path.join(tmp, f"m{rank}.pt"),
-                          model_save_path_finetune=os.path.join(tmp, f"f{rank}.pt"))
+                          model_save_path_finetune=os.path.join(tmp, f"f{rank}.pt"),
+                          step_random=None)      # (the patched torch.randn_like below must be what the captured step draws with)
     opt = optim.Adam(model.parameters(), lr=LR)
     train_model_device(cfg, dev, model, dds, list(range(n_train)), list(range(n_train, n_train + 8)), opt,
                        losses.regression_loss, seed=5)
