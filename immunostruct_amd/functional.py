@@ -137,10 +137,13 @@ class TailGate:
     bandwidth-bound update then runs beside the tail instead of behind it (engine.CapturedTrainStep, optim.Adam.step_overlapped)."""
     enabled = False
     event = None
+    # IMMUNOSTRUCT_ADAM_GATE_LAYER = k >= 0: the mark sits behind the backward launch of EGNN layer k instead (the update then runs
+    # beside the backward launches of the layers below k, whose HBM use is a third of the copy rate)
+    layer = int(os.environ.get("IMMUNOSTRUCT_ADAM_GATE_LAYER", "-1"))
 
     @classmethod
-    def mark(cls):
-        if cls.enabled:
+    def mark(cls, layer=-1):
+        if cls.enabled and layer == cls.layer:
             cls.event = torch.cuda.Event()
             cls.event.record()
 
@@ -682,6 +685,7 @@ class EGNNStackFn(torch.autograd.Function):
             rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
             above = (dZ1, dD, dx)
             g_hd, g_psd_next, g_xc = d_h, dpsd, dx
+            TailGate.mark(i)
         # the gather of layer 0's per-edge gradients completes dL/dpsd_0 (and dL/dx_0): its own launch (no layer below)
         dZ1, dD, dx = above
         with KernelTimer.span("gather_segment_sum"):      # (accumulates into dx: not repeatable)
