@@ -23,6 +23,9 @@
 
 namespace is {
 
+#ifndef CA_MOMENTS_F64
+#define CA_MOMENTS_F64 1
+#endif
 constexpr int CA_HEADS = 8;
 constexpr int CA_THREADS = 1024;   // one (token, head) item per thread for T <= 128: the block is pure latency (one workgroup per
                                    // graph, 128 graphs on 256 CUs), so the serial exp loops per thread are what it costs
@@ -183,16 +186,59 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     const float mx = gamma > 0.f ? gamma * cmax : gamma * cmin;
     // first and second moment of the row's softmax ABOUT THE TOKEN MEAN c0: the backward needs the variance sq / den - m^2, and
     // formed from raw moments it loses the digits |c0|^2 / var has (the values of a graph share an offset)
-    float den = 0.f, num = 0.f, sq = 0.f;
-    for (int j = 0; j < T; ++j) {
+    // The long sums of the head's kernels -- the classifier's dot products, the backward's sums over the (token, head) items -- run
+    // in fp64: the head's backward amplifies the round-off of what it is given ~ 100 x (its gradients are small differences), and
+    // fp32 chains of 104 - 832 terms left the logit 3.8 x and the gradients at the head's inputs 2.7 x further from the fp64 oracle
+    // than torch's blocked fp32 sums -- the "systematic factor" of the full-size gradient tests in rounds 3 - 4
+    // (tests/tools/grad_error_probe_model.py, HISTORY.md 7.10).  The kernels are latency-bound: the wider adds cost little.
+    // The softmax moments below (the saved variance is what the backward multiplies its gradients with): CA_MOMENTS_F64 = 0 plain
+    // fp32 chains (rounds 1 - 3), 1 (default) blocks of 8 in fp32 + block sums in fp64, 2 every term in fp64.
+    double den_d = 0.0, num_d = 0.0, sq_d = 0.0;
+#if CA_MOMENTS_F64 == 2
+    for (int j = 0; j < T; ++j) {      // every term into the fp64 sums (comb_attn_cls_fwd 21.8 -> 27 us)
       const float cj = c[j];
       const float e = __expf(gamma * cj - mx);
       const float dj = cj - c0;
-      den += e; num += e * dj; sq += e * dj * dj;
+      const double ed = (double)e * (double)dj;
+      den_d += (double)e; num_d += ed; sq_d += ed * (double)dj;
     }
-    const float inv = 1.0f / den;
-    const float mc = num * inv;          // centred mean
-    const float m = c0 + mc;
+#elif CA_MOMENTS_F64 == 1
+    // blocks of 8 terms summed in fp32, the block sums in fp64: the chain a term's round-off travels through is 8 long, not T
+    int j = 0;
+    for (; j + 8 <= T; j += 8) {
+      float d8 = 0.f, n8 = 0.f, s8 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float cj = c[j + u];
+        const float e = __expf(gamma * cj - mx);
+        const float dj = cj - c0;
+        const float t = e * dj;
+        d8 += e; n8 += t; s8 += t * dj;
+      }
+      den_d += (double)d8; num_d += (double)n8; sq_d += (double)s8;
+    }
+    for (; j < T; ++j) {
+      const float cj = c[j];
+      const float e = __expf(gamma * cj - mx);
+      const float dj = cj - c0;
+      const float t = e * dj;
+      den_d += (double)e; num_d += (double)t; sq_d += (double)(t * dj);
+    }
+#else
+    {
+      float den = 0.f, num = 0.f, sq = 0.f;
+      for (int j = 0; j < T; ++j) {
+        const float cj = c[j];
+        const float e = __expf(gamma * cj - mx);
+        const float dj = cj - c0;
+        den += e; num += e * dj; sq += e * dj * dj;
+      }
+      den_d = (double)den; num_d = (double)num; sq_d = (double)sq;
+    }
+#endif
+    const double inv_d = 1.0 / den_d, mc_d = num_d * inv_d;
+    const float inv = (float)inv_d;
+    const float m = (float)((double)c0 + mc_d);      // (mc: the centred mean)
     float contrib = on ? co.alpha[hd] * m : 0.f;
     contrib += __shfl_xor(contrib, 1, 64);
     contrib += __shfl_xor(contrib, 2, 64);
@@ -204,7 +250,7 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
       }
       if (stats != nullptr) {
         float* st = stats + ((size_t)b * items + w) * CA_NSTAT;
-        st[0] = gamma; st[1] = mx; st[2] = inv; st[3] = m; st[4] = sq * inv - mc * mc;      // [4]: the row's variance
+        st[0] = gamma; st[1] = mx; st[2] = inv; st[3] = m; st[4] = (float)(sq_d * inv_d - mc_d * mc_d);      // [4]: the row's variance
       }
     }
   }
@@ -212,17 +258,28 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_fwd_kernel(
     __syncthreads();
     const int ldw = cls.hid + 1;
     if (tid < cls.hid) {
-      float acc = cls.b1[tid];
-      for (int k = 0; k < T; ++k) acc += w1t[k * ldw + tid] * zs[k];
-      acc = fmaxf(acc, 0.0f);
+      // four interleaved partial sums (k mod 4), combined as ((s0 + s1) + (s2 + s3)) + bias: a quarter of the dependent chain
+      // (the same order in csrc/mlp_head.hip: the two kernels give the same bits)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= T; k += 4) {
+        s0 += (double)w1t[k * ldw + tid] * (double)zs[k];
+        s1 += (double)w1t[(k + 1) * ldw + tid] * (double)zs[k + 1];
+        s2 += (double)w1t[(k + 2) * ldw + tid] * (double)zs[k + 2];
+        s3 += (double)w1t[(k + 3) * ldw + tid] * (double)zs[k + 3];
+      }
+      for (; k < T; ++k) s0 += (double)w1t[k * ldw + tid] * (double)zs[k];
+      const double accd = ((s0 + s1) + (s2 + s3)) + (double)cls.b1[tid];
+      float acc = fmaxf((float)accd, 0.0f);
       if (cls.a1 != nullptr) cls.a1[(size_t)b * cls.hid + tid] = acc;
       if (cls.mask != nullptr) acc *= cls.mask[(size_t)b * cls.hid + tid];
       hs[tid] = acc;
     }
     __syncthreads();
     if (tid < cls.out) {
-      float acc = cls.b2[tid];
-      for (int h = 0; h < cls.hid; ++h) acc += cls.W2[tid * cls.hid + h] * hs[h];
+      double accd = (double)cls.b2[tid];
+      for (int h = 0; h < cls.hid; ++h) accd += (double)cls.W2[tid * cls.hid + h] * (double)hs[h];
+      float acc = (float)accd;
       if (cls.act2 == 1) acc = fmaxf(acc, 0.0f);
       cls.y[(size_t)b * cls.out + tid] = acc;
     }
@@ -399,21 +456,27 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
     if (tid < cls.hid) {
       const float a = cls.a1_in[(size_t)b * cls.hid + tid];
       const float m = cls.mask != nullptr ? cls.mask[(size_t)b * cls.hid + tid] : 1.0f;
-      float g = 0.0f;
+      double gd = 0.0;
       for (int o = 0; o < cls.out; ++o) {
         float g2 = cls.gy[(size_t)b * cls.out + o];
         if (cls.act2 == 1 && !(cls.y_in[(size_t)b * cls.out + o] > 0.0f)) g2 = 0.0f;
-        g += g2 * cls.W2[o * cls.hid + tid];
+        gd += (double)g2 * (double)cls.W2[o * cls.hid + tid];
       }
+      float g = (float)gd;
       g *= m;
       if (!(a > 0.0f)) g = 0.0f;
       ghs[tid] = g;
     }
     __syncthreads();
     for (int j = tid; j < T; j += CA_THREADS) {
-      float v = 0.0f;
-      for (int h = 0; h < cls.hid; ++h) v += ghs[h] * w1s[h * ldw + j];
-      dzs[j] = v;
+      double v0 = 0.0, v1 = 0.0;
+      int h = 0;
+      for (; h + 2 <= cls.hid; h += 2) {
+        v0 += (double)ghs[h] * (double)w1s[h * ldw + j];
+        v1 += (double)ghs[h + 1] * (double)w1s[(h + 1) * ldw + j];
+      }
+      if (h < cls.hid) v0 += (double)ghs[h] * (double)w1s[h * ldw + j];
+      dzs[j] = (float)(v0 + v1);
     }
     __syncthreads();      // w1s is dead: the phases below reuse the block
   }
@@ -452,14 +515,20 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
   // per-head sums in a fixed order: threads with tid % 8 == h hold head h
   if (tid < 3 * CA_HEADS) {
     const int which = tid / CA_HEADS, h = tid % CA_HEADS;
-    float s = 0.f;
-    for (int t = h; t < CA_THREADS; t += CA_HEADS) s += acc[which][t];
-    partials[(size_t)b * CA_PART + tid] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // (four interleaved partial sums: a quarter of the dependent chain)
+    for (int t = h; t < CA_THREADS; t += 4 * CA_HEADS) {
+      s0 += (double)acc[which][t]; s1 += (double)acc[which][t + CA_HEADS];
+      s2 += (double)acc[which][t + 2 * CA_HEADS]; s3 += (double)acc[which][t + 3 * CA_HEADS];
+    }
+    partials[(size_t)b * CA_PART + tid] = (float)((s0 + s1) + (s2 + s3));
   }
   if (tid == 3 * CA_HEADS) {
-    float s = 0.f;
-    for (int t = 0; t < CA_THREADS; t += CA_HEADS) s += acc[3][t];
-    partials[(size_t)b * CA_PART + 3 * CA_HEADS] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int t = 0; t < CA_THREADS; t += 4 * CA_HEADS) {
+      s0 += (double)acc[3][t]; s1 += (double)acc[3][t + CA_HEADS];
+      s2 += (double)acc[3][t + 2 * CA_HEADS]; s3 += (double)acc[3][t + 3 * CA_HEADS];
+    }
+    partials[(size_t)b * CA_PART + 3 * CA_HEADS] = (float)((s0 + s1) + (s2 + s3));
   }
   // ---- phase 2: per key token j: dc_j = sum_{i,h} dm p_{ih}(j) (1 + gamma (c_j - m)) + direct ----
   // the (i,h) items are split over SPLIT thread groups so that (nearly) all threads work; the group partial
@@ -468,23 +537,36 @@ __global__ __launch_bounds__(CA_THREADS) void comb_attn_bwd_kernel(
   {
     const int split = CA_THREADS / T >= 8 ? 8 : (CA_THREADS / T >= 4 ? 4 : CA_THREADS / T);      // T * split <= CA_THREADS
     const int grp = tid / T, j = tid - grp * T;
-    float a = 0.f;
+    double* accd = reinterpret_cast<double*>(&acc[0][0]);      // viewed as [8][CA_TMAX] doubles (4 * CA_THREADS floats: 16 KB)
+    static_assert(8 * CA_TMAX * sizeof(double) <= 4 * CA_THREADS * sizeof(float), "the group partials do not fit acc");
     if (grp < split) {
+      double a = 0.0;
       const float cj = c[j];
       const int chunk = (items + split - 1) / split;
       const int w_lo = grp * chunk, w_hi = min(items, w_lo + chunk);
-      for (int w = w_lo; w < w_hi; ++w) {
+      int w = w_lo;
+      for (; w + 8 <= w_hi; w += 8) {      // blocks of 8 terms in fp32, the block sums in fp64 (as the forward's moments)
+        float a8 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float gam = s_gamma[w + u];
+          const float p = __expf(gam * cj - s_mx[w + u]) * s_inv[w + u];
+          a8 += s_dm[w + u] * p * (1.0f + gam * (cj - s_m[w + u]));
+        }
+        a += (double)a8;
+      }
+      for (; w < w_hi; ++w) {
         const float gam = s_gamma[w];
         const float p = __expf(gam * cj - s_mx[w]) * s_inv[w];
-        a += s_dm[w] * p * (1.0f + gam * (cj - s_m[w]));
+        a += (double)(s_dm[w] * p * (1.0f + gam * (cj - s_m[w])));
       }
-      (&acc[0][0])[grp * CA_TMAX + j] = a;      // acc viewed as [8][CA_TMAX]
+      accd[grp * CA_TMAX + j] = a;
     }
     __syncthreads();
     if (tid < T) {
-      float v = dxi[tid];
-      for (int k = 0; k < split; ++k) v += (&acc[0][0])[k * CA_TMAX + tid];
-      ca_store_grad(X, b, tid, v);
+      double v = (double)dxi[tid];
+      for (int k = 0; k < split; ++k) v += accd[k * CA_TMAX + tid];
+      ca_store_grad(X, b, tid, (float)v);
     }
   }
 }

@@ -69,8 +69,20 @@ __global__ __launch_bounds__(256) void mlp2_fwd_kernel(
   const bool live = s0 + s < d.B;
   for (int h = u; h < d.hid; h += 32) {
     const float* xr = xs + s * d.xrow + mlp_xoff(d, h, 0);
-    float acc = b1[h];
-    for (int k = 0; k < d.in; ++k) acc += w1t[k * ldw + h] * xr[k];
+    // (fp64 accumulators: these heads feed the loss, whose gradient is a small difference of their outputs -- a 104-term fp32 chain
+    //  left the logit 3.8 x further from the fp64 value than torch's blocked fp32 dot product; csrc/combined_attention.hip, HISTORY.md 7.10)
+    //  four interleaved partial sums (k mod 4), combined as ((p0 + p1) + (p2 + p3)) + bias: a quarter of the dependent chain)
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= d.in; k += 4) {
+      p0 += (double)w1t[k * ldw + h] * (double)xr[k];
+      p1 += (double)w1t[(k + 1) * ldw + h] * (double)xr[k + 1];
+      p2 += (double)w1t[(k + 2) * ldw + h] * (double)xr[k + 2];
+      p3 += (double)w1t[(k + 3) * ldw + h] * (double)xr[k + 3];
+    }
+    for (; k < d.in; ++k) p0 += (double)w1t[k * ldw + h] * (double)xr[k];
+    const double accd = ((p0 + p1) + (p2 + p3)) + (double)b1[h];
+    float acc = (float)accd;
     if (d.act1 == 1) acc = fmaxf(acc, 0.0f);
     if (live && a1_out != nullptr) a1_out[(size_t)(s0 + s) * d.hid + h] = acc;
     if (mask != nullptr && live) acc *= mask[(size_t)(s0 + s) * d.hid + h];
@@ -78,8 +90,9 @@ __global__ __launch_bounds__(256) void mlp2_fwd_kernel(
   }
   __syncthreads();
   for (int o = u; o < d.out; o += 32) {
-    float acc = b2[o];
-    for (int h = 0; h < d.hid; ++h) acc += w2s[o * d.hid + h] * hs[s * d.hid + h];
+    double accd = (double)b2[o];
+    for (int h = 0; h < d.hid; ++h) accd += (double)w2s[o * d.hid + h] * (double)hs[s * d.hid + h];
+    float acc = (float)accd;
     if (d.act2 == 1) acc = fmaxf(acc, 0.0f);
     if (live) y[(size_t)(s0 + s) * d.out + o] = acc;
   }

@@ -254,7 +254,7 @@ def test_egnn_stack_gradients_at_the_stress_shape(cuda_device):
             continue
         r_hip = H.worst_ratio(hip[key].cpu(), f64[key], GRAD_TOL)
         r_ref = H.worst_ratio(f32[key], f64[key], GRAD_TOL)
-        assert r_hip <= max(1.0, 4.0 * r_ref), f"{key}: HIP {r_hip:.2f} x the bound from the fp64 gradient, the fp32 oracle {r_ref:.2f} x"
+        assert r_hip <= max(1.0, 2.0 * r_ref), f"{key}: HIP {r_hip:.2f} x the bound from the fp64 gradient, the fp32 oracle {r_ref:.2f} x"
         if r_hip > worst[1]:
             worst = (key, r_hip)
     print("stress-shape stack: worst gradient", worst, "nodes", n, "edges", raw.num_edges)

@@ -14,7 +14,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 BATCH = 16
 OUT_TOL, GRAD_TOL = 1e-5, 1e-4      # element-wise (tests/helpers.py): SURVEY 8c / BASELINE.md: 1e-5 rel on outputs, 1e-4 on gradients
-FULL_SIZE_FACTOR = 6.0      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
+FULL_SIZE_FACTOR = 2.0      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
 
 
 def _with_eps(fn, eps_list, device):
@@ -211,14 +211,15 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
         # arithmetic's own distance from it.  That distance is itself one draw of a round-off realisation, so it is taken as the
         # larger of TWO realisations of the fp32 oracle: the batch as given, and the same batch with its edge list permuted
         # (every scatter-add then runs in another order; the two differ by up to 1.6 x on the worst tensors).
-        # Measured (round 4, printed by this test with -s): eight tensors exceed the element-wise bound, all on the coordinate
-        # path (coord_mlp.* of layers 2 - 4, edge_mlp.* of layer 2: sums over 146 k edges that cancel to ~1e-3 of their terms);
-        # the worst, GCN_layers.3.coord_mlp.2.weight, is 8.9 x the bound where the fp32 oracle is 3.0 x, and over the eight the
-        # HIP path sits at 2.0 - 4.0 x the fp32 oracle's distance.  What that systematic factor is NOT (each measured): the
-        # kernels' v_exp_f32 / v_rcp_f32 SiLU (a ~1 ulp sigmoid, -DIS_SILU_ACCURATE, moved the worst tensor from 9.09 x to
-        # 8.93 x), the MFMA pipe (bit-equal to an ascending fp32 FMA chain: tools/ubench/mfma_exact.hip), the order of the 512
-        # workgroup records' sum (formed in fp64: unchanged).  Round 3 allowed 8 x; the factor is now the measured 4.0 + the
-        # spread of the CPU oracle's own realisation.
+        # Rounds 3 - 4 needed 8 x / 6 x here: eight tensors of the coordinate path sat at 2 - 4 x the fp32 oracle's distance (worst
+        # 8.9 x the element-wise bound where the oracle has 3.0 x).  The cause was not in the EGNN stack (stack alone, random
+        # upstream gradient: as accurate as the oracle, tests/tools/grad_error_probe.py) but in the FUSION HEAD: its classifier's
+        # 104-term fp32 dot-product chain left the logit 3.8 x, and the softmax moments its backward multiplies with left the
+        # gradient at the head's inputs 2.7 x, further from fp64 than torch's blocked fp32 sums -- and that backward amplifies what
+        # it is given ~ 100 x, into every gradient below it (tests/tools/grad_error_probe_model.py).  With those sums in fp64
+        # (blocks of 8 in fp32, block sums in fp64: csrc/combined_attention.hip, csrc/mlp_head.hip) ONE tensor exceeds the
+        # element-wise bound, GCN_layers.3.coord_mlp.2.weight at 1.2 x where the fp32 oracle has 3.0 x, and the HIP gradients are
+        # closer to fp64 than the oracle's on the tensors that used to fail.  Factor now 2 (HISTORY.md 7.10).
         sd_64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
         it64 = FR.forward("HybridModelv2", sd_64, H.oracle_graph(raw, torch.float64), seq.double(), prop.double(), eps=eps.double())
         FR.regression_loss(it64["recon_x"], seq.double(), it64["mu"], it64["logvar"], it64["final_output"], y.double(), H.VAE_IN).backward()
@@ -310,7 +311,7 @@ def test_other_attention_head_counts_vs_oracle(cuda_device, name, heads):
         else:
             r_hip = H.worst_ratio(p.grad.cpu(), sd_64[pname].grad, GRAD_TOL)
             r_ref = H.worst_ratio(ref_grad, sd_64[pname].grad, GRAD_TOL)
-            assert r_hip <= max(1.0, 5.0 * r_ref), (f"grad {pname}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
+            assert r_hip <= max(1.0, FULL_SIZE_FACTOR * r_ref), (f"grad {pname}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
                                                     f"gradient, the fp32 oracle {r_ref:.2f} x")
 
 
@@ -362,7 +363,7 @@ def test_other_hidden_sizes_vs_oracle(cuda_device, name, hidden, seed):
         else:
             r_hip = H.worst_ratio(p.grad.cpu(), sd_64[pname].grad, GRAD_TOL)
             r_ref = H.worst_ratio(ref_grad, sd_64[pname].grad, GRAD_TOL)
-            assert r_hip <= max(1.0, 5.0 * r_ref), (f"grad {pname}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
+            assert r_hip <= max(1.0, FULL_SIZE_FACTOR * r_ref), (f"grad {pname}: HIP is {r_hip:.2f} x the element-wise bound away from the fp64 "
                                                     f"gradient, the fp32 oracle {r_ref:.2f} x")
     from immunostruct_amd.engine import StaticGraphBatch
     with pytest.raises(NotImplementedError):
