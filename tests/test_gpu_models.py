@@ -273,7 +273,7 @@ def test_other_attention_head_counts_vs_oracle(cuda_device, name, heads):
     """``self_attention_heads`` is a constructor argument of the reference's models (hybrid_models.py:241-251).  The fused node
     attention covers 1 and 8 heads; other counts run the scores / softmax / column mean as device-side torch ops
     (models/layers.py) around the same HIP value / output projection.  Loss and every parameter gradient vs the oracle (fp64
-    yardstick: within the element-wise bound of the fp64 gradient, or within 5 x the fp32 oracle's own distance from it)."""
+    yardstick: within the element-wise bound of the fp64 gradient, or within FULL_SIZE_FACTOR x the fp32 oracle's own distance from it)."""
     dev = cuda_device
     b = 8          # (tiny batches make the bias gradients of vae_fc22 -- b-term sums of cancelling values that also carry the fusion
     raw = synthetic.make_batch(b, seed=33, deg_extra=3)      # head's closed-form gradient -- sit at 0.5 - 1.5 x the bound: b = 5 is a coin toss)
