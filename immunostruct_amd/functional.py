@@ -535,6 +535,25 @@ def _launch_stack_layers(h0, ld_h0, din0, ea, fe, csr, params, head, n_layers, f
     return layers, h_in, x, psd
 
 
+def _bucket_slice(layer_params, plan):
+    """the slice of a flat gradient bucket (distributed.FlatGradReducer: ``p._grad_dest``) that holds this layer's gradients in
+    the plan's layout, or None (no reducer, another parameter order, a gradient being accumulated over several backward passes)"""
+    d0 = getattr(layer_params[0], "_grad_dest", None)
+    if d0 is None or not d0.is_cuda or d0.dtype != torch.float32:
+        return None
+    base = d0._base if d0._base is not None else d0
+    if base.dim() != 1 or not base.is_contiguous():
+        return None
+    p0 = d0.data_ptr()
+    for p, off, sh in zip(layer_params, plan.offsets, plan.shapes):
+        d = getattr(p, "_grad_dest", None)
+        if (d is None or p.grad is not None or tuple(d.shape) != tuple(sh) or not d.is_contiguous() or d.data_ptr() != p0 + 4 * off
+                or (d._base if d._base is not None else d) is not base):
+            return None
+    so = d0.storage_offset()
+    return base[so:so + plan.total]
+
+
 class EGNNStackFn(torch.autograd.Function):
     """L chained EGNNConv layers on the fused layer kernels: one launch per layer forward (``csrc/egnn_layer_fwd.hip``),
     node data path + edge pass + source gather per layer backward, one batched weight-gradient launch and one batched
@@ -614,7 +633,10 @@ class EGNNStackFn(torch.autograd.Function):
         P = PARAMS_PER_LAYER
         g_hd = _lib.f32c(g_h) if g_h is not None else torch.zeros(n, HIDDEN, **f32)
         plans = [layer_plan(layers[i]["din"], fe, dev) for i in range(L)]
-        gflat = [torch.empty(pl.total, **f32) for pl in plans]
+        # data-parallel runs: a layer's eleven gradient tensors lie in the reducer's flat bucket in exactly the plan's order
+        # (module parameter order), so the reduction of the partial records writes them THERE -- nothing to pack afterwards
+        gflat = [_bucket_slice(params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER], plans[i]) for i in range(L)]
+        gflat = [g if g is not None else torch.empty(pl.total, **f32) for g, pl in zip(gflat, plans)]
         # no gradient at the final coordinates (unused, or never produced): the last layer's backward skips its
         # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
         g_xc = _lib.f32c(g_x) if g_x is not None else None
@@ -1416,7 +1438,9 @@ class LinearSmallBatchFn(torch.autograd.Function):
         dest = ctx.dest
         # (not while a gradient is being accumulated over several backward passes: the slice IS the accumulator then)
         direct = (dest is not None and w.grad is None and dest.shape == w.shape and dest.is_contiguous() and dest.device == w.device)
-        dw = dest if direct else torch.empty(n, k, dtype=torch.float32, device=w.device)
+        # (a NEW view object of the slice: autograd's AccumulateGrad adopts a gradient without copying only when nothing else
+        #  references the tensor it is handed -- the reducer's own view object would be cloned, 12 MB, and packed back)
+        dw = dest.view_as(dest) if direct else torch.empty(n, k, dtype=torch.float32, device=w.device)
         db = torch.empty(n, dtype=torch.float32, device=w.device) if ctx.has_bias else None
         # the input gradient first: the rest of the branch's backward waits for it, nothing waits for the weight gradient
         gx = None
@@ -1513,7 +1537,7 @@ class VaeLatentFn(torch.autograd.Function):
             kin = int(w1.shape[1])
             dest = ctx.fc1_dest
             direct = (dest is not None and w1.grad is None and dest.shape == w1.shape and dest.is_contiguous() and dest.device == w1.device)
-            dw1 = dest if direct else torch.empty(hd, kin, **f32)
+            dw1 = dest.view_as(dest) if direct else torch.empty(hd, kin, **f32)      # (a new view object: see LinearSmallBatchFn)
             db1 = torch.empty(hd, **f32) if ctx.fc1_bias is not None else None
             with KernelTimer.span("linear_wgrad"):
                 _lib.check(lib.is_linear_wgrad(_lib.ptr(d_a1), hd, _lib.ptr(x), kin, _lib.ptr(dw1), _lib.ptr(db1), b, hd, kin, st),
