@@ -141,11 +141,11 @@ class FlatGradReducer:
         finally:
             self.sources(saved)
 
-    def reduce_bucket(self, i, async_op=False):
-        """pack bucket i (one multi-tensor copy of the gradients that are not already in place), all-reduce (SUM; divided
-        by the world size here unless ``divide`` is off), re-point the gradients; returns the work handle"""
+    def pack(self, i, from_grad=False):
+        """one multi-tensor copy of bucket i's gradients that are not already in place (``from_grad``: from the current ``.grad``
+        tensors even when sources are bound -- the engine packs INSIDE the graph it is capturing, whose gradient buffers those are)"""
         b = self.buckets[i]
-        src = b["sources"] if b["sources"] is not None else [p.grad for p in b["params"]]
+        src = b["sources"] if (b["sources"] is not None and not from_grad) else [p.grad for p in b["params"]]
         dsts, srcs = [], []
         for g, v in zip(src, b["views"]):
             if g is None:
@@ -155,6 +155,13 @@ class FlatGradReducer:
                 srcs.append(g.view_as(v) if g.is_contiguous() else g.contiguous().view_as(v))
         if srcs:
             torch._foreach_copy_(dsts, srcs)
+
+    def reduce_bucket(self, i, async_op=False):
+        """pack bucket i (unless the captured graph that produced the bound sources packed it itself: ``packed``), all-reduce
+        (SUM; divided by the world size here unless ``divide`` is off), re-point the gradients; returns the work handle"""
+        b = self.buckets[i]
+        if not (b.get("packed") and b["sources"] is not None):
+            self.pack(i)
         work = None
         if self._collective:
             if self.divide:

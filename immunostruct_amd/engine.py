@@ -32,6 +32,9 @@ from .graph import CSRIndex, PackedGraphBatch
 # ("operation not permitted when stream is capturing", first met under a one-rank RCCL group in round 4)
 _CAPTURE = {"capture_error_mode": "thread_local"}
 _EARLY_PREPARE = os.environ.get("IMMUNOSTRUCT_ADAM_EARLY_PREPARE", "0") == "1"
+# data-parallel steps: the gradient buckets are packed by the captured graph that produced the gradients (its last nodes) instead of
+# by an eager multi-tensor copy between the replay and the collective (IMMUNOSTRUCT_DP_PACK_IN_GRAPH=0: the eager pack)
+_PACK_IN_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_PACK_IN_GRAPH", "1") != "0"
 
 
 class StaticGraphBatch(PackedGraphBatch):
@@ -258,8 +261,11 @@ class CapturedTrainStep:
             self.graph_a1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a1, **_CAPTURE):
                 loss = self._stage1()
+                if _PACK_IN_GRAPH:
+                    self.reducer.pack(0, from_grad=True)      # the bucket's pack as the graph's last node: no eager launch behind the replay
             # a graph always writes the gradient buffers it allocated while capturing: pack from those
             self.reducer.bind_sources(0)
+            self.reducer.buckets[0]["packed"] = _PACK_IN_GRAPH
             self.reducer.reduce_bucket(0)         # .grad of the first bucket now aliases its persistent flat buffer
             bnd, bnd_grads = self._bnd, self._bnd_grads
             for res in self._reserved_candidates:
@@ -270,9 +276,12 @@ class CapturedTrainStep:
                 try:
                     with torch.cuda.graph(graph, pool=self.graph_a1.pool(), **_CAPTURE):
                         self._stage2(retain=res != self._reserved_candidates[-1])
+                        if _PACK_IN_GRAPH:
+                            self.reducer.pack(1, from_grad=True)
                 finally:
                     HF.RESERVED_CUS = saved
                 self.reducer.bind_sources(1)
+                self.reducer.buckets[1]["packed"] = _PACK_IN_GRAPH
                 self.reducer.reduce_bucket(1)
                 self._a2[res] = (graph, self.reducer.sources())
             self.graph_a2, sources = self._a2[self.reserved]
@@ -288,10 +297,15 @@ class CapturedTrainStep:
                     self._optimizer_step()
                     from .functional import Stamps
                     Stamps.mark("optimizer done")
+                elif _PACK_IN_GRAPH:
+                    for i in range(len(self.reducer.buckets)):
+                        self.reducer.pack(i, from_grad=True)
             if dump:
                 self.graph_a.debug_dump(dump)
             if not self.fused_optimizer:
                 self.reducer.bind_sources()
+                for b in self.reducer.buckets:
+                    b["packed"] = _PACK_IN_GRAPH
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
             self._forms[False] = (loss, self.reducer.sources())
         if not self.fused_optimizer:
