@@ -179,15 +179,16 @@ __global__ __launch_bounds__(256) void step_random_kernel(RandBatch batch, unsig
     for (int i = 0; i < 4; ++i)
       if (4 * qd + i < J.n) J.out[4 * qd + i] = v[i];
   }
-  // every thread has read the step counter (above); the last workgroup to get here advances it for the next launch
+  // every thread of the workgroup has read (and used) the step counter before the barrier below; the workgroup that takes the last
+  // ticket advances it for the next launch.  No fence: nothing is handed from workgroup to workgroup -- the ticket is a device-scope
+  // atomic, and the counter's new value is only read by the NEXT launch (an agent-scope fence here is an L2 write-back +
+  // invalidate per workgroup: it was most of this launch's 12 us)
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
     if (atomicAdd(&state[2], 1ULL) == total - 1) {
       state[1] = step + 1;
       state[2] = 0;
-      __threadfence();
     }
   }
 }
