@@ -1,4 +1,5 @@
 """GPU parity of the drop-in model classes: HIP path vs golden vectors from the reference and vs the oracle."""
+import os
 import unittest.mock as mock
 
 import numpy as np
@@ -14,7 +15,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 BATCH = 16
 OUT_TOL, GRAD_TOL = 1e-5, 1e-4      # element-wise (tests/helpers.py): SURVEY 8c / BASELINE.md: 1e-5 rel on outputs, 1e-4 on gradients
-FULL_SIZE_FACTOR = 2.0      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
+FULL_SIZE_FACTOR = float(os.environ.get("IMMUNOSTRUCT_TEST_FULL_SIZE_FACTOR", "2.0"))      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
 
 
 def _with_eps(fn, eps_list, device):
