@@ -784,6 +784,13 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # (everything that takes host time without GPU work -- the collector pass, the creation of the timing events -- happens HERE,
+    #  in front of the settle blocks: between the last settle block and the timed region the GPU must not sit idle, or the timed
+    #  steps start on a device that has dropped its clocks: 15 steps of ramp, +2 % on a 30-step mean)
+    gc.collect()
+    gc.disable()          # no collector pause inside the (tens of milliseconds long) timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    flush_c_stdio()       # RCCL's version banner sits in libc's stdout buffer: push it out now, not after the JSON line
     # untimed: keep replaying until the step time is stable (clocks / caches / allocator of a cold box), at most ~0.5 s;
     # every rank runs the same number of blocks (the stop decision is rank 0's)
     settle, prev = [], None
@@ -804,13 +811,8 @@ def main():
         if stop:
             break
         prev = cur
-    flush_c_stdio()       # RCCL's version banner sits in libc's stdout buffer: push it out now, not after the JSON line
     HF.KernelTimer.reset()
     HF.KernelTimer.enabled = args.eager and not args.no_kernel_timers
-
-    gc.collect()
-    gc.disable()          # no collector pause inside the (tens of milliseconds long) timed region
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
     last = None
@@ -822,7 +824,10 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     HF.KernelTimer.enabled = False
-    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))      # device time between the steps' first launches
+    per_step = [a.elapsed_time(b) for a, b in zip(marks, marks[1:])]      # device time between the steps' first launches
+    if os.environ.get("IMMUNOSTRUCT_BENCH_STEP_TRACE"):      # debugging aid: the timed steps in order (which ones are slow?)
+        print("[step trace ms] " + " ".join(f"{v:.3f}" for v in per_step), file=sys.stderr)
+    per_step = sorted(per_step)
     if os.environ.get("IMMUNOSTRUCT_HOST_TIMES"):     # debugging aid: host-side cost of one isolated step vs its GPU time
         for i in range(5):
             fence()
