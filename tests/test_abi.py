@@ -14,8 +14,46 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(is_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_prototypes():
+    """name -> list of parameter kinds ("p" pointer, "i" int, "f" float, "l" long long) as the header declares them"""
+    text = open(os.path.join(ROOT, "include", "immunostruct_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for name, args in re.findall(r"\b(?:int|long long|void|float)\s+(is_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = " ".join(args.split())
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a or a.startswith("hipStream_t"):
+                    kinds.append("p")
+                elif a.startswith("long long"):
+                    kinds.append("l")
+                elif a.startswith("float"):
+                    kinds.append("f")
+                elif a.startswith(("int", "int32_t", "unsigned")):
+                    kinds.append("i")
+                else:
+                    raise AssertionError(f"{name}: parameter {a!r} of a kind the ABI does not use")
+        out[name] = kinds
+    return out
+
+
 def test_header_declares_the_bound_symbols():
     assert header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_header_parameter_lists_equal_the_bound_signatures():
+    """every declared entry point has the parameter COUNT and, parameter by parameter, the kind (pointer / int / float / long long)
+    the ctypes binding passes -- a drift between include/immunostruct_hip.h and _lib.SIGNATURES is a silent stack mismatch"""
+    kind_of = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_longlong: "l"}
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, kinds in protos.items():
+        bound = [kind_of[t] for t in _lib.SIGNATURES[name]]
+        assert len(bound) == len(kinds), f"{name}: header declares {len(kinds)} parameters, the binding passes {len(bound)}"
+        assert bound == kinds, f"{name}: header {''.join(kinds)} vs binding {''.join(bound)}"
 
 
 def test_library_exports_every_declared_symbol():
