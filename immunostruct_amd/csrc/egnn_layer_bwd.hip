@@ -67,8 +67,9 @@ namespace is {
 
 #ifdef IS_STAGE_STAMPS
 __device__ long long g_stamps_b[24];
-#define STAMPB(k) do { if (blockIdx.x == 300 && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMPP(k) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_WG (gridDim.x > 300 ? 300 : 100)
+#define STAMPB(k) do { if (blockIdx.x == STAMP_WG && threadIdx.x == 0 && tile == blockIdx.x) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPP(k) do { if (blockIdx.x == STAMP_WG && threadIdx.x == 0) g_stamps_b[k] = __builtin_amdgcn_s_memtime(); } while (0)
 // stamp once every outstanding vector-memory access of the wave has returned (perturbs the schedule: diagnosis only)
 #define STAMPP_W(k) do { __builtin_amdgcn_s_waitcnt(0x0F70); STAMPP(k); } while (0)
 #else
@@ -82,12 +83,30 @@ constexpr int NV16 = 16;   // nodes per tile without a tile list
 constexpr int NVB_LISTED = 24;    // most nodes a listed tile may hold
 constexpr int RP_TILES = 8;       // tiles per workgroup whose rowptr slice is fetched ahead (B = 128: 3; the stress slice: 8)
 
+// Round 5: with plain 16-node tiles the node phase runs 48 rows per pass (three tiles: all of a workgroup's tiles at B = 128) and its
+// dzn1 tile overlays the g_psd tile (dead behind the dh product's barrier) -- 38.4 KB instead of 68.6 KB, which fits BESIDE the two
+// weight tiles (34.8 KB) in a workgroup's half of the CU's LDS.  The weight tiles and the rowptr slices are then staged at the very
+// START of the kernel, under the node phase's front, instead of behind its last barrier (stage stamps: 6.5 - 13 k of 158 k cycles
+// between the end of the node phase and the first window).  Listed tiles (24-node pitch: 64-row passes) and the z1-recompute build
+// (its Pd tile) keep the overlay of rounds 2 - 4.
+#ifndef IS_BWD_EARLY_STAGE
+#define IS_BWD_EARLY_STAGE 1      // (0: A/B builds with the staging of rounds 2 - 4)
+#endif
+template <int NVB>
+struct BwdLayout {
+  static constexpr bool EARLY = (NVB == 16) && (IS_LAYER_M1 != 0) && (IS_BWD_EARLY_STAGE != 0);
+  static constexpr int PROWS = EARLY ? 48 : 64;
+  static constexpr int LDP = 132;
+};
+
 template <int FE_MAX, int NVB>
-struct Bwd16Smem {
+struct alignas(16) Bwd16Smem {
   float w2t[H * LD];
   float wc1t[H * LD];
-  float bufA[WB16][TE16 * LD];
-  float bufB[WB16][TE16 * LD];
+  union {
+    struct { float bufA[WB16][TE16 * LD]; float bufB[WB16][TE16 * LD]; } w;
+    float node[BwdLayout<NVB>::EARLY ? BwdLayout<NVB>::PROWS * (BwdLayout<NVB>::LDP + LD) : 1];      // EARLY: [g_psd | dzn1] tile, dh tile
+  } u;
   float pdt[IS_LAYER_M1 ? 1 : NVB * H];   // Pd rows of this tile's destination nodes (z1 recompute only)
   int rp[NVB + 1];
   int rp_tab[RP_TILES][NVB + 1];   // rowptr slices of this workgroup's first RP_TILES tiles (fetched once, in front of the edge loop)
@@ -143,11 +162,13 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     const float* __restrict__ m1s, const float* __restrict__ dy1s, const float* __restrict__ geos) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
-  constexpr int MT = 4, PROWS = 16 * MT, LDP = 132;          // node phase: up to 64 rows (several tiles) per pass
+  constexpr bool EARLY = BwdLayout<NVB>::EARLY;
+  constexpr int PROWS = BwdLayout<NVB>::PROWS, MT = PROWS / 16, LDP = BwdLayout<NVB>::LDP;      // node phase: rows (several tiles) per pass
   constexpr int PITCH = (NVB + 15) / 16 * 16;                // rows reserved per tile in a pass
   constexpr int TPP = PROWS / PITCH;                         // tiles per pass
-  static_assert(sizeof(float) * PROWS * (LDP + 2 * LD) <= sizeof(float) * (2 * H * LD + 2 * WB16 * TE16 * LD),
+  static_assert(EARLY || sizeof(float) * PROWS * (LDP + 2 * LD) <= sizeof(float) * (2 * H * LD + 2 * WB16 * TE16 * LD),
                 "the node phase's tiles must fit the (not yet staged) weight tiles + window buffers");
+  static_assert(sizeof(Bwd16Smem<FE_MAX, NVB>) <= 80 * 1024, "two workgroups per CU");
   __shared__ Bwd16Smem<FE_MAX, NVB> sm;
   wg_clock_start(wg_clock);
   // (kernel arguments live in scalar registers for the whole launch and this kernel has ~45 of them: what can be derived is --
@@ -170,10 +191,27 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   // ================= P1 + P2: source gather and node data path of ALL tiles of this workgroup =================
   // (before the persistent edge loop: its weight-gradient accumulators do not exist yet, so the 80 operand registers
   //  of the node phase cost nothing, they are fetched once per workgroup, and the gathers of several tiles overlap)
+  // the staging of everything the edge loop reads from LDS without knowing a gradient: the two weight tiles (transposed), the
+  // rowptr slices of this workgroup's tiles.  EARLY: here, before the node phase (one L2 round trip: every workgroup reads the same
+  // 32 KB), published by the node phase's barriers; otherwise behind the node phase, whose tiles overlay the weight tiles
+  auto stage_edge_tables = [&]() {
+    for (int idx = tid; idx < RP_TILES * (NVB + 1); idx += 256) {
+      const int k = idx / (NVB + 1), i = idx - k * (NVB + 1);
+      const int t = blockIdx.x + k * gridDim.x;
+      if (t < num_tiles) {
+        const int a0 = (tiles != nullptr) ? tiles[1 + t] : t * NV16;
+        const int cnt = (tiles != nullptr) ? min(NVB, tiles[2 + t] - a0) : min(NV16, N - a0);
+        sm.rp_tab[k][i] = rowptr[a0 + min(i, cnt)];
+      }
+    }
+    load_matrix_lds_t(sm.w2t, W2, tid, 256);
+    if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
+  };
+  if constexpr (EARLY) stage_edge_tables();
   {
-    float* ps_ = &sm.w2t[0];                  // [PROWS][LDP]  g_psd rows     (w2t | wc1t | bufA | bufB are contiguous)
-    float* gs = ps_ + PROWS * LDP;            // [PROWS][LD]   dh
-    float* zs = gs + PROWS * LD;              // [PROWS][LD]   dzn1
+    float* ps_ = EARLY ? &sm.u.node[0] : &sm.w2t[0];      // [PROWS][LDP]  g_psd rows     (not EARLY: w2t | wc1t | bufA | bufB are contiguous)
+    float* gs = ps_ + PROWS * LDP;                         // [PROWS][LD]   dh
+    float* zs = EARLY ? ps_ : gs + PROWS * LD;             // [PROWS][LD]   dzn1 (EARLY: over the g_psd rows, dead behind the dh product's barrier)
     const bool has_psd = nb.g_psd != nullptr;
     const int col = wave * 16 + r;
     // transposed-weight operands of this wave's output columns (operand pack: coalesced 16-byte loads, L2).  Fetched per
@@ -299,10 +337,12 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
             *reinterpret_cast<f32x4*>(nb.g_psd + (size_t)v * 128 + 16 * j + 4 * sub) = acc[j];
           if (sub < 3) nb.gxtot[v * 3 + sub] = x_dst + acc3;
         }
+        if (PROWS == 64 || lr < PROWS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 16 * j + 4 * sub) = acc[j];
-          *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 64 + 16 * j + 4 * sub) = (v >= 0) ? pdv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 16 * j + 4 * sub) = acc[j];
+            *reinterpret_cast<f32x4*>(ps_ + lr * LDP + 64 + 16 * j + 4 * sub) = (v >= 0) ? pdv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       } else {
         // stage g_psd (or g_h) rows of the pass: all loads first, LDS stores afterwards
@@ -413,22 +453,15 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     }
   }
 
+#ifdef IS_ABL_NONODE
+  __syncthreads();      // (timing-only build without a node phase: its barriers are what publishes the early staging)
+#endif
   // P3 reads the node phase's d_hn rows (written above by this workgroup, behind a barrier) through a restrict pointer:
   // without it every prefetch of the edge loop is ordered against every store of the loop
   const float* __restrict__ g_hn = nb.d_hn;
   // the rowptr slices of this workgroup's tiles: every tile of the persistent loop is known now, so its slice is fetched here,
   // under the weight staging, instead of at the tile's start (there it was a dependent load + two barriers per tile)
-  for (int idx = tid; idx < RP_TILES * (NVB + 1); idx += 256) {
-    const int k = idx / (NVB + 1), i = idx - k * (NVB + 1);
-    const int t = blockIdx.x + k * gridDim.x;
-    if (t < num_tiles) {
-      const int a0 = (tiles != nullptr) ? tiles[1 + t] : t * NV16;
-      const int cnt = (tiles != nullptr) ? min(NVB, tiles[2 + t] - a0) : min(NV16, N - a0);
-      sm.rp_tab[k][i] = rowptr[a0 + min(i, cnt)];
-    }
-  }
-  load_matrix_lds_t(sm.w2t, W2, tid, 256);
-  if constexpr (GX) load_matrix_lds_t(sm.wc1t, Wc1, tid, 256);
+  if constexpr (!EARLY) stage_edge_tables();
 
 #if !IS_LAYER_M1
   const float wr_c = W1[lane * ldw + 2 * din];
@@ -460,8 +493,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   // rows [16w, 16w+16) = channels, column 0 = radial weight, columns 1 .. Fe = edge-feature weights
   f32x4 dWra = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float* bufA = sm.bufA[wave];
-  float* bufB = sm.bufB[wave];
+  float* bufA = sm.u.w.bufA[wave];
+  float* bufB = sm.u.w.bufB[wave];
   // raw-buffer views: scalar bases, one lane-constant byte offset per access pattern, range-checked where rows past a
   // tile's end must read as zero / must not be written (no per-element predication, no 64-bit vector address math)
   const int voff_tile = (4 * q * H + r) * 4;            // element (row 4q [+ t], column r [+ 16 nt]) of a [16][64] tile
@@ -488,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     const int* rp = (tk < RP_TILES) ? sm.rp_tab[tk] : sm.rp;
     // first tile: the tables and weight tiles are staged; later tiles need no barrier here (every window ends with one, and a
     // tile's rowptr slice has its own table row) unless a slice is staged on the fly
-    if (tk == 0 || tk >= RP_TILES || !IS_LAYER_M1) __syncthreads();
+    if ((tk == 0 && !EARLY) || tk >= RP_TILES || !IS_LAYER_M1) __syncthreads();      // (EARLY: the node phase's barriers published them)
     if (tk >= RP_TILES && tid <= NVB) sm.rp[tid] = rowptr[v0 + min(tid, nv)];
 #if !IS_LAYER_M1
 #pragma unroll
@@ -828,9 +861,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #pragma unroll
         for (int wt = 0; wt < WB16; ++wt)
 #ifdef IS_ABL_NOMFMA
-          if (win + wt * TE16 < e_end) dWc1[0][0] += sm.bufA[wt][lane] * sm.bufB[wt][lane];
+          if (win + wt * TE16 < e_end) dWc1[0][0] += sm.u.w.bufA[wt][lane] * sm.u.w.bufB[wt][lane];
 #else
-          if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.bufA[wt], sm.bufB[wt], wave, lane);
+          if (win + wt * TE16 < e_end) mm16_outer_rows(dWc1, sm.u.w.bufA[wt], sm.u.w.bufB[wt], wave, lane);
 #endif
       }
 
@@ -926,9 +959,9 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #pragma unroll
       for (int wt = 0; wt < WB16; ++wt)
 #ifdef IS_ABL_NOMFMA
-        if (win + wt * TE16 < e_end) dW2[0][0] += sm.bufA[wt][lane] * sm.bufB[wt][lane];
+        if (win + wt * TE16 < e_end) dW2[0][0] += sm.u.w.bufA[wt][lane] * sm.u.w.bufB[wt][lane];
 #else
-        if (win + wt * TE16 < e_end) mm16_outer_rows(dW2, sm.bufA[wt], sm.bufB[wt], wave, lane);
+        if (win + wt * TE16 < e_end) mm16_outer_rows(dW2, sm.u.w.bufA[wt], sm.u.w.bufB[wt], wave, lane);
 #endif
 
       if (nvalid > 0) {
@@ -1005,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           for (int s = 0; s < 4; ++s) {
             const int e = 4 * q + s;
             const float b = sm.e_ra[wt][e * RA_LD + min(r, FE_MAX)];     // columns past 1 + FE_MAX are zero
-            dWra = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.bufA[wt][e * LD + wave * 16 + r], r <= FE_MAX ? b : 0.0f, dWra, 0, 0, 0);
+            dWra = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.w.bufA[wt][e * LD + wave * 16 + r], r <= FE_MAX ? b : 0.0f, dWra, 0, 0, 0);
           }
         }
       // ---- SEG: dPd[v] += sum over the window's in-edges of v of dz1, dx[v] -= sum of dL/dd -- as [nodes x edges] x
@@ -1020,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           for (int s = 0; s < 4; ++s) {
             const int e = 4 * q + s;
             const int dl = sm.e_dl[wt][e];
-            const float bh = sm.bufA[wt][e * LD + wave * 16 + r];
+            const float bh = sm.u.w.bufA[wt][e * LD + wave * 16 + r];
             float bx = 0.0f;
             if (wave == XW) bx = sm.e_gx[wt][min(r, 2)][e];
 #pragma unroll
@@ -1032,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
           }
         }
 #else
-      seg_h[0][0] += sm.bufA[0][lane]; seg_x[0][0] += sm.e_gx[0][0][r];
+      seg_h[0][0] += sm.u.w.bufA[0][lane]; seg_x[0][0] += sm.e_gx[0][0][r];
 #endif
       __syncthreads();
     }
@@ -1064,7 +1097,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       part[H * H + o * H + i] = dWc1[nt][t];
     }
   {
-    float* vec = &sm.bufB[0][0];  // [wave][slot][64]
+    float* vec = &sm.u.w.bufB[0][0];  // [wave][slot][64]
     constexpr int SLOTS = 3;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {

@@ -37,12 +37,20 @@ def layer_slots():
     return 2 * (_MAX_BWD_GRID - max(0, min(RESERVED_CUS, _MAX_BWD_GRID - 1)))
 
 
+_FORCE_BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "")
+# 1 (default): the backward layer launches run as ONE 512-thread workgroup per CU wherever csrc/egnn_layer_bwd8.hip covers the
+# shape; 0: always two 256-thread workgroups per CU (csrc/egnn_layer_bwd.hip) -- the A/B switch of round 5
+BWD_PAIRED = os.environ.get("IMMUNOSTRUCT_BWD_PAIRED", "1") == "1"
+
+
 def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     """The backward edge kernel runs ceil(tiles / slots) rounds of persistent workgroups.  Greedy tiles (~62 edges)
     fill the 64-edge windows but only pay when they save a whole round; on the B = 128 benchmark batch both cuts need
     3 rounds and the fuller windows are slower per round (measured 82 vs 78 us), at B = 512 they save 2 of 12."""
     if fe > 1:
         return False          # the listed-tile instantiation exists for Fe <= 1 only (LDS)
+    if _FORCE_BWD_TILES in ("0", "1"):
+        return _FORCE_BWD_TILES == "1"      # experiments only (tools/): the rule below is the measured one
     rounds = lambda tiles: (tiles + slots - 1) // slots
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
@@ -642,8 +650,14 @@ class EGNNStackFn(torch.autograd.Function):
         g_xc = _lib.f32c(g_x) if g_x is not None else None
         # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
         tiles = csr.tiles(64, 24) if use_bwd_tiles(n, e, layer_slots(), fe) else None
+        # the PAIRED form (csrc/egnn_layer_bwd8.hip): one 512-thread workgroup per CU = two groups that share the staged weight tiles
+        # and write ONE partial record -- half the records per launch.  Plain 16-node tiles, Fe <= 1, z3 read back.
+        paired = BWD_PAIRED and tiles is None and SAVE_Z3 and bool(lib.is_egnn_layer_bwd_paired_supported(fe, 0))
+        bwd_entry = lib.is_egnn_layer_bwd_paired if paired else lib.is_egnn_layer_bwd
         if tiles is not None:
             grid_e = max(1, min(layer_slots(), tiles.numel() - 2))
+        elif paired:
+            grid_e = max(1, min(layer_slots() // 2, ((n + 15) // 16 + 1) // 2))
         else:
             grid_e = max(1, min(layer_slots(), (n + 15) // 16))
         wg_stride, wg_proj = lib.is_egnn_node_wgrad_stride(), lib.is_egnn_node_wgrad_proj_floats()
@@ -683,7 +697,7 @@ class EGNNStackFn(torch.autograd.Function):
             # (idempotent: every output is written from inputs the launch does not change -- bench.py times it K times back to back)
             clk = LaunchClock.slot("bwd_nocoord" if (g_xc is None and above is None) else "bwd", i, grid_e, dev)
             KernelTimer.launch("egnn_layer_bwd_nocoord" if (g_xc is None and above is None) else "egnn_layer_bwd", lambda: _lib.check(
-                lib.is_egnn_layer_bwd(
+                bwd_entry(
                     _lib.ptr(psd), _lib.ptr(psd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(lay["x"]), _lib.ptr(ea),
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),

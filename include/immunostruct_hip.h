@@ -114,6 +114,22 @@ int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x
                       const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                       const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
                       long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream);
+/* The PAIRED form of is_egnn_layer_bwd (csrc/egnn_layer_bwd8.hip): `grid` workgroups of 512 threads -- two groups of four waves that
+ * are what two co-resident 256-thread workgroups of is_egnn_layer_bwd were (group g of workgroup b owns the tiles of its workgroup
+ * b + g * grid), sharing one staged copy of the weight tiles (requested at the kernel's start, under the node phase) and writing ONE
+ * partial record per workgroup (`partials` holds `grid` records: half the bytes into is_reduce_partials_batched).  Same arguments,
+ * outputs and per-tile arithmetic as is_egnn_layer_bwd.  Covers the default build (z1 / geometry / z3 read back), plain 16-node
+ * tiles (tiles == NULL) and Fe <= 1: is_egnn_layer_bwd_paired_supported(Fe, listed_tiles) tells, -38 otherwise; grid <= ceil(N/16). */
+int is_egnn_layer_bwd_paired_supported(int Fe, int listed_tiles);
+int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
+                             const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
+                             const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
+                             const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
+                             float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                             const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
+                             const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
+                             const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
+                             long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream);
 /* How this library's backward layer kernel gets the first edge-MLP activation (a build-time choice, csrc/Makefile M1=0|1|2):
  * 2 (default): it READS the pre-activation z1 from m1s [max(E,16), 64] -- pass the same array to is_egnn_layer_fwd, which fills
  * it (dy1s = NULL in both calls); 1: it reads m1 = SiLU(z1) from m1s and SiLU'(z1) from dy1s (both filled by the forward);

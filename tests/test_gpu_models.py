@@ -370,8 +370,8 @@ def test_reference_default_command_line_at_full_size_vs_oracle(cuda_device, name
     lh = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=seq_loss).regression_loss(res[0], seq.to(dev), res[1], res[2], res[3], y.to(dev))
     lh.backward()
     assert abs(float(lh.detach()) - lo64) <= 1e-5 * abs(lo64)
-    with torch.no_grad():
-        emb = _with_eps(lambda: model(g, seq.to(dev), prop.to(dev), return_embedding=True), [eps], dev)[0]
+    with torch.no_grad():      # (the reference's StructureModel ignores return_embedding, ablation_models.py:160-180: the pooled graph embedding
+        emb = _with_eps(lambda: model._encode(g, seq.to(dev), prop.to(dev), need_attention=False), [eps], dev)["x_gat_node"]      # is read where it is formed)
     outs = {"final_output": res[3], "x_gat_node": emb}
     if seq_loss:
         outs.update({"mu": res[1], "logvar": res[2], "recon_x": res[0]})

@@ -13,7 +13,9 @@ raw = synthetic.make_batch(int(os.environ.get("B", 128)), seed=1)
 g = PackedGraphBatch.from_raw(raw, device=dev)
 layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(dev) for i in range(6)]
 lib = _lib.load()
-lib.is_debug_stamps_bwd.argtypes = [ctypes.c_void_p]; lib.is_debug_stamps_bwd.restype = ctypes.c_int
+from immunostruct_amd import functional as HF
+read_stamps = lib.is_debug_stamps_bwd8 if HF.BWD_PAIRED else lib.is_debug_stamps_bwd      # IMMUNOSTRUCT_BWD_PAIRED=0: the 256-thread kernel's stamps
+read_stamps.argtypes = [ctypes.c_void_p]; read_stamps.restype = ctypes.c_int
 h0 = g.ndata["x"][:, :20].contiguous(); x0 = g.ndata["x"][:, 20:].contiguous(); ea = g.edata["edge_attr"]
 bn = ["tile start", "rp+pdt staged, z loads issued", "S0", "E3", "barrier1", "WG1+MM3", "barrier2", "dz2,SA,E1", "barrier3", "WG2+MM4", "barrier4",
       "GEO(+barrier5)", "WG3+SEG(+barrier6)"]
@@ -28,7 +30,7 @@ for rep in range(4):
     ev1.record()
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 24)()
-    assert lib.is_debug_stamps_bwd(ctypes.cast(buf, ctypes.c_void_p)) == 0
+    assert read_stamps(ctypes.cast(buf, ctypes.c_void_p)) == 0
     t = list(buf)
     print(f"rep {rep}: backward of the stack {ev0.elapsed_time(ev1) * 1e3:.0f} us")
     print("  first tile:", " ".join(f"{bn[i]}:+{t[i] - t[i - 1]}" for i in range(1, 13)), " total", t[12] - t[0])
