@@ -305,8 +305,12 @@ class TrainStepWorkload:
         # form it timed at construction (serial; two-stage per number of reserved CUs), the standalone all-reduce time of every
         # bucket (all ranks call this: it holds collectives), and the RCCL channel bound in effect
         return dict(launch="hipGraph replay",
-                    grad_allreduce=dict(form="two-stage backward, bucket 0 overlapped" if c.two_stage else "serial",
-                                        reserved_cus=c.reserved if c.two_stage else None,
+                    grad_allreduce=dict(form=({"graph": "one graph: serial, collectives captured",
+                                               "graph2": "one graph: two-stage backward, bucket 0 overlapped, collectives captured"}[c.one_graph]
+                                              if c.one_graph else
+                                              ("two-stage backward, bucket 0 overlapped" if c.two_stage else "serial")),
+                                        one_graph_error=c.one_graph_error,
+                                        reserved_cus=c.reserved if (c.two_stage and not c.one_graph) else None,
                                         buckets=[int(b["flat"].numel()) for b in r.buckets], tuned_ms=c.dp_times,
                                         standalone_allreduce=D.time_all_reduce(r),
                                         nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"),

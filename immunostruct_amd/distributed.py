@@ -156,11 +156,12 @@ class FlatGradReducer:
         if srcs:
             torch._foreach_copy_(dsts, srcs)
 
-    def reduce_bucket(self, i, async_op=False):
-        """pack bucket i (unless the captured graph that produced the bound sources packed it itself: ``packed``), all-reduce
+    def reduce_bucket(self, i, async_op=False, prepacked=False):
+        """pack bucket i (unless the captured graph that produced the bound sources packed it itself: ``packed``; or the caller
+        just did: ``prepacked`` -- the one-graph forms, whose capture holds pack AND collective), all-reduce
         (SUM; divided by the world size here unless ``divide`` is off), re-point the gradients; returns the work handle"""
         b = self.buckets[i]
-        if not (b.get("packed") and b["sources"] is not None):
+        if not prepacked and not (b.get("packed") and b["sources"] is not None):
             self.pack(i)
         work = None
         if self._collective:

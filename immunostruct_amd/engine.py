@@ -35,6 +35,12 @@ _EARLY_PREPARE = os.environ.get("IMMUNOSTRUCT_ADAM_EARLY_PREPARE", "0") == "1"
 # data-parallel steps: the gradient buckets are packed by the captured graph that produced the gradients (its last nodes) instead of
 # by an eager multi-tensor copy between the replay and the collective (IMMUNOSTRUCT_DP_PACK_IN_GRAPH=0: the eager pack)
 _PACK_IN_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_PACK_IN_GRAPH", "1") != "0"
+# The data-parallel step as ONE captured graph (round 5): pack, the all-reduce(s) and the optimizer update are captured together with
+# forward and backward -- ProcessGroupNCCL's collectives are stream operations, so RCCL's kernels become nodes of the graph (the
+# asynchronous form forks onto the process group's stream and joins at ``work.wait()``): one replay per step, no graph boundaries, no
+# host-side wait.  "auto" (default): captured where the process group is "nccl", timed against the multi-graph forms, kept if
+# faster; "0": never; "1": forced (an error while capturing is kept in ``one_graph_error`` and the multi-graph forms run).
+_ONE_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_ONE_GRAPH", "auto")
 
 
 class StaticGraphBatch(PackedGraphBatch):
@@ -322,12 +328,82 @@ class CapturedTrainStep:
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, **_CAPTURE):
                     self.optimizer.step()
-        if len(self._forms) == 2:
+        self.one_graph = False
+        self.graph_c = {}
+        self.one_graph_error = None
+        if not self.fused_optimizer and _ONE_GRAPH != "0" and self._collectives_capturable():
+            self._capture_one_graph()
+        if len(self._forms) == 2 or (self.graph_c and _ONE_GRAPH == "auto"):
             self._choose_form(model, optimizer)
+        elif self.graph_c and _ONE_GRAPH == "1":
+            self._use_form("graph2" if "graph2" in self.graph_c and self.two_stage else next(iter(self.graph_c)))
         else:
             self._use_form(self.two_stage)
 
+    def _collectives_capturable(self):
+        """the reducer issues collectives on a backend whose collectives are stream operations (nccl = RCCL); gloo's run on the host"""
+        import torch.distributed as dist
+        if not getattr(self.reducer, "_collective", False) or not dist.is_initialized():
+            return False
+        return dist.get_backend() == "nccl"
+
+    def _capture_one_graph(self):
+        """graph_c["graph"]: forward, backward, pack, all-reduce of every bucket, update -- the serial form as one graph;
+        graph_c["graph2"] (when the model splits at the EGNN stack): stage 1, bucket 0 on the wire (asynchronous: a fork inside the
+        graph), stack backward beside it, bucket 1, join, update(s) -- the two-stage form as one graph.  A failure to capture (a
+        stack that cannot capture its collectives) is recorded verbatim and leaves the multi-graph forms in charge."""
+        red = self.reducer
+        saved = red.sources()
+        try:
+            forms = {}
+            graph = torch.cuda.CUDAGraph()
+            split = self._split_update()      # (the update in the parts the eager warm-up steps ran it in: their chunk tables exist)
+            with torch.cuda.graph(graph, **_CAPTURE):
+                loss = self._fwd_bwd()
+                for i in range(len(red.buckets)):
+                    red.pack(i, from_grad=True)
+                    red.reduce_bucket(i, prepacked=True)
+                    if split:
+                        self.optimizer.step_subset(red.buckets[i]["params"], first=i == 0)
+                if not split:
+                    self.optimizer.step()
+            forms["graph"] = (graph, loss)
+            if self._forms.get(True) is not None and self._late is not None and len(red.buckets) == 2:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, **_CAPTURE):
+                    loss = self._stage1()
+                    red.pack(0, from_grad=True)
+                    work0 = red.reduce_bucket(0, async_op=True, prepacked=True)
+                    self._stage2()
+                    red.pack(1, from_grad=True)
+                    work1 = red.reduce_bucket(1, async_op=True, prepacked=True)
+                    if self._split_update():
+                        if work0 is not None:
+                            work0.wait()
+                        self.optimizer.step_subset(red.buckets[0]["params"], first=True)
+                        if work1 is not None:
+                            work1.wait()
+                        self.optimizer.step_subset(red.buckets[1]["params"], first=False)
+                    else:
+                        for w in (work0, work1):
+                            if w is not None:
+                                w.wait()
+                        self.optimizer.step()
+                forms["graph2"] = (graph, loss)
+            self.graph_c = forms
+        except Exception as exc:      # noqa: BLE001 -- whatever the stack raises is the finding
+            self.one_graph_error = f"{type(exc).__name__}: {exc}"
+            self.graph_c = {}
+            torch.cuda.synchronize()
+        finally:
+            red.sources(saved)
+
     def _use_form(self, two_stage, reserved=None):
+        if isinstance(two_stage, str):      # a one-graph form
+            self.one_graph = two_stage
+            self.loss = self.graph_c[two_stage][1]
+            return
+        self.one_graph = False
         self.two_stage = two_stage
         if two_stage and reserved is not None:
             self.reserved = reserved
@@ -343,7 +419,8 @@ class CapturedTrainStep:
         import torch.distributed as dist
         multi = dist.is_initialized() and dist.get_world_size() > 1
         snap = _snapshot(model, optimizer)
-        cands = [(True, r) for r in self._reserved_candidates] + [(False, None)]
+        cands = ([(True, r) for r in self._reserved_candidates] if True in self._forms else []) + \
+                ([(False, None)] if False in self._forms else []) + [(k, None) for k in self.graph_c]
         times = []
         for form, res in cands:
             self._use_form(form, res)
@@ -360,14 +437,14 @@ class CapturedTrainStep:
         if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
         t = [1e3 * v / steps for v in t.tolist()]
-        best = min(range(len(cands) - 1), key=lambda i: t[i])
-        self.dp_times = {"two_stage_ms": t[best], "serial_ms": t[-1],
-                         "two_stage_ms_by_reserved_cus": {str(r): t[i] for i, (_, r) in enumerate(cands[:-1])}}
+        two = [i for i, (f, _) in enumerate(cands) if f is True]
+        ser = [i for i, (f, _) in enumerate(cands) if f is False]
+        self.dp_times = {"two_stage_ms": min((t[i] for i in two), default=None), "serial_ms": t[ser[0]] if ser else None,
+                         "two_stage_ms_by_reserved_cus": {str(cands[i][1]): t[i] for i in two},
+                         "one_graph_ms": {cands[i][0]: t[i] for i in range(len(cands)) if isinstance(cands[i][0], str)}}
         _restore(model, optimizer, snap)
-        if t[best] < t[-1]:
-            self._use_form(True, cands[best][1])
-        else:
-            self._use_form(False)
+        best = min(range(len(cands)), key=lambda i: t[i])
+        self._use_form(*cands[best])
 
     def _load(self, g, seq, prop, y):
         rand = self._rand.pairs() if self._rand is not None else []      # the prefetched random tensors ride on the same launch
@@ -593,7 +670,9 @@ class CapturedTrainStep:
         self._refresh_random()
         def update(i):
             (self.graph_b if i is None else self.graph_b[i]).replay()
-        if self.two_stage:
+        if self.one_graph:
+            self.graph_c[self.one_graph][0].replay()      # forward ... collectives ... update: one graph
+        elif self.two_stage:
             self.graph_a1.replay()
             # bucket 0 is in flight while graph A2 runs the stack backward
             self._reduce_and_update(self.graph_a2.replay, update)

@@ -87,8 +87,12 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(out, src) and torch.equal(red, src)
 
-    for mode in ("1", "0", "auto"):
-        os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = mode
+    from immunostruct_amd import engine
+    for mode in ("1", "0", "auto", "graph", "graph2", "graph-auto"):
+        # "graph" / "graph2": the step as ONE captured graph with RCCL's collectives inside (serial / two-stage), forced;
+        # "graph-auto": every form captured and timed, the fastest kept.  The first three: the multi-graph forms alone
+        engine._ONE_GRAPH = {"graph": "1", "graph2": "1", "graph-auto": "auto"}.get(mode, "0")
+        os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = {"graph": "0", "graph2": "1", "graph-auto": "auto"}.get(mode, mode)
         model = copy.deepcopy(start)
         model.train()
         opt = optim.Adam(model.parameters(), lr=LR)
@@ -113,14 +117,20 @@ def main():
             torch.cuda.synchronize()
         per_step = [(b - a) / steps for a, b in zip(before, (cnt.calls, cnt.async_calls, cnt.waits))]
         nb = len(reducer.buckets)
-        assert per_step[0] == nb, f"{per_step[0]} collectives per replayed step, {nb} buckets"
-        if cap.two_stage or cap._split_update():
-            assert per_step[1] >= 1 and per_step[2] == per_step[1], f"async collectives {per_step[1]}, waits {per_step[2]} per step"
+        if mode in ("graph", "graph2"):
+            assert cap.one_graph_error is None, f"the collectives could not be captured: {cap.one_graph_error}"
+            assert cap.one_graph == mode, (cap.one_graph, sorted(cap.graph_c))
+        if cap.one_graph:
+            assert per_step[0] == 0, f"{per_step[0]} collectives issued from the host per replayed one-graph step"
+        else:
+            assert per_step[0] == nb, f"{per_step[0]} collectives per replayed step, {nb} buckets"
+            if cap.two_stage or cap._split_update():
+                assert per_step[1] >= 1 and per_step[2] == per_step[1], f"async collectives {per_step[1]}, waits {per_step[2]} per step"
         worst = compare(model, ref, f"captured data-parallel step (IMMUNOSTRUCT_DP_OVERLAP={mode}) under a 1-rank RCCL group vs eager",
                         2e-2 * LR * steps)
         timing = D.time_all_reduce(reducer)
         assert timing is not None and len(timing) == nb and all(t["ms"] > 0 for t in timing)
-        print(f"mode {mode}: form {'two-stage' if cap.two_stage else 'serial'}, buckets {[int(b['flat'].numel()) for b in reducer.buckets]}, "
+        print(f"mode {mode}: form {cap.one_graph or ('two-stage' if cap.two_stage else 'serial')}, one-graph error {cap.one_graph_error}, buckets {[int(b['flat'].numel()) for b in reducer.buckets]}, "
               f"collectives/step {per_step[0]:.0f} (async {per_step[1]:.0f}, waits {per_step[2]:.0f}), max parameter difference {worst:.3e}, "
               f"standalone all-reduce {timing}, tuned {cap.dp_times}", flush=True)
         del cap
