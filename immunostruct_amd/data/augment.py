@@ -27,7 +27,7 @@ from ..graph import PackedGraphBatch
 from .utils import AMINO_ACIDS, RandomRotation, collate
 
 __all__ = ["SplitDataset", "ExtendedDataset", "collate_amino_acid", "mask_single_structure", "mask_single_structure_pair",
-           "mask_structure", "mask_sequence", "augment_batch_on_device", "augment_pair_on_device", "mask_sequence_on_device"]
+           "mask_structure", "mask_sequence", "mask_sequence_pair", "augment_batch_on_device", "augment_pair_on_device", "mask_sequence_on_device"]
 
 N_AA = len(AMINO_ACIDS)
 PAD_INDEX = N_AA            # 'J', the last symbol of the 21-letter alphabet
@@ -89,6 +89,17 @@ def mask_sequence(full, peptide, count):
     return full
 
 
+def mask_sequence_pair(full, full_wt, peptide, count):
+    """the pair form: the SAME ``count`` random positions of both sequences become the padding symbol"""
+    assert len(full) == len(full_wt)
+    pad = torch.zeros(full.shape[1], dtype=full.dtype)
+    pad[PAD_INDEX] = 1
+    for pos in random.sample(range(len(full) - len(peptide)), count):
+        full[pos] = pad
+        full_wt[pos] = pad
+    return full, full_wt
+
+
 class SplitDataset:
     """``dataset[idx]`` -> ``(graph, sequence, target, property)`` or the same with (cancer, wild-type) pairs;
     ``peptide_length`` tells ``mask_sequence`` how many trailing positions belong to the peptide; ``full`` = False: the
@@ -134,7 +145,10 @@ class SplitDataset:
                 if not self.comparative:
                     sequence = mask_sequence(sequence.clone(), sequence[tail], self.sequence_pad_count)
                 else:
-                    sequence = tuple(mask_sequence(s.clone(), s[tail], self.sequence_pad_count) for s in sequence)
+                    # ONE draw of positions for the pair: ImmunoPredDatasetComparative.mask_sequence pads ``full`` and ``full_wt`` at
+                    # the same places (data/immmunopred_dataloader.py:216-231; found by the round-5 pin against that code -- rounds
+                    # 1 - 4 drew twice here, the device form always drew once)
+                    sequence = mask_sequence_pair(sequence[0].clone(), sequence[1].clone(), sequence[0][tail], self.sequence_pad_count)
         if self.return_amino_acid:
             return updated, sequence, target, prop, (amino if self.split == "train" else torch.tensor([0]))
         return graph, sequence, target, prop          # the reference returns the ORIGINAL graph here
@@ -170,47 +184,58 @@ def _random_orthogonal(batch, device, generator):
     return torch.stack([q1, q2, q3], dim=2)
 
 
-def augment_batch_on_device(x, batch_size, generator=None, rotate=True, mask_single=True, structure_pad_count=0):
+def augment_batch_on_device(x, batch_size, generator=None, rotate=True, mask_single=True, structure_pad_count=0, picks=None):
     """In place on the node-feature buffer ``x`` ((batch_size * n) x (20 + 3)) of an assembled batch: per-graph random
     orthogonal transform of the coordinates, one masked real residue per graph (all-ones one-hot), ``structure_pad_count``
     blanked residues per graph.  Returns the masked residues' types (int64, one per graph; 0 for a graph with no real
-    residue, which is left unmasked -- the reference's fallback)."""
+    residue, which is left unmasked -- the reference's fallback).
+    ``picks`` (tests): the random choices given instead of drawn -- ``rotation`` (b, 3, 3), ``node`` (b,), ``pad_nodes`` (b, k) --
+    so that the RULES can be checked against what the reference's loader produced from its own picks (tests/golden/augment.npz)."""
     b = int(batch_size)
+    picks = picks or {}
     feats = x.view(b, x.shape[0] // b, x.shape[1])
     n = feats.shape[1]
     rows = torch.arange(b, device=x.device)
     if rotate:
-        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], _random_orthogonal(b, x.device, generator))
+        rot = picks["rotation"].to(x) if "rotation" in picks else _random_orthogonal(b, x.device, generator)
+        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], rot)
     onehot = feats[:, :, :-3]
     amino = torch.zeros(b, dtype=torch.int64, device=x.device)
     if mask_single:
         valid = onehot.sum(-1) > 0
-        score = torch.rand(b, n, device=x.device, generator=generator).masked_fill(~valid, -1.0)
-        node = score.argmax(1)
+        if "node" in picks:
+            node = picks["node"].to(x.device)
+        else:
+            score = torch.rand(b, n, device=x.device, generator=generator).masked_fill(~valid, -1.0)
+            node = score.argmax(1)
         picked = onehot[rows, node]
         found = valid.any(1)
         amino = torch.where(found, picked.argmax(1), amino)
         onehot[rows, node] = torch.where(found[:, None], torch.ones_like(picked), picked)
     if structure_pad_count > 0:
-        nodes = torch.rand(b, n, device=x.device, generator=generator).topk(structure_pad_count, dim=1).indices
+        nodes = (picks["pad_nodes"].to(x.device) if "pad_nodes" in picks
+                 else torch.rand(b, n, device=x.device, generator=generator).topk(structure_pad_count, dim=1).indices)
         r = rows[:, None].expand_as(nodes)
         keep = (onehot[r, nodes].sum(-1, keepdim=True) > 1).to(x.dtype)      # the self-supervision node stays
         onehot[r, nodes] = onehot[r, nodes] * keep
     return amino
 
 
-def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=True, structure_pad_count=0):
+def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=True, structure_pad_count=0, picks=None):
     """In place on the node-feature buffer ``x2`` ((2 * pairs * n) x (20 + 3)) of a merged (cancer; wild-type) batch: an
     independent random orthogonal transform per graph, ONE masked residue per pair member chosen as the reference does
     (``data/immmunopred_dataloader.py:253-271``: a uniformly random real residue of the cancer graph among those whose type
     also occurs in the wild-type graph, and a uniformly random wild-type residue of that type), ``structure_pad_count``
-    blanked residues per graph.  Returns the masked type per pair (int64; 0 for a pair without a common type, left unmasked)."""
+    blanked residues per graph.  Returns the masked type per pair (int64; 0 for a pair without a common type, left unmasked).
+    ``picks`` (tests): ``rotation`` (2b, 3, 3), ``node_c`` / ``node_w`` (b,), ``pad_nodes`` (2b, k) given instead of drawn."""
     b = int(pairs)
+    picks = picks or {}
     feats = x2.view(2 * b, x2.shape[0] // (2 * b), x2.shape[1])
     n = feats.shape[1]
     dev = x2.device
     if rotate:
-        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], _random_orthogonal(2 * b, dev, generator))
+        rot = picks["rotation"].to(x2) if "rotation" in picks else _random_orthogonal(2 * b, dev, generator)
+        feats[:, :, -3:] = torch.bmm(feats[:, :, -3:], rot)
     onehot = feats[:, :, :-3]
     oc, ow = onehot[:b], onehot[b:]                                  # views: writes go to the buffer
     rows = torch.arange(b, device=dev)
@@ -220,13 +245,19 @@ def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=T
         type_c = oc.argmax(-1)                                         # (b, n)
         present_w = (ow.sum(1) > 0) & True                             # (b, 20): types that occur in the wild-type graph
         ok = real_c & torch.gather(present_w, 1, type_c)               # cancer nodes with a partner
-        score = torch.rand(b, n, device=dev, generator=generator).masked_fill(~ok, -1.0)
-        node_c = score.argmax(1)
+        if "node_c" in picks:
+            node_c = picks["node_c"].to(dev)
+        else:
+            score = torch.rand(b, n, device=dev, generator=generator).masked_fill(~ok, -1.0)
+            node_c = score.argmax(1)
         found = ok.any(1)
         t = type_c[rows, node_c]
         same = (ow[rows, :, t] > 0) & (ow.sum(-1) == 1)                # wild-type nodes of that type
-        score_w = torch.rand(b, n, device=dev, generator=generator).masked_fill(~same, -1.0)
-        node_w = score_w.argmax(1)
+        if "node_w" in picks:
+            node_w = picks["node_w"].to(dev)
+        else:
+            score_w = torch.rand(b, n, device=dev, generator=generator).masked_fill(~same, -1.0)
+            node_w = score_w.argmax(1)
         found = found & same.any(1)
         amino = torch.where(found, t, amino)
         pc, pw = oc[rows, node_c], ow[rows, node_w]
@@ -234,14 +265,15 @@ def augment_pair_on_device(x2, pairs, generator=None, rotate=True, mask_single=T
         ow[rows, node_w] = torch.where(found[:, None], torch.ones_like(pw), pw)
     if structure_pad_count > 0:
         rows2 = torch.arange(2 * b, device=dev)
-        nodes = torch.rand(2 * b, n, device=dev, generator=generator).topk(structure_pad_count, dim=1).indices
+        nodes = (picks["pad_nodes"].to(dev) if "pad_nodes" in picks
+                 else torch.rand(2 * b, n, device=dev, generator=generator).topk(structure_pad_count, dim=1).indices)
         r = rows2[:, None].expand_as(nodes)
         keep = (onehot[r, nodes].sum(-1, keepdim=True) > 1).to(x2.dtype)      # the self-supervision node stays
         onehot[r, nodes] = onehot[r, nodes] * keep
     return amino
 
 
-def mask_sequence_on_device(seq, count, peptide_length=11, generator=None, pairs=False):
+def mask_sequence_on_device(seq, count, peptide_length=11, generator=None, pairs=False, positions=None):
     """In place on the one-hot sequences ``seq`` (B x L x 21): ``count`` random non-peptide positions -> padding symbol.
     ``pairs``: ``seq`` is a merged ``[cancer; wild-type]`` batch of 2b rows and rows i and b + i get the SAME positions, as
     ``ImmunoPredDatasetComparative.mask_sequence`` pads ``full`` and ``full_wt`` (``data/immmunopred_dataloader.py:216-231``)"""
@@ -251,9 +283,11 @@ def mask_sequence_on_device(seq, count, peptide_length=11, generator=None, pairs
     if pairs:
         if b % 2:
             raise ValueError("a merged pair batch has an even number of rows")
-        pos = torch.rand(b // 2, length, device=seq.device, generator=generator).topk(count, dim=1).indices.repeat(2, 1)
+        pos = (positions.to(seq.device) if positions is not None      # (tests: (b / 2, count) positions given instead of drawn)
+               else torch.rand(b // 2, length, device=seq.device, generator=generator).topk(count, dim=1).indices).repeat(2, 1)
     else:
-        pos = torch.rand(b, length, device=seq.device, generator=generator).topk(count, dim=1).indices
+        pos = (positions.to(seq.device) if positions is not None
+               else torch.rand(b, length, device=seq.device, generator=generator).topk(count, dim=1).indices)
     r = torch.arange(b, device=seq.device)[:, None].expand_as(pos)
     seq[r, pos] = torch.nn.functional.one_hot(torch.tensor(PAD_INDEX, device=seq.device), seq.shape[2]).to(seq.dtype)
     return seq

@@ -162,3 +162,86 @@ def test_augment_pair_on_device_rules():
             d1 = torch.cdist(f1[g, rows, -3:], f1[g, rows, -3:], compute_mode="donot_use_mm_for_euclid_dist")
             assert torch.allclose(d0, d1, atol=2e-3)
             assert int(((f0[g, :, :-3].sum(1) == 1) & (f1[g, :, :-3].sum(1) == 0)).sum()) <= 2
+
+
+# ---- the reference's own loader outputs (tests/golden/augment.npz, oracle/make_golden_augment.py): the pin that travels ----
+def _golden_augment():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment.npz"))
+
+
+def _item_seed(kind, idx):
+    return 1000 * (1 if kind == "single" else 2) + idx
+
+
+def test_host_forms_reproduce_the_reference_loader_golden():
+    """``SplitDataset`` (train split, ``return_amino_acid``, 7 blanked residues, 9 padded positions) seeded like the reference run
+    that wrote the golden: identical graphs, sequences and amino-acid labels, single items and pairs"""
+    gold = _golden_augment()
+    spc, qpc, pep = int(gold["structure_pads"]), int(gold["sequence_pads"]), int(gold["peptide"])
+    ds = D.SyntheticImmunoDataset(int(gold["single_n"]), seed=int(gold["single_seed"]))
+    split = A.SplitDataset(ds, "train", return_amino_acid=True, structure_pad_count=spc, sequence_pad_count=qpc, peptide_length=pep)
+    for idx in range(len(ds)):
+        random.seed(_item_seed("single", idx)); np.random.seed(_item_seed("single", idx))
+        g, seq, _, _, amino = split[idx]
+        assert np.array_equal(g.ndata["x"].numpy(), gold[f"single/{idx}/x"]) and np.array_equal(seq.numpy(), gold[f"single/{idx}/seq"])
+        assert np.array_equal(amino.numpy(), gold[f"single/{idx}/amino"])
+    dp = D.SyntheticPairedDataset(int(gold["paired_n"]), seed=int(gold["paired_seed"]))
+    split = A.SplitDataset(dp, "train", comparative=True, return_amino_acid=True, structure_pad_count=spc, sequence_pad_count=qpc,
+                           peptide_length=pep)
+    for idx in range(len(dp)):
+        random.seed(_item_seed("paired", idx)); np.random.seed(_item_seed("paired", idx))
+        graphs, seqs, _, _, amino = split[idx]
+        for k in (0, 1):
+            assert np.array_equal(graphs[k].ndata["x"].numpy(), gold[f"paired/{idx}/{k}/x"]), (idx, k)
+            assert np.array_equal(seqs[k].numpy(), gold[f"paired/{idx}/{k}/seq"]), (idx, k)
+        assert np.array_equal(amino.numpy(), gold[f"paired/{idx}/amino"])
+
+
+def _device_forms_against_golden(dev):
+    gold = _golden_augment()
+    spc, qpc, pep = int(gold["structure_pads"]), int(gold["sequence_pads"]), int(gold["peptide"])
+    ds = D.SyntheticImmunoDataset(int(gold["single_n"]), seed=int(gold["single_seed"]))
+    b = len(ds)
+    x = torch.cat([ds[i][0].ndata["x"] for i in range(b)]).to(dev)
+    seq = torch.stack([ds[i][1] for i in range(b)]).to(dev)
+    T = lambda key, dt: torch.as_tensor(np.stack([gold[f"single/{i}/{key}"] for i in range(b)])).to(dt)
+    amino = A.augment_batch_on_device(x, b, structure_pad_count=spc,
+                                      picks=dict(rotation=T("rotation", torch.float32)[:, 0], node=T("node", torch.int64), pad_nodes=T("pad_nodes", torch.int64)))
+    A.mask_sequence_on_device(seq, qpc, peptide_length=pep, positions=T("positions", torch.int64))
+    want = T("x", torch.float32).reshape(-1, x.shape[1])
+    assert torch.equal(x[:, :-3].cpu(), want[:, :-3]), "one-hot part: masked / blanked residues"
+    assert float((x[:, -3:].cpu() - want[:, -3:]).abs().max()) <= 2e-5 * float(want[:, -3:].abs().max()), "rotated coordinates (fp32 vs the reference's fp64 product)"
+    assert torch.equal(amino.cpu(), T("amino", torch.int64).flatten())
+    assert torch.equal(seq.cpu(), T("seq", torch.float32))
+    # pairs: the merged [cancer; wild-type] batch
+    dp = D.SyntheticPairedDataset(int(gold["paired_n"]), seed=int(gold["paired_seed"]))
+    b = len(dp)
+    P = lambda key, k, dt: torch.as_tensor(np.stack([gold[f"paired/{i}/{k}/{key}"] for i in range(b)])).to(dt)
+    x2 = torch.cat([dp[i][0][k].ndata["x"] for k in (0, 1) for i in range(b)]).to(dev)
+    seq2 = torch.cat([torch.stack([dp[i][1][k] for i in range(b)]) for k in (0, 1)]).to(dev)
+    picks = dict(rotation=torch.cat([P("rotation", 0, torch.float32), P("rotation", 1, torch.float32)]),
+                 node_c=P("node", 0, torch.int64), node_w=P("node", 1, torch.int64),
+                 pad_nodes=torch.cat([P("pad_nodes", 0, torch.int64), P("pad_nodes", 1, torch.int64)]))
+    amino = A.augment_pair_on_device(x2, b, structure_pad_count=spc, picks=picks)
+    pos = torch.as_tensor(np.stack([gold[f"paired/{i}/positions"] for i in range(b)]))
+    A.mask_sequence_on_device(seq2, qpc, peptide_length=pep, pairs=True, positions=pos)
+    want = torch.cat([P("x", 0, torch.float32), P("x", 1, torch.float32)]).reshape(-1, x2.shape[1])
+    assert torch.equal(x2[:, :-3].cpu(), want[:, :-3]), "pairs: one-hot part"
+    assert float((x2[:, -3:].cpu() - want[:, -3:]).abs().max()) <= 2e-5 * float(want[:, -3:].abs().max())
+    assert torch.equal(amino.cpu(), torch.as_tensor(np.stack([gold[f"paired/{i}/amino"] for i in range(b)])).flatten())
+    assert torch.equal(seq2.cpu(), torch.cat([P("seq", 0, torch.float32), P("seq", 1, torch.float32)]))
+
+
+def test_device_forms_apply_the_reference_rules_to_the_reference_picks():
+    """the whole-batch forms draw differently by construction; given the picks the reference's loader made (rotation, self-supervision
+    node, blanked nodes, padded positions) they must produce what it produced"""
+    _device_forms_against_golden(torch.device("cpu"))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_device_forms_on_the_gpu_box_against_the_reference_golden(cuda_device):
+    _device_forms_against_golden(cuda_device)
