@@ -347,6 +347,7 @@ class IedbWorkload(TrainStepWorkload):
         if self.finetune:
             return self.losses.BCE_loss(recon, seq, mu, logvar, final, y)
         return self.losses.regression_loss(recon, seq, mu, logvar, final, y)
+    forward_loss.fused_loss = True      # (utils.Losses only: engine.CapturedTrainStep may let the head join the sequence branch early)
 
     def batch(self, i):
         b = self.pool[i % len(self.pool)]
@@ -504,6 +505,7 @@ class PairedWorkload(TrainStepWorkload):
     def forward_loss(self, m, g2, seq2, prop2, y2):
         return self._paired_loss(m, self.losses.BCE_loss, (g2, seq2, y2[:y2.numel() // 2], prop2), self.dev, self.contrastive,
                                  self.coeff)
+    forward_loss.fused_loss = True
 
     def batch(self, i):
         b = self.pool[i % len(self.pool)]

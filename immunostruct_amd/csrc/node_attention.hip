@@ -1052,10 +1052,18 @@ extern "C" long long is_attn_colmean_probs_floats(int B, int n, int heads) {
     else hipLaunchKernelGGL((is::attn16_bwd_kernel<12>), dim3(B), dim3(768), 0, st, __VA_ARGS__);                            \
   } while (0)
 namespace is {
-inline bool attn16_applies(int n, int heads) {
-  const char* e = getenv("IMMUNOSTRUCT_ATTN_TILES");      // "32": the 32-row-block kernels everywhere (A/B, tests)
-  return heads == 1 && n <= 192 && !(e != nullptr && atoi(e) == 32);
+// IMMUNOSTRUCT_ATTN_TILES=32: the 32-row-block kernels everywhere (A/B runs, tests).  Read ONCE per process: a forward and its
+// backward pick the layout of the saved probabilities independently (16- or 32-row tiles, same buffer size), so a value that
+// changed between the two -- or between the capture of a forward and its replay -- would make the backward read the other layout
+// and return wrong gradients without an error.  A/B runs select the kernels per process.
+inline bool attn16_forced_off() {
+  static const bool off = [] {
+    const char* e = getenv("IMMUNOSTRUCT_ATTN_TILES");
+    return e != nullptr && atoi(e) == 32;
+  }();
+  return off;
 }
+inline bool attn16_applies(int n, int heads) { return heads == 1 && n <= 192 && !attn16_forced_off(); }
 }
 
 extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,

@@ -115,19 +115,23 @@ class FlatGradReducer:
         for p in self.params:
             p.grad = None
 
-    def bind_sources(self, bucket=None):
+    def bind_sources(self, bucket=None, packed=False):
         """Remember the CURRENT .grad tensors as the pack sources (used with captured graphs, where the
-        backward always writes the same buffers while ``.grad`` is re-pointed at the bucket)."""
+        backward always writes the same buffers while ``.grad`` is re-pointed at the bucket).  ``packed``: the graph that wrote
+        them packs the bucket itself (its last nodes) -- the bit belongs to THESE sources: binding others resets it, so that
+        :meth:`reduce_bucket` never skips the pack for gradients of a graph that did not pack."""
         for i, b in enumerate(self.buckets):
             if bucket is None or bucket == i:
                 b["sources"] = [p.grad for p in b["params"]]
+                b["packed"] = bool(packed)
 
     def sources(self, value=None):
-        """get (a copy of) / set the bound pack sources of all buckets -- the engine switches between captured forms"""
+        """get (a copy of) / set the bound pack sources of all buckets, each WITH its packed bit: [(sources, packed), ...] -- the
+        engine switches between captured forms"""
         if value is None:
-            return [list(b["sources"]) if b["sources"] is not None else None for b in self.buckets]
+            return [(list(b["sources"]) if b["sources"] is not None else None, bool(b.get("packed"))) for b in self.buckets]
         for b, v in zip(self.buckets, value):
-            b["sources"] = v
+            b["sources"], b["packed"] = (v if isinstance(v, tuple) else (v, False))
 
     @contextlib.contextmanager
     def live_gradients(self):
@@ -135,7 +139,7 @@ class FlatGradReducer:
         eager backward produces, not from the captured graph's gradient buffers the sources are bound to"""
         saved = self.sources()
         for b in self.buckets:
-            b["sources"] = None
+            b["sources"], b["packed"] = None, False
         try:
             yield self
         finally:

@@ -172,7 +172,8 @@ class CapturedTrainStep:
     (cancer, wild-type) pairs: ``forward_loss`` then receives pairs of static buffers).
 
     ``forward_loss(model, graph, seq, prop, y) -> scalar loss`` defines the step body (so the same
-    engine serves the regression / BCE / comparative stages).  Construction runs ``warmup`` (>= 1) REAL
+    engine serves the regression / BCE / comparative stages).  Set ``forward_loss.fused_loss = True`` when the loss reads the
+    reconstruction through ``utils.Losses`` only (every in-tree step does): the head then joins the sequence branch early.  Construction runs ``warmup`` (>= 1) REAL
     eager train steps on the template batch (they update the model like any other step), then captures.
     """
 
@@ -183,6 +184,10 @@ class CapturedTrainStep:
                              "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
         g, seq, prop, y = template
         self.model, self.optimizer, self.reducer, self.forward_loss = model, optimizer, reducer, forward_loss
+        # ``forward_loss.fused_loss = True``: the caller's promise that the loss reads the reconstruction through ``utils.Losses`` /
+        # ``functional.vae_loss`` only -- the models may then join the sequence branch at the latent (functional.SpeculativeBackward).
+        # A ``forward_loss`` without it (say, ``F.mse_loss`` on ``recon_x``) gets the full join: 1.7 % slower, never a missing edge
+        self._fused_loss = bool(getattr(forward_loss, "fused_loss", False))
         # paired (cancer, wild-type) batches: graph / sequence / property are 2-tuples, one static buffer set per member
         self.paired = isinstance(g, (tuple, list))
         if self.paired:
@@ -195,9 +200,11 @@ class CapturedTrainStep:
             self.sgraph = StaticGraphBatch(g, edge_capacity)
             self.seq, self.prop = torch.zeros_like(seq), torch.zeros_like(prop)
         self.y = torch.zeros_like(y)
-        # step_random (functional.StepRandom): where the step's dropout masks and reparameterisation noise come from.  None: the
+        # step_random (functional.StepRandom): where the step's dropout masks and reparameterisation noise come from.  None (this
+        # constructor's default; the device-resident training loops of ``procedures`` and ``bench.py`` pass "device"): the
         # models draw them inside the step with torch's generator (every replay of a graph that does launches two generator-state
-        # fills in front of it).  "device": one launch of the library's own generator inside the step (is_step_random).
+        # fills in front of it).  "device": one launch of the library's own generator inside the step (is_step_random); its key
+        # differs per engine of a process, ``random_state()`` / ``load_random_state()`` carry it across a checkpoint.
         # "prefetch": torch's generator, one step ahead, outside the captured step, handed over with the batch (same values as
         # eager steps draw; measured slower: the helper stream's launches disturb the persistent layer kernels).  Off by
         # default: a ``forward_loss`` that patches the draws (tests with fixed noise) would be bypassed
@@ -270,8 +277,7 @@ class CapturedTrainStep:
                 if _PACK_IN_GRAPH:
                     self.reducer.pack(0, from_grad=True)      # the bucket's pack as the graph's last node: no eager launch behind the replay
             # a graph always writes the gradient buffers it allocated while capturing: pack from those
-            self.reducer.bind_sources(0)
-            self.reducer.buckets[0]["packed"] = _PACK_IN_GRAPH
+            self.reducer.bind_sources(0, packed=_PACK_IN_GRAPH)
             self.reducer.reduce_bucket(0)         # .grad of the first bucket now aliases its persistent flat buffer
             bnd, bnd_grads = self._bnd, self._bnd_grads
             for res in self._reserved_candidates:
@@ -286,8 +292,7 @@ class CapturedTrainStep:
                             self.reducer.pack(1, from_grad=True)
                 finally:
                     HF.RESERVED_CUS = saved
-                self.reducer.bind_sources(1)
-                self.reducer.buckets[1]["packed"] = _PACK_IN_GRAPH
+                self.reducer.bind_sources(1, packed=_PACK_IN_GRAPH)
                 self.reducer.reduce_bucket(1)
                 self._a2[res] = (graph, self.reducer.sources())
             self.graph_a2, sources = self._a2[self.reserved]
@@ -309,9 +314,7 @@ class CapturedTrainStep:
             if dump:
                 self.graph_a.debug_dump(dump)
             if not self.fused_optimizer:
-                self.reducer.bind_sources()
-                for b in self.reducer.buckets:
-                    b["packed"] = _PACK_IN_GRAPH
+                self.reducer.bind_sources(packed=_PACK_IN_GRAPH)
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
             self._forms[False] = (loss, self.reducer.sources())
         if not self.fused_optimizer:
@@ -398,6 +401,14 @@ class CapturedTrainStep:
         finally:
             red.sources(saved)
 
+    def random_state(self):
+        """the state of the step's random-tensor provider (None without one): save it beside the optimizer state to resume a run"""
+        return self._rand.state_dict() if self._rand is not None else None
+
+    def load_random_state(self, sd):
+        if self._rand is not None and sd is not None:
+            self._rand.load_state_dict(sd)
+
     def _use_form(self, two_stage, reserved=None):
         if isinstance(two_stage, str):      # a one-graph form
             self.one_graph = two_stage
@@ -474,7 +485,7 @@ class CapturedTrainStep:
         if overlap and self._tail_late is None:
             HF.StackBoundary.begin()
         try:
-            with SpeculativeBackward(), HF.StepRandom.use(self._rand):      # the backward below is seeded with the unit gradient
+            with SpeculativeBackward(self._fused_loss), HF.StepRandom.use(self._rand):      # the backward below is seeded with the unit gradient
                 loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         finally:
             bnd = HF.StackBoundary.end() if (overlap and self._tail_late is None) else None
@@ -573,7 +584,7 @@ class CapturedTrainStep:
         self.reducer.zero()
         HF.StackBoundary.begin()
         try:
-            with HF.SpeculativeBackward(), HF.StepRandom.use(self._rand):
+            with HF.SpeculativeBackward(self._fused_loss), HF.StepRandom.use(self._rand):
                 loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         finally:
             bnd = HF.StackBoundary.end()

@@ -1207,21 +1207,42 @@ class StepRandom:
     engine draws the next step's values on a helper stream while the current step runs (:meth:`prefetch`) and hands them over
     with the batch (:meth:`pairs`, the same ``is_multi_copy`` launch)."""
     active = None
+    _created = 0      # providers of mode "device" created in this process: each gets its own Philox key
 
-    def __init__(self, device, mode="prefetch"):
+    def __init__(self, device, mode="prefetch", stream_id=None):
         """``mode`` "prefetch": as above.  "device": the step's tensors come from ONE launch of the library's own generator
         (``is_step_random``: Philox4x32-10 on a device-resident state seeded from ``torch.cuda.initial_seed()``) issued inside the step at
         its first draw -- no helper stream, nothing outside the captured graph, one launch instead of three; the values are not
-        torch's streams (same distributions; reproducible for a given seed)."""
+        torch's streams (same distributions; reproducible for a given seed).
+        ``stream_id`` (mode "device"): mixed into the key, default = the number of providers created before this one -- the engines
+        of a run's stages (pretrain, finetune: one ``CapturedTrainStep`` each, same device seed) then draw DIFFERENT mask / noise
+        sequences instead of replaying the first stage's; the creation order of a seeded run is fixed, so the run
+        stays reproducible.  :meth:`state_dict` / :meth:`load_state_dict` carry key and step counter across a checkpoint."""
         if mode not in ("prefetch", "device"):
             raise ValueError("StepRandom mode must be 'prefetch' or 'device'")
         self.mode = mode
         self.slots, self.cursor = [], 0
         self.pending = self.ready = self._keep = None
         if mode == "device":
-            self.state = torch.tensor([torch.cuda.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+            if stream_id is None:
+                stream_id = StepRandom._created
+            StepRandom._created += 1
+            key = (torch.cuda.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id)) & 0x7FFFFFFFFFFFFFFF
+            self.state = torch.tensor([key, 0, 0], dtype=torch.int64, device=device)
         else:
             self.stream = torch.cuda.Stream(device=device)
+
+    def state_dict(self):
+        """mode "device": the generator's key and step counter (host copies) -- what a resumed run needs to continue the sequence"""
+        if self.mode != "device":
+            return {"mode": self.mode}
+        return {"mode": "device", "state": [int(v) for v in self.state.tolist()]}
+
+    def load_state_dict(self, sd):
+        if sd.get("mode") != self.mode:
+            raise ValueError(f"StepRandom: checkpoint of mode {sd.get('mode')!r} into a provider of mode {self.mode!r}")
+        if self.mode == "device":
+            self.state.copy_(torch.tensor(sd["state"], dtype=torch.int64))      # in place: captured steps hold the address
 
     def _launch(self, slots):
         import ctypes
@@ -1732,12 +1753,23 @@ class SpeculativeBackward:
     # and the step does not get shorter (HISTORY.md 7.7): off unless IMMUNOSTRUCT_DEFER_LOSS=1
     defer = os.environ.get("IMMUNOSTRUCT_DEFER_LOSS", "0") == "1"
 
+    # the caller's promise that the loss consumes the reconstruction through :func:`vae_loss` (``utils.Losses``): only then may the
+    # models let the main stream join the sequence branch at the LATENT (models/_core.py EARLY_JOIN) -- a loss that reads ``recon_x``
+    # with plain torch ops on the main stream would otherwise have no dependency on the decoder's GEMM (a missing edge
+    # inside a captured graph).  engine.CapturedTrainStep passes ``getattr(forward_loss, "fused_loss", False)``.
+    early_join = False
+
+    def __init__(self, early_join=False):
+        self._early_join = bool(early_join)
+
     def __enter__(self):
-        self._saved, SpeculativeBackward.enabled = SpeculativeBackward.enabled, SpeculativeBackward.allowed
+        self._saved = (SpeculativeBackward.enabled, SpeculativeBackward.early_join)
+        SpeculativeBackward.enabled = SpeculativeBackward.allowed
+        SpeculativeBackward.early_join = self._early_join and SpeculativeBackward.allowed
         return self
 
     def __exit__(self, *exc):
-        SpeculativeBackward.enabled = self._saved
+        SpeculativeBackward.enabled, SpeculativeBackward.early_join = self._saved
         return False
 
 
@@ -1899,6 +1931,12 @@ def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_
         if res is not None:
             return res
     pre = _speculate_recon_backward(recon, x, c_mse) if recon is not None else None
+    if pre is None and torch.is_tensor(recon):
+        # no speculation (a reconstruction weight of 0, a non-contiguous or foreign ``recon``): this launch reads ``recon`` on the
+        # caller's stream, which under the models' early join has only waited for the latent -- wait for the decoder here
+        ev = getattr(recon, "_ready_event", None)
+        if ev is not None:
+            torch.cuda.current_stream(recon.device).wait_event(ev)
     return VaeLossFn.apply(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, pre)
 
 

@@ -30,6 +30,7 @@ from .layers import MultiHeadAttention, SelfAttention
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
 OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
 EARLY_JOIN = os.environ.get("IMMUNOSTRUCT_EARLY_JOIN", "1") != "0"
+JOIN_COUNTS = {"early": 0, "full": 0}      # how the main stream joined the sequence branch, per forward (tests)
 # the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer).  "auto": its
 # forward (~100 us of side work) should end with the stack + node attention, not stretch more layer launches than it must -- the
 # longer a layer launch, the earlier the fork.  Measured on the round-3 kernels (same box, ms per step): B = 128 graphs / 72 k edges
@@ -308,10 +309,19 @@ class MultimodalNet(nn.Module):
             # passed when the node attention ends -- instead of behind the decoder's GEMM (a cross-queue wait of ~15 us in the
             # replayed step's timeline, round 3)
             ev = o.pop("_latent_ready", None)
-            if EARLY_JOIN and HF.SpeculativeBackward.enabled and ev is not None and torch.is_grad_enabled():
+            if (EARLY_JOIN and HF.SpeculativeBackward.enabled and HF.SpeculativeBackward.early_join and ev is not None
+                    and torch.is_grad_enabled()):
+                # (early_join: the step's loss promised to read the reconstruction through functional.vae_loss -- which runs on the
+                #  branch's stream when it speculates, and waits for ``_ready_event`` when it does not)
                 main.wait_event(ev)
+                done = torch.cuda.Event()
+                done.record(side)
+                if torch.is_tensor(o.get("recon_x")):
+                    o["recon_x"]._ready_event = done
+                JOIN_COUNTS["early"] += 1
             else:
                 main.wait_stream(side)
+                JOIN_COUNTS["full"] += 1
             for t in o.values():
                 for u in (t if isinstance(t, tuple) else (t,)):
                     if torch.is_tensor(u):

@@ -190,7 +190,8 @@ class Adam(torch.optim.Optimizer):
         with torch.cuda.stream(side):
             side.wait_event(gate)
             for gs, te, _ in work:
-                _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+                if not gs.pop("prepared_early", False):      # (prepare() already advanced the step: twice would double the count)
+                    _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
                 if te is not None:
                     _lib.check(lib.is_adam_apply(_lib.ptr(te), int(te.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
                                                  _lib.stream_ptr()), "is_adam_apply")
@@ -219,7 +220,8 @@ class Adam(torch.optim.Optimizer):
             if not capturing:
                 self.refresh_group(group, gs)
             if first:
-                _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+                if not gs.pop("prepared_early", False):      # (prepare() already advanced the step on another stream)
+                    _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
                 gs["prepared"] = True
                 gs["updated"] = set()
             elif not gs["prepared"] or any(id(p) in gs["updated"] for p in sub):

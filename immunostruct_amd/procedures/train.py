@@ -246,6 +246,13 @@ def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_
     return train_losses, val_losses
 
 
+def _reads_recon_through_losses(loss_function):
+    """the promise ``engine.CapturedTrainStep`` asks for (``forward_loss.fused_loss``): the loss is a method of ``utils.Losses``, which
+    hands the reconstruction to ``functional.vae_loss`` -- any other callable gets the full stream join in the models"""
+    from ..utils import Losses
+    return isinstance(getattr(loss_function, "__self__", None), Losses)
+
+
 def train_model_device(config, device, model, dataset, train_index, val_index, optimizer, loss_function, scheduler=None,
                        stage="pretrain", seed=0):
     """``train_model`` on a :class:`~immunostruct_amd.data.DeviceResidentDataset`: same epoch
@@ -256,6 +263,7 @@ def train_model_device(config, device, model, dataset, train_index, val_index, o
     def forward_loss(m, g, seq, prop, y):
         recon, mu, logvar, final = m(g, seq, prop)
         return loss_function(recon, seq, mu, logvar, final, y)
+    forward_loss.fused_loss = _reads_recon_through_losses(loss_function)
 
     return _device_fit(config, model, optimizer, scheduler, stage, seed, dataset.device, train_index, val_index,
                        dataset.new_batch, lambda idx, buf, train: dataset.gather_into(idx, *buf), forward_loss,
@@ -284,6 +292,7 @@ def train_model_comparative_device(config, device, model, dataset_cancer, datase
     def forward_loss(m, g2, seq2, prop2, y2):
         # y2 holds the targets of both members; the pair's label is the cancer member's
         return _paired_loss(m, loss_function, (g2, seq2, y2[:y2.numel() // 2], prop2), device, contrastive, coeff)
+    forward_loss.fused_loss = _reads_recon_through_losses(loss_function)
 
     return _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_index, val_index,
                        lambda b: both.new_batch(2 * b), lambda idx, buf, train: both.gather_into(torch.cat([idx, idx + shift]), *buf),

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from ..utils import PairedContrastiveLoss
-from .train import _add_contrastive, _device_fit, _fit, _to
+from .train import _add_contrastive, _device_fit, _fit, _reads_recon_through_losses, _to
 
 __all__ = ["train_model_SSL", "train_model_comparative_SSL", "train_model_SSL_device", "train_model_comparative_SSL_device"]
 
@@ -69,6 +69,7 @@ def train_model_SSL_device(config, device, model, dataset, train_index, val_inde
         if m.training:
             return loss_function(recon, seq, mu, logvar, final, y, pred, amino[int(y.numel())])
         return loss_function(recon, seq, mu, logvar, final, y, torch.tensor([]), torch.tensor([]))
+    forward_loss.fused_loss = _reads_recon_through_losses(loss_function)
 
     def assemble(idx, buf, train):
         g, seq, prop, y = dataset.gather_into(idx, *buf)
@@ -120,6 +121,7 @@ def train_model_comparative_SSL_device(config, device, model, dataset_cancer, da
             loss = 0.5 * (loss_function(recon[0], seq2[:b], mu[0], logvar[0], final, target, pa, aa)
                           + loss_function(recon[1], seq2[b:], mu[1], logvar[1], final, target, pa, aa))
         return _add_contrastive(loss, contrastive, emb, target, coeff)
+    forward_loss.fused_loss = _reads_recon_through_losses(loss_function)
 
     def assemble(idx, buf, train):
         g2, seq2, prop2, y2 = both.gather_into(torch.cat([idx, idx + shift]), *buf)

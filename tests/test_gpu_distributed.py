@@ -121,15 +121,18 @@ def test_bench_line_under_a_one_rank_rccl_group(cuda_device):
     cfg = line["config"]
     assert cfg["dist_backend"] == "nccl" and cfg["rccl_ranks"] == 1 and line["n_gpus"] == 1
     ar = cfg["grad_allreduce"]
-    assert ar["form"] in ("serial", "two-stage backward, bucket 0 overlapped")
+    assert ar["form"] in ("serial", "two-stage backward, bucket 0 overlapped", "one graph: serial, collectives captured",
+                          "one graph: two-stage backward, bucket 0 overlapped, collectives captured")
+    assert ar["one_graph_error"] is None, ar["one_graph_error"]      # RCCL's collectives were captured into the step's graph
     assert ar["tuned_ms"] is not None and ar["tuned_ms"]["serial_ms"] > 0            # auto: every candidate was replayed with the collectives
+    assert set(ar["tuned_ms"]["one_graph_ms"]) == {"graph", "graph2"} and all(v > 0 for v in ar["tuned_ms"]["one_graph_ms"].values())
     assert ar["standalone_allreduce"] and all(b["ms"] > 0 for b in ar["standalone_allreduce"])      # time_all_reduce under nccl
     assert sum(ar["buckets"]) == sum(b["floats"] for b in ar["standalone_allreduce"])
     # same loss as without the group: a fixed number of steps on both sides (no adaptive settle blocks, no form timing -- its
     # replays advance the random streams), so that both runs draw the same dropout masks and noise
-    fixed = dict(IMMUNOSTRUCT_BENCH_SETTLE_BLOCKS="2", IMMUNOSTRUCT_DP_OVERLAP="0")
+    fixed = dict(IMMUNOSTRUCT_BENCH_SETTLE_BLOCKS="2", IMMUNOSTRUCT_DP_OVERLAP="0", IMMUNOSTRUCT_DP_ONE_GRAPH="1")
     packed = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29574", **fixed), "--force-pack")
-    assert packed["config"]["dist_backend"] == "nccl" and packed["config"]["grad_allreduce"]["form"] == "serial"
+    assert packed["config"]["dist_backend"] == "nccl" and packed["config"]["grad_allreduce"]["form"] == "one graph: serial, collectives captured"
     plain = _bench_line(_rccl_env(**fixed))
     assert plain["config"]["dist_backend"] is None and plain["config"]["grad_allreduce"] is None
     a, b = packed["config"]["final_loss"], plain["config"]["final_loss"]

@@ -525,6 +525,63 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
         H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 3 captured steps")
 
 
+@pytest.mark.parametrize("promise", [False, True])
+def test_loss_that_reads_the_reconstruction_with_torch_ops_gets_the_full_join(cuda_device, promise):
+    """the models let the main stream join the sequence branch at the LATENT (``models/_core.py`` EARLY_JOIN) -- safe only
+    when the loss reads ``recon_x`` through ``functional.vae_loss``.  A ``forward_loss`` WITHOUT the ``fused_loss`` promise that uses
+    ``F.mse_loss`` on the reconstruction must get the full join (every forward counted), a promised one the early join; the captured
+    step of the custom loss equals the eager one."""
+    import torch.nn.functional as F
+    from immunostruct_amd import optim
+    from immunostruct_amd.distributed import FlatGradReducer
+    from immunostruct_amd.engine import CapturedTrainStep
+    from immunostruct_amd.models import _core
+    dev = cuda_device
+    raws = [synthetic.make_batch(6, seed=s, deg_extra=2) for s in (61, 62)]
+    batches = [(H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev), torch.from_numpy(r.prop).to(dev),
+                torch.from_numpy(r.y_reg).to(dev)) for r in raws]
+    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
+    eps = H.make_eps(9, 6).to(dev)
+
+    def forward_loss(m, g, seq, prop, y):
+        with mock.patch("torch.randn_like", lambda t: eps.to(t.dtype)):
+            recon, mu, logvar, final = m(g, seq, prop)
+        if promise:
+            return losses.regression_loss(recon, seq, mu, logvar, final, y)
+        return 2.0 * F.mse_loss(final.flatten(), y) + 0.5 * F.mse_loss(recon, seq.reshape(recon.shape)) - 0.25 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+    forward_loss.fused_loss = promise
+
+    def run(captured):
+        model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=6))
+        model.eval()
+        red = FlatGradReducer(model.parameters(), world=1)
+        opt = optim.Adam(model.parameters(), lr=1e-5)
+        out = []
+        if captured:
+            before = dict(_core.JOIN_COUNTS)
+            eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1)
+            took = {k: _core.JOIN_COUNTS[k] - before[k] for k in before}
+            assert took["early" if promise else "full"] >= 2 and took["full" if promise else "early"] == 0, took
+            for b in batches:
+                out.append(float(eng(*b)))
+        else:
+            for b in [batches[0]] + batches:
+                red.zero()
+                loss = forward_loss(model, *b)
+                loss.backward()
+                opt.step()
+                out.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    l_e, sd_e = run(False)
+    l_c, sd_c = run(True)
+    for a, b in zip(l_e[1:], l_c):
+        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
+    for k in sd_e:
+        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 2 captured steps")
+
+
 def test_full_step_is_deterministic_at_full_residency(cuda_device):
     """utils/seed.py:18 (deterministic algorithms) is part of the reference's contract: the whole captured step of the benchmark's
     size -- B = 128 x 190 nodes, every workgroup slot of the chip taken by the persistent layer kernels -- replayed twice from the
@@ -641,11 +698,15 @@ def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
         recon, mu, logvar, final = m(g, seq, prop)
         return losses.regression_loss(recon, seq, mu, logvar, final, y)
 
-    def run(seed, mode):
+    from immunostruct_amd import functional as HF
+
+    def run(seed, mode, fresh_process=True):
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
         model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
         model.train()
         torch.manual_seed(seed)
+        if fresh_process:
+            HF.StepRandom._created = 0      # (a run of its own: the first engine of a process)
         eng = CapturedTrainStep(model, optim.Adam(model.parameters(), lr=1e-4), FlatGradReducer(model.parameters(), world=1), forward_loss,
                                 batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1, step_random=mode)
         if mode == "device":
@@ -657,6 +718,9 @@ def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
 
     a, b, c = run(5, "device"), run(5, "device"), run(6, "device")
     assert a == b and a != c and len(set(a)) == len(a) and all(np.isfinite(a))
+    # the SECOND engine of a run (its finetune stage: same device seed) draws another sequence, not the first stage's again
+    d = run(5, "device", fresh_process=False)
+    assert d != a and all(np.isfinite(d))
 
 
 @pytest.mark.parametrize("form", ["two_pass", "merged"])
