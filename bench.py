@@ -132,7 +132,7 @@ def kernel_sources_sha256():
     """digest of the sources the layer kernels are built from: a PMC traffic figure measured for other sources is stale"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("egnn_layer_fwd.hip", "egnn_layer_bwd.hip", "common.h", "node16.h"):
+    for name in ("egnn_layer_fwd.hip", "egnn_layer_bwd.hip", "egnn_layer_bwd8.hip", "common.h", "node16.h"):
         with open(os.path.join(ROOT, "immunostruct_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -156,7 +156,14 @@ def measured_traffic(traffic_key):
     return ent.get("bytes"), f"{TRAFFIC_FILE} ({rec.get('commit', '?')}): separate rocprofv3 --pmc passes of this workload, same kernel sources"
 
 
-def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None):
+def _paired_bwd_in_use(n_nodes, n_edges, fe):
+    """whether the backward layer launches of this batch run as the paired 512-thread kernel (functional.EgnnStackFn's rule)"""
+    from immunostruct_amd import _lib
+    return bool(HF.BWD_PAIRED and HF.SAVE_Z3 and not HF.use_bwd_tiles(int(n_nodes), int(n_edges), HF.layer_slots(), fe)
+                and _lib.load().is_egnn_layer_bwd_paired_supported(fe, 0))
+
+
+def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None, paired_bwd=False):
     """``dins``: input width of the layers whose launches run the FULL pass (coordinate branch included).
     ``insitu``: {"bwd": {"slot": [us ...], "span": [...]}, "fwd": ..., "gather": ...} from the workgroup clocks of the REPLAYED
     step (functional.LaunchClock.durations) -- the primary timing of every entry is the ``slot`` time (end of the previous layer
@@ -186,7 +193,7 @@ def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu
               "branches included" if how == "insitu" else
               "HIP events on the launching stream around eager launches")
     sec = lambda name: round(ev[name], 2) if (how == "insitu" and name in ev) else None
-    roof = dict(kernel="egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+    roof = dict(kernel="egnn_layer_bwd8_kernel (paired: one 512-thread workgroup per CU)" if paired_bwd else "egnn_layer_bwd_kernel", bound="mfma", achieved=round(tf_b, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(tf_b / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src, launches=n_b,
                 mean_launch_us=round(us_b, 2), timing=method, eager_us=sec("egnn_layer_bwd"),
                 algorithmic_flop_per_launch=f_bwd, algorithmic_bytes_per_launch=b_bwd,
@@ -367,7 +374,8 @@ class IedbWorkload(TrainStepWorkload):
         # the timed launches are the five full ones per step (layer 0: Din = 20, layers 1-4: Din = 64); the last layer's
         # launch skips the coordinate MLP (its output is unused by the model) and is timed under its own name
         key = "iedb_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2 and not self.args.symmetric_edges) else None
-        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu)
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu,
+                                    paired_bwd=_paired_bwd_in_use(self.n_nodes, self.n_edges, 1))
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import functional_ref as FR
@@ -519,7 +527,8 @@ class PairedWorkload(TrainStepWorkload):
 
     def roofline(self, timers, insitu=None):
         key = "paired_B128_deg2" if (self.args.batch == 128 and self.args.deg_extra == 2) else None
-        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu)
+        return roofline_from_timers(timers, self.n_nodes, self.n_edges, (20, 64, 64, 64, 64), 1, key, insitu,
+                                    paired_bwd=_paired_bwd_in_use(self.n_nodes, self.n_edges, 1))
 
     def cpu_baseline(self, budget_s=24.0):
         from oracle import functional_ref as FR
@@ -834,6 +843,29 @@ def main():
     if os.environ.get("IMMUNOSTRUCT_BENCH_STEP_TRACE"):      # debugging aid: the timed steps in order (which ones are slow?)
         print("[step trace ms] " + " ".join(f"{v:.3f}" for v in per_step), file=sys.stderr)
     per_step = sorted(per_step)
+    # the reference's loop reads the loss back on the host every step (procedures/train.py:29 ``loss.item()``): the same replay with
+    # that read, outside the timed region -- the host then waits for every step before it enqueues the next one
+    host_read = None
+    if not args.eager:
+        n_hr = min(args.steps, 20)
+        fence()
+        h0 = time.perf_counter()
+        acc = 0.0
+        for i in range(n_hr):
+            l = step(args.warmup + i)
+            if l is not None:
+                acc += float(l)                     # .item(): a device -> host copy and a synchronisation per step
+            else:
+                torch.cuda.synchronize()            # (a workload without a loss: the synchronisation alone)
+        fence()
+        hdt = time.perf_counter() - h0
+        if world > 1:
+            t = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            hdt = float(t.item())
+        host_read = dict(steps=n_hr, ms_per_step=round(hdt / n_hr * 1e3, 3), mean_loss=round(acc / n_hr, 6),
+                         note="the same replayed step followed by float(loss) on the host, as the reference's loop does "
+                              "(procedures/train.py:29); `value` is the device-throughput figure without that read")
     if os.environ.get("IMMUNOSTRUCT_HOST_TIMES"):     # debugging aid: host-side cost of one isolated step vs its GPU time
         for i in range(5):
             fence()
@@ -918,6 +950,22 @@ def main():
                       rccl_ranks=torch.distributed.get_world_size() if ddp else 1,
                       dist_backend=torch.distributed.get_backend() if ddp else None)
         config.update(extra_config)
+        if host_read is not None:
+            host_read["value"] = round(wl.graphs_per_step * world / (host_read["ms_per_step"] * 1e-3), 1)
+            host_read["unit"] = "graphs/s"
+        if roof is not None and "hbm_view" in roof:
+            # the figures BASELINE.json's metric names ("GNN-gather achieved HBM GB/s", ">= 40 % of the HBM roofline on the gather /
+            # scatter kernel"), plainly, beside the MFMA fraction the dominant kernel is bounded by: fractions of the 8 TB/s SPEC
+            roof["hbm_frac"] = roof["hbm_view"]["frac"]      # dominant (fused layer backward) kernel, algorithmic bytes / slot time
+            gk = roof.get("gather_kernel")
+            if gk is not None:
+                roof["gather_frac"] = gk["frac"]              # the residual pure gather launch (layer 0), algorithmic bytes / slot time
+                span = (roof.get("insitu_us", {}).get("gather") or {}).get("span")
+                if span:
+                    gb = gk["achieved"] * gk["mean_launch_us"] * 1e-6      # GB per launch
+                    gk["span_us"] = span["mean"]
+                    gk["achieved_over_span"] = round(gb / (span["mean"] * 1e-6), 1)
+                    gk["frac_over_span"] = round(gb / (span["mean"] * 1e-6) / PEAK_HBM_GBS, 4)
         line = dict(metric=getattr(wl, "metric", "peptide-MHC graphs/sec (train step)"), value=round(graphs / dt, 1), unit="graphs/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=config,
@@ -925,11 +973,21 @@ def main():
                                  settle_blocks_ms=settle,
                                  note="device time per step from HIP events between the steps (rank 0); settle_blocks_ms = the "
                                       "untimed 5-step blocks replayed after the warm-up until two agreed within 2 %"),
-                    roofline=roof, hbm_copy_ceiling=ceiling, cpu_baseline=cpu, e2e=e2e,
+                    step_with_host_read=host_read, roofline=roof, hbm_copy_ceiling=ceiling, cpu_baseline=cpu, e2e=e2e,
                     kernel_timers_us={k: [v[0], round(v[1] * 1e3, 2)] for k, v in timers.items()})
         flush_c_stdio()
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
+        # teardown in dependency order: the captured graphs (which may hold RCCL's collective nodes) go first, then the process group --
+        # destroying the communicator under a live graph that references it aborted one run in a dozen on the one-rank RCCL group
+        torch.cuda.synchronize()
+        for name in ("captured", "graphs"):
+            if hasattr(wl, name):
+                setattr(wl, name, None)
+        gc.collect()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

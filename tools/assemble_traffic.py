@@ -16,7 +16,7 @@ src, dst = sys.argv[1], sys.argv[2]
 label = sys.argv[3] if len(sys.argv) > 3 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
                                                              cwd=ROOT).stdout.strip() or "?"
 out = {"commit": label, "kernel_sources_sha256": kernel_sources_sha256(),
-       "sources": ["immunostruct_amd/csrc/egnn_layer_fwd.hip", "immunostruct_amd/csrc/egnn_layer_bwd.hip", "immunostruct_amd/csrc/common.h",
+       "sources": ["immunostruct_amd/csrc/egnn_layer_fwd.hip", "immunostruct_amd/csrc/egnn_layer_bwd.hip", "immunostruct_amd/csrc/egnn_layer_bwd8.hip", "immunostruct_amd/csrc/common.h",
                    "immunostruct_amd/csrc/node16.h"],
        "method": "tools/pmc_traffic.sh per workload: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
                  "bench.py --eager --steps 3; bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, MI355X_MICROARCH.md)"}

@@ -49,8 +49,11 @@ def main():
         us = sum(d for _, d in fetch[name]) / len(fetch[name]) / 1e3
         out[s] = dict(fetch_kib=round(f, 1), write_kib=round(w, 1), bytes=int((2 * f + w) * 1024), launches_sampled=len(fetch[name]),
                       mean_us_under_pmc=round(us, 2))
-    for base in ("egnn_layer_bwd_kernel", "egnn_layer_fwd_kernel"):
-        cands = [(v["launches_sampled"], k) for k, v in out.items() if k.startswith(base + "<")]
+    # (the backward layer launch is egnn_layer_bwd_kernel -- two 256-thread workgroups per CU -- or, since round 5, its paired
+    #  512-thread form egnn_layer_bwd8_kernel: whichever the workload launched most is "the backward layer kernel")
+    for base, names in (("egnn_layer_bwd_kernel", ("egnn_layer_bwd_kernel", "egnn_layer_bwd8_kernel")),
+                        ("egnn_layer_fwd_kernel", ("egnn_layer_fwd_kernel",))):
+        cands = [(v["launches_sampled"], k) for k, v in out.items() if any(k.startswith(n + "<") for n in names)]
         if cands:
             out[base] = dict(out[max(cands)[1]], instantiation=max(cands)[1])
     json.dump(out, sys.stdout, indent=1)

@@ -29,7 +29,7 @@ python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
 IMMUNOSTRUCT_FORCE_COLLECTIVE=1 MASTER_PORT=29591 python bench.py --force-pack --steps 30 --warmup 5 --no-cpu-baseline --no-e2e > $out/bench_iedb_rccl1.json 2> $out/bench_iedb_rccl1.err
 cut -c1-200 $out/bench_iedb_rccl1.json
 # SQ counters of the two layer kernels and the node weight-gradient launch (instruction mix, LDS conflicts, waits)
-bash tools/pmc_passes.sh $out/sq_counters_layer_bwd.txt egnn_layer_bwd_kernel
+bash tools/pmc_passes.sh $out/sq_counters_layer_bwd.txt egnn_layer_bwd
 bash tools/pmc_passes.sh $out/sq_counters_layer_fwd.txt egnn_layer_fwd_kernel
 bash tools/pmc_passes.sh $out/sq_counters_node_wgrad.txt egnn_node_wgrad16
 # config 2's second stage and the edge-density sweep
