@@ -56,7 +56,7 @@ H = 64
 # "device" = one launch of the library's generator inside the step; IMMUNOSTRUCT_STEP_RANDOM=torch: torch's generator inside the
 # step (rounds 1 - 3: two generator-state fills in front of every replay), =prefetch: torch's generator one step ahead
 STEP_RANDOM = {"torch": None}.get(os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"), os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"))
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
 def layer_algorithmic(n_nodes, n_edges, din, fe):
@@ -764,6 +764,7 @@ def main():
     ap.add_argument("--model", default="HybridModelv2", help="iedb: the model class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="iedb, one GPU: skip the batcher-inclusive epoch over 27 000 resident graphs")
+    ap.add_argument("--no-host-read", action="store_true", help="skip the step_with_host_read sample (profiled runs: the last step of the trace stays a plain replay)")
     ap.add_argument("--e2e-graphs", type=int, default=27000)
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-copy-ceiling", action="store_true", help="skip the measured device-to-device copy bandwidth (2 x 1 GiB)")
@@ -846,7 +847,7 @@ def main():
     # the reference's loop reads the loss back on the host every step (procedures/train.py:29 ``loss.item()``): the same replay with
     # that read, outside the timed region -- the host then waits for every step before it enqueues the next one
     host_read = None
-    if not args.eager:
+    if not args.eager and not args.no_host_read:
         n_hr = min(args.steps, 20)
         fence()
         h0 = time.perf_counter()

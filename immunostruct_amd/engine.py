@@ -336,6 +336,15 @@ class CapturedTrainStep:
         self.one_graph_error = None
         if not self.fused_optimizer and _ONE_GRAPH != "0" and self._collectives_capturable():
             self._capture_one_graph()
+            # every rank replays the same form or the collectives stop matching: a form is a candidate only where EVERY rank
+            # captured it (an eager MIN all-reduce of the two success flags; one rank's failure withdraws the form everywhere)
+            import torch.distributed as dist
+            have = torch.tensor([1.0 if k in self.graph_c else 0.0 for k in ("graph", "graph2")], device=self.y.device)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            for k, ok in zip(("graph", "graph2"), have.tolist()):
+                if ok < 0.5 and k in self.graph_c:
+                    del self.graph_c[k]
+                    self.one_graph_error = self.one_graph_error or f"form {k!r} was not captured on every rank"
         if len(self._forms) == 2 or (self.graph_c and _ONE_GRAPH == "auto"):
             self._choose_form(model, optimizer)
         elif self.graph_c and _ONE_GRAPH == "1":

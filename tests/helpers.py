@@ -127,7 +127,8 @@ ROW_REPORT = __import__("os").environ.get("IMMUNOSTRUCT_TEST_ROW_REPORT")      #
 # over the whole GPU suite (IMMUNOSTRUCT_TEST_ROW_REPORT) every tensor but three sits below 2.2 x, the worst -- rows of
 # GCN_layers.0.edge_mlp.2.weight's gradient that are sums of ~10^3 cancelling terms, against an fp32 reference that carries the
 # same kind of error -- at 9.4 x.
-ROW_FACTOR = 16.0
+# Round 5: 16 -> 12 (the whole GPU suite re-measured: worst 9.1 x -- the same tensor --, second 7.1 x, every other tensor < 3.3 x).
+ROW_FACTOR = 12.0
 
 
 def _row_worst(b, diff, tol):

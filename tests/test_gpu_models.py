@@ -15,7 +15,12 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 BATCH = 16
 OUT_TOL, GRAD_TOL = 1e-5, 1e-4      # element-wise (tests/helpers.py): SURVEY 8c / BASELINE.md: 1e-5 rel on outputs, 1e-4 on gradients
-FULL_SIZE_FACTOR = float(os.environ.get("IMMUNOSTRUCT_TEST_FULL_SIZE_FACTOR", "2.0"))      # full-size gradients: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test)
+# full-size gradients / outputs: allowed multiple of the fp32 oracle's own distance from fp64 (see the [190-128] test).  Round 5: 1.0 --
+# wherever the element-wise bound against fp64 is missed, the HIP path must be at least as close to fp64 as the reference arithmetic in
+# fp32 (the worse of two summation orders) is; rounds 3 / 4 needed 8 / 2.  Measured with the allowance off (factor 0): ONE tensor of
+# all oracle tests misses the bound, GCN_layers.3.coord_mlp.2.weight at B = 128: 1.2 x where the fp32 oracle has 3.0 x
+FULL_SIZE_FACTOR = float(os.environ.get("IMMUNOSTRUCT_TEST_FULL_SIZE_FACTOR", "1.0"))
+TRAJECTORY_FACTOR = max(2.0, FULL_SIZE_FACTOR)      # weights after 10 AdamW steps: the fp32 oracle's own drift depends on the host's BLAS (HISTORY.md 7.13)
 
 
 def _with_eps(fn, eps_list, device):
@@ -220,7 +225,7 @@ def test_full_train_step_gradients_vs_oracle(cuda_device, n_pad, b):
         # it is given ~ 100 x, into every gradient below it (tests/tools/grad_error_probe_model.py).  With those sums in fp64
         # (blocks of 8 in fp32, block sums in fp64: csrc/combined_attention.hip, csrc/mlp_head.hip) ONE tensor exceeds the
         # element-wise bound, GCN_layers.3.coord_mlp.2.weight at 1.2 x where the fp32 oracle has 3.0 x, and the HIP gradients are
-        # closer to fp64 than the oracle's on the tensors that used to fail.  Factor now 2 (HISTORY.md 7.10).
+        # closer to fp64 than the oracle's on the tensors that used to fail.  Factor 2 since then (HISTORY.md 7.10), 1 since round 5.
         sd_64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
         it64 = FR.forward("HybridModelv2", sd_64, H.oracle_graph(raw, torch.float64), seq.double(), prop.double(), eps=eps.double())
         FR.regression_loss(it64["recon_x"], seq.double(), it64["mu"], it64["logvar"], it64["final_output"], y.double(), H.VAE_IN).backward()
@@ -1005,7 +1010,7 @@ def test_paired_training_trajectory_matches_oracle(cuda_device):
         r_ref = H.worst_ratio(sd[k].detach(), sd64[k].detach(), 2e-4)
         if r_hip > worst_w[1]:
             worst_w = (k, r_hip, r_ref)
-        assert r_hip <= max(1.0, FULL_SIZE_FACTOR * r_ref), (f"{k} after {steps} paired steps: HIP is {r_hip:.2f} x the element-wise bound away from "
+        assert r_hip <= max(1.0, TRAJECTORY_FACTOR * r_ref), (f"{k} after {steps} paired steps: HIP is {r_hip:.2f} x the element-wise bound away from "
                                                              f"the fp64 trajectory, the fp32 oracle {r_ref:.2f} x")
     print(f"worst relative loss difference over {steps} paired steps of B = {nb} pairs: {worst:.2e}; worst weights {worst_w}")
 

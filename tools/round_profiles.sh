@@ -21,7 +21,7 @@ for wl in iedb paired stress; do
   cut -c1-230 $out/bench_$wl.json
 done
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o rr -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-e2e > $out/prof.log 2> $out/prof.err
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o rr -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-e2e --no-host-read > $out/prof.log 2> $out/prof.err
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/kernel_stats.txt 2>> $out/prof.err
 python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
