@@ -69,3 +69,66 @@ def test_pooling_equals_view_mean_under_padding():
     idx = torch.repeat_interleave(torch.arange(4), 190)
     assert torch.allclose(graph_ref.global_mean_pool(x, idx), x.view(4, 190, 64).mean(1), atol=1e-12)
     assert torch.allclose(graph_ref.global_max_pool(x, idx), x.view(4, 190, 64).amax(1))
+
+
+def test_egnn_restatement_equals_the_paper_equations_in_dense_form():
+    """An INDEPENDENT formulation of the same layer, written from Satorras et al. 2021 eqs. 3 - 6 with DGL's documented choices as
+    dense all-pairs tensors (an [n, n] multiplicity matrix instead of index gathers / ``index_add``; the per-pair message computed for
+    EVERY ordered pair and weighted by the multiplicity), graph by graph: nothing of ``graph_ref.egnn_conv``'s code path -- its
+    gathers, its scatter-adds, its degree count, its batching offsets -- is shared.  fp64, three layers deep, with edge features
+    (one per ordered pair: parallel edges are given equal features), with parallel edges, isolated and padded nodes."""
+    dtype = torch.float64
+    fe = 3
+    rng = np.random.RandomState(7)
+    n_graphs, n = 3, 23
+    srcs, dsts, feats = [], [], []
+    pair_feat = rng.uniform(-1, 1, size=(n_graphs, n, n, fe))
+    mult = np.zeros((n_graphs, n, n), dtype=np.int64)           # mult[g, dst, src]
+    for g in range(n_graphs):
+        real = n - 3 - g                                        # trailing padded nodes: no edges, zero features / coordinates
+        for _ in range(4 * real):
+            s, d = rng.randint(0, real), rng.randint(0, real - 1)     # (node real - 1 never receives: zero in-degree among the real ones)
+            k = 2 if rng.rand() < 0.15 else 1                   # some parallel edges
+            mult[g, d, s] += k
+            for _ in range(k):
+                srcs.append(g * n + s); dsts.append(g * n + d); feats.append(pair_feat[g, d, s])
+    order = rng.permutation(len(srcs))
+    src = torch.tensor(np.array(srcs)[order]); dst = torch.tensor(np.array(dsts)[order])
+    a = torch.tensor(np.array(feats)[order], dtype=dtype)
+    N = n_graphs * n
+    h = torch.tensor(rng.normal(size=(N, 20)), dtype=dtype)
+    x = torch.tensor(rng.normal(size=(N, 3)) * 4.0, dtype=dtype)
+    for g in range(n_graphs):
+        h[g * n + n - 3 - g:(g + 1) * n] = 0
+        x[g * n + n - 3 - g:(g + 1) * n] = 0
+    sd = {k: v.to(dtype) for k, v in H.det_sd(H.egnn_shapes([20, 64, 64], fe, prefix="L"), seed=4).items()}
+
+    def dense_layer(p, hg, xg, m, ag):
+        """one graph: hg [n, d], xg [n, 3], m [n, n] multiplicities (row = receiver i, column = sender j), ag [n, n, fe]"""
+        W = lambda name: sd[p + name + ".weight"]
+        B = lambda name: sd[p + name + ".bias"]
+        silu = lambda t: t * torch.sigmoid(t)
+        nn_ = hg.shape[0]
+        diff = xg[None, :, :] - xg[:, None, :]                               # [i, j] = x_j - x_i   (sender minus receiver)
+        radial = (diff ** 2).sum(-1, keepdim=True)                           # squared distance
+        unit = diff / (radial.sqrt() + 1e-30)
+        f = torch.cat([hg[None, :, :].expand(nn_, nn_, -1), hg[:, None, :].expand(nn_, nn_, -1), radial, ag], dim=-1)   # [h_j, h_i, r, a]
+        m1 = silu(f @ W("edge_mlp.0").T + B("edge_mlp.0"))
+        mij = silu(m1 @ W("edge_mlp.2").T + B("edge_mlp.2"))                # eq. 3
+        scal = silu(mij @ W("coord_mlp.0").T + B("coord_mlp.0")) @ W("coord_mlp.2").T       # phi_x, bias-free last layer
+        mw = m.to(dtype)[:, :, None]
+        h_neigh = (mw * mij).sum(1)                                          # eq. 5: sum over in-edges
+        deg = m.sum(1).clamp(min=1).to(dtype)[:, None]
+        x_new = xg + (mw * unit * scal).sum(1) / deg                         # eq. 4 with DGL's mean
+        h_new = silu(torch.cat([hg, h_neigh], -1) @ W("node_mlp.0").T + B("node_mlp.0")) @ W("node_mlp.2").T + B("node_mlp.2")   # eq. 6, no residual
+        return h_new, x_new
+
+    h_s, x_s, h_d, x_d = h, x, h, x
+    for layer in range(3):
+        p = f"L{layer}."
+        h_s, x_s = graph_ref.egnn_conv(sd, p, src, dst, N, h_s, x_s, a)
+        outs = [dense_layer(p, h_d[g * n:(g + 1) * n], x_d[g * n:(g + 1) * n], torch.tensor(mult[g]), torch.tensor(pair_feat[g], dtype=dtype))
+                for g in range(n_graphs)]
+        h_d, x_d = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        assert torch.allclose(h_s, h_d, rtol=1e-11, atol=1e-11), f"layer {layer}: h differs by {float((h_s - h_d).abs().max()):.2e}"
+        assert torch.allclose(x_s, x_d, rtol=1e-11, atol=1e-11), f"layer {layer}: x differs by {float((x_s - x_d).abs().max()):.2e}"
