@@ -26,7 +26,7 @@ The index arrays are exactly what ``graph.CSRIndex`` builds per graph (stable so
 with a handful of vectorised torch calls.  Joining graphs with the property / HLA tables (pandas, ``preprocess.py:45-145``)
 stays with the caller, who passes ``labels = {name: (full_sequence, mprop1, mprop2, immunogenicity, foreignness)}``.
 
-The pickles are read WITHOUT torch_geometric: an allow-list unpickler maps every ``torch_geometric.*`` class to an inert
+The pickles are read WITHOUT torch_geometric: an allow-list unpickler maps every ``torch_geometric.*`` class (and unneeded pandas / networkx / graphein attachments) to an inert
 attribute bag, loads tensors / storages / plain containers and refuses every other global; the four fields are looked up in
 the bag (PyG 2.x keeps them in ``_store._mapping``, 1.x in ``__dict__``).
 That layout follows the PyG sources; no real file was available to this build, so it is unverified against one
@@ -209,7 +209,12 @@ class PackedDataset:
 
 # ---- the reference's pickles ------------------------------------------------------------------------------
 class _Bag:
-    """stand-in for any torch_geometric class inside a pickle: keeps the state, runs no code"""
+    """stand-in for any torch_geometric class (and for the attachments of the packages in ``_INERT_ROOTS``) inside a pickle: keeps
+    the state, runs no code -- as a class (NEWOBJ / BUILD), as a callable (REDUCE) and as a plain value (a class object stored in an
+    attribute, e.g. ``Data._edge_attr_cls``)"""
+
+    def __new__(cls, *args, **kwargs):
+        return object.__new__(cls)
 
     def __init__(self, *args, **kwargs):
         pass
@@ -222,12 +227,25 @@ class _Bag:
 _ALLOWED_GLOBALS = {
     ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "set"),
     ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"),
-    ("builtins", "slice"), ("builtins", "range"),
+    ("builtins", "slice"), ("builtins", "range"), ("builtins", "frozenset"), ("builtins", "object"), ("builtins", "bytearray"),
+    ("builtins", "bytes"), ("builtins", "complex"),
+    ("_codecs", "encode"),                 # how protocol 2 spells a bytes object (str -> bytes, latin-1): pure
+    ("copyreg", "_reconstructor"),         # cls.__new__ of a class that went through this same allow-list
+    ("copy_reg", "_reconstructor"),
     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
     ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch.serialization", "_get_layout"),
     ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
     ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
 }
+
+
+# Packages whose objects may ride on a graph file WITHOUT being needed: graphein's nx -> PyG conversion (the reference's writer,
+# preprocessing/cancer_graph_construction_new_KBG.py:92-143) copies graph-level attributes into the ``Data`` object -- residue ids and
+# names (lists of str), edge kinds (lists of sets), and, depending on its version / ``columns``, a distance matrix or the PDB table as
+# pandas / numpy objects.  The reader needs ``x``, ``coords``, ``edge_index``, ``name``; everything of these packages becomes an inert
+# bag (no import, no code), so such a file loads instead of being refused.  Any OTHER global (os, subprocess, builtins.eval,
+# torch.storage._load_from_bytes ...) still raises.
+_INERT_ROOTS = ("torch_geometric", "pandas", "networkx", "graphein", "biopandas", "scipy", "Bio")
 
 
 class _Unpickler(pickle.Unpickler):
@@ -238,11 +256,13 @@ class _Unpickler(pickle.Unpickler):
     and never need it."""
 
     def find_class(self, module, name):
-        if module.split(".")[0] == "torch_geometric":
-            return _Bag
+        if module == "__builtin__":      # protocol-2 streams (torch.save's default) name the builtins the Python-2 way
+            module = "builtins"
         if (module, name) in _ALLOWED_GLOBALS or (module == "torch" and name.endswith("Storage")) \
                 or (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage")):
             return super().find_class(module, name)
+        if module.split(".")[0] in _INERT_ROOTS or module.split(".")[0] == "numpy":      # (numpy beyond the array reconstruction above)
+            return _Bag
         raise pickle.UnpicklingError(f"global {module}.{name} is not allowed in a graph file")
 
 
@@ -266,7 +286,15 @@ def _field(obj, key):
 def load_pyg_pickle(path):
     """``(x, coords, edge_index, name)`` of one of the reference's per-structure files"""
     obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
-    return tuple(_field(obj, k) for k in ("x", "coords", "edge_index", "name"))
+    out = tuple(_field(obj, k) for k in ("x", "coords", "edge_index", "name"))
+    for k, v in zip(("x", "coords", "edge_index"), out):
+        if not torch.is_tensor(v):
+            v = torch.as_tensor(np.asarray(v)) if isinstance(v, (np.ndarray, list, tuple)) else v
+        if not torch.is_tensor(v):
+            raise ValueError(f"{path}: field {k!r} is a {type(v).__name__}, not a tensor")
+    if not isinstance(out[3], str):
+        raise ValueError(f"{path}: field 'name' is a {type(out[3]).__name__}, not a string")
+    return out
 
 
 def list_structure_names(directory):

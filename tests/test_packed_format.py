@@ -272,3 +272,83 @@ def test_graph_file_reader_refuses_foreign_globals(tmp_path):
     torch.save({"x": Smuggle()}, path2)
     with pytest.raises(pickle.UnpicklingError, match="_load_from_bytes"):
         D.load_pyg_pickle(path2)
+
+
+def test_reader_on_a_file_shaped_like_pyg_2_5_with_graphein_attachments(tmp_path):
+    """What ``torch.save(g_pyg, ...)`` of the reference's writer leaves on disk (preprocessing/cancer_graph_construction_new_KBG.py:92-143),
+    reproduced from the sources of torch_geometric 2.5.3 and graphein's nx -> PyG convertor without either package: ``Data.__dict__`` =
+    ``{_edge_attr_cls, _tensor_attr_cls, _store}`` with the two attribute classes stored AS CLASS OBJECTS, ``_store`` a
+    ``GlobalStorage`` whose ``__getstate__`` turns its weak ``_parent`` reference into the ``Data`` object itself (a cycle in the
+    pickle), and the mapping holding, beside the four fields the reader needs, what graphein copies over: residue ids / names (lists
+    of str), edge kinds (a list of sets), b-factors, and a distance matrix as a pandas DataFrame.  The reader must return the four
+    fields, bit-exact, without importing pandas' unpickling machinery for the attachment (it becomes an inert bag)."""
+    import weakref
+    import pandas as pd
+    names = ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage")
+    mods = {n: types.ModuleType(n) for n in names}
+
+    class BaseStorage:
+        def __init__(self, _parent=None, **kwargs):
+            self.__dict__["_mapping"] = dict(kwargs)
+            self.__dict__["_parent"] = weakref.ref(_parent) if _parent is not None else None
+
+        def __getstate__(self):               # (torch_geometric/data/storage.py: the weak reference becomes the object)
+            out = self.__dict__.copy()
+            parent = out.get("_parent")
+            if parent is not None:
+                out["_parent"] = parent()
+            return out
+
+        def __setstate__(self, mapping):
+            for k, v in mapping.items():
+                self.__dict__[k] = v
+
+    class GlobalStorage(BaseStorage):
+        pass
+
+    class DataEdgeAttr:
+        pass
+
+    class DataTensorAttr:
+        pass
+
+    class Data:
+        def __init__(self, **fields):
+            self.__dict__["_tensor_attr_cls"] = DataTensorAttr
+            self.__dict__["_edge_attr_cls"] = DataEdgeAttr
+            self.__dict__["_store"] = GlobalStorage(_parent=self, **fields)
+
+        def __getstate__(self):
+            return self.__dict__.copy()
+
+        def __setstate__(self, mapping):
+            for k, v in mapping.items():
+                self.__dict__[k] = v
+
+    for cls, mod in ((Data, "torch_geometric.data.data"), (DataEdgeAttr, "torch_geometric.data.data"),
+                     (DataTensorAttr, "torch_geometric.data.data"), (BaseStorage, "torch_geometric.data.storage"),
+                     (GlobalStorage, "torch_geometric.data.storage")):
+        cls.__module__, cls.__qualname__ = mod, cls.__name__
+        setattr(mods[mod], cls.__name__, cls)
+    sys.modules.update(mods)
+    rs = np.random.RandomState(3)
+    n = 9
+    x = torch.from_numpy(rs.rand(n, 22).astype(np.float32))
+    coords = torch.from_numpy(rs.normal(size=(n, 3)).astype(np.float32))
+    ei = torch.from_numpy(rs.randint(0, n, size=(2, 20)))
+    path = os.path.join(tmp_path, "full.pt")
+    try:
+        g = Data(edge_index=ei, coords=coords, name="7abcImmunoGILGFVFTL_A0201", node_id=[f"A:GLY:{i}" for i in range(n)],
+                 residue_name=["GLY"] * n, chain_id=["A"] * n, b_factor=torch.from_numpy(rs.rand(n).astype(np.float32)),
+                 kind=[{"peptide_bond"}, {"hbond", "ionic"}] * 10, num_nodes=n,
+                 dist_mat=pd.DataFrame(rs.rand(n, n), index=[f"r{i}" for i in range(n)]))
+        g._store._mapping["x"] = x            # (the writer assigns ``g_pyg.x`` last)
+        torch.save(g, path)
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+    assert "torch_geometric" not in sys.modules
+    gx, gc, ge, gn = D.load_pyg_pickle(path)
+    assert torch.equal(gx, x) and torch.equal(gc, coords) and torch.equal(ge, ei) and gn == "7abcImmunoGILGFVFTL_A0201"
+    packed = D.convert_pyg_directory(str(tmp_path))
+    assert packed.names == ["GILGFVFTL_A0201"] and packed.x.shape == (1, n, 23)
