@@ -133,6 +133,49 @@ def test_egnn_layer_forward_backward(cuda_device, case, din):
     print(case, din, {k: f"{v:.1e}" for k, v in report.items()})
 
 
+@pytest.mark.parametrize("case", ["b4", "ragged_5x40", "deg8_windows_differ", "past_the_rowptr_table"])
+def test_paired_backward_kernel_equals_the_256_thread_kernel(cuda_device, case, monkeypatch):
+    """``is_egnn_layer_bwd_paired`` (one 512-thread workgroup per CU, csrc/egnn_layer_bwd8.hip) against ``is_egnn_layer_bwd`` on a
+    two-layer stack (so that the gathered form runs): per-tile arithmetic is the same source on the same tiles -- the two
+    translation units may contract multiply-adds differently, so the comparison is at 1e-5 (an order below the oracle tolerance for gradients; measured 2 - 3e-7 of the tensor scale),
+    not bit for bit; the weight gradients also differ in the order their partial records are added (pairs first), in fp64.
+    Shapes that exercise the lockstep bookkeeping: a ragged last tile, tiles whose TWO groups have different window counts (in-degree
+    8: 1 - 3 windows per tile), a workgroup with more tiles than the staged ``rowptr`` table holds (> 8 per group: 400 graphs)."""
+    from immunostruct_amd import functional as HF
+    from immunostruct_amd.nn import egnn_stack_forward
+    raw = {"b4": lambda: synthetic.make_batch(4, seed=8),
+           "ragged_5x40": lambda: synthetic.make_batch(5, seed=9, n_pad=40, n_real_choices=(36, 38, 40)),
+           "deg8_windows_differ": lambda: synthetic.make_batch(24, seed=10, deg_extra=8),
+           "past_the_rowptr_table": lambda: synthetic.make_batch(440, seed=11, deg_extra=2)}[case]()
+    dev = cuda_device
+    monkeypatch.setattr(HF, "_FORCE_BWD_TILES", "0")      # plain 16-node tiles in both runs (the paired kernel's domain)
+    g = H.product_graph(raw, dev)
+    torch.manual_seed(3)
+    layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(dev) for i in range(2)]
+    h0, x0, ea = g.ndata["x"][:, :20].contiguous(), g.ndata["x"][:, 20:].contiguous(), g.edata["edge_attr"]
+    gh = torch.randn(raw.num_nodes, 64, device=dev)
+    gx = torch.randn(raw.num_nodes, 3, device=dev)
+
+    def run(paired):
+        monkeypatch.setattr(HF, "BWD_PAIRED", paired)
+        hh, xx = h0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+        h, x = egnn_stack_forward(layers, g, hh, xx, ea)
+        ((h * gh).sum() + (x * gx).sum()).backward()
+        torch.cuda.synchronize()
+        return {"dh": hh.grad.clone(), "dx": xx.grad.clone(), **{f"{i}.{k}": p.grad.clone() for i, l in enumerate(layers) for k, p in l.named_parameters()}}
+    assert _lib.load().is_egnn_layer_bwd_paired_supported(1, 0) == 1
+    a, b = run(False), run(True)
+    worst = 0.0
+    for k in a:
+        worst = max(worst, H.assert_close(b[k].cpu(), a[k].cpu(), 1e-5, f"{case} grad {k}"))
+    print(case, f"worst scaled difference between the two kernels {worst:.2e}")
+    c = run(True)
+    for k in b:
+        assert torch.equal(b[k], c[k]), f"{case}: {k} of the paired kernel differs between two runs"
+
+
 def test_egnn_layer_is_deterministic(cuda_device):
     raw = synthetic.make_batch(4, seed=8)
     a, _ = _run_layer(raw, 64, 1, cuda_device)
