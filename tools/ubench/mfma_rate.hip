@@ -45,6 +45,9 @@ __global__ void kern(float* out, long long* cycles, int iters) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, ab, acc[n], 0, 0, 0);
+    } else if (MODE == 6) {   // 16 MFMA 16x16x4 on ONE accumulator: a dependent chain (SrcC = the previous vDst)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0], 0, 0, 0);
     } else if (MODE == 4) {   // 8 x (mfma + 4 fma): overlap test
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
@@ -93,5 +96,6 @@ int main() {
   run<3>("v_exp_f32", 16);
   run<4>("mfma16 + 4 fma (per group)", 8);
   run<5>("mfma_f32_16x16x16_bf16", 16);
+  run<6>("mfma_f32_16x16x4, one acc", 16);
   return 0;
 }
