@@ -34,7 +34,10 @@ namespace is {
 #ifdef IS_STAGE_STAMPS
 __device__ long long g_stamps_b8[24];
 #define STAMP8_WG 150
-#define STAMPB8(k) do { if (blockIdx.x == STAMP8_WG && threadIdx.x == 0 && tk == 0) g_stamps_b8[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef STAMP8_TK
+#define STAMP8_TK 0      // which tile (round) of the stamped workgroup the window stamps belong to (-DSTAMP8_TK=1: a steady-state one)
+#endif
+#define STAMPB8(k) do { if (blockIdx.x == STAMP8_WG && threadIdx.x == 0 && tk == STAMP8_TK) g_stamps_b8[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMPP8(k) do { if (blockIdx.x == STAMP8_WG && threadIdx.x == 0) g_stamps_b8[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMPB8(k) do { } while (0)
