@@ -53,9 +53,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 H = 64
 # where the captured step's dropout masks / reparameterisation noise come from (engine.CapturedTrainStep step_random):
-# "device" = one launch of the library's generator inside the step; IMMUNOSTRUCT_STEP_RANDOM=torch: torch's generator inside the
-# step (rounds 1 - 3: two generator-state fills in front of every replay), =prefetch: torch's generator one step ahead
-STEP_RANDOM = {"torch": None}.get(os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"), os.environ.get("IMMUNOSTRUCT_STEP_RANDOM", "device"))
+# "device" = one launch of the library's generator inside the step, as the device-resident training loops of ``procedures`` run it
+# (None would be torch's generator inside the step: two generator-state fills in front of every replay)
+STEP_RANDOM = "device"
 TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
@@ -982,6 +982,8 @@ def main():
         # teardown in dependency order: the captured graphs (which may hold RCCL's collective nodes) go first, then the process group --
         # destroying the communicator under a live graph that references it aborted one run in a dozen on the one-rank RCCL group
         torch.cuda.synchronize()
+        if getattr(wl, "captured", None) is not None:
+            wl.captured.close()
         for name in ("captured", "graphs"):
             if hasattr(wl, name):
                 setattr(wl, name, None)

@@ -93,9 +93,6 @@ SIGNATURES = {
     "is_vae_latent_bwd_wgrad": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     "is_recon_mse": [_P, _P, _P, _LL, _F, _P, _P],
     "is_vae_loss": [_P, _P, _P, _LL, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P],
-    "is_loss_pred_term": [_P, _P, _P, _I, _I, _F, _F, _P, _P],
-    "is_loss_kld_term": [_P, _P, _P, _P, _I, _F, _P, _P],
-    "is_loss_total": [_P, _LL, _I, _I, _F, _F, _F, _P, _P, _P, _P],
 }
 
 

@@ -170,33 +170,3 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
                      c_kld, (float*)nullptr, out, total);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
-
-// The three terms of is_vae_loss as separate launches (same sums, same bits): the prediction term on the stream the logit is
-// produced on, the KLD term where mu / logvar are, and the total -- stage 2 of the reconstruction term (partials[] from
-// is_recon_mse) plus the two raw sums the other launches left in sums[1] (KLD) / sums[2] (prediction) -- wherever both are
-// complete.  sums: 4 floats of device memory shared by the three.
-extern "C" int is_loss_pred_term(const float* logit, const float* y, float* d_logit, int batch, int mode, float pos_weight,
-                                 float c_pred, float* sums, void* stream) {
-  if (batch <= 0 || logit == nullptr || y == nullptr || d_logit == nullptr || sums == nullptr) return -22;
-  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_PRED>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
-                     (const float*)nullptr, 0, 0LL, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     0, logit, y, d_logit, batch, mode, pos_weight, c_pred, 0.0f, 0.0f, sums, (float*)nullptr, (float*)nullptr);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-extern "C" int is_loss_kld_term(const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total, float c_kld,
-                                float* sums, void* stream) {
-  if (latent_total <= 0 || mu == nullptr || logvar == nullptr || d_mu == nullptr || d_logvar == nullptr || sums == nullptr) return -22;
-  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_KLD>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
-                     (const float*)nullptr, 0, 0LL, mu, logvar, d_mu, d_logvar, latent_total, (const float*)nullptr,
-                     (const float*)nullptr, (float*)nullptr, 1, 0, 1.0f, 0.0f, 0.0f, c_kld, sums, (float*)nullptr, (float*)nullptr);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-extern "C" int is_loss_total(const float* partials, long long recon_total, int latent_total, int batch, float c_pred, float c_mse,
-                             float c_kld, float* sums, float* out, float* total, void* stream) {
-  if (batch <= 0 || recon_total <= 0 || partials == nullptr || sums == nullptr || out == nullptr) return -22;
-  hipLaunchKernelGGL(is::loss_finish_kernel<is::PART_MSE>, dim3(1), dim3(is::FIN_BLOCK), 0, static_cast<hipStream_t>(stream),
-                     partials, recon_parts(recon_total), recon_total, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
-                     (float*)nullptr, latent_total, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, batch, 0, 1.0f,
-                     c_pred, c_mse, c_kld, sums, out, total);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
-}

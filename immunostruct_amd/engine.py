@@ -15,8 +15,9 @@ Replay needs fixed addresses and launch geometry:
 * ``load(batch)`` copies a device-resident batch into those buffers (async D2D on the same stream);
   this is the on-GPU batcher's hand-over point.
 
-With data parallelism the gradient all-reduce (RCCL) stays outside the graphs: graph A = zero +
-forward + loss + backward, eager all-reduce of the flat bucket, graph B = optimizer step.
+With data parallelism the gradient all-reduce (RCCL) runs between the graphs: graph A = zero + forward +
+loss + backward + bucket pack, all-reduce of the flat bucket(s), graph B = optimizer step per bucket
+(``IMMUNOSTRUCT_DP_ONE_GRAPH``: the collectives inside one graph).
 """
 from __future__ import annotations
 
@@ -31,16 +32,16 @@ from .graph import CSRIndex, PackedGraphBatch
 # (hipEventQuery) at any time -- in the default "global" mode such a call from ANOTHER thread invalidates the capture in progress
 # ("operation not permitted when stream is capturing", first met under a one-rank RCCL group in round 4)
 _CAPTURE = {"capture_error_mode": "thread_local"}
-_EARLY_PREPARE = os.environ.get("IMMUNOSTRUCT_ADAM_EARLY_PREPARE", "0") == "1"
-# data-parallel steps: the gradient buckets are packed by the captured graph that produced the gradients (its last nodes) instead of
-# by an eager multi-tensor copy between the replay and the collective (IMMUNOSTRUCT_DP_PACK_IN_GRAPH=0: the eager pack)
-_PACK_IN_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_PACK_IN_GRAPH", "1") != "0"
 # The data-parallel step as ONE captured graph (round 5): pack, the all-reduce(s) and the optimizer update are captured together with
 # forward and backward -- ProcessGroupNCCL's collectives are stream operations, so RCCL's kernels become nodes of the graph (the
 # asynchronous form forks onto the process group's stream and joins at ``work.wait()``): one replay per step, no graph boundaries, no
-# host-side wait.  "auto" (default): captured where the process group is "nccl", timed against the multi-graph forms, kept if
-# faster; "0": never; "1": forced (an error while capturing is kept in ``one_graph_error`` and the multi-graph forms run).
-_ONE_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_ONE_GRAPH", "auto")
+# host-side wait.  "0" (default since round 6: the form has only ever run under a ONE-rank RCCL group -- no multi-GPU node was
+# available to this build -- and a graph that holds RCCL's nodes must be released before the process group, `close()`); "auto":
+# captured where the process group is "nccl", timed against the multi-graph forms on all ranks, kept if faster; "1": forced wherever it
+# was captured (an error while capturing is kept in ``one_graph_error`` and the multi-graph forms run).
+_ONE_GRAPH = os.environ.get("IMMUNOSTRUCT_DP_ONE_GRAPH", "0")
+if _ONE_GRAPH not in ("auto", "0", "1"):
+    raise ValueError("IMMUNOSTRUCT_DP_ONE_GRAPH must be auto, 0 or 1")
 
 
 class StaticGraphBatch(PackedGraphBatch):
@@ -178,7 +179,7 @@ class CapturedTrainStep:
     """
 
     def __init__(self, model, optimizer, reducer, forward_loss, template, edge_capacity, warmup=3, preserve_state=False,
-                 step_random=None):
+                 step_random=None, random_stream=0):
         if warmup < 1:
             raise ValueError("warmup must be >= 1: optimizer state and BLAS handles have to be created by an eager "
                              "step BEFORE the capture (state created inside a capture is re-initialised on every replay)")
@@ -200,16 +201,16 @@ class CapturedTrainStep:
             self.sgraph = StaticGraphBatch(g, edge_capacity)
             self.seq, self.prop = torch.zeros_like(seq), torch.zeros_like(prop)
         self.y = torch.zeros_like(y)
-        # step_random (functional.StepRandom): where the step's dropout masks and reparameterisation noise come from.  None (this
-        # constructor's default; the device-resident training loops of ``procedures`` and ``bench.py`` pass "device"): the
-        # models draw them inside the step with torch's generator (every replay of a graph that does launches two generator-state
-        # fills in front of it).  "device": one launch of the library's own generator inside the step (is_step_random); its key
-        # differs per engine of a process, ``random_state()`` / ``load_random_state()`` carry it across a checkpoint.
-        # "prefetch": torch's generator, one step ahead, outside the captured step, handed over with the batch (same values as
-        # eager steps draw; measured slower: the helper stream's launches disturb the persistent layer kernels).  Off by
-        # default: a ``forward_loss`` that patches the draws (tests with fixed noise) would be bypassed
+        # step_random: where the step's dropout masks and reparameterisation noise come from.  None (this constructor's default, and
+        # what every parity test uses: a ``forward_loss`` that patches the draws would be bypassed otherwise): the models draw them
+        # inside the step with torch's generator (every replay of such a graph launches two generator-state fills in front of it).
+        # "device" (the device-resident training loops of ``procedures`` and ``bench.py``): one launch of the library's own
+        # generator inside the step (functional.StepRandom, is_step_random); ``random_stream`` is mixed into its key -- the index
+        # of the run's stage --, ``random_state()`` / ``load_random_state()`` carry key and counter across a checkpoint.
         from .functional import StepRandom
-        self._rand = StepRandom(self.y.device, step_random) if step_random else None
+        if step_random not in (None, "device"):
+            raise ValueError("step_random must be None or 'device'")
+        self._rand = StepRandom(self.y.device, stream_id=random_stream) if step_random else None
         self._load(*template)
         self.fused_optimizer = not reducer.packing   # single rank: optimizer inside the same graph
         if getattr(reducer, "_collective", False) and hasattr(optimizer, "grad_scale") and reducer.divide:
@@ -233,10 +234,6 @@ class CapturedTrainStep:
         self._want_two_stage = reducer.packing and mode != "0"
         self._late = None
         self.dp_times = None
-        # None: not classified yet; False: no overlapped optimizer step; list: the EGNN stack's own parameters
-        # (IMMUNOSTRUCT_ADAM_OVERLAP=1: measured, no gain -- the tail is bandwidth-bound, HISTORY.md -- hence off by default)
-        self._tail_late = None if os.environ.get("IMMUNOSTRUCT_ADAM_OVERLAP", "0") == "1" else False
-        self._split = None
         snap = _snapshot(model, optimizer) if preserve_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -274,10 +271,9 @@ class CapturedTrainStep:
             self.graph_a1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a1, **_CAPTURE):
                 loss = self._stage1()
-                if _PACK_IN_GRAPH:
-                    self.reducer.pack(0, from_grad=True)      # the bucket's pack as the graph's last node: no eager launch behind the replay
+                self.reducer.pack(0, from_grad=True)      # the bucket's pack as the graph's last node: no eager launch behind the replay
             # a graph always writes the gradient buffers it allocated while capturing: pack from those
-            self.reducer.bind_sources(0, packed=_PACK_IN_GRAPH)
+            self.reducer.bind_sources(0, packed=True)
             self.reducer.reduce_bucket(0)         # .grad of the first bucket now aliases its persistent flat buffer
             bnd, bnd_grads = self._bnd, self._bnd_grads
             for res in self._reserved_candidates:
@@ -288,11 +284,10 @@ class CapturedTrainStep:
                 try:
                     with torch.cuda.graph(graph, pool=self.graph_a1.pool(), **_CAPTURE):
                         self._stage2(retain=res != self._reserved_candidates[-1])
-                        if _PACK_IN_GRAPH:
-                            self.reducer.pack(1, from_grad=True)
+                        self.reducer.pack(1, from_grad=True)
                 finally:
                     HF.RESERVED_CUS = saved
-                self.reducer.bind_sources(1, packed=_PACK_IN_GRAPH)
+                self.reducer.bind_sources(1, packed=True)
                 self.reducer.reduce_bucket(1)
                 self._a2[res] = (graph, self.reducer.sources())
             self.graph_a2, sources = self._a2[self.reserved]
@@ -305,16 +300,16 @@ class CapturedTrainStep:
             with torch.cuda.graph(self.graph_a, **_CAPTURE):
                 loss = self._fwd_bwd()
                 if self.fused_optimizer:
-                    self._optimizer_step()
+                    self.optimizer.step()
                     from .functional import Stamps
                     Stamps.mark("optimizer done")
-                elif _PACK_IN_GRAPH:
+                else:
                     for i in range(len(self.reducer.buckets)):
                         self.reducer.pack(i, from_grad=True)
             if dump:
                 self.graph_a.debug_dump(dump)
             if not self.fused_optimizer:
-                self.reducer.bind_sources(packed=_PACK_IN_GRAPH)
+                self.reducer.bind_sources(packed=True)
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
             self._forms[False] = (loss, self.reducer.sources())
         if not self.fused_optimizer:
@@ -345,12 +340,13 @@ class CapturedTrainStep:
                 if ok < 0.5 and k in self.graph_c:
                     del self.graph_c[k]
                     self.one_graph_error = self.one_graph_error or f"form {k!r} was not captured on every rank"
-        if len(self._forms) == 2 or (self.graph_c and _ONE_GRAPH == "auto"):
+        if self.graph_c and _ONE_GRAPH == "1":      # forced: no timing may hand the step back to a multi-graph form
+            self._use_form("graph2" if "graph2" in self.graph_c and mode != "0" else "graph")
+        elif len(self._forms) == 2 or self.graph_c:
             self._choose_form(model, optimizer)
-        elif self.graph_c and _ONE_GRAPH == "1":
-            self._use_form("graph2" if "graph2" in self.graph_c and self.two_stage else next(iter(self.graph_c)))
         else:
             self._use_form(self.two_stage)
+        self._drop_unused_forms()
 
     def _collectives_capturable(self):
         """the reducer issues collectives on a backend whose collectives are stream operations (nccl = RCCL); gloo's run on the host"""
@@ -362,53 +358,60 @@ class CapturedTrainStep:
     def _capture_one_graph(self):
         """graph_c["graph"]: forward, backward, pack, all-reduce of every bucket, update -- the serial form as one graph;
         graph_c["graph2"] (when the model splits at the EGNN stack): stage 1, bucket 0 on the wire (asynchronous: a fork inside the
-        graph), stack backward beside it, bucket 1, join, update(s) -- the two-stage form as one graph.  A failure to capture (a
-        stack that cannot capture its collectives) is recorded verbatim and leaves the multi-graph forms in charge."""
+        graph), stack backward beside it, bucket 1, join, update(s) -- the two-stage form as one graph.  Each form is captured on its
+        own: a failure (a stack that cannot capture its collectives) is recorded verbatim in ``one_graph_error`` and withdraws that
+        form only; the multi-graph forms stay in charge of whatever is missing."""
         red = self.reducer
         saved = red.sources()
-        try:
-            forms = {}
-            graph = torch.cuda.CUDAGraph()
-            split = self._split_update()      # (the update in the parts the eager warm-up steps ran it in: their chunk tables exist)
-            with torch.cuda.graph(graph, **_CAPTURE):
-                loss = self._fwd_bwd()
-                for i in range(len(red.buckets)):
-                    red.pack(i, from_grad=True)
-                    red.reduce_bucket(i, prepacked=True)
-                    if split:
-                        self.optimizer.step_subset(red.buckets[i]["params"], first=i == 0)
-                if not split:
-                    self.optimizer.step()
-            forms["graph"] = (graph, loss)
-            if self._forms.get(True) is not None and self._late is not None and len(red.buckets) == 2:
+        split = self._split_update()      # (the update in the parts the eager warm-up steps ran it in: their chunk tables exist)
+
+        def serial():
+            loss = self._fwd_bwd()
+            for i in range(len(red.buckets)):
+                red.pack(i, from_grad=True)
+                red.reduce_bucket(i, prepacked=True)
+                if split:
+                    self.optimizer.step_subset(red.buckets[i]["params"], first=i == 0)
+            if not split:
+                self.optimizer.step()
+            return loss
+
+        def two_stage():
+            loss = self._stage1()
+            red.pack(0, from_grad=True)
+            work0 = red.reduce_bucket(0, async_op=True, prepacked=True)
+            self._stage2()
+            red.pack(1, from_grad=True)
+            work1 = red.reduce_bucket(1, async_op=True, prepacked=True)
+            if split:
+                if work0 is not None:
+                    work0.wait()
+                self.optimizer.step_subset(red.buckets[0]["params"], first=True)
+                if work1 is not None:
+                    work1.wait()
+                self.optimizer.step_subset(red.buckets[1]["params"], first=False)
+            else:
+                for w in (work0, work1):
+                    if w is not None:
+                        w.wait()
+                self.optimizer.step()
+            return loss
+
+        bodies = [("graph", serial)]
+        if self._forms.get(True) is not None and self._late is not None and len(red.buckets) == 2:
+            bodies.append(("graph2", two_stage))
+        self.graph_c = {}
+        for name, body in bodies:
+            try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, **_CAPTURE):
-                    loss = self._stage1()
-                    red.pack(0, from_grad=True)
-                    work0 = red.reduce_bucket(0, async_op=True, prepacked=True)
-                    self._stage2()
-                    red.pack(1, from_grad=True)
-                    work1 = red.reduce_bucket(1, async_op=True, prepacked=True)
-                    if self._split_update():
-                        if work0 is not None:
-                            work0.wait()
-                        self.optimizer.step_subset(red.buckets[0]["params"], first=True)
-                        if work1 is not None:
-                            work1.wait()
-                        self.optimizer.step_subset(red.buckets[1]["params"], first=False)
-                    else:
-                        for w in (work0, work1):
-                            if w is not None:
-                                w.wait()
-                        self.optimizer.step()
-                forms["graph2"] = (graph, loss)
-            self.graph_c = forms
-        except Exception as exc:      # noqa: BLE001 -- whatever the stack raises is the finding
-            self.one_graph_error = f"{type(exc).__name__}: {exc}"
-            self.graph_c = {}
-            torch.cuda.synchronize()
-        finally:
-            red.sources(saved)
+                    loss = body()
+                self.graph_c[name] = (graph, loss)
+            except Exception as exc:      # noqa: BLE001 -- whatever the stack raises is the finding
+                self.one_graph_error = (self.one_graph_error + "; " if self.one_graph_error else "") + f"{name}: {type(exc).__name__}: {exc}"
+                torch.cuda.synchronize()
+            finally:
+                red.sources(saved)
 
     def random_state(self):
         """the state of the step's random-tensor provider (None without one): save it beside the optimizer state to resume a run"""
@@ -467,97 +470,25 @@ class CapturedTrainStep:
         self._use_form(*cands[best])
 
     def _load(self, g, seq, prop, y):
-        rand = self._rand.pairs() if self._rand is not None else []      # the prefetched random tensors ride on the same launch
         if self.paired:
             pairs = [(y, self.y)]
             for sg, gi, si, ss, pi, ps in zip(self.sgraph, g, seq, self.seq, prop, self.prop):
                 pairs += sg.copy_pairs(gi) + [(si, ss), (pi, ps)]
-            multi_copy(pairs + rand)
+            multi_copy(pairs)
         else:
-            multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)] + rand)
-
-    def _refresh_random(self):
-        """hand the prefetched random tensors over when ``_load`` did not (replay() on buffers the on-device batcher filled)"""
-        if self._rand is not None:
-            rand = self._rand.pairs()
-            if rand:
-                multi_copy(rand)
+            multi_copy(self.sgraph.copy_pairs(g) + [(seq, self.seq), (prop, self.prop), (y, self.y)])
 
     def _fwd_bwd(self):
         from . import functional as HF
-        from .functional import Stamps
+        from .functional import SpeculativeBackward, Stamps, unit_gradient
         Stamps.mark("step start")
         self.reducer.zero()
-        self._early_prepare()
-        from .functional import SpeculativeBackward, unit_gradient
-        overlap = self.fused_optimizer and self._tail_late is not False and hasattr(self.optimizer, "step_overlapped")
-        if overlap and self._tail_late is None:
-            HF.StackBoundary.begin()
-        try:
-            with SpeculativeBackward(self._fused_loss), HF.StepRandom.use(self._rand):      # the backward below is seeded with the unit gradient
-                loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
-        finally:
-            bnd = HF.StackBoundary.end() if (overlap and self._tail_late is None) else None
-        if bnd is not None:
-            # first (eager) step: the parameters that get their gradients from the EGNN stack's tail -- everything else may be
-            # updated beside that tail (False: the model has no such split, plain optimizer step)
-            late = self._stack_only_params(loss, bnd) if bnd else []
-            self._tail_late = late if (late and len(late) < len(self.reducer.params)) else False
+        with SpeculativeBackward(self._fused_loss), HF.StepRandom.use(self._rand):      # the backward below is seeded with the unit gradient
+            loss = self.forward_loss(self.model, self.sgraph, self.seq, self.prop, self.y)
         Stamps.mark("loss done")
-        HF.TailGate.enabled, HF.TailGate.event = bool(overlap and self._tail_late), None
-        try:
-            loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
-        finally:
-            HF.TailGate.enabled = False
+        loss.backward(unit_gradient(loss.device))      # d loss / d loss = 1: recognised by the fused loss (no fill, no scaling)
         Stamps.mark("backward done (main stream)")
         return loss.detach()
-
-    def _early_prepare(self):
-        """single-GPU step, IMMUNOSTRUCT_ADAM_EARLY_PREPARE=1: the optimizer's one-thread launch (step count, bias corrections) goes
-        to the models' side stream at the TOP of the step -- it depends on nothing but the previous step's update -- instead of
-        sitting, with a queue hand-over, in front of the update on the critical chain"""
-        if not (self.fused_optimizer and _EARLY_PREPARE and hasattr(self.optimizer, "prepare") and getattr(self.optimizer, "_groups", None)):
-            return
-        from .models import _core
-        main = torch.cuda.current_stream()
-        side = _core._side_stream(self.y.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.optimizer.prepare()
-        self._prepared_on = side
-
-    def _optimizer_step(self):
-        """single-GPU step: the update of everything but the EGNN stack's own parameters runs on the models' side stream beside the
-        stack backward's tail (functional.TailGate) when IMMUNOSTRUCT_ADAM_OVERLAP=1; default: one launch at the end"""
-        from . import functional as HF
-        gate = HF.TailGate.event
-        HF.TailGate.event = None
-        side = getattr(self, "_prepared_on", None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            self._prepared_on = None
-        if self._tail_late and gate is not None:
-            from .models import _core
-            self.optimizer.step_overlapped(self._tail_late, gate, _core._side_stream(self.y.device))
-        else:
-            self.optimizer.step()
-
-    def _stack_only_params(self, loss, bnd):
-        """the parameters reachable from the loss ONLY through the EGNN stack outputs ``bnd`` (autograd graph walk)"""
-        def leaves(roots, stop):
-            seen, todo, out = set(), [r for r in roots if r is not None], set()
-            while todo:
-                fn = todo.pop()
-                if fn in seen or fn in stop:
-                    continue
-                seen.add(fn)
-                if hasattr(fn, "variable"):
-                    out.add(id(fn.variable))
-                todo.extend(f for f, _ in fn.next_functions if f is not None)
-            return out
-        cut = set(t.grad_fn for t in bnd if t.grad_fn is not None)
-        below, above = leaves(list(cut), set()), leaves([loss.grad_fn], cut)
-        return [p for p in self.reducer.params if id(p) in below and id(p) not in above]
 
     # ---- two-stage backward (data-parallel overlap) ---------------------------------
     def _classify(self, loss, bnd):
@@ -619,12 +550,8 @@ class CapturedTrainStep:
         self._bnd = self._bnd_grads = None
 
     def _split_update(self):
-        """data-parallel forms with two gradient buckets: update bucket by bucket, each as soon as its all-reduce is done
-        (IMMUNOSTRUCT_DP_SPLIT_UPDATE=0: one update after both)"""
-        if self._split is None:
-            self._split = os.environ.get("IMMUNOSTRUCT_DP_SPLIT_UPDATE", "1") != "0"      # read once: not per replay
-        return (self._split and not self.fused_optimizer and len(self.reducer.buckets) == 2
-                and hasattr(self.optimizer, "step_subset"))
+        """data-parallel forms with two gradient buckets: update bucket by bucket, each as soon as its all-reduce is done"""
+        return not self.fused_optimizer and len(self.reducer.buckets) == 2 and hasattr(self.optimizer, "step_subset")
 
     def _reduce_and_update(self, stage2, update):
         """the part of a data-parallel step behind the (first-stage) backward: all-reduce bucket by bucket, ``stage2()`` (the stack
@@ -660,12 +587,6 @@ class CapturedTrainStep:
             self.optimizer.step_subset(self.reducer.buckets[i]["params"], first=i == 0)
 
     def _body(self, eager=False):
-        if eager and self._rand is not None:
-            self._refresh_random()
-            try:
-                return self._body()
-            finally:
-                self._rand.prefetch()
         if self._want_two_stage:
             loss = self._stage1()
             self._reduce_and_update(self._stage2 if self.two_stage else None, self._eager_update)
@@ -673,7 +594,7 @@ class CapturedTrainStep:
         loss = self._fwd_bwd()
         if self.fused_optimizer:
             self.reducer.all_reduce_mean()
-            self._optimizer_step()
+            self.optimizer.step()
         else:
             self._reduce_and_update(None, self._eager_update)
         return loss
@@ -687,7 +608,6 @@ class CapturedTrainStep:
         on-device batcher (``data.DeviceResidentDataset.gather_into``) writes them directly."""
         if hasattr(self.optimizer, "refresh"):
             self.optimizer.refresh()      # learning-rate schedulers: host value -> device copy read by the captured step
-        self._refresh_random()
         def update(i):
             (self.graph_b if i is None else self.graph_b[i]).replay()
         if self.one_graph:
@@ -700,6 +620,28 @@ class CapturedTrainStep:
             self.graph_a.replay()
             if self.graph_b is not None:
                 self._reduce_and_update(None, update)
-        if self._rand is not None:
-            self._rand.prefetch()      # the next step's draws, on the helper stream, beside this step
         return self.loss
+
+    def _drop_unused_forms(self):
+        """the captured forms that lost the choice are released: they hold pool memory and -- the one-graph forms -- RCCL's nodes"""
+        if self.one_graph:
+            self.graph_c = {self.one_graph: self.graph_c[self.one_graph]}
+            self.graph_a = self.graph_a1 = self.graph_a2 = self.graph_b = None
+            self._a2 = {}
+        else:
+            self.graph_c = {}
+            if self.two_stage:
+                self.graph_a = None
+                self._a2 = {self.reserved: self._a2[self.reserved]}
+            else:
+                self.graph_a1 = self.graph_a2 = None
+                self._a2 = {}
+
+    def close(self):
+        """Release every captured graph (after a synchronize).  Call BEFORE ``torch.distributed.destroy_process_group()``: a graph
+        that holds RCCL's collective nodes must not outlive its communicator (an abort at process exit was seen when it did)."""
+        torch.cuda.synchronize()
+        self.graph_c = {}
+        self._a2 = {}
+        self.graph_a = self.graph_a1 = self.graph_a2 = self.graph_b = None
+        torch.cuda.synchronize()

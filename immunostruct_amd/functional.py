@@ -20,8 +20,8 @@ SAVE_Z3 = os.environ.get("IMMUNOSTRUCT_SAVE_Z3", "1") == "1"      # 0: the backw
 # workgroups per layer of the batched node weight-gradient launch, by kind (node block: 12 MFMAs per 4-row step; next
 # pre-projection: 8).  13 x 56 = 728 <= 3 x 256 resident.  Equal work per workgroup (72 : 48) is SLOWER (82 -> 92 us): the launch
 # lasts as long as its longest workgroup, ~2.9 us per 16-row chunk whatever the kind (HISTORY.md, round 3)
-WGRAD_GRID_NODE = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID_NODE", "56"))
-WGRAD_GRID_PROJ = int(os.environ.get("IMMUNOSTRUCT_WGRAD_GRID_PROJ", "56"))
+WGRAD_GRID_NODE = 56
+WGRAD_GRID_PROJ = 56
 FWD_CHUNKS_MAX = 2048
 FWD_CHUNK_EDGES = 32
 # Data-parallel mode of the two persistent layer kernels: their grids normally fill EVERY workgroup slot of the chip (2 per CU),
@@ -29,7 +29,7 @@ FWD_CHUNK_EDGES = 32
 # be scheduled away -- costs the launch a whole extra round.  With RESERVED_CUS = R the grids stop at 2 * (256 - R) workgroups
 # (forward: 8 * (256 - R) wave chunks), so that a collective of up to 2 R workgroup slots (NCCL_MAX_NCHANNELS bounds its footprint)
 # fits BESIDE a layer kernel.  Set by engine.CapturedTrainStep for the overlapped (two-stage) form; 0 = single-GPU behaviour.
-RESERVED_CUS = int(os.environ.get("IMMUNOSTRUCT_RESERVED_CUS", "0"))
+RESERVED_CUS = 0
 
 
 def layer_slots():
@@ -37,7 +37,6 @@ def layer_slots():
     return 2 * (_MAX_BWD_GRID - max(0, min(RESERVED_CUS, _MAX_BWD_GRID - 1)))
 
 
-_FORCE_BWD_TILES = os.environ.get("IMMUNOSTRUCT_BWD_TILES", "")
 # 1 (default): the backward layer launches run as ONE 512-thread workgroup per CU wherever csrc/egnn_layer_bwd8.hip covers the
 # shape; 0: always two 256-thread workgroups per CU (csrc/egnn_layer_bwd.hip) -- the A/B switch of round 5
 BWD_PAIRED = os.environ.get("IMMUNOSTRUCT_BWD_PAIRED", "1") == "1"
@@ -49,8 +48,6 @@ def use_bwd_tiles(num_nodes, num_edges, slots, fe):
     3 rounds and the fuller windows are slower per round (measured 82 vs 78 us), at B = 512 they save 2 of 12."""
     if fe > 1:
         return False          # the listed-tile instantiation exists for Fe <= 1 only (LDS)
-    if _FORCE_BWD_TILES in ("0", "1"):
-        return _FORCE_BWD_TILES == "1"      # experiments only (tools/): the rule below is the measured one
     rounds = lambda tiles: (tiles + slots - 1) // slots
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
@@ -136,24 +133,6 @@ class Stamps:
         vals = cls.buf[:len(cls.names)].tolist()
         t0 = min(v for v in vals if v > 0)
         return sorted(((v - t0) / 100.0, n) for v, n in zip(vals, cls.names))     # microseconds (100 MHz clock)
-
-
-class TailGate:
-    """Marks, inside the EGNN stack's backward, the point in front of its tail (the batched node weight-gradient launch and the
-    reduction of the partial records: ~110 us in which only the stack's own parameters still wait for their gradients).  The
-    engine waits for this event on its side stream before it applies the optimizer update of every OTHER parameter there -- the
-    bandwidth-bound update then runs beside the tail instead of behind it (engine.CapturedTrainStep, optim.Adam.step_overlapped)."""
-    enabled = False
-    event = None
-    # IMMUNOSTRUCT_ADAM_GATE_LAYER = k >= 0: the mark sits behind the backward launch of EGNN layer k instead (the update then runs
-    # beside the backward launches of the layers below k, whose HBM use is a third of the copy rate)
-    layer = int(os.environ.get("IMMUNOSTRUCT_ADAM_GATE_LAYER", "-1"))
-
-    @classmethod
-    def mark(cls, layer=-1):
-        if cls.enabled and layer == cls.layer:
-            cls.event = torch.cuda.Event()
-            cls.event.record()
 
 
 class LaunchClock:
@@ -721,7 +700,6 @@ class EGNNStackFn(torch.autograd.Function):
             rjobs.append((part_e, grid_e, _EDGE_STRIDE, _EDGE_STRIDE, plans[i].edge_map, gflat[i]))
             above = (dZ1, dD, dx)
             g_hd, g_psd_next, g_xc = d_h, dpsd, dx
-            TailGate.mark(i)
         # the gather of layer 0's per-edge gradients completes dL/dpsd_0 (and dL/dx_0): its own launch (no layer below)
         dZ1, dD, dx = above
         with KernelTimer.span("gather_segment_sum"):      # (accumulates into dx: not repeatable)
@@ -750,7 +728,6 @@ class EGNNStackFn(torch.autograd.Function):
                            "is_node_proj_bwd")
             rjobs.append((part_p, grid_n, _PROJ_STRIDE, _PROJ_STRIDE, plans[0].proj_map, gflat[0]))
         arr = (_lib.WgradLayer * len(wjobs))(*wjobs)
-        TailGate.mark()
         with KernelTimer.span("egnn_node_wgrad_batched"):
             _lib.check(lib.is_egnn_node_wgrad_batched(ctypes.cast(arr, ctypes.c_void_p), len(wjobs), grid_wn, grid_wp, n, st),
                        "is_egnn_node_wgrad_batched")
@@ -1197,55 +1174,37 @@ _ones_cache = {}
 
 
 class StepRandom:
-    """The random tensors of a train step -- dropout keep-masks, the reparameterisation noise -- drawn OUTSIDE the captured step,
-    one step ahead, with the very calls the models make (``F.dropout`` of a ones tensor, ``torch.randn_like``: torch's generator,
-    same order, same values as an eager step would draw).
+    """The random tensors of a train step -- dropout keep-masks, the reparameterisation noise -- from ONE launch of the library's own
+    generator inside the step (``is_step_random``: Philox4x32-10 on a device-resident state seeded from ``torch.cuda.initial_seed()``),
+    issued at the step's first draw.
 
     Why: a captured graph that uses torch's generator makes every ``CUDAGraph.replay()`` launch two fill kernels (the generator's
     seed and offset) in front of the graph -- 10.6 us on the step's critical chain -- and the three draws are launch-bound torch
-    kernels inside the step.  With a provider active (``StepRandom.use``) the models get static buffers instead of drawing; the
-    engine draws the next step's values on a helper stream while the current step runs (:meth:`prefetch`) and hands them over
-    with the batch (:meth:`pairs`, the same ``is_multi_copy`` launch)."""
+    kernels inside the step.  With a provider active (``StepRandom.use``) the models get static buffers instead of drawing.  The
+    values are not torch's streams (same distributions; reproducible for a given seed and ``stream_id``).  (Drawing with torch's
+    generator one step ahead on a helper stream was measured slower and is gone: HISTORY.md 7.8.)"""
     active = None
-    _created = 0      # providers of mode "device" created in this process: each gets its own Philox key
 
-    def __init__(self, device, mode="prefetch", stream_id=None):
-        """``mode`` "prefetch": as above.  "device": the step's tensors come from ONE launch of the library's own generator
-        (``is_step_random``: Philox4x32-10 on a device-resident state seeded from ``torch.cuda.initial_seed()``) issued inside the step at
-        its first draw -- no helper stream, nothing outside the captured graph, one launch instead of three; the values are not
-        torch's streams (same distributions; reproducible for a given seed).
-        ``stream_id`` (mode "device"): mixed into the key, default = the number of providers created before this one -- the engines
-        of a run's stages (pretrain, finetune: one ``CapturedTrainStep`` each, same device seed) then draw DIFFERENT mask / noise
-        sequences instead of replaying the first stage's; the creation order of a seeded run is fixed, so the run
-        stays reproducible.  :meth:`state_dict` / :meth:`load_state_dict` carry key and step counter across a checkpoint."""
-        if mode not in ("prefetch", "device"):
-            raise ValueError("StepRandom mode must be 'prefetch' or 'device'")
-        self.mode = mode
+    def __init__(self, device, stream_id=0):
+        """``stream_id`` is mixed into the Philox key: the engines of a run's stages pass their stage's index (``procedures``: pretrain
+        0, finetune 1) so that they draw DIFFERENT mask / noise sequences from the same device seed -- a property of the stage, not
+        of how many providers the process built before (a resumed process that builds only the finetune engine draws what the full
+        run drew there).  :meth:`state_dict` / :meth:`load_state_dict` carry key and step counter across a checkpoint."""
+        self.mode = "device"
         self.slots, self.cursor = [], 0
-        self.pending = self.ready = self._keep = None
-        if mode == "device":
-            if stream_id is None:
-                stream_id = StepRandom._created
-            StepRandom._created += 1
-            key = (torch.cuda.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id)) & 0x7FFFFFFFFFFFFFFF
-            self.state = torch.tensor([key, 0, 0], dtype=torch.int64, device=device)
-        else:
-            self.stream = torch.cuda.Stream(device=device)
+        key = (torch.cuda.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id)) & 0x7FFFFFFFFFFFFFFF
+        self.state = torch.tensor([key, 0, 0], dtype=torch.int64, device=device)
 
     def state_dict(self):
-        """mode "device": the generator's key and step counter (host copies) -- what a resumed run needs to continue the sequence"""
-        if self.mode != "device":
-            return {"mode": self.mode}
+        """the generator's key and step counter (host copies) -- what a resumed run needs to continue the sequence"""
         return {"mode": "device", "state": [int(v) for v in self.state.tolist()]}
 
     def load_state_dict(self, sd):
-        if sd.get("mode") != self.mode:
-            raise ValueError(f"StepRandom: checkpoint of mode {sd.get('mode')!r} into a provider of mode {self.mode!r}")
-        if self.mode == "device":
-            self.state.copy_(torch.tensor(sd["state"], dtype=torch.int64))      # in place: captured steps hold the address
+        if sd.get("mode") != "device":
+            raise ValueError(f"StepRandom: checkpoint of mode {sd.get('mode')!r}")
+        self.state.copy_(torch.tensor(sd["state"], dtype=torch.int64))      # in place: captured steps hold the address
 
     def _launch(self, slots):
-        import ctypes
         jobs = [_lib.RandJob(s["buf"].data_ptr(), s["buf"].numel(), 0 if s["kind"] == "randn" else 1, float(s["p"])) for s in slots]
         arr = (_lib.RandJob * len(jobs))(*jobs)
         _lib.check(_lib.load().is_step_random(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _lib.ptr(self.state), _lib.stream_ptr()),
@@ -1270,58 +1229,27 @@ class StepRandom:
         """the models' draws inside this context come from ``provider`` (None: they draw themselves)"""
         return cls._Use(provider)
 
-    @staticmethod
-    def _sample(kind, like, p):
-        if kind == "randn":
-            return torch.randn_like(like)
-        return torch.nn.functional.dropout(like, p=p, training=True)
-
     def draw(self, kind, like, p=0.0):
         i, self.cursor = self.cursor, self.cursor + 1
         if i == len(self.slots):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("StepRandom: a draw the eager warm-up step did not make appeared during capture")
-            if self.mode == "device":      # the first (eager) step learns the step's draws one by one: a launch each
-                if like.dtype != torch.float32:
-                    raise RuntimeError("StepRandom: float32 draws only")
-                self.slots.append({"kind": kind, "p": p, "buf": torch.empty(like.shape, dtype=torch.float32, device=like.device)})
-                self._launch(self.slots[-1:])
-                return self.slots[-1]["buf"]
-            buf = self._sample(kind, like, p)      # the first (eager) step: drawn in place, like any eager step
-            self.slots.append({"kind": kind, "like": like if kind == "dropout" else torch.empty_like(like), "p": p, "buf": buf})
-            return buf
+            if like.dtype != torch.float32:
+                raise RuntimeError("StepRandom: float32 draws only")
+            # the first (eager) step learns the step's draws one by one: a launch each
+            self.slots.append({"kind": kind, "p": p, "buf": torch.empty(like.shape, dtype=torch.float32, device=like.device)})
+            self._launch(self.slots[-1:])
+            return self.slots[-1]["buf"]
         s = self.slots[i]
         if s["kind"] != kind or s["buf"].shape != like.shape or s["p"] != p:
             raise RuntimeError(f"StepRandom: draw {i} was {s['kind']} {tuple(s['buf'].shape)} p={s['p']}, now {kind} {tuple(like.shape)} p={p}")
-        if i == 0 and self.mode == "device":
+        if i == 0:
             self._launch(self.slots)      # every tensor of the step, on the stream of the step's first draw (the others follow it)
         return s["buf"]
 
-    def prefetch(self):
-        """draw the next step's values (slot order = the models' draw order) on the helper stream"""
-        if not self.slots or self.mode != "prefetch":
-            return
-        with torch.cuda.stream(self.stream):
-            self.pending = [self._sample(s["kind"], s["like"], s["p"]) for s in self.slots]
-            self.ready = torch.cuda.Event()
-            self.ready.record()
-
-    def pairs(self):
-        """(source, destination) copies that hand the prefetched values to the step's static buffers; the current stream waits for
-        the draws.  [] when nothing is pending (the values in the buffers have not been consumed yet)"""
-        if self.pending is None:
-            return []
-        cur = torch.cuda.current_stream()
-        cur.wait_event(self.ready)
-        pend, self.pending = self.pending, None
-        for t in pend:
-            t.record_stream(cur)
-        self._keep = pend
-        return [(t, s["buf"]) for t, s in zip(pend, self.slots)]
-
 
 def randn_like(t):
-    """``torch.randn_like(t)``, or the engine's prefetched draw (:class:`StepRandom`)"""
+    """``torch.randn_like(t)``, or the step's draw from the engine's provider (:class:`StepRandom`)"""
     prov = StepRandom.active
     return torch.randn_like(t) if prov is None else prov.draw("randn", t)
 
@@ -1746,12 +1674,6 @@ class SpeculativeBackward:
     section 5.1).  The backward node of ``vae_fc4`` recognises the gradient it was speculated for by its buffer and hands the
     stored results on; any other seed (a scaled loss) makes it launch normally -- the speculation is then wasted, not wrong."""
     enabled = False
-    allowed = os.environ.get("IMMUNOSTRUCT_SPECULATIVE_BACKWARD", "1") != "0"
-    # the sequence terms of the loss evaluated on the sequence branch's stream, the prediction term on the head's, the total
-    # formed in the backward (SeqTermsFn / vae_loss) instead of the one-launch loss on the head's stream;
-    # measured: the head's stream loses two cross-queue hops and 4 us of loss launch (comb_attn_fwd -> comb_attn_bwd 22.8 -> 7 us),
-    # and the step does not get shorter (HISTORY.md 7.7): off unless IMMUNOSTRUCT_DEFER_LOSS=1
-    defer = os.environ.get("IMMUNOSTRUCT_DEFER_LOSS", "0") == "1"
 
     # the caller's promise that the loss consumes the reconstruction through :func:`vae_loss` (``utils.Losses``): only then may the
     # models let the main stream join the sequence branch at the LATENT (models/_core.py EARLY_JOIN) -- a loss that reads ``recon_x``
@@ -1764,8 +1686,8 @@ class SpeculativeBackward:
 
     def __enter__(self):
         self._saved = (SpeculativeBackward.enabled, SpeculativeBackward.early_join)
-        SpeculativeBackward.enabled = SpeculativeBackward.allowed
-        SpeculativeBackward.early_join = self._early_join and SpeculativeBackward.allowed
+        SpeculativeBackward.enabled = True
+        SpeculativeBackward.early_join = self._early_join
         return self
 
     def __exit__(self, *exc):
@@ -1773,9 +1695,8 @@ class SpeculativeBackward:
         return False
 
 
-def _speculate_recon_backward(recon, x, c_mse, join=True):
-    """-> (d_recon, partials) with stage 1 and the producer's backward launched on the producer's stream, or None
-    (``join=False``: the caller's stream does not wait for stage 1 -- nothing on it reads the partial sums)"""
+def _speculate_recon_backward(recon, x, c_mse):
+    """-> (d_recon, partials) with stage 1 and the producer's backward launched on the producer's stream, or None"""
     node = recon.grad_fn if torch.is_tensor(recon) else None
     if (not SpeculativeBackward.enabled or node is None or type(node).__name__ != "LinearSmallBatchFnBackward" or not recon.is_cuda
             or recon.dtype != torch.float32 or not recon.is_contiguous() or getattr(node, "fwd_stream", None) is None
@@ -1796,140 +1717,15 @@ def _speculate_recon_backward(recon, x, c_mse, join=True):
             gx, dw, db = LinearSmallBatchFn.launch_backward(node, d_recon, node.needs_input_grad[0])
     node.spec = (d_recon, gx, dw, db)
     if side != main:
-        if join:
-            main.wait_event(ready)
+        main.wait_event(ready)
         for t in (d_recon, partials, gx, dw, db, xs):
             if t is not None:
                 t.record_stream(main)
     return d_recon, partials
 
 
-class SeqTermsSlot:
-    """what :func:`vae_loss` leaves for :class:`SeqTermsFn`'s backward: the sequence terms' gradients and the total's operands"""
-    __slots__ = ("stream", "grads", "total_args", "scale")
-
-    def __init__(self, stream):
-        self.stream, self.grads, self.total_args, self.scale = stream, None, None, None
-
-
-def _launch_loss_total(slot):
-    lib = _lib.load()
-    partials, rt, lt, b, c_pred, c_mse, c_kld, sums, out, total = slot.total_args
-    slot.total_args = None
-    _lib.check(lib.is_loss_total(_lib.ptr(partials), rt, lt, b, float(c_pred), float(c_mse), float(c_kld), _lib.ptr(sums), _lib.ptr(out),
-                                 _lib.ptr(total), _lib.stream_ptr()), "is_loss_total")
-
-
-class SeqTermsFn(torch.autograd.Function):
-    """Identity on the latent ``z`` on its way to the fusion head, applied on the sequence branch's stream once the reconstruction
-    is enqueued (``models/_core.py``).  It exists for its backward: the loss terms that depend on the sequence branch only --
-    reconstruction MSE, KLD -- reach ``recon`` / ``mu`` / ``logvar`` from HERE, a node of the sequence branch's own stream that runs
-    when the head's gradient of ``z`` arrives, instead of from the loss node on the head's stream.  With the gradients computed
-    ahead by :func:`vae_loss` on this stream, the head's stream neither waits for the reconstruction in the forward nor hands
-    anything to this stream at the start of the backward: two cross-queue hops and the one-workgroup loss launch (~ 22 us) leave
-    the step's critical chain.  The total -- the last thing that needs both streams' terms -- is formed by this backward too."""
-
-    @staticmethod
-    def forward(ctx, z, mu, logvar, recon, slot):
-        ctx.slot = slot
-        ctx.set_materialize_grads(False)
-        return z.view_as(z)
-
-    @staticmethod
-    def backward(ctx, gz):
-        slot = ctx.slot
-        if slot.grads is None:          # no loss asked for the sequence terms
-            return gz, None, None, None, None
-        d_recon, d_mu, d_lv = slot.grads
-        _launch_loss_total(slot)
-        if slot.scale is not None:      # a seed other than unit_gradient(): DeferredLossFn's backward (which ran first) left it here
-            d_mu, d_lv = torch._foreach_mul([d_mu, d_lv], slot.scale)
-            d_recon = d_recon * slot.scale      # (a new buffer: vae_fc4's backward then launches normally)
-        slot.grads = None
-        return gz, d_mu, d_lv, d_recon, None
-
-
-class DeferredLossFn(torch.autograd.Function):
-    """The loss node of the deferred form: the prediction term's launch on the logit's stream; ``total`` and ``terms`` are written
-    by :class:`SeqTermsFn`'s backward (valid once the backward has run -- the engine's steps read them after the step)"""
-
-    @staticmethod
-    def forward(ctx, logit, y, mode, pos_weight, c_pred, sums, slot, out, total):
-        lib = _lib.load()
-        logit_c = _lib.f32c(logit.reshape(-1))
-        y_c = _lib.f32c(y.reshape(-1).to(torch.float32))
-        b = int(logit_c.numel())
-        if y_c.numel() != b:
-            raise ValueError(f"target has {y_c.numel()} elements, prediction {b}")
-        d_logit = torch.empty(b, dtype=torch.float32, device=logit.device)
-        _lib.check(lib.is_loss_pred_term(_lib.ptr(logit_c), _lib.ptr(y_c), _lib.ptr(d_logit), b, int(mode), float(pos_weight), float(c_pred),
-                                         _lib.ptr(sums), _lib.stream_ptr()), "is_loss_pred_term")
-        ctx.slot, ctx.logit_shape = slot, logit.shape
-        ctx.set_materialize_grads(False)
-        ctx.save_for_backward(d_logit)
-        ctx.mark_non_differentiable(out)
-        return total, out
-
-    @staticmethod
-    def backward(ctx, g, _g_terms):
-        (d_logit,) = ctx.saved_tensors
-        if g is None:
-            return (None,) * 9
-        if g is not _unit_gradients.get((g.device.type, g.device.index)):
-            ctx.slot.scale = g
-            d_logit = d_logit * g
-        return d_logit.reshape(ctx.logit_shape), None, None, None, None, None, None, None, None
-
-
-def attach_sequence_terms(z, mu, logvar, recon):
-    """-> z for the fusion head, with the sequence terms' gradients routed through :class:`SeqTermsFn` (call on the sequence
-    branch's stream); None when the deferred loss does not apply (then nothing changes)"""
-    if not (SpeculativeBackward.enabled and SpeculativeBackward.defer and torch.is_grad_enabled() and torch.is_tensor(recon)
-            and recon.is_cuda and z.requires_grad and recon.requires_grad):
-        return None
-    slot = SeqTermsSlot(torch.cuda.current_stream(z.device))
-    out = SeqTermsFn.apply(z, mu, logvar, recon, slot)
-    mu._seq_slot = slot
-    return out
-
-
-def _vae_loss_deferred(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, slot):
-    """prediction term on the caller's stream, reconstruction + KLD terms on the sequence branch's (``slot.stream``), no wait
-    between them; -> (total, terms) or None when the speculation does not apply"""
-    if float(c_mse) == 0.0 or mu.dtype != torch.float32 or logvar.dtype != torch.float32 or not (mu.is_contiguous() and logvar.is_contiguous()):
-        return None
-    if type(getattr(recon, "grad_fn", None)).__name__ != "LinearSmallBatchFnBackward" or getattr(recon.grad_fn, "fwd_stream", None) != slot.stream:
-        return None
-    pre = _speculate_recon_backward(recon, x, c_mse, join=False)
-    if pre is None:
-        return None
-    lib = _lib.load()
-    dev = logit.device
-    main = torch.cuda.current_stream(dev)
-    sums = torch.empty(4, dtype=torch.float32, device=dev)      # [1] KLD, [2] prediction: each written by its launch before the total reads it
-    out = torch.empty(4, dtype=torch.float32, device=dev)
-    total = torch.empty((), dtype=torch.float32, device=dev)
-    with torch.cuda.stream(slot.stream):
-        d_mu, d_lv = torch.empty_like(mu), torch.empty_like(logvar)
-        _lib.check(lib.is_loss_kld_term(_lib.ptr(mu), _lib.ptr(logvar), _lib.ptr(d_mu), _lib.ptr(d_lv), int(mu.numel()), float(c_kld),
-                                        _lib.ptr(sums), _lib.stream_ptr()), "is_loss_kld_term")
-    for t in (sums, out, total):
-        t.record_stream(slot.stream)
-    for t in (d_mu, d_lv):
-        t.record_stream(main)
-    slot.grads = (pre[0], d_mu, d_lv)
-    slot.total_args = (pre[1], int(recon.numel()), int(mu.numel()), int(logit.numel()), c_pred, c_mse, c_kld, sums, out, total)
-    slot.scale = None
-    return DeferredLossFn.apply(logit, y, mode, pos_weight, c_pred, sums, slot, out, total)
-
-
 def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld):
     """Returns (total, terms[4] = {total, prediction, recon MSE, KLD})."""
-    slot = getattr(mu, "_seq_slot", None) if torch.is_tensor(mu) else None
-    if slot is not None and slot.grads is None and SpeculativeBackward.enabled and torch.is_grad_enabled() and recon is not None:
-        res = _vae_loss_deferred(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, slot)
-        if res is not None:
-            return res
     pre = _speculate_recon_backward(recon, x, c_mse) if recon is not None else None
     if pre is None and torch.is_tensor(recon):
         # no speculation (a reconstruction weight of 0, a non-contiguous or foreign ``recon``): this launch reads ``recon`` on the
@@ -1937,6 +1733,11 @@ def vae_loss(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_
         ev = getattr(recon, "_ready_event", None)
         if ev is not None:
             torch.cuda.current_stream(recon.device).wait_event(ev)
+        elif SpeculativeBackward.early_join and recon.is_cuda:
+            # a view / slice of the reconstruction lost the attribute (a Python attribute of the tensor OBJECT): wait for everything
+            # the sequence branch's stream has been given -- never a missing edge, at worst the full join's cost
+            from .models._core import _side_stream
+            torch.cuda.current_stream(recon.device).wait_stream(_side_stream(recon.device))
     return VaeLossFn.apply(recon, x, mu, logvar, logit, y, mode, pos_weight, c_pred, c_mse, c_kld, pre)
 
 

@@ -108,7 +108,7 @@ def greedy_node_tiles(rowptr, num_edges, cap_edges, max_nodes):
 # workgroups make it P (B = 128, E = 72 k: 35 + 35 edges = 3 + 3 tiles -> 42 + 28 edges = 3 + 2 tiles; forward layer launch 48 ->
 # 43.5 us).  Used only when the chunks are node-aligned with some slack (>= 6 edges per pair) and the grid is the full one.
 FULL_GRID_CHUNKS = 2048
-CHUNK_SHARES = __import__("os").environ.get("IMMUNOSTRUCT_FWD_SHARES", "auto")      # "auto" | "flat"
+CHUNK_SHARES = "auto"      # "flat": equal shares everywhere (module constant: the chunk-partition tests compare both)
 
 
 NODE_PASS_ROWS = 64      # rows of one pass of the forward kernel's node half (csrc/egnn_layer_fwd.hip ROWS)

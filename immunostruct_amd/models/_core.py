@@ -28,8 +28,8 @@ from ..nn import EGNNConv, egnn_stack_forward, egnn_stack_prelaunch, stack_is_na
 from .layers import MultiHeadAttention, SelfAttention
 
 NODE_ONEHOT = 20  # amino-acid one-hot columns of ndata['x'] (data/preprocess.py:40-41)
-OVERLAP_BRANCHES = os.environ.get("IMMUNOSTRUCT_OVERLAP_BRANCHES", "1") != "0"
-EARLY_JOIN = os.environ.get("IMMUNOSTRUCT_EARLY_JOIN", "1") != "0"
+OVERLAP_BRANCHES = True      # the sequence branch on a forked stream (module constants, not switches: tests set them to compare forms)
+EARLY_JOIN = True            # the fusion head joins the sequence branch at the latent (engine steps whose loss promised to, below)
 JOIN_COUNTS = {"early": 0, "full": 0}      # how the main stream joined the sequence branch, per forward (tests)
 # the sequence branch starts when this layer (0-based) of the EGNN stack has finished (clamped to the last layer).  "auto": its
 # forward (~100 us of side work) should end with the stack + node attention, not stretch more layer launches than it must -- the
@@ -44,7 +44,7 @@ def fork_after_layer(num_edges):
     if FORK_AFTER_LAYER is not None:
         return FORK_AFTER_LAYER
     return 2 if num_edges >= FORK_AUTO_EDGES else 3
-MERGE_PAIRS = os.environ.get("IMMUNOSTRUCT_MERGE_PAIRS", "1") != "0"      # paired models: one encoder pass over [cancer; wild-type]
+MERGE_PAIRS = True      # paired models: one encoder pass over [cancer; wild-type]
 if OVERLAP_BRANCHES and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # the sequence branch runs on a forked stream by design; autograd's per-call warning about it is noise here
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -242,11 +242,6 @@ class MultimodalNet(nn.Module):
                     z = torch.cat([z, p], dim=1)
                 self._latent_done(o, prop)
                 recon = self.decode_vae(z)
-            if not self._pair_rows and sp.graph:
-                # the loss's sequence terms reach recon / mu / logvar through a node of THIS stream (functional.SeqTermsFn): the
-                # head's stream then never waits for the reconstruction (engine steps only; None: nothing changes)
-                zt = HF.attach_sequence_terms(z, mu, logvar, recon)
-                z = z if zt is None else zt
             o.update(mu=mu, logvar=logvar, z_vae=z, recon_x=recon)
         else:
             self._latent_done(o, prop)
@@ -256,7 +251,7 @@ class MultimodalNet(nn.Module):
         """everything the fusion head needs from the sequence branch exists (latent + property embedding): draw the classifier's
         dropout mask -- on the sequence branch's stream, long before the head needs it; the decoder draws nothing, so the
         order of the random draws is the reference's -- and mark the point: the head may start here, it does not need the
-        reconstruction (``_encode``: IMMUNOSTRUCT_EARLY_JOIN)"""
+        reconstruction (``_encode``: ``EARLY_JOIN``)"""
         if not self.SPEC.ssl and prop.is_cuda:
             rows = prop.shape[0] // 2 if self._pair_rows else prop.shape[0]
             o["_cls_mask"] = (HF.sequential_dropout_mask(self.classifier, rows, prop.device),)
@@ -392,7 +387,7 @@ class MultimodalNet(nn.Module):
         gradient-accumulation kernels for the twice-used parameters -- and the outputs are split afterwards.
         Inputs: the reference's 2-tuples (merged here when both graphs are plain batches with the same node layout), or
         an already merged batch (one graph of 2B graphs, sequences / properties with 2B rows: what the on-GPU batcher
-        delivers).  Static (capacity-padded) buffers and IMMUNOSTRUCT_MERGE_PAIRS=0 take two encoder passes."""
+        delivers).  Static (capacity-padded) buffers take two encoder passes."""
         merged = None
         if isinstance(graphs, PackedGraphBatch):
             if graphs.batch_size % 2 or seqs.shape[0] != graphs.batch_size:

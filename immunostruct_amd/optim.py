@@ -137,69 +137,9 @@ class Adam(torch.optim.Optimizer):
             gs, table = self._table(group, params, capturing)
             if not capturing:
                 self.refresh_group(group, gs)
-            if gs.pop("prepared_early", False):      # prepare() already advanced the step on another stream
-                _lib.check(lib.is_adam_apply(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
-                                             _lib.stream_ptr()), "is_adam_apply")
-            else:
-                _lib.check(lib.is_adam_step(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
-                                            _lib.stream_ptr()), "is_adam_step")
+            _lib.check(lib.is_adam_step(_lib.ptr(table), int(table.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
+                                        _lib.stream_ptr()), "is_adam_step")
         return loss
-
-    @torch.no_grad()
-    def prepare(self):
-        """The step's one-thread part (step count + bias corrections: ``is_adam_prepare``) on the CURRENT stream, ahead of the
-        update: the engine issues it on the models' side stream at the top of the step, where its launch latency (~4 us + a
-        queue hand-over in front of the 30 us update, on the step's critical chain) costs nothing; :meth:`step` then only
-        applies.  Needs the chunk tables' group state: call after at least one ordinary step."""
-        lib = _lib.load()
-        capturing = torch.cuda.is_current_stream_capturing()
-        for group in self.param_groups:
-            gs = self._groups.get(id(group))
-            if gs is None:
-                raise RuntimeError("prepare() before the first step(): the group state does not exist yet")
-            if not capturing:
-                self.refresh_group(group, gs)
-            _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
-            gs["prepared_early"] = True
-
-    @torch.no_grad()
-    def step_overlapped(self, late, gate, side):
-        """The same update as :meth:`step`, in two launches per group: the parameters NOT in ``late`` on the stream ``side`` as soon
-        as the event ``gate`` has passed (the engine records it in front of the tail of the backward pass: their gradients are
-        final by then, and the bandwidth-bound update then runs BESIDE that tail instead of behind it), the ``late`` ones on the
-        current stream after ``side`` has finished.  Same arithmetic, same step count (advanced once)."""
-        lib = _lib.load()
-        capturing = torch.cuda.is_current_stream_capturing()
-        main = torch.cuda.current_stream()
-        late_ids = set(id(p) for p in late)
-        work = []
-        for group in self.param_groups:
-            early_p = [p for p in group["params"] if p.grad is not None and id(p) not in late_ids]
-            late_p = [p for p in group["params"] if p.grad is not None and id(p) in late_ids]
-            if not early_p and not late_p:
-                continue
-            te = self._table(group, early_p, capturing) if early_p else None
-            tl = self._table(group, late_p, capturing) if late_p else None
-            gs = (te or tl)[0]
-            if not capturing:
-                self.refresh_group(group, gs)
-            work.append((gs, te[1] if te else None, tl[1] if tl else None))
-        # the early gradients come from launches on the main stream in front of ``gate`` (heads, attention tail) or from the side
-        # stream itself (sequence branch): waiting for the gate orders this update behind both -- NOT behind the tail of the
-        # backward pass, which the main stream runs meanwhile
-        with torch.cuda.stream(side):
-            side.wait_event(gate)
-            for gs, te, _ in work:
-                if not gs.pop("prepared_early", False):      # (prepare() already advanced the step: twice would double the count)
-                    _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
-                if te is not None:
-                    _lib.check(lib.is_adam_apply(_lib.ptr(te), int(te.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
-                                                 _lib.stream_ptr()), "is_adam_apply")
-        main.wait_stream(side)
-        for gs, _, tl in work:
-            if tl is not None:
-                _lib.check(lib.is_adam_apply(_lib.ptr(tl), int(tl.shape[0]), _lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]),
-                                             _lib.stream_ptr()), "is_adam_apply")
 
     @torch.no_grad()
     def step_subset(self, params, first):
@@ -220,8 +160,7 @@ class Adam(torch.optim.Optimizer):
             if not capturing:
                 self.refresh_group(group, gs)
             if first:
-                if not gs.pop("prepared_early", False):      # (prepare() already advanced the step on another stream)
-                    _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
+                _lib.check(lib.is_adam_prepare(_lib.ptr(gs["state"]), _lib.ptr(gs["hyper"]), _lib.stream_ptr()), "is_adam_prepare")
                 gs["prepared"] = True
                 gs["updated"] = set()
             elif not gs["prepared"] or any(id(p) in gs["updated"] for p in sub):

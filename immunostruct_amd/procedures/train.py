@@ -186,9 +186,11 @@ def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_
         first = assemble(train_index[rank:rank + bsz * world:world][:bsz], buf, True)
         # the engine's construction runs one eager warm-up step on this batch and then restores model + optimizer
         # (step_random: the captured step's dropout masks / noise from the library's generator, seeded from the device seed set
-        #  above -- config.step_random = None keeps torch's generator inside the step)
+        #  above and the STAGE -- pretrain 0, finetune 1: a property of the run's stage, not of what the process built before;
+        #  config.step_random = None keeps torch's generator inside the step)
         captured = CapturedTrainStep(model, optimizer, reducer, forward_loss, first, edge_capacity=edge_capacity(bsz),
-                                     warmup=1, preserve_state=True, step_random=getattr(config, "step_random", "device"))
+                                     warmup=1, preserve_state=True, step_random=getattr(config, "step_random", "device"),
+                                     random_stream=0 if stage == "pretrain" else 1)
     tails = {}
 
     def eager_batch(idx, train):
@@ -243,6 +245,8 @@ def _device_fit(config, model, optimizer, scheduler, stage, seed, device, train_
             if wandb is not None and getattr(wandb, "run", None) is not None:
                 wandb.log({stage + "_train_loss": train_loss, stage + "_val_loss": val_loss})
             print(f"Epoch {epoch + 1}, Train Loss: {train_loss:.4f}, Val Loss: {val_loss:.4f}")
+    if captured is not None:
+        captured.close()      # the captured graphs (they may hold RCCL's nodes) go before the caller can destroy the process group
     return train_losses, val_losses
 
 

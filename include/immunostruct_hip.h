@@ -421,18 +421,6 @@ int is_vae_loss(const float* recon, const float* x, float* d_recon, long long re
                 float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out, float* total,
                 void* stream);
 
-/* The three terms of is_vae_loss as separate launches with the same sums in the same order (bit-identical results): the
- * prediction term (Losses.regression_loss / BCE_loss on the logit, utils/loss.py) on the stream the logit is produced on, the
- * KLD term where mu / logvar are, the total (stage 2 of the reconstruction term from is_recon_mse's partials[] + the raw sums
- * the other two left in sums[1] / sums[2]) wherever both are complete -- no wait between the prediction and the sequence
- * terms.  sums: 4 floats of device memory shared by the three launches.                                                    */
-int is_loss_pred_term(const float* logit, const float* y, float* d_logit, int batch, int mode, float pos_weight,
-                      float c_pred, float* sums, void* stream);
-int is_loss_kld_term(const float* mu, const float* logvar, float* d_mu, float* d_logvar, int latent_total, float c_kld,
-                     float* sums, void* stream);
-int is_loss_total(const float* partials, long long recon_total, int latent_total, int batch, float c_pred, float c_mse,
-                  float c_kld, float* sums, float* out, float* total, void* stream);
-
 
 #ifdef __cplusplus
 }

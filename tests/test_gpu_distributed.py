@@ -117,7 +117,12 @@ def test_bench_line_under_a_one_rank_rccl_group(cuda_device):
     """``IMMUNOSTRUCT_FORCE_COLLECTIVE=1 python bench.py --gpus 1 --force-pack``: the data-parallel step (gradient buckets,
     RCCL all-reduce per bucket between the captured graphs, 1/world inside Adam) in a fresh child under a real ``nccl`` process
     group; the same seeded steps without the group end at the same loss."""
-    line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29571"), "--force-pack")
+    # the default (round 6): the multi-graph forms only -- the one-graph forms are opt-in until a run with >= 2 ranks has seen them
+    line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29570"), "--force-pack")
+    ar = line["config"]["grad_allreduce"]
+    assert ar["form"] in ("serial", "two-stage backward, bucket 0 overlapped") and not ar["tuned_ms"]["one_graph_ms"]
+    # IMMUNOSTRUCT_DP_ONE_GRAPH=auto: every form captured, timed on all ranks, the fastest kept
+    line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29571", IMMUNOSTRUCT_DP_ONE_GRAPH="auto"), "--force-pack")
     cfg = line["config"]
     assert cfg["dist_backend"] == "nccl" and cfg["rccl_ranks"] == 1 and line["n_gpus"] == 1
     ar = cfg["grad_allreduce"]

@@ -148,7 +148,7 @@ def test_paired_backward_kernel_equals_the_256_thread_kernel(cuda_device, case, 
            "deg8_windows_differ": lambda: synthetic.make_batch(24, seed=10, deg_extra=8),
            "past_the_rowptr_table": lambda: synthetic.make_batch(440, seed=11, deg_extra=2)}[case]()
     dev = cuda_device
-    monkeypatch.setattr(HF, "_FORCE_BWD_TILES", "0")      # plain 16-node tiles in both runs (the paired kernel's domain)
+    monkeypatch.setattr(HF, "use_bwd_tiles", lambda *a: False)      # plain 16-node tiles in both runs (the paired kernel's domain)
     g = H.product_graph(raw, dev)
     torch.manual_seed(3)
     layers = [EGNNConv(20 if i == 0 else 64, 64, 64, 1).to(dev) for i in range(2)]
@@ -697,44 +697,6 @@ def test_hip_adam_in_parts_is_the_single_step(cuda_device, kind, wd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["step", "subset", "overlapped"])
-def test_hip_adam_early_prepare_advances_the_step_once(cuda_device, form):
-    """``prepare()`` (the one-thread part of the step issued ahead of the update) followed by ANY form of the update --
-    ``step``, ``step_subset(first=True)``, ``step_overlapped`` -- advances the step count once per step and leaves the parameters of
-    plain ``step()`` calls (the later two used to run ``is_adam_prepare`` again: count + 2, wrong bias corrections)"""
-    from immunostruct_amd import optim
-    g = torch.Generator().manual_seed(13)
-    shapes = [(64, 70), (33,), (5, 3)]
-    ref_p = [torch.randn(*s, generator=g).to(cuda_device).requires_grad_(True) for s in shapes]
-    new_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
-    ref, new = optim.Adam(ref_p, lr=1e-2), optim.Adam(new_p, lr=1e-2)
-    side = torch.cuda.Stream()
-    for step in range(4):
-        for a, b in zip(ref_p, new_p):
-            gr = torch.randn(a.shape, generator=g).to(cuda_device)
-            a.grad, b.grad = gr.clone(), gr.clone()
-        ref.step()
-        if step == 0:
-            new.step()                  # (the group state prepare() needs exists after one ordinary step)
-            continue
-        new.prepare()
-        if form == "step":
-            new.step()
-        elif form == "subset":
-            new.step_subset(new_p[:1], first=True)
-            new.step_subset(new_p[1:], first=False)
-        else:
-            gate = torch.cuda.Event()
-            gate.record()
-            new.step_overlapped(new_p[2:], gate, side)
-        torch.cuda.synchronize()
-    gs_ref, gs_new = next(iter(ref._groups.values())), next(iter(new._groups.values()))
-    assert float(gs_new["state"][0]) == float(gs_ref["state"][0]) == 4.0
-    for a, b in zip(ref_p, new_p):
-        assert torch.equal(a.detach(), b.detach()), f"{form}: param {tuple(a.shape)}"
-
-
-@pytest.mark.gpu
 def test_hip_adam_subset_update_needs_its_first_part(cuda_device):
     """a later part of a step without the step's first part would reuse the previous step's step size / bias corrections:
     step_subset refuses it (no first part yet; the same parameters twice since the last first part)"""
@@ -1031,9 +993,9 @@ def test_step_random_launch_matches_the_philox_checker_and_its_distributions(cud
     dev = cuda_device
     seed = 0x1234567_89ABCDE
     torch.manual_seed(seed)
-    prov = HF.StepRandom(dev, "device", stream_id=0)
+    prov = HF.StepRandom(dev, stream_id=0)
     assert int(prov.state[0]) == seed and int(prov.state[1]) == 0
-    other = HF.StepRandom(dev, "device", stream_id=1)      # (another engine of the same run: its own key; default ids count up)
+    other = HF.StepRandom(dev, stream_id=1)      # (the engine of another stage of the same run: its own key)
     assert int(other.state[0]) == (seed + 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF != seed
     sd = prov.state_dict()
     assert sd == {"mode": "device", "state": [seed, 0, 0]}
@@ -1069,7 +1031,7 @@ def test_step_random_launch_matches_the_philox_checker_and_its_distributions(cud
     assert prov.state.data_ptr() == ptr and prov.state_dict() == saved
     with HF.StepRandom.use(prov):
         assert torch.equal(HF.randn_like(like_n), a3)
-    big = HF.StepRandom(dev, "device")
+    big = HF.StepRandom(dev)
     with HF.StepRandom.use(big):
         z = HF.randn_like(torch.empty(1 << 20, device=dev)).double()
         m = HF.dropout_mask(4096, 256, 0.3, dev)

@@ -140,15 +140,11 @@ def test_comparative_train_step_matches_reference_golden(cuda_device, name, wt):
     print(tag, {k: f"{v:.1e}" for k, v in errs.items()})
 
 
-@pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("seed_kind", ["unit", "scaled", "plain"])
-def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, seed_kind, defer, monkeypatch):
+def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, seed_kind):
     """functional.SpeculativeBackward (the engine's steps): the reconstruction term's backward launched from the loss gives,
     bit for bit, the gradients of the ordinary backward when the backward is seeded with ``unit_gradient()``; with any other
-    seed (a scaled loss, a plain ``backward()``) the speculated results are dropped and the ordinary path runs.
-    ``defer``: the loss in three launches (prediction term on the head's stream, KLD beside the reconstruction term on the
-    sequence branch's, total formed by ``SeqTermsFn``'s backward) -- same value, same gradients, bit for bit; the value is read
-    after the backward, as the engine does."""
+    seed (a scaled loss, a plain ``backward()``) the speculated results are dropped and the ordinary path runs."""
     from immunostruct_amd import functional as HF
     dev = cuda_device
     raw = synthetic.make_batch(6, seed=71, deg_extra=2)
@@ -156,8 +152,6 @@ def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, 
     eps = H.make_eps(4, 6)
     seq, prop, y = torch.from_numpy(raw.one_hot_sequence()).to(dev), torch.from_numpy(raw.prop).to(dev), torch.from_numpy(raw.y_reg).to(dev)
     losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
-
-    monkeypatch.setattr(HF.SpeculativeBackward, "defer", defer)
 
     def run(speculate):
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
@@ -170,7 +164,6 @@ def test_speculative_reconstruction_backward_is_the_plain_backward(cuda_device, 
             loss = losses.regression_loss(res[0], seq, res[1], res[2], res[3], y)
         node = res[0].grad_fn
         assert (getattr(node, "spec", None) is not None) == speculate      # launched ahead only when asked to
-        assert (type(loss.grad_fn).__name__ == "DeferredLossFnBackward") == (speculate and defer)
         if seed_kind == "unit":
             loss.backward(HF.unit_gradient(dev))
         elif seed_kind == "scaled":
@@ -631,61 +624,6 @@ def test_full_step_is_deterministic_at_full_residency(cuda_device):
             assert torch.equal(gi[k], runs[0][1][k]), f"{k}: the gradient of two replays of the same step differs in its bits"
 
 
-@pytest.mark.parametrize("always_pack", [False, True])
-def test_prefetched_random_tensors_reproduce_eager_training(cuda_device, always_pack, monkeypatch):
-    """``CapturedTrainStep(step_random="prefetch")``: dropout masks and the reparameterisation noise are drawn one step ahead,
-    outside the captured step, with the calls the models make -- a model in TRAINING mode (both dropouts active, noise from
-    torch's generator) then takes the steps an eager loop with the same seed takes: same draws, in the same order."""
-    from immunostruct_amd import functional as HF
-    from immunostruct_amd.distributed import FlatGradReducer
-    from immunostruct_amd.engine import CapturedTrainStep
-    from immunostruct_amd import optim
-    dev = cuda_device
-    monkeypatch.setenv("IMMUNOSTRUCT_DP_OVERLAP", "1")
-    raws = [synthetic.make_batch(6, seed=s, deg_extra=d) for s, d in ((61, 2), (62, 3), (63, 1), (64, 2))]
-    batches = [(H.product_graph(r, dev), torch.from_numpy(r.one_hot_sequence()).to(dev),
-                torch.from_numpy(r.prop).to(dev), torch.from_numpy(r.y_reg).to(dev)) for r in raws]
-    losses = Losses(H.VAE_IN, {0: 81.0, 1: 19.0}, sequence=True)
-
-    def forward_loss(m, g, seq, prop, y):
-        recon, mu, logvar, final = m(g, seq, prop)
-        return losses.regression_loss(recon, seq, mu, logvar, final, y)
-
-    def run(captured):
-        model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
-        model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
-        model.train()
-        red = FlatGradReducer(model.parameters(), world=1, always_pack=always_pack)
-        opt = optim.Adam(model.parameters(), lr=1e-4)
-        torch.manual_seed(4321)
-        out = []
-        if captured:
-            eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1,
-                                    step_random="prefetch")
-            assert len(eng._rand.slots) == 3 and [s["kind"] for s in eng._rand.slots] == ["dropout", "randn", "dropout"]
-            for b in batches:
-                out.append(float(eng(*b)))
-        else:
-            for b in [batches[0]] + batches:
-                red.zero()
-                loss = forward_loss(model, *b)
-                loss.backward()
-                red.all_reduce_mean()
-                opt.step()
-                out.append(float(loss.detach()))
-        return out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-
-    l_e, sd_e = run(False)
-    l_c, sd_c = run(True)
-    l_e = l_e[1:]   # drop the warm-up step's loss
-    assert len(set(l_e)) == len(l_e)
-    for a, b in zip(l_e, l_c):
-        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_c)
-    for k in sd_e:
-        H.assert_close(sd_c[k], sd_e[k], 1e-5, f"{k} after 4 captured steps with prefetched random tensors")
-    assert HF.StepRandom.active is None
-
-
 def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
     """``CapturedTrainStep(step_random="device")``: a model in TRAINING mode draws its dropout masks and noise from the library's
     generator inside the captured step (one launch per step, no torch generator in the graph): the same seed gives the same
@@ -705,15 +643,13 @@ def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
 
     from immunostruct_amd import functional as HF
 
-    def run(seed, mode, fresh_process=True):
+    def run(seed, mode, stream=0):
         model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
         model.load_state_dict(H.det_sd({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8))
         model.train()
         torch.manual_seed(seed)
-        if fresh_process:
-            HF.StepRandom._created = 0      # (a run of its own: the first engine of a process)
         eng = CapturedTrainStep(model, optim.Adam(model.parameters(), lr=1e-4), FlatGradReducer(model.parameters(), world=1), forward_loss,
-                                batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1, step_random=mode)
+                                batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1, step_random=mode, random_stream=stream)
         if mode == "device":
             assert [s["kind"] for s in eng._rand.slots] == ["dropout", "randn", "dropout"]
         out = [float(eng(*b)) for b in batches + batches]
@@ -723,9 +659,10 @@ def test_device_side_step_random_tensors_train_reproducibly(cuda_device):
 
     a, b, c = run(5, "device"), run(5, "device"), run(6, "device")
     assert a == b and a != c and len(set(a)) == len(a) and all(np.isfinite(a))
-    # the SECOND engine of a run (its finetune stage: same device seed) draws another sequence, not the first stage's again
-    d = run(5, "device", fresh_process=False)
-    assert d != a and all(np.isfinite(d))
+    # the engine of a run's SECOND stage (finetune: same device seed, stream 1) draws another sequence, not the first stage's again --
+    # and the same one whatever the process built before it (the key is a property of the stage, not a process counter)
+    d, e = run(5, "device", stream=1), run(5, "device", stream=1)
+    assert d != a and d == e and all(np.isfinite(d))
 
 
 @pytest.mark.parametrize("form", ["two_pass", "merged"])

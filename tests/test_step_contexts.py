@@ -5,10 +5,10 @@ from immunostruct_amd import functional as HF
 def test_speculative_backward_context_toggles_and_restores():
     assert HF.SpeculativeBackward.enabled is False
     with HF.SpeculativeBackward():
-        assert HF.SpeculativeBackward.enabled == HF.SpeculativeBackward.allowed
+        assert HF.SpeculativeBackward.enabled is True
         with HF.SpeculativeBackward():
-            assert HF.SpeculativeBackward.enabled == HF.SpeculativeBackward.allowed
-        assert HF.SpeculativeBackward.enabled == HF.SpeculativeBackward.allowed
+            assert HF.SpeculativeBackward.enabled is True
+        assert HF.SpeculativeBackward.enabled is True
     assert HF.SpeculativeBackward.enabled is False
 
 

@@ -133,6 +133,7 @@ def main():
         print(f"mode {mode}: form {cap.one_graph or ('two-stage' if cap.two_stage else 'serial')}, one-graph error {cap.one_graph_error}, buckets {[int(b['flat'].numel()) for b in reducer.buckets]}, "
               f"collectives/step {per_step[0]:.0f} (async {per_step[1]:.0f}, waits {per_step[2]:.0f}), max parameter difference {worst:.3e}, "
               f"standalone all-reduce {timing}, tuned {cap.dp_times}", flush=True)
+        cap.close()      # the graphs of this form (RCCL's nodes among them) go before the next engine is built
         del cap
     print("RCCL 1-RANK CHECK OK", flush=True)
     dist.destroy_process_group()
