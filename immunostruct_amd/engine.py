@@ -294,9 +294,6 @@ class CapturedTrainStep:
             self._forms[True] = (loss, sources)
         if not self.two_stage or mode == "auto":
             self.graph_a = torch.cuda.CUDAGraph()
-            dump = os.environ.get("IMMUNOSTRUCT_GRAPH_DUMP")       # debugging aid: the captured step as a dot file (tools/graph_edges.py)
-            if dump:
-                self.graph_a.enable_debug_mode()
             with torch.cuda.graph(self.graph_a, **_CAPTURE):
                 loss = self._fwd_bwd()
                 if self.fused_optimizer:
@@ -306,8 +303,6 @@ class CapturedTrainStep:
                 else:
                     for i in range(len(self.reducer.buckets)):
                         self.reducer.pack(i, from_grad=True)
-            if dump:
-                self.graph_a.debug_dump(dump)
             if not self.fused_optimizer:
                 self.reducer.bind_sources(packed=True)
                 self.reducer.all_reduce_mean()    # .grad now aliases the persistent flat bucket(s)
