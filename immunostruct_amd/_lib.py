@@ -27,6 +27,7 @@ _RETURNS_LONGLONG = {"is_attn_colmean_probs_floats", "is_contrastive_scratch_flo
                      "is_linear_dgrad_scratch_floats"}
 SIGNATURES = {
     "is_version": [],
+    "is_last_error_string": [],
     "is_mfma_selftest": [_P, _P, _P, _P],
     "is_mfma_outer_selftest": [_P, _P, _P, _P],
     "is_egnn_layer_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
@@ -156,7 +157,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name in _RETURNS_LONGLONG else _I
+        fn.restype = ctypes.c_longlong if name in _RETURNS_LONGLONG else (ctypes.c_char_p if name == "is_last_error_string" else _I)
     _lib = lib
     return lib
 
@@ -202,4 +203,5 @@ def rows_ld(t):
 
 def check(code, what):
     if code != 0:
-        raise HipExtensionError(f"{what} failed with code {code}")
+        detail = load().is_last_error_string().decode("utf-8", "replace")      # (same thread: the failing call was just made)
+        raise HipExtensionError(f"{what} failed with code {code}" + (f": {detail}" if detail else ""))

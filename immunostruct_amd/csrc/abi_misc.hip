@@ -1,7 +1,27 @@
 // Library identification + a tiny MFMA layout self-test used by the GPU test-suite.
 #include "common.h"
+#include <stdio.h>
 
 namespace is {
+
+// ---- the calling thread's last failure (common.h: fail / launch_status; C ABI: is_last_error_string) ----
+static thread_local char g_last_error[320] = "";
+
+int fail(const char* entry, int code) {
+  const char* why = code == -22 ? "invalid argument (a size, pointer or combination the entry point does not accept)"
+                  : code == -38 ? "not covered by this build of the kernel (the caller takes the other form)"
+                  : code == -5  ? "the device call failed"
+                                : "failed";
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", entry, why, code);
+  return code;
+}
+
+int launch_status(const char* entry) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s: %s (-5)", entry, hipGetErrorName(e), hipGetErrorString(e));
+  return -5;
+}
 
 // out[32 x 64] = A[32 x 64] * W[64 x 64]^T through the same mm_rows path the kernels use.
 __global__ __launch_bounds__(64) void mfma_selftest_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -45,14 +65,19 @@ __global__ __launch_bounds__(64) void mfma_outer_selftest_kernel(const float* __
 
 extern "C" int is_version(void) { return 100; }  // 0.1.0
 
+// text of the calling thread's most recent failed entry point ("" when none failed yet): the entry point's name, the reason behind
+// its code and, for a failed launch, HIP's own error name and string.  The pointer stays valid for the thread's lifetime; the text
+// changes with the thread's next failure (a successful call leaves it alone).
+extern "C" const char* is_last_error_string(void) { return is::g_last_error; }
+
 extern "C" int is_mfma_selftest(const float* A, const float* W, float* out, void* stream) {
   hipLaunchKernelGGL(is::mfma_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), A, W, out);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* stream) {
   hipLaunchKernelGGL(is::mfma_outer_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), G, M, out);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 
@@ -63,7 +88,7 @@ __global__ void timestamp_kernel(long long* slot) { *slot = (long long)wall_cloc
 }
 extern "C" int is_debug_timestamp(long long* slot, void* stream) {
   hipLaunchKernelGGL(is::timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 
@@ -95,10 +120,10 @@ __global__ __launch_bounds__(512) void emulated_collective_kernel(float* buf, lo
 }
 extern "C" int is_debug_emulated_collective(float* buf, long long n, int grid, int passes, long long ticks, long long* elapsed,
                                             void* stream) {
-  if (grid <= 0 || n < 0 || (reinterpret_cast<uintptr_t>(buf) & 15) != 0) return -22;
+  if (grid <= 0 || n < 0 || (reinterpret_cast<uintptr_t>(buf) & 15) != 0) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::emulated_collective_kernel, dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream), buf, n, passes, ticks,
                      elapsed);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 
@@ -118,10 +143,10 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restric
 }
 }
 extern "C" int is_debug_stream_copy(const void* src, void* dst, long long n16, int grid, void* stream) {
-  if (grid <= 0 || n16 < 0 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return -22;
+  if (grid <= 0 || n16 < 0 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::stream_copy_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const is::f32x4*>(src), static_cast<is::f32x4*>(dst), n16);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 
@@ -196,17 +221,17 @@ __global__ __launch_bounds__(256) void step_random_kernel(RandBatch batch, unsig
 
 // jobs: host array of njobs (<= 8) records { float* out; long long n; int kind; float p; }; state: 3 x uint64 of device memory
 extern "C" int is_step_random(const void* jobs, int njobs, unsigned long long* state, void* stream) {
-  if (njobs <= 0 || njobs > is::RAND_MAX_JOBS || state == nullptr) return -22;
+  if (njobs <= 0 || njobs > is::RAND_MAX_JOBS || state == nullptr) return is::fail(__func__, -22);
   is::RandBatch batch;
   const is::RandJob* src = static_cast<const is::RandJob*>(jobs);
   long long maxn = 0;
   for (int i = 0; i < njobs; ++i) {
-    if (src[i].n <= 0 || src[i].out == nullptr || src[i].kind < 0 || src[i].kind > 1 || !(src[i].p >= 0.0f && src[i].p <= 1.0f)) return -22;
+    if (src[i].n <= 0 || src[i].out == nullptr || src[i].kind < 0 || src[i].kind > 1 || !(src[i].p >= 0.0f && src[i].p <= 1.0f)) return is::fail(__func__, -22);
     batch.job[i] = src[i];
     maxn = src[i].n > maxn ? src[i].n : maxn;
   }
   int blocks = (int)((maxn / 4 + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
   hipLaunchKernelGGL(is::step_random_kernel, dim3(blocks, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch, state);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -625,16 +625,16 @@ extern "C" int is_comb_attn_partials_floats(int B) { return B * is::CA_PART; }
 extern "C" int is_comb_attn_grad_floats(int F) { return 7 * F + F * F; }
 
 static int ca_parts_from(is::CaParts& P, const void* parts, int nparts, int T, bool need_dx) {
-  if (nparts <= 0 || nparts > is::CA_MAX_PARTS) return -22;
+  if (nparts <= 0 || nparts > is::CA_MAX_PARTS) return is::fail(__func__, -22);
   const is::CaPart* src = static_cast<const is::CaPart*>(parts);
   int total = 0;
   for (int p = 0; p < nparts; ++p) {
     P.part[p] = src[p];
-    if (src[p].x == nullptr || src[p].width <= 0 || src[p].ld < src[p].width || (need_dx && src[p].dx == nullptr)) return -22;
+    if (src[p].x == nullptr || src[p].width <= 0 || src[p].ld < src[p].width || (need_dx && src[p].dx == nullptr)) return is::fail(__func__, -22);
     total += src[p].width;
   }
   P.n = nparts;
-  return total == T ? 0 : -22;
+  return total == T ? 0 : is::fail(__func__, -22);
 }
 
 // parts: host array of nparts (<= 4) records { const float* x; float* dx; int width, ld; } -- the T = sum(width) scalar tokens of
@@ -643,23 +643,23 @@ extern "C" int is_comb_attn_fwd(const void* parts, int nparts, const float* wq, 
                                 const float* bv, const float* Wc, const float* bc, float* z, float* stats, int B,
                                 int T, int F, void* stream) {
   if (B <= 0) return 0;
-  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
+  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return is::fail(__func__, -22);
   is::CaParts P;
-  if (ca_parts_from(P, parts, nparts, T, false) != 0) return -22;
+  if (ca_parts_from(P, parts, nparts, T, false) != 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::CaCls none{};
   if (F == 16) hipLaunchKernelGGL((is::comb_attn_fwd_kernel<16, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, none);
   else hipLaunchKernelGGL((is::comb_attn_fwd_kernel<32, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, none);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_comb_attn_bwd(const void* parts, int nparts, const float* stats, const float* dz, const float* wq, const float* bq,
                                 const float* wk, const float* wv, const float* bv, const float* Wc, const float* bc,
                                 float* partials, float* grads, int B, int T, int F, void* stream) {
   if (B <= 0) return 0;
-  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return -22;
+  if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32)) return is::fail(__func__, -22);
   is::CaParts P;
-  if (ca_parts_from(P, parts, nparts, T, true) != 0) return -22;
+  if (ca_parts_from(P, parts, nparts, T, true) != 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::CaCls none{};
   if (F == 16) {
@@ -669,7 +669,7 @@ extern "C" int is_comb_attn_bwd(const void* parts, int nparts, const float* stat
     hipLaunchKernelGGL((is::comb_attn_bwd_kernel<32, false>), dim3(B), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, none);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 static bool ca_cls_ok(int hid, int out, int act2) { return hid > 0 && hid <= is::CA_CLS_HID && out > 0 && out <= 64 && (act2 == 0 || act2 == 1); }
@@ -685,14 +685,14 @@ extern "C" int is_comb_attn_cls_fwd(const void* parts, int nparts, const float* 
   if (B <= 0) return 0;
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32) || !ca_cls_ok(hid, out, act2) || W1 == nullptr || b1 == nullptr ||
       W2 == nullptr || b2 == nullptr || z == nullptr || y == nullptr)
-    return -22;
+    return is::fail(__func__, -22);
   is::CaParts P;
-  if (ca_parts_from(P, parts, nparts, T, false) != 0) return -22;
+  if (ca_parts_from(P, parts, nparts, T, false) != 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::CaCls cls{W1, b1, W2, b2, mask, a1, y, nullptr, nullptr, nullptr, nullptr, nullptr, hid, out, act2, B};
   if (F == 16) hipLaunchKernelGGL((is::comb_attn_fwd_kernel<16, true>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, cls);
   else hipLaunchKernelGGL((is::comb_attn_fwd_kernel<32, true>), dim3(B), dim3(is::CA_THREADS), 0, st, P, wq, bq, wk, wv, bv, Wc, bc, z, stats, T, cls);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_comb_attn_cls_grad_floats(int T, int hid, int out) { return hid * T + hid + out * hid + out; }
@@ -709,9 +709,9 @@ extern "C" int is_comb_attn_cls_bwd(const void* parts, int nparts, const float* 
   if (B <= 0) return 0;
   if (T <= 0 || T > is::CA_TMAX || (F != 16 && F != 32) || !ca_cls_ok(hid, out, act2) || W1 == nullptr || W2 == nullptr ||
       z == nullptr || a1 == nullptr || gy == nullptr || gcls == nullptr || (act2 == 1 && y == nullptr))
-    return -22;
+    return is::fail(__func__, -22);
   is::CaParts P;
-  if (ca_parts_from(P, parts, nparts, T, true) != 0) return -22;
+  if (ca_parts_from(P, parts, nparts, T, true) != 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::CaCls cls{W1, nullptr, W2, nullptr, mask, nullptr, nullptr, a1, y, gy, z, gcls, hid, out, act2, B};
   const float* dz = nullptr;
@@ -722,5 +722,5 @@ extern "C" int is_comb_attn_cls_bwd(const void* parts, int nparts, const float* 
     hipLaunchKernelGGL((is::comb_attn_bwd_kernel<32, true>), dim3(B + 1), dim3(is::CA_THREADS), 0, st, P, stats, dz, wq, bq, wk, wv, bv, Wc, bc, partials, T, cls);
     hipLaunchKernelGGL(is::comb_attn_finish_kernel<32>, dim3(1), dim3(256), 0, st, partials, B, wq, bq, wk, wv, bv, Wc, grads);
   }
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -22,6 +22,12 @@
 
 namespace is {
 
+// ---- host side: what went wrong, for the caller (is_last_error_string).  Every entry point returns 0 or a negative errno-style
+// code and never throws; the text of the calling THREAD's last failure is kept beside the code: the entry point, the reason, and
+// for a failed launch HIP's own error string.  (Defined in abi_misc.hip.)
+int fail(const char* entry, int code);          // records "<entry>: <reason> (<code>)", returns code
+int launch_status(const char* entry);           // hipGetLastError(): 0, or records "<entry>: <hip error string> (-5)" and returns -5
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -576,7 +576,7 @@ extern "C" long long is_contrastive_work_floats(int B) { return 4LL * B * is::CZ
 extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld_e, int E, const float* pos, const float* W1,
                                   const float* gamma, const float* beta, const float* W2, float lambda, float* scratch,
                                   float* loss, const float* gate, float scale, int B, void* stream) {
-  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_e < E) return -22;
+  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_e < E) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long sides = 2 * is::side_floats(B);
   float* PAIR = scratch + sides;
@@ -588,16 +588,16 @@ extern "C" int is_contrastive_fwd(const float* emb_c, const float* emb_w, int ld
   hipLaunchKernelGGL(is::contr_side_fwd_b_kernel, sgrid, sblock, 0, st, W2, scratch, B);
   hipLaunchKernelGGL(is::contr_pair_fwd_kernel, dim3(nblocks), dim3(256), 0, st, scratch, pos, lambda, PAIR, CORR, partials, B);
   hipLaunchKernelGGL(is::contr_finish_kernel, dim3(1), dim3(256), 0, st, partials, nblocks * 4, scratch, B, loss, gate, scale);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // target [B] -> pos [B] = (target > mean(target)) as 1.0 / 0.0 (reference utils/contrastive.py:45) and gate [1] = 1.0 if the
 // target holds exactly two distinct values else 0.0 (the reference's early-out, :38-43, as a device-side factor).  One
 // launch instead of ~11 elementwise / reduction launches.  1 <= B <= 1024.
 extern "C" int is_contrastive_targets(const float* target, float* pos, float* gate, int B, void* stream) {
-  if (B < 1 || B > 1024) return -22;
+  if (B < 1 || B > 1024) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::contr_targets_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), target, pos, gate, B);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // g_loss [1] = upstream gradient of the scalar loss (multiplied by scale * gate as in the forward); demb_c, demb_w [B, ld_d]
@@ -605,7 +605,7 @@ extern "C" int is_contrastive_targets(const float* target, float* pos, float* ga
 extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float* gamma, const float* W2, float lambda,
                                   const float* scratch, float* work, const float* g_loss, const float* gate, float scale,
                                   float* demb_c, float* demb_w, int ld_d, int E, int B, void* stream) {
-  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_d < E) return -22;
+  if (B < 2 || B > 256 || E <= 0 || E > 256 || ld_d < E) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long sides = 2 * is::side_floats(B);
   const float* PAIR = scratch + sides;
@@ -618,5 +618,5 @@ extern "C" int is_contrastive_bwd(const float* pos, const float* W1, const float
   hipLaunchKernelGGL(is::contr_side_bwd_a_kernel, dim3(is::SB_BLOCKS, 2), sblock, 0, st, gamma, W2, scratch, DZ, wk, B);
   hipLaunchKernelGGL(is::contr_side_bwd_b_kernel, dim3((E + is::SB_COLS - 1) / is::SB_COLS, 2), sblock, 0, st, W1, wk, g_loss, gate,
                      scale, demb_c, demb_w, ld_d, E, B);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -241,10 +241,10 @@ __global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* _
 // db [N] (may be NULL).
 extern "C" int is_linear_wgrad(const float* gy, int ld_g, const float* x, int ld_x, float* dW, float* db, int B, int N, int K,
                                void* stream) {
-  if (B <= 0 || N <= 0 || K <= 0) return -22;
+  if (B <= 0 || N <= 0 || K <= 0) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::linear_wgrad_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
                      gy, ld_g, x, ld_x, dW, db, B, N, K);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // floats of the split-contraction scratch of is_linear_dgrad
@@ -257,7 +257,7 @@ extern "C" long long is_linear_dgrad_scratch_floats(int B, int N, int K) {
 // N outputs, as stored).  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats.  Two launches.
 extern "C" int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld_w, float* gx, float* scratch, int B, int N, int K,
                                void* stream) {
-  if (B <= 0 || N <= 0 || K <= 0) return -22;
+  if (B <= 0 || N <= 0 || K <= 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int chunks = (N + is::DG_KC - 1) / is::DG_KC, mtiles = (B + is::DG_M - 1) / is::DG_M;
   hipLaunchKernelGGL(is::linear_dgrad_splitk_kernel, dim3((K + is::DG_N - 1) / is::DG_N, chunks, mtiles), dim3(256), 0, st, gy, ld_g,
@@ -265,14 +265,14 @@ extern "C" int is_linear_dgrad(const float* gy, int ld_g, const float* W, int ld
   const long long total = (long long)B * K;
   hipLaunchKernelGGL(is::linear_dgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scratch, gx, B, K,
                      chunks, mtiles);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // y [B, K] = x [B, ld_x] (N valid columns) W^T + bias, W [K, ld_w] (N valid columns; the nn.Linear weight as stored), bias [K]
 // or NULL.  scratch: is_linear_dgrad_scratch_floats(B, N, K) floats (the same split of the contraction).  Two launches.
 extern "C" int is_linear_fwd_long(const float* x, int ld_x, const float* W, int ld_w, const float* bias, float* y, float* scratch,
                                   int B, int N, int K, void* stream) {
-  if (B <= 0 || N <= 0 || K <= 0) return -22;
+  if (B <= 0 || N <= 0 || K <= 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int chunks = (N + is::DG_KC - 1) / is::DG_KC, mtiles = (B + is::DG_M - 1) / is::DG_M;
   hipLaunchKernelGGL(is::linear_fwd_splitk_kernel, dim3((K + is::DG_N - 1) / is::DG_N, chunks, mtiles), dim3(256), 0, st, x, ld_x, W,
@@ -280,5 +280,5 @@ extern "C" int is_linear_fwd_long(const float* x, int ld_x, const float* W, int 
   const long long total = (long long)B * K;
   hipLaunchKernelGGL(is::linear_dgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scratch, y, B, K,
                      chunks, mtiles, bias);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

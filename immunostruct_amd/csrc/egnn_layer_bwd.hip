@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 #if !IS_BWD_Z3R
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps_bwd(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b), sizeof(long long) * 24) == hipSuccess ? 0 : -5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b), sizeof(long long) * 24) == hipSuccess ? 0 : is::fail(__func__, -5);
 }
 #endif
 #endif
@@ -1158,7 +1158,7 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
 #define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
 #if IS_BWD_Z3R
 #define IS_LAUNCH_LB_G(FE, NVB) do { if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, false); } while (0)
-  if (!gx) return -22;
+  if (!gx) return is::fail(__func__, -22);
 #else
 #define IS_LAUNCH_LB_G(FE, NVB)                                        \
   do {                                                                 \
@@ -1175,7 +1175,7 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
 #undef IS_LAUNCH_LB_G
 #undef IS_LAUNCH_LB_D
 #undef IS_LAUNCH_LB
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 }  // namespace is
 
@@ -1210,11 +1210,11 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
                                  long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream) {
   if (N <= 0) return 0;
-  if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
+  if ((long long)N * is::H * 4 >= 0x7ffff000LL) return is::fail(__func__, -22);      // 32-bit byte offsets of the raw-buffer views (8.3 M nodes)
   // (the gathered dZ1n / dDn rows of the layer above are addressed the same way: E * 256 bytes < 0x7fffe000 -- the layer that wrote
   //  them, and this one's own z2 / dZ1 views, already required that of the same E)
   if ((IS_LAYER_M1 != 0 && m1s == nullptr) || (IS_LAYER_M1 == 1 && dy1s == nullptr) || (IS_LAYER_GEO && geos == nullptr))
-    return -22;      // this build reads them
+    return is::fail(__func__, -22);      // this build reads them
   const bool gather = dZ1n != nullptr;
   const bool gx = gather || g_xout != nullptr;
   if (Fe < 0 || Fe > 8 || grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||
@@ -1223,7 +1223,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                   g_psd == nullptr || gxtot == nullptr)) ||
       (gx && z3s == nullptr && bc1 == nullptr) || (tiles != nullptr && Fe > 1) ||
       ld_p != 2 * is::H || ld_dpd != 2 * is::H || ldw != 2 * din + 1 + Fe)      // the layouts the kernels are built for
-    return -22;
+    return is::fail(__func__, -22);
   const bool z3r = gx && z3s == nullptr;      // z3 was not saved by the forward: recomputed from z2 (the other translation unit)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};

@@ -815,7 +815,7 @@ __global__ __launch_bounds__(512) void egnn_layer_bwd8_kernel(
 
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps_bwd8(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b8), sizeof(long long) * 24) == hipSuccess ? 0 : -5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_b8), sizeof(long long) * 24) == hipSuccess ? 0 : is::fail(__func__, -5);
 }
 #endif
 
@@ -839,22 +839,22 @@ extern "C" int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld
                                         long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, void* stream) {
   (void)ps; (void)pd; (void)x; (void)srcs; (void)bc1; (void)dy1s;      // (inputs of the recompute forms of is_egnn_layer_bwd)
 #if !IS_BWD8_BUILT
-  return -38;
+  return is::fail(__func__, -38);
 #else
   if (N <= 0) return 0;
-  if (tiles != nullptr || Fe < 0 || Fe > 1) return -38;
-  if ((long long)N * is::H * 4 >= 0x7ffff000LL) return -22;
-  if (m1s == nullptr || geos == nullptr) return -22;
+  if (tiles != nullptr || Fe < 0 || Fe > 1) return is::fail(__func__, -38);
+  if ((long long)N * is::H * 4 >= 0x7ffff000LL) return is::fail(__func__, -22);
+  if (m1s == nullptr || geos == nullptr) return is::fail(__func__, -22);
   const bool gather = dZ1n != nullptr;
   const bool gx = gather || g_xout != nullptr;
-  if (gx && z3s == nullptr) return -38;      // the z3-recompute form lives in egnn_layer_bwd_z3r.hip
+  if (gx && z3s == nullptr) return is::fail(__func__, -38);      // the z3-recompute form lives in egnn_layer_bwd_z3r.hip
   if (grid <= 0 || (din != 20 && din != 64) || zn1 == nullptr || bpack == nullptr || dzn1 == nullptr ||
       d_hn == nullptr || (g_psd != nullptr && dh_total == nullptr) || (g_psd == nullptr && g_h == nullptr) ||
       (gather && (g_xout != nullptr || dDn == nullptr || dxn == nullptr || rowptr_src == nullptr || pos_by_src == nullptr ||
                   g_psd == nullptr || gxtot == nullptr)) ||
       ld_p != 2 * is::H || ld_dpd != 2 * is::H || ldw != 2 * din + 1 + Fe)
-    return -22;
-  if (grid > (N + 15) / 16) return -22;      // every workgroup owns at least one tile
+    return is::fail(__func__, -22);
+  if (grid > (N + 15) / 16) return is::fail(__func__, -22);      // every workgroup owns at least one tile
   hipStream_t st = static_cast<hipStream_t>(stream);
   const is::NodeBwd8Args nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
   const dim3 block(512);
@@ -867,6 +867,6 @@ extern "C" int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld
   else IS_LAUNCH_B8_D(false, false);
 #undef IS_LAUNCH_B8_D
 #undef IS_LAUNCH_B8
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 #endif
 }

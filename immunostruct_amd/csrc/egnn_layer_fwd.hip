@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void egnn_layer_fwd_kernel(
 
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps3(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps3), sizeof(long long) * 64) == hipSuccess ? 0 : -5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps3), sizeof(long long) * 64) == hipSuccess ? 0 : is::fail(__func__, -5);
 }
 #endif
 
@@ -575,10 +575,10 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
   const bool save = z2s != nullptr;
   if (nchunks <= 0 || (nchunks % is::W3) != 0 || Fe < 0 || Fe > 8 || (din != 20 && din != 64) || fpack == nullptr || h == nullptr ||
       h_out == nullptr || (save && zn1 == nullptr) || (psd_next != nullptr && b1n == nullptr) || (m1s == nullptr && dy1s != nullptr))
-    return -22;
+    return is::fail(__func__, -22);
   // 32-bit byte offsets inside every buffer (raw buffer addressing)
   const long long lim = 0x7fffffffLL;
-  if ((long long)N * ld_p * 4 > lim || (long long)N * ld_hn * 4 > lim || (long long)(E + 16) * 64 * 4 > lim) return -22;
+  if ((long long)N * ld_p * 4 > lim || (long long)N * ld_hn * 4 > lim || (long long)(E + 16) * 64 * 4 > lim) return is::fail(__func__, -22);
   if (Fe == 0) ea = x;   // never used as a feature, but the clamped prefetch address must be valid
   const dim3 grid(nchunks / is::W3), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -593,5 +593,5 @@ extern "C" int is_egnn_layer_fwd(const float* ps, const float* pd, int ld_p, con
 #undef IS_LAUNCH_LF_C
 #undef IS_LAUNCH_LF_D
 #undef IS_LAUNCH_LF
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -261,14 +261,14 @@ extern "C" int is_node_proj_fwd(const float* h, int ld_h, int din, const float* 
   const dim3 grid(std::min((N + 3) / 4, 2048)), block(256);
   if (din == 20) hipLaunchKernelGGL(is::node_proj_fwd_kernel<20>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b0, b1, psd, N);
   else if (din == 64) hipLaunchKernelGGL(is::node_proj_fwd_kernel<64>, grid, block, 0, IS_STREAM(stream), h, ld_h, W1, ldw, b0, b1, psd, N);
-  else return -22;
+  else return is::fail(__func__, -22);
   IS_RET();
 }
 
 extern "C" int is_node_proj_bwd(const float* g_h, const float* g_psd, const float* h, int ld_h, int din,
                                 const float* W1, int ldw, float* dh_total, float* partials, int grid, int N,
                                 void* stream) {
-  if (N <= 0 || grid <= 0 || din <= 0 || din > 64) return -22;
+  if (N <= 0 || grid <= 0 || din <= 0 || din > 64) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::node_proj_bwd_kernel, dim3(grid), dim3(256), 0, IS_STREAM(stream), g_h, g_psd, h, ld_h, din, W1, ldw, dh_total, partials, N);
   IS_RET();
 }
@@ -278,7 +278,7 @@ extern "C" int is_reduce_partials_scratch_floats(int stride) { return is::RED_SP
 // record p starts at partials + p*stride; its first `count` floats are reduced
 extern "C" int is_reduce_partials(const float* partials, int nparts, int stride, int count, const int32_t* map,
                                   float* dst, float* scratch, void* stream) {
-  if (nparts <= 0 || stride <= 0 || count <= 0 || count > stride) return -22;
+  if (nparts <= 0 || stride <= 0 || count <= 0 || count > stride) return is::fail(__func__, -22);
   const dim3 block(256);
   if (nparts <= is::RED_SPLIT) {
     hipLaunchKernelGGL(is::reduce_partials_direct, dim3((count + 255) / 256), block, 0, IS_STREAM(stream), partials, nparts, stride, count, map, dst);
@@ -291,13 +291,13 @@ extern "C" int is_reduce_partials(const float* partials, int nparts, int stride,
 
 // jobs: host array of `njobs` (<= 24) records {partials, map, dst, scratch, nparts, stride, count, pad}
 extern "C" int is_reduce_partials_batched(const void* jobs, int njobs, void* stream) {
-  if (njobs <= 0 || njobs > is::RED_MAX_JOBS) return -22;
+  if (njobs <= 0 || njobs > is::RED_MAX_JOBS) return is::fail(__func__, -22);
   is::ReduceBatch batch;
   const is::ReduceJob* src = static_cast<const is::ReduceJob*>(jobs);
   int maxcount = 0;
   for (int i = 0; i < njobs; ++i) {
     batch.job[i] = src[i];
-    if (src[i].count <= 0 || src[i].count > src[i].stride || src[i].nparts <= 0) return -22;
+    if (src[i].count <= 0 || src[i].count > src[i].stride || src[i].nparts <= 0) return is::fail(__func__, -22);
     maxcount = src[i].count > maxcount ? src[i].count : maxcount;
   }
   const dim3 block(256);

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void egnn_node_wgrad16_batched_kernel(Wgrad
 
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps_node(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_node), sizeof(long long) * 16) == hipSuccess ? 0 : -5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_node), sizeof(long long) * 16) == hipSuccess ? 0 : is::fail(__func__, -5);
 }
 #endif
 
@@ -488,13 +488,13 @@ extern "C" int is_node_pack_floats(void) { return is::NODE_PACK_FLOATS; }
 extern "C" int is_stack_prologue(const void* jobs, int njobs, const float* h, int ld_h, int din, const float* W1, int ldw,
                                  const float* b0, const float* b1, float* psd, const float* x_src, int ld_x, float* x_dst,
                                  int N, void* stream) {
-  if (njobs <= 0 || njobs > is::NODE_PACK_MAX || N <= 0 || (din != 20 && din != 64)) return -22;
-  if (x_dst != nullptr && (x_src == nullptr || ld_x < 3)) return -22;
+  if (njobs <= 0 || njobs > is::NODE_PACK_MAX || N <= 0 || (din != 20 && din != 64)) return is::fail(__func__, -22);
+  if (x_dst != nullptr && (x_src == nullptr || ld_x < 3)) return is::fail(__func__, -22);
   is::NodePackBatch batch;
   const is::NodePackJob* src = static_cast<const is::NodePackJob*>(jobs);
   for (int i = 0; i < njobs; ++i) {
     batch.job[i] = src[i];
-    if ((src[i].din != 20 && src[i].din != 64) || ((src[i].W1n == nullptr) != (src[i].W1nb == nullptr))) return -22;
+    if ((src[i].din != 20 && src[i].din != 64) || ((src[i].W1n == nullptr) != (src[i].W1nb == nullptr))) return is::fail(__func__, -22);
   }
   const int proj_blocks = std::min((N + 23) / 24, 1024);
   if (din == 20)
@@ -503,7 +503,7 @@ extern "C" int is_stack_prologue(const void* jobs, int njobs, const float* h, in
   else
     hipLaunchKernelGGL(is::stack_prologue_kernel<64>, dim3(proj_blocks + 4 * njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch,
                        njobs, proj_blocks, h, ld_h, W1, ldw, b0, b1, psd, x_src, ld_x, x_dst, N);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_egnn_node_wgrad_stride(void) { return is::WG_STRIDE; }
@@ -517,17 +517,17 @@ extern "C" int is_egnn_node_wgrad_proj_floats(void) { return is::WG_PROJ; }
 // A record with dzn1 == NULL is a projection-only job (PROJ part from g_psd and the first dho columns of h_out, row stride
 // ld_ho); a record with g_psd == NULL leaves the PROJ part untouched.
 extern "C" int is_egnn_node_wgrad_batched(const void* layers, int nlayers, int grid_node, int grid_proj, int N, void* stream) {
-  if (N <= 0 || grid_node <= 0 || grid_proj <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return -22;
-  if ((long long)N * 128 * 4 >= 0x7ffff000LL) return -22;      // 32-bit byte offsets of the raw-buffer row loads (4.1 M nodes)
+  if (N <= 0 || grid_node <= 0 || grid_proj <= 0 || nlayers <= 0 || nlayers > is::WGRAD_MAX_LAYERS) return is::fail(__func__, -22);
+  if ((long long)N * 128 * 4 >= 0x7ffff000LL) return is::fail(__func__, -22);      // 32-bit byte offsets of the raw-buffer row loads (4.1 M nodes)
   is::WgradBatch batch;
   const is::WgradLayer* src = static_cast<const is::WgradLayer*>(layers);
   for (int i = 0; i < nlayers; ++i) {
     batch.layer[i] = src[i];
-    if ((src[i].din != 20 && src[i].din != 64) || src[i].dho < 0 || src[i].dho > 64) return -22;
-    if (src[i].g_psd == nullptr && src[i].dzn1 == nullptr) return -22;
+    if ((src[i].din != 20 && src[i].din != 64) || src[i].dho < 0 || src[i].dho > 64) return is::fail(__func__, -22);
+    if (src[i].g_psd == nullptr && src[i].dzn1 == nullptr) return is::fail(__func__, -22);
   }
   auto rows_of = [N](int grid) { return (((N + grid - 1) / grid) + 15) / 16 * 16; };
   hipLaunchKernelGGL(is::egnn_node_wgrad16_batched_kernel, dim3(std::max(grid_node, grid_proj), 2 * nlayers), dim3(256), 0,
                      static_cast<hipStream_t>(stream), batch, N, grid_node, rows_of(grid_node), grid_proj, rows_of(grid_proj));
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -141,10 +141,10 @@ static int recon_parts(long long recon_total) {
 // produced (the sequence branch's stream) and hand is_vae_loss the partials (recon = NULL there).
 extern "C" int is_recon_mse(const float* recon, const float* x, float* d_recon, long long recon_total, float gscale,
                             float* partials, void* stream) {
-  if (recon_total <= 0 || recon == nullptr || x == nullptr || d_recon == nullptr || partials == nullptr) return -22;
+  if (recon_total <= 0 || recon == nullptr || x == nullptr || d_recon == nullptr || partials == nullptr) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::recon_mse_kernel, dim3(recon_parts(recon_total)), dim3(is::LOSS_BLOCK), 0, static_cast<hipStream_t>(stream),
                      recon, x, d_recon, partials, recon_total, gscale);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // mode 0 = regression (MSE on the logit), 1 = BCE-with-logits(pos_weight).
@@ -156,7 +156,7 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
                            const float* logit, const float* y, float* d_logit, int batch, int mode,
                            float pos_weight, float c_pred, float c_mse, float c_kld, float* partials, float* out,
                            float* total, void* stream) {
-  if (batch <= 0) return -22;
+  if (batch <= 0) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   int nparts = 0;
   if (recon_total > 0) {
@@ -168,5 +168,5 @@ extern "C" int is_vae_loss(const float* recon, const float* x, float* d_recon, l
   hipLaunchKernelGGL(is::loss_finish_kernel<7>, dim3(1), dim3(is::FIN_BLOCK), 0, st, partials, nparts, recon_total, mu,
                      logvar, d_mu, d_logvar, latent_total, logit, y, d_logit, batch, mode, pos_weight, c_pred, c_mse,
                      c_kld, (float*)nullptr, out, total);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+namespace is { int fail(const char* entry, int code); int launch_status(const char* entry); }      // (common.h: the thread's last failure)
+
 namespace is {
 
 constexpr int MLP_SPW = 8;        // samples per workgroup
@@ -210,12 +212,12 @@ extern "C" int is_mlp2_fwd(const float* x, int ld_x, const float* W1, const floa
                            int act1, int act2, void* stream) {
   if (B == 0) return 0;
   is::MlpDims d{B, in, hid, out, ld_x, hgroup > 0 ? (hid / (hgroup > 0 ? hgroup : 1)) * in : in, hgroup, act1, act2};
-  if (!is::mlp_dims_ok(d)) return -22;
+  if (!is::mlp_dims_ok(d)) return is::fail(__func__, -22);
   const size_t lds = sizeof(float) * ((size_t)in * (hid + 1) + (size_t)out * hid + (size_t)is::MLP_SPW * d.xrow + (size_t)is::MLP_SPW * hid);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)is::mlp2_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(is::mlp2_fwd_kernel, dim3((B + is::MLP_SPW - 1) / is::MLP_SPW), dim3(256), lds, static_cast<hipStream_t>(stream),
                      x, W1, b1, W2, b2, mask, a1_out, y, d);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // number of workgroups (= partial records) and floats per record of is_mlp2_bwd
@@ -229,11 +231,11 @@ extern "C" int is_mlp2_bwd(const float* x, int ld_x, const float* W1, const floa
                            int hgroup, int act1, int act2, void* stream) {
   if (B == 0) return 0;
   is::MlpDims d{B, in, hid, out, ld_x, hgroup > 0 ? (hid / (hgroup > 0 ? hgroup : 1)) * in : in, hgroup, act1, act2};
-  if (!is::mlp_dims_ok(d)) return -22;
+  if (!is::mlp_dims_ok(d)) return is::fail(__func__, -22);
   const size_t lds = sizeof(float) * ((size_t)hid * (in + 1) + (size_t)out * hid + (size_t)is::MLP_SPW * d.xrow +
                                       2 * (size_t)is::MLP_SPW * hid + (size_t)is::MLP_SPW * out);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)is::mlp2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(is::mlp2_bwd_kernel, dim3((B + is::MLP_SPW - 1) / is::MLP_SPW), dim3(256), lds, static_cast<hipStream_t>(stream),
                      x, W1, W2, mask, a1, y, gy, gx, partials, d);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64 * NB) void attn16_bwd_kernel(
 
 #ifdef IS_STAGE_STAMPS
 extern "C" int is_debug_stamps_attn(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_attn), sizeof(long long) * 16) == hipSuccess ? 0 : -5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(is::g_stamps_attn), sizeof(long long) * 16) == hipSuccess ? 0 : is::fail(__func__, -5);
 }
 #endif
 
@@ -1069,15 +1069,15 @@ inline bool attn16_applies(int n, int heads) { return heads == 1 && n <= 192 && 
 extern "C" int is_attn_colmean_fwd(const float* qk, const float* x, float* ctx, float* abar, float* probs, int B, int n,
                                    int heads, void* stream) {
   if (B <= 0) return 0;
-  if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
+  if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return is::fail(__func__, -22);
   const float* none = nullptr;
   float* nout = nullptr;
   if (is::attn16_applies(n, heads)) {
     ATTN16_FWD(qk, x, ctx, abar, probs, n, none, none, none, none, nout, nout);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
+    return is::launch_status(__func__);
   }
   ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, none, none, none, none, nout, nout);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // Single head: the same pass followed, in the same launch, by the pooled tail hid = W_v ctx + b_v (a1_out [B,64], may be
@@ -1087,28 +1087,28 @@ extern "C" int is_attn_colmean_fwd_tail(const float* qk, const float* x, float* 
                                         const float* wv, const float* bv, const float* wc, const float* bc, float* a1_out,
                                         float* y_out, int B, int n, void* stream) {
   if (B <= 0) return 0;
-  if (n <= 0 || n > 256 || wv == nullptr || bv == nullptr || wc == nullptr || bc == nullptr || y_out == nullptr) return -22;
+  if (n <= 0 || n > 256 || wv == nullptr || bv == nullptr || wc == nullptr || bc == nullptr || y_out == nullptr) return is::fail(__func__, -22);
   const int heads = 1;
   if (is::attn16_applies(n, heads)) {
     ATTN16_FWD(qk, x, ctx, abar, probs, n, wv, bv, wc, bc, a1_out, y_out);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
+    return is::launch_status(__func__);
   }
   ATTN_DISPATCH(attn_colmean_fwd_kernel, qk, x, ctx, abar, probs, n, heads, wv, bv, wc, bc, a1_out, y_out);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // dqk [B*n, 128] (every entry written), dx [B*n, 64] (direct term through ctx = abar^T x).
 extern "C" int is_attn_colmean_bwd(const float* qk, const float* x, const float* abar, const float* probs,
                                    const float* g_ctx, float* dqk, float* dx, int B, int n, int heads, void* stream) {
   if (B <= 0) return 0;
-  if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return -22;
+  if (n <= 0 || n > 256 || (heads != 1 && heads != 8)) return is::fail(__func__, -22);
   const is::AttnTailBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (is::attn16_applies(n, heads)) {
     ATTN16_BWD(qk, x, abar, probs, g_ctx, dqk, dx, n, none);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
+    return is::launch_status(__func__);
   }
   ATTN_DISPATCH_BWD(B, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, none);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // Single head with the pooled tail of is_attn_colmean_fwd_tail behind it: gy [B,64] is the gradient of the tail's output y;
@@ -1119,15 +1119,15 @@ extern "C" int is_attn_colmean_bwd_tail(const float* qk, const float* x, const f
                                         const float* a1, float* dqk, float* dx, float* gtail, int B_, int n, void* stream) {
   if (B_ <= 0) return 0;
   if (n <= 0 || n > 256 || gy == nullptr || wv == nullptr || wc == nullptr || pooled == nullptr || a1 == nullptr || gtail == nullptr)
-    return -22;
+    return is::fail(__func__, -22);
   const int heads = 1;
   const float* g_ctx = nullptr;
   const is::AttnTailBwd tail{gy, wv, wc, pooled, a1, gtail, B_};
   const int B = B_ + is::TAIL_SLABS;      // grid: the graphs + the parameter-gradient workgroups
   if (is::attn16_applies(n, heads)) {
     ATTN16_BWD(qk, x, abar, probs, g_ctx, dqk, dx, n, tail);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
+    return is::launch_status(__func__);
   }
   ATTN_DISPATCH_BWD(B_, qk, x, abar, probs, g_ctx, dqk, dx, n, heads, tail);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

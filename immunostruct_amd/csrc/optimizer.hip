@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+namespace is { int fail(const char* entry, int code); int launch_status(const char* entry); }      // (common.h: the thread's last failure)
+
 namespace is {
 
 struct AdamChunk {
@@ -78,7 +80,7 @@ extern "C" int is_adam_step(const void* chunks, int nchunks, float* state, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(is::adam_prepare_kernel, dim3(1), dim3(1), 0, st, state, hyper);
   hipLaunchKernelGGL(is::adam_step_kernel, dim3(nchunks), dim3(256), 0, st, static_cast<const is::AdamChunk*>(chunks), state, hyper);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // The same step in parts, for a caller that updates the parameters of one group in SEVERAL launches (the engine: the parameters
@@ -87,11 +89,11 @@ extern "C" int is_adam_step(const void* chunks, int nchunks, float* state, const
 // is_adam_step == is_adam_prepare + is_adam_apply.
 extern "C" int is_adam_prepare(float* state, const float* hyper, void* stream) {
   hipLaunchKernelGGL(is::adam_prepare_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), state, hyper);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 extern "C" int is_adam_apply(const void* chunks, int nchunks, const float* state, const float* hyper, void* stream) {
   if (nchunks <= 0) return 0;
   hipLaunchKernelGGL(is::adam_step_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const is::AdamChunk*>(chunks), state, hyper);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -126,7 +126,7 @@ extern "C" int is_gather_segment_sum(const float* rows, const float* vec3, const
   if (N <= 0) return 0;
   hipLaunchKernelGGL(is::gather_segment_sum_kernel, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
                      rows, vec3, ptr, pos, out_rows, ld_out, out_vec3, N, wg_clock);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_ptr, float* out_mean, float* out_max,
@@ -134,7 +134,7 @@ extern "C" int is_segment_pool_fwd(const float* x, int ld_x, const int32_t* seg_
   if (num_segments <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(is::segment_pool_fwd_kernel, dim3(num_segments, (C + 63) / 64), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ld_x, seg_ptr, out_mean, out_max, C);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 extern "C" int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_ptr, const float* out_max,
@@ -143,7 +143,7 @@ extern "C" int is_segment_pool_bwd(const float* x, int ld_x, const int32_t* seg_
   if (num_segments <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(is::segment_pool_bwd_kernel, dim3(num_segments, (C + 63) / 64), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ld_x, seg_ptr, out_max, g_mean, g_max, dx, ld_dx, C);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -176,19 +176,19 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(CopyBatch batch) {
 
 // jobs: host array of njobs (<= 24) records { const void* src; void* dst; long long bytes; }, bytes % 4 == 0
 extern "C" int is_multi_copy(const void* jobs, int njobs, void* stream) {
-  if (njobs <= 0 || njobs > is::COPY_MAX_JOBS) return -22;
+  if (njobs <= 0 || njobs > is::COPY_MAX_JOBS) return is::fail(__func__, -22);
   is::CopyBatch batch;
   const is::CopyJob* src = static_cast<const is::CopyJob*>(jobs);
   long long maxb = 0;
   for (int i = 0; i < njobs; ++i) {
-    if (src[i].bytes < 0 || (src[i].bytes & 3)) return -22;
+    if (src[i].bytes < 0 || (src[i].bytes & 3)) return is::fail(__func__, -22);
     batch.job[i] = src[i];
     maxb = src[i].bytes > maxb ? src[i].bytes : maxb;
   }
   int blocks = (int)((maxb / 16 + 255) / 256);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
   hipLaunchKernelGGL(is::multi_copy_kernel, dim3(blocks, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), batch);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,24 +299,24 @@ extern "C" int is_batch_gather(const long long* idx, int B, int n, int F, int Fe
                                int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* src_sorted, int32_t* dst_sorted,
                                int32_t* pos_by_src, float* ea, const void* rows, int nrows, void* stream) {
   if (B <= 0) return 0;
-  if (n <= 0 || F <= 0 || Fe < 0 || nrows < 0 || nrows > is::BATCH_ROWS_MAX || (nrows > 0 && rows == nullptr)) return -22;
+  if (n <= 0 || F <= 0 || Fe < 0 || nrows < 0 || nrows > is::BATCH_ROWS_MAX || (nrows > 0 && rows == nullptr)) return is::fail(__func__, -22);
   is::BatchSrc S{x_all, eoff, rowptr_dst_all, rowptr_src_all, src_all, dst_all, pos_all, ea_all};
   is::BatchDst D{x, rowptr_dst, rowptr_src, src_sorted, dst_sorted, pos_by_src, ea};
   is::RowGathers R{};
   R.n = nrows;
   for (int j = 0; j < nrows; ++j) {
     R.job[j] = static_cast<const is::RowGather*>(rows)[j];
-    if (R.job[j].src == nullptr || R.job[j].dst == nullptr || R.job[j].floats <= 0) return -22;
+    if (R.job[j].src == nullptr || R.job[j].dst == nullptr || R.job[j].floats <= 0) return is::fail(__func__, -22);
   }
   hipLaunchKernelGGL(is::batch_gather_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), idx, B, n, F, Fe, S, D, R);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // rowptr [N + 1] (device) -> chunk_ptr [k + 1][2] int32: the edge-balanced node partition the layer kernels walk (graph.py
 // `balanced_node_chunks`), recomputed on the device after the batcher wrote a new rowptr -- one launch, no host sync.
 // shares: 0 = equal shares; 1 = the two-level shares of graph.py chunk_shares (the caller passes 1 only for the full grid).
 extern "C" int is_chunk_partition(const int32_t* rowptr, int N, int k, int shares, int32_t* chunk_ptr, void* stream) {
-  if (N < 0 || k <= 0 || rowptr == nullptr || chunk_ptr == nullptr) return -22;
+  if (N < 0 || k <= 0 || rowptr == nullptr || chunk_ptr == nullptr) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::chunk_partition_kernel, dim3((k + 256) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr, N, k, shares, chunk_ptr);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }

@@ -304,10 +304,10 @@ static bool vae_dims_ok(int B, int Hd, int L, int P) {
 extern "C" int is_vae_latent_fwd(const float* a1, const float* W21, const float* b21, const float* W22, const float* b22,
                                  const float* eps, const float* p, int P, const float* W3, const float* b3, float* mu,
                                  float* logvar, float* zp, float* h3, int B, int Hd, int L, void* stream) {
-  if (!vae_dims_ok(B, Hd, L, P) || (P > 0 && p == nullptr)) return -22;
+  if (!vae_dims_ok(B, Hd, L, P) || (P > 0 && p == nullptr)) return is::fail(__func__, -22);
   hipLaunchKernelGGL(is::vae_latent_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a1, W21, b21, W22, b22,
                      eps, p, P, W3, b3, mu, logvar, zp, h3, Hd);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // number of floats of the weight-gradient vector [dW21 | dW22 | db21 | db22 | dW3 | db3]
@@ -319,11 +319,11 @@ extern "C" int is_vae_latent_bwd_data(const float* g_h3, const float* h3, const 
                                       const float* eps, const float* logvar, const float* a1, const float* W21, const float* W22,
                                       int P, const float* W3, float* d_a3, float* dmu, float* dlv, float* d_p, float* d_a1, int B,
                                       int Hd, int L, void* stream) {
-  if (!vae_dims_ok(B, Hd, L, P) || (P > 0 && d_p == nullptr)) return -22;
+  if (!vae_dims_ok(B, Hd, L, P) || (P > 0 && d_p == nullptr)) return is::fail(__func__, -22);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(is::vae_latent_bwd_data_kernel, dim3((B + 15) / 16, 4), dim3(256), 0, st, g_h3, h3, g_mu, g_lv, g_zp, eps, logvar,
                      a1, W21, W22, P, W3, d_a3, dmu, dlv, d_p, d_a1, B, Hd);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // the weight pass: wgrad [is_vae_latent_grad_floats] from a1, zp and what is_vae_latent_bwd_data left in d_a3 / dmu / dlv.
@@ -331,11 +331,11 @@ extern "C" int is_vae_latent_bwd_data(const float* g_h3, const float* h3, const 
 // the weight gradient of vae_fc1 there: the big one goes first, this one -- one-wave workgroups, no LDS -- trails).
 extern "C" int is_vae_latent_bwd_wgrad(const float* a1, const float* dmu, const float* dlv, const float* zp, const float* d_a3,
                                        int P, float* wgrad, int B, int Hd, int L, void* stream) {
-  if (!vae_dims_ok(B, Hd, L, P)) return -22;
+  if (!vae_dims_ok(B, Hd, L, P)) return is::fail(__func__, -22);
   const int wtiles = 4 * (Hd / 16) + (Hd / 16) * ((is::VL + P + 15) / 16);
   hipLaunchKernelGGL(is::vae_latent_bwd_wgrad_kernel, dim3(wtiles), dim3(64), 0, static_cast<hipStream_t>(stream), a1, dmu, dlv, zp,
                      d_a3, P, B, Hd, wgrad);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+  return is::launch_status(__func__);
 }
 
 // both halves back to back; scratch: d_a3 [B,Hd], dmu, dlv [B,32].

@@ -286,15 +286,18 @@ def _field(obj, key):
 def load_pyg_pickle(path):
     """``(x, coords, edge_index, name)`` of one of the reference's per-structure files"""
     obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
-    out = tuple(_field(obj, k) for k in ("x", "coords", "edge_index", "name"))
-    for k, v in zip(("x", "coords", "edge_index"), out):
-        if not torch.is_tensor(v):
-            v = torch.as_tensor(np.asarray(v)) if isinstance(v, (np.ndarray, list, tuple)) else v
+    vals = []
+    for k in ("x", "coords", "edge_index"):
+        v = _field(obj, k)
+        if not torch.is_tensor(v) and isinstance(v, (np.ndarray, list, tuple)):
+            v = torch.as_tensor(np.asarray(v))      # (an array- or list-valued field: the CONVERTED value is what is returned)
         if not torch.is_tensor(v):
             raise ValueError(f"{path}: field {k!r} is a {type(v).__name__}, not a tensor")
-    if not isinstance(out[3], str):
-        raise ValueError(f"{path}: field 'name' is a {type(out[3]).__name__}, not a string")
-    return out
+        vals.append(v)
+    name = _field(obj, "name")
+    if not isinstance(name, str):
+        raise ValueError(f"{path}: field 'name' is a {type(name).__name__}, not a string")
+    return (*vals, name)
 
 
 def list_structure_names(directory):

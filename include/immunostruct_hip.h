@@ -22,8 +22,10 @@
  * device memory owned by the caller, fp32 / int32, row-major, contiguous unless
  * a leading dimension `ld_*` (in elements) is given.  Kernels are enqueued on
  * `stream` (a hipStream_t passed as void*) and are asynchronous.  Every function
- * returns 0 on success, -22 (EINVAL) on a bad argument, -5 (EIO) if the launch
- * failed; it never throws, allocates or keeps pointers.  Hidden width is 64.
+ * returns 0 on success, -22 (EINVAL) on a bad argument, -38 (ENOSYS) for a shape
+ * this build's form of the kernel does not cover, -5 (EIO) if the launch failed;
+ * it never throws, allocates or keeps pointers -- is_last_error_string() has the
+ * text behind the calling thread's last non-zero code.  Hidden width is 64.
  */
 #ifndef IMMUNOSTRUCT_HIP_H
 #define IMMUNOSTRUCT_HIP_H
@@ -34,6 +36,11 @@ extern "C" {
 
 /* library version: major*10000 + minor*100 + patch */
 int is_version(void);
+
+/* The calling thread's most recent failure as text: "<entry point>: <reason> (<code>)", with HIP's error name and string for a
+ * failed launch; "" while nothing failed on this thread.  Thread-local, never NULL, valid for the thread's lifetime (the text is
+ * replaced by the thread's next failure).  SURVEY.md 8(b): "no global mutable state except an error string (thread-local)".   */
+const char* is_last_error_string(void);
 
 /* MFMA operand/accumulator layout self-tests (one wave).
  *   is_mfma_selftest:       out[32x64] = A[32x64] * W[64x64]^T

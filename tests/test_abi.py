@@ -20,7 +20,7 @@ def header_prototypes():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     out = {}
-    for name, args in re.findall(r"\b(?:int|long long|void|float)\s+(is_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for name, args in re.findall(r"\b(?:int|long long|void|float|const char\s*\*)\s*(is_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = " ".join(args.split())
         kinds = []
         if args and args != "void":
@@ -60,6 +60,27 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_symbols():
         assert hasattr(lib, name), f"{name} missing from {_lib.LIB_PATH}"
+
+
+def test_failures_carry_their_text():
+    """every entry point returns a bare errno-style code; the calling thread's last failure is kept as text (no GPU needed: the
+    argument checks come first) and ``_lib.check`` raises with it"""
+    import pytest
+    lib = _lib.load()
+    assert lib.is_reduce_partials(None, 0, 0, 0, None, None, None, None) == -22
+    text = lib.is_last_error_string().decode()
+    assert text.startswith("is_reduce_partials: invalid argument") and text.endswith("(-22)")
+    assert lib.is_version() >= 100 and lib.is_last_error_string().decode() == text      # a successful call leaves it alone
+    assert lib.is_egnn_layer_bwd_paired(*([None] * 2 + [128] + [None] * 5 + [131, 64] + [None] * 10 + [128, None, None, None, 1, 16, 8] + [None] * 19)) == -38
+    assert "is_egnn_layer_bwd_paired: not covered by this build" in lib.is_last_error_string().decode()      # Fe = 8: the 256-thread kernel's
+    with pytest.raises(_lib.HipExtensionError, match=r"code -22: is_multi_copy: invalid argument"):
+        _lib.check(lib.is_multi_copy(None, 0, None), "is_multi_copy")
+    # thread-local: another thread starts with an empty text
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.is_last_error_string().decode()))
+    t.start(); t.join()
+    assert seen == [""]
 
 
 def test_version_and_scratch_sizes():

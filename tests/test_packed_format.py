@@ -190,6 +190,43 @@ def fabricate_named(directory, names, seed=11):
             sys.modules.pop(name, None)
 
 
+def test_reader_returns_the_converted_value_of_array_and_list_fields(tmp_path):
+    """a file whose ``x`` / ``coords`` / ``edge_index`` is a numpy array or a list passed the reader's check on a CONVERTED
+    copy while the caller received the unconverted object; the tensors are what comes back, and the converter packs the file"""
+    mods = {name: types.ModuleType(name) for name in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data")}
+
+    class Data:
+        def __init__(self, **fields):
+            self.__dict__.update(fields)      # (the 1.x layout: fields in the object's own dict)
+
+    Data.__module__, Data.__qualname__ = "torch_geometric.data.data", "Data"
+    mods["torch_geometric.data.data"].Data = Data
+    sys.modules.update(mods)
+    rs = np.random.RandomState(4)
+    n = 9
+    x, coords = rs.rand(n, 22).astype(np.float32), rs.normal(size=(n, 3)).astype(np.float32)
+    edges = [[int(v) for v in rs.randint(0, n, size=14)], [int(v) for v in rs.randint(0, n, size=14)]]
+    path = os.path.join(tmp_path, "a000.pt")
+    try:
+        torch.save(Data(x=x, coords=coords, edge_index=edges, name="AF_0_ImmunoGILGFVFTL_A0201"), path)
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+    gx, gc, ge, gn = D.load_pyg_pickle(path)
+    assert all(torch.is_tensor(t) for t in (gx, gc, ge)) and gn == "AF_0_ImmunoGILGFVFTL_A0201"
+    assert torch.equal(gx, torch.from_numpy(x)) and torch.equal(gc, torch.from_numpy(coords)) and torch.equal(ge, torch.tensor(edges))
+    packed = D.convert_pyg_directory(str(tmp_path))
+    assert packed.names == ["GILGFVFTL_A0201"] and packed.x.shape == (1, n, 23) and int(packed.eoff[-1]) == 14
+    with pytest.raises(ValueError, match="not a tensor"):
+        sys.modules.update(mods)
+        try:
+            torch.save(Data(x="nope", coords=coords, edge_index=edges, name="AF_1_ImmunoX_Y"), os.path.join(tmp_path, "b.pt"))
+        finally:
+            for name in mods:
+                sys.modules.pop(name, None)
+        D.load_pyg_pickle(os.path.join(tmp_path, "b.pt"))
+
+
 def test_reference_path_flags_build_the_datasets(tmp_path):
     """``--graph-dir-* / --property-path-* / --hla-path`` (train_IEDB_wFT.py:26-29, train_Cancer_wFT.py:30-39): graph files +
     tables -> datasets in the TABLE's row order with the joined labels (``data.reference_inputs`` over ``data.tables``)"""
