@@ -949,7 +949,10 @@ def main():
                       edges_per_batch=int(wl.n_edges), parallelism=f"dp{world}",
                       final_loss=None if final_loss is None else round(final_loss, 7),
                       rccl_ranks=torch.distributed.get_world_size() if ddp else 1,
-                      dist_backend=torch.distributed.get_backend() if ddp else None)
+                      dist_backend=torch.distributed.get_backend() if ddp else None,
+                      # operators that left the HIP kernels' build for a device-side torch composition (functional.composed_path):
+                      # {} = every operator of the timed step ran on the hand-written kernels
+                      composed_paths=dict(HF.COMPOSED_PATHS))
         config.update(extra_config)
         if host_read is not None:
             host_read["value"] = round(wl.graphs_per_step * world / (host_read["ms_per_step"] * 1e-3), 1)

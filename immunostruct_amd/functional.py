@@ -100,6 +100,23 @@ class StackBoundary:
         return out
 
 
+COMPOSED_PATHS = {}      # reason -> how often a shape OUTSIDE the HIP kernels' build ran as a device-side torch composition
+
+
+def composed_path(reason):
+    """Note that an operator ran from device-side torch ops because its shape lies outside what the HIP kernels are built for
+    (more than 256 nodes per graph or other head counts than 1 / 8 in the node attention, an EGNN width other than 64, more than
+    256 contrastive pairs): same arithmetic, same oracle tests, but NOT the measured path.  The first occurrence of every reason
+    warns; ``COMPOSED_PATHS`` keeps the counts (``bench.py`` prints them in ``config.composed_paths``: {} for every workload it
+    times), so a caller who leaves the envelope sees it instead of a silently slower run."""
+    if reason not in COMPOSED_PATHS:
+        import warnings
+        warnings.warn(f"immunostruct_amd: {reason} -- outside the HIP kernels' build, running as a device-side torch composition "
+                      "(correct, tested against the oracle, much slower; functional.COMPOSED_PATHS counts the calls)", RuntimeWarning,
+                      stacklevel=3)
+    COMPOSED_PATHS[reason] = COMPOSED_PATHS.get(reason, 0) + 1
+
+
 class Stamps:
     """Debug aid (IMMUNOSTRUCT_STAMPS=1): device wall-clock stamps at named points of a step, also inside a captured
     HIP graph -- the only way to see the schedule of a replayed graph without a profiler's perturbation."""

@@ -19,7 +19,12 @@ import torch.nn.functional as F
 
 
 def attend(q, k, v, heads):
-    """softmax(q k^T / sqrt(d_head)) v for (b, n, d) inputs; returns (out (b,n,d), weights (b,heads,n,n))."""
+    """softmax(q k^T / sqrt(d_head)) v for (b, n, d) inputs; returns (out (b,n,d), weights (b,heads,n,n)).  The FULL attention
+    output from torch ops: what the max-pooling variant (StructureModelv2, ablation_models.py:296-299) and explicit ``forward``
+    calls need -- the HIP kernels produce the pooled mean only (``pooled_mean``), which is all the other models read."""
+    if q.is_cuda:
+        from .. import functional as HF
+        HF.composed_path("full (n x d) node attention output (max pooling / explicit forward; kernels: the pooled mean)")
     b, n, d = q.shape
     dh = d // heads
     q, k, v = (t.reshape(b, n, heads, dh).transpose(1, 2) for t in (q, k, v))
@@ -56,6 +61,7 @@ def attend_pooled_mean(x, wq, bq, wk, bk, wv, bv, heads, need_weights=False, qk=
                 w = torch.softmax(torch.matmul(q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2).transpose(-1, -2))
                                   * (1.0 / math.sqrt(dh)), dim=-1)
     else:
+        HF.composed_path(f"node attention with {heads} head(s) over {n} nodes per graph at width {dm} (kernels: 1 or 8 heads, <= 256 nodes, width 64)")
         q5 = qk.view(b, n, 2, heads, dh)
         q, k = q5[:, :, 0].transpose(1, 2), q5[:, :, 1].transpose(1, 2)
         w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)), dim=-1)
@@ -121,6 +127,9 @@ class MultiHeadAttention(nn.Module):
     def pooled_mean(self, x, need_weights=False, qk=None):
         """mean over rows of ``forward(x)[0]`` (the output projection commutes with the mean)."""
         if self.w_q.in_features != self.w_q.out_features or self.w_q.out_features != 64:
+            if x.is_cuda:
+                from .. import functional as HF
+                HF.composed_path(f"node attention at width {self.w_q.in_features} -> {self.w_q.out_features} (kernels: width 64)")
             out, w = self.forward(x)
             return out.mean(dim=1), w
         return attend_pooled_mean(x, self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias,

@@ -125,6 +125,8 @@ def egnn_stack_forward(layers, graph, node_feat, coord_feat, edge_feat=None, hea
             raise NotImplementedError("EGNN layers of sizes the HIP kernels are not built for run from torch ops and cannot be "
                                       "captured into a HIP graph (engine.CapturedTrainStep): train them with the eager loops")
         HF._lib.require_device(node_feat, coord_feat)
+        HF.composed_path(f"EGNN layers of sizes {[(l.in_size, l.hidden_size, l.out_size, l.edge_feat_size) for l in layers][:2]}... "
+                         "(kernels: hidden = out = 64, 20 or 64 inputs, <= 8 edge features)")
         h, x = node_feat, coord_feat
         csr, e = graph.csr(), graph.num_edges()
         for i, layer in enumerate(layers):

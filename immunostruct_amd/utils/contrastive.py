@@ -88,6 +88,10 @@ class PairedContrastiveLoss(nn.Module):
             return HF.paired_contrastive(embedding_cancer, embedding_wt, pos, self.projector[0].weight.detach(),
                                          bn.weight.detach(), bn.bias.detach(), self.projector[3].weight.detach(),
                                          self.lambda_off_diag, gate=gate, scale=scale)
+        if embedding_cancer.is_cuda:
+            from .. import functional as HF
+            HF.composed_path(f"paired contrastive loss over {tuple(embedding_cancer.shape)} embeddings, projector width {self.z_dim} "
+                             "(kernels: 2 .. 256 pairs, embedding <= 256, width 128)")
         zc = self.projector(embedding_cancer)
         zw = self.projector(embedding_wt)
         b = zc.shape[0]

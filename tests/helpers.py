@@ -113,7 +113,7 @@ def assert_close(a, b, tol, what=""):
     row = _row_worst(b, diff, tol)
     if ROW_REPORT:
         with open(ROW_REPORT, "a") as f:
-            f.write(f"{row:.3f}\t{tuple(b.shape)}\t{tol:.1e}\t{what}\n")
+            f.write(f"{row:.3f}\t{worst:.3f}\t{tuple(b.shape)}\t{tol:.1e}\t{what}\n")
     assert row <= ROW_FACTOR, (f"{what}: against the scale of its own ROW an entry is {row:.2f} x the bound (allowed {ROW_FACTOR:g} x; "
                                f"rtol {tol:.1e})")
     return float(diff.max()) / scale
@@ -128,7 +128,8 @@ ROW_REPORT = __import__("os").environ.get("IMMUNOSTRUCT_TEST_ROW_REPORT")      #
 # GCN_layers.0.edge_mlp.2.weight's gradient that are sums of ~10^3 cancelling terms, against an fp32 reference that carries the
 # same kind of error -- at 9.4 x.
 # Round 5: 16 -> 12 (the whole GPU suite re-measured: worst 9.1 x -- the same tensor --, second 7.1 x, every other tensor < 3.3 x).
-ROW_FACTOR = 12.0
+# Round 6: 12 -> 10 (worst 9.1 x, the same tensor; every other comparison of the suite <= 7.1 x, all but four < 2.2 x).
+ROW_FACTOR = 10.0
 
 
 def _row_worst(b, diff, tol):

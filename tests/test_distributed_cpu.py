@@ -1,4 +1,5 @@
-"""Data-parallel logic on CPU: 2 gloo ranks must reproduce the 1-rank gradient of the full batch."""
+"""Data-parallel logic on CPU: 2 and 4 gloo ranks must reproduce the 1-rank gradient of the full batch."""
+import pytest
 import os
 import socket
 
@@ -43,10 +44,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gradient_equals_single_rank(tmp_path, world):
+    """the shards of the epoch permutation (``perm[r::world]``) cover the batch, the flat bucket's all-reduce + 1 / world is the
+    full-batch mean gradient -- for two ranks and for four (the logic beyond world = 2)"""
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
+    assert got["idx"].numel() == 8 // world
     net = _net()
     data = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10
     y = torch.linspace(-1, 1, 8)

@@ -10,9 +10,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(script_args, port):
+def _run(script_args, port, ranks=2):
     env = dict(os.environ, IMMUNOSTRUCT_DIST_BACKEND="gloo", IMMUNOSTRUCT_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
@@ -79,6 +79,18 @@ def test_data_parallel_parity_on_the_hip_model(cuda_device, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "split-auto"])
+def test_data_parallel_parity_with_four_ranks(cuda_device, mode):
+    """Beyond world = 2 without new hardware: FOUR gloo ranks sharing cuda:0, B / 4 graphs each, through the
+    captured data-parallel step -- forced two-stage (``split``) and chosen by timing (``split-auto``: every candidate replayed with
+    the collectives, the maximum over the ranks decides).  Asserted inside tools/dp_parity_check.py: the chosen form gathered from
+    all ranks is ONE form, the ranks' parameters after 3 Adam steps are bit-identical, and they equal 1 rank x B eager."""
+    res = _run([os.path.join("tools", "dp_parity_check.py"), mode], 29558 + (mode == "split-auto"), ranks=4)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "DP PARITY OK" in res.stdout and res.stdout.count("split parity (4 ranks") == 4
+
+
+@pytest.mark.gpu
 def test_bench_launches_its_own_ranks(cuda_device):
     """``python bench.py --gpus 2`` WITHOUT torchrun (how the driver starts N = 1): the script becomes the launcher, one
     child per rank, rank 0's single JSON line on stdout, n_gpus == the number asked for and == the process group's size."""
@@ -121,6 +133,7 @@ def test_bench_line_under_a_one_rank_rccl_group(cuda_device):
     line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29570"), "--force-pack")
     ar = line["config"]["grad_allreduce"]
     assert ar["form"] in ("serial", "two-stage backward, bucket 0 overlapped") and not ar["tuned_ms"]["one_graph_ms"]
+    assert line["config"]["composed_paths"] == {}      # every operator of the timed step ran on the hand-written kernels
     # IMMUNOSTRUCT_DP_ONE_GRAPH=auto: every form captured, timed on all ranks, the fastest kept
     line = _bench_line(_rccl_env(IMMUNOSTRUCT_FORCE_COLLECTIVE="1", MASTER_PORT="29571", IMMUNOSTRUCT_DP_ONE_GRAPH="auto"), "--force-pack")
     cfg = line["config"]

@@ -1,7 +1,7 @@
 """GPU parity tests of the individual HIP kernels against the CPU oracle (through the C ABI).
 
 Tolerances (scaled max error = max|hip - oracle| / max|oracle|, fp32 both sides):
-  forward values 2e-5, gradients 1e-4 -- the fp32 oracle itself is ~1e-6..1e-5 away from the
+  forward values 1e-5, gradients 1e-4 -- the fp32 oracle itself is ~1e-6..1e-5 away from the
   fp64 oracle on these quantities, and the kernels use a different (hoisted, MFMA k-split)
   summation order.  Deterministic kernels: repeated runs must be bit-identical.
 """
@@ -20,7 +20,7 @@ from oracle import graph_ref
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
-FWD_TOL, GRAD_TOL = 2e-5, 1e-4
+FWD_TOL, GRAD_TOL = 1e-5, 1e-4      # SURVEY 8c (round 6: forward 2e-5 -> 1e-5; measured worst 0.09 x the old bound over the suite)
 
 
 def test_mfma_layout_selftests(cuda_device):
@@ -207,9 +207,9 @@ def test_egnn_vs_fp64_error_budget(cuda_device):
     e_hip = H.rel_err(h.cpu(), outs[torch.float64][0])
     e_f32 = H.rel_err(outs[torch.float32][0], outs[torch.float64][0])
     print(f"6-layer h: hip-vs-f64 {e_hip:.2e}, f32oracle-vs-f64 {e_f32:.2e}")
-    assert e_hip <= max(8 * e_f32, 2e-5)
-    H.assert_close(h.cpu(), outs[torch.float32][0], 5e-5, "6-layer h vs fp32 oracle")
-    H.assert_close(x.cpu(), outs[torch.float32][1], 5e-5, "6-layer x vs fp32 oracle")
+    assert e_hip <= max(8 * e_f32, 1e-5)
+    H.assert_close(h.cpu(), outs[torch.float32][0], 1e-5, "6-layer h vs fp32 oracle")
+    H.assert_close(x.cpu(), outs[torch.float32][1], 1e-5, "6-layer x vs fp32 oracle")
 
 
 def test_egnn_stack_prelaunched_forward_is_the_plain_stack(cuda_device):
@@ -289,8 +289,8 @@ def test_egnn_stack_gradients_at_the_stress_shape(cuda_device):
         for k, p_ in layer.named_parameters():
             hip[f"dGCN_layers.{i}.{k}"] = p_.grad
     f32, f64 = ref[torch.float32], ref[torch.float64]
-    H.assert_close(hip["h"].cpu(), f32["h"], 5e-5, "stack h")
-    H.assert_close(hip["x"].cpu(), f32["x"], 5e-5, "stack x")
+    H.assert_close(hip["h"].cpu(), f32["h"], 1e-5, "stack h")
+    H.assert_close(hip["x"].cpu(), f32["x"], 1e-5, "stack x")
     worst = ("", 0.0)
     for key in f64:
         if not key.startswith("d"):
@@ -315,8 +315,8 @@ def test_egnn_golden_trajectory(cuda_device):
                 layer = EGNNConv(20 if i == 0 else 64, 64, 64, fe).to(cuda_device)
                 layer.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"GCN_layers.{i}.")})
                 h, x = layer(g, h, x, g.edata["edge_attr"])
-                H.assert_close(h.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/h"], 3e-5, f"fe{fe} layer{i} h vs f64 golden")
-                H.assert_close(x.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/x"], 3e-5, f"fe{fe} layer{i} x vs f64 golden")
+                H.assert_close(h.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/h"], 1e-5, f"fe{fe} layer{i} h vs f64 golden")
+                H.assert_close(x.cpu(), gold[f"egnn/fe{fe}/f64/layer{i}/x"], 1e-5, f"fe{fe} layer{i} x vs f64 golden")
 
 
 @pytest.mark.parametrize("mode", ["mean", "max", "meanmax"])
@@ -434,13 +434,13 @@ def test_combined_attention_closed_form(cuda_device, feat, tokens):
     z = HF.combined_attention_mean(xd, mha)
     (z * torch.from_numpy(gup).to(cuda_device)).sum().backward()
     H.assert_close(z.detach().cpu(), ref.detach(), 2e-6, "combined attention z")
-    H.assert_close(xd.grad.cpu(), x64.grad, 2e-5, "combined attention dx")
+    H.assert_close(xd.grad.cpu(), x64.grad, 1e-5, "combined attention dx")
     for name, p in mha.named_parameters():
         refg = sd64["c." + name].grad
         if float(refg.abs().max()) < 1e-12:
             assert float(p.grad.abs().max()) == 0.0, name      # key bias: exactly no influence
         else:
-            H.assert_close(p.grad.cpu(), refg, 2e-5, f"combined attention d{name}")
+            H.assert_close(p.grad.cpu(), refg, 1e-5, f"combined attention d{name}")
     # the same row handed over as pieces laid side by side (what the models do: [x_gat | z_vae], or the four pieces of a pair):
     # same bits as the concatenated row, one contiguous gradient per piece
     cuts = [0, 64, tokens] if tokens == 104 else [0, 64, 104, 168, tokens]
@@ -526,14 +526,14 @@ def test_node_attention_pooled_mean(cuda_device, heads, n, need_weights):
     H.assert_close(pooled.detach().cpu(), ref.detach(), 5e-6, "pooled attention")
     if need_weights:
         H.assert_close(w.cpu(), w_ref.detach(), 5e-6, "attention weights")
-    H.assert_close(xd.grad.cpu(), x64.grad, 5e-5, "d pooled / d x")
+    H.assert_close(xd.grad.cpu(), x64.grad, 1e-5, "d pooled / d x")
     gmax = max(float(v.grad.abs().max()) for v in sd64.values())
     for name, p in mha.named_parameters():
         refg = sd64["a." + name].grad
         if float(refg.abs().max()) < 1e-9 * gmax:      # key bias: softmax is shift invariant
             assert float(p.grad.abs().max()) < 1e-5 * gmax, name
         else:
-            H.assert_close(p.grad.cpu(), refg, 5e-5, f"d pooled / d {name}")
+            H.assert_close(p.grad.cpu(), refg, 1e-5, f"d pooled / d {name}")
 
 
 @pytest.mark.gpu

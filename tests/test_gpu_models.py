@@ -398,6 +398,41 @@ def test_reference_default_command_line_at_full_size_vs_oracle(cuda_device, name
     print("worst ratio to the element-wise bound against the fp64 gradient: %s HIP %.3f x, fp32 oracle %.3f x" % worst)
 
 
+def test_shapes_outside_the_kernels_build_are_reported(cuda_device, monkeypatch):
+    """A constructor argument the HIP kernels are not built for (here: 4 attention heads, an EGNN width of 32) runs as a device-side
+    torch composition -- tested against the oracle above, but not the measured path: the first use warns, ``functional.COMPOSED_PATHS``
+    counts, ``bench.py`` prints the counts (``config.composed_paths``); the reference's defaults leave the registry empty."""
+    import warnings
+    from immunostruct_amd import functional as HF
+    dev = cuda_device
+    raw = synthetic.make_batch(4, seed=3)
+    seq, prop = torch.from_numpy(raw.one_hot_sequence()).to(dev), torch.from_numpy(raw.prop).to(dev)
+    monkeypatch.setattr(HF, "COMPOSED_PATHS", {})
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")      # the default model must not warn
+        for name in ("HybridModelv2", "StructureModel", "HybridModelv2_Comparative"):
+            model = model_map[name](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+            g = H.product_graph(raw, dev)
+            (model.forward_comparative((g, g), (seq, seq), (prop, prop)) if name.endswith("Comparative") else model(g, seq, prop))
+    assert HF.COMPOSED_PATHS == {}
+    model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev, self_attention_heads=4).to(dev)
+    with pytest.warns(RuntimeWarning, match="node attention with 4 head.*outside the HIP kernels' build"):
+        model(H.product_graph(raw, dev), seq, prop)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")      # ... once per reason
+        model(H.product_graph(raw, dev), seq, prop)
+    assert list(HF.COMPOSED_PATHS.values()) == [2]
+    model = model_map["HybridModelv2"](vae_input_dim=H.VAE_IN, device=dev, gat_hidden_channels=32).to(dev)
+    with pytest.warns(RuntimeWarning, match="EGNN layers of sizes"):
+        model(H.product_graph(raw, dev), seq, prop)
+    assert len(HF.COMPOSED_PATHS) == 4 and all(v >= 1 for v in HF.COMPOSED_PATHS.values())      # (+ the width-32 attention, in full)
+    # the max-pooling ablation needs the full attention output: torch ops by design, and said so
+    monkeypatch.setattr(HF, "COMPOSED_PATHS", {})
+    model = model_map["StructureModelv2"](vae_input_dim=H.VAE_IN, device=dev).to(dev)
+    with pytest.warns(RuntimeWarning, match="full \\(n x d\\) node attention output"):
+        model(H.product_graph(raw, dev), seq, prop)
+
+
 @pytest.mark.parametrize("name,hidden,seed", [("HybridModelv2", 32, 41), ("HybridModelv2", 128, 41), ("StructureModelv2", 48, 42)])
 def test_other_hidden_sizes_vs_oracle(cuda_device, name, hidden, seed):
     """``gat_hidden_channels`` is a constructor argument of the reference's models (hybrid_models.py:247).  The HIP layer kernels are

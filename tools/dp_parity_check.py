@@ -1,9 +1,11 @@
 """Data-parallel parity on the HIP model, one process per rank (SURVEY.md section 4 iv), two checks:
 
-``split``: 2 ranks x B/2 graphs through the CAPTURED two-stage step (bucket 0 all-reduced under the stack backward,
+``split``: N ranks (2 or 4) x B/N graphs through the CAPTURED two-stage step (bucket 0 all-reduced under the stack backward,
            1/world inside Adam) == 1 rank x B graphs EAGER, same weights after 3 Adam steps.  The whole batch is the
            concatenation of the ranks' halves; the loss is a mean over the batch, so the mean of the two half-batch
            gradients is the full-batch gradient.
+``split-auto``: the same with the form chosen by timing (IMMUNOSTRUCT_DP_OVERLAP=auto): every rank must arrive at the same form.
+           Both gather the chosen form from all ranks and require the ranks' parameters to be bit-identical after the steps.
 ``tail`` : ``procedures.train_model_device`` with a shard length that is NOT a multiple of the batch size (three replayed
            steps + one eager trailing step per epoch, which must pack the eager step's own gradients) == an all-eager
            data-parallel loop written out here with plain ``dist.all_reduce`` per parameter.
@@ -54,9 +56,11 @@ def compare(a, b, what, tol):
     return worst
 
 
-def check_split(rank, world, dev):
-    half, steps = 16, 3
-    ds = SyntheticImmunoDataset(2 * half * steps, seed=11)
+def check_split(rank, world, dev, overlap="1"):
+    total, steps = 32, 3
+    per = total // world                            # graphs per rank and step (world 2: 16, world 4: 8)
+    assert per * world == total
+    ds = SyntheticImmunoDataset(total * steps, seed=11)
     dds = DeviceResidentDataset(ds, dev)
     losses = Losses(VAE_IN, ds.class_weights, sequence=True)
     model = make_model(dev, 7)                      # same seed on every rank
@@ -67,24 +71,36 @@ def check_split(rank, world, dev):
         recon, mu, logvar, final = m(g, seq, prop)
         return losses.regression_loss(recon, seq, mu, logvar, final, y)
 
-    os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = "1"     # force the two-stage form
+    os.environ["IMMUNOSTRUCT_DP_OVERLAP"] = overlap     # "1": force the two-stage form; "auto": timed on all ranks, one choice for all
     opt = optim.Adam(model.parameters(), lr=LR)
     reducer = D.FlatGradReducer(model.parameters(), world=world)
-    ids = lambda s, r: torch.arange(s * 2 * half + r * half, s * 2 * half + (r + 1) * half, device=dev)
-    buf = dds.new_batch(half)
+    ids = lambda s, r: torch.arange(s * total + r * per, s * total + (r + 1) * per, device=dev)
+    buf = dds.new_batch(per)
     dds.gather_into(ids(0, rank), *buf)
     model.train()
-    cap = CapturedTrainStep(model, opt, reducer, forward_loss, buf, edge_capacity=half * dds.max_edges, warmup=1,
+    cap = CapturedTrainStep(model, opt, reducer, forward_loss, buf, edge_capacity=per * dds.max_edges, warmup=1,
                             preserve_state=True)
-    assert cap.two_stage and len(reducer.buckets) == 2
+    assert len(reducer.buckets) == 2 and (cap.two_stage or overlap == "auto")
+    # every rank replays the SAME form (ranks replaying different forms would stop matching their collectives): the choice --
+    # forced, or timed with the maximum over the ranks -- is gathered and compared
+    forms = [None] * world
+    dist.all_gather_object(forms, (bool(cap.two_stage), cap.reserved if cap.two_stage else None, cap.one_graph))
+    assert all(f == forms[0] for f in forms), f"the ranks chose different forms: {forms}"
+    if overlap == "auto":
+        assert cap.dp_times is not None and cap.dp_times["serial_ms"] > 0 and cap.dp_times["two_stage_ms"] > 0
     for s in range(steps):
         dds.gather_into(ids(s, rank), cap.sgraph, cap.seq, cap.prop, cap.y)
         cap.replay()
     torch.cuda.synchronize()
+    # the ranks' parameters after the steps are the same BITS (same reduced gradients, same update)
+    mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    root = mine.clone()
+    dist.broadcast(root, src=0)
+    assert torch.equal(mine, root), f"rank {rank}: parameters differ from rank 0's after {steps} steps"
     # one rank, whole batch, eager, no collective
     ref.train()
     ropt = optim.Adam(ref.parameters(), lr=LR)
-    whole = dds.new_batch(2 * half)
+    whole = dds.new_batch(total)
     for s in range(steps):
         g, seq, prop, y = dds.gather_into(torch.cat([ids(s, r) for r in range(world)]), *whole)
         ropt.zero_grad(set_to_none=True)
@@ -92,9 +108,10 @@ def check_split(rank, world, dev):
         ropt.step()
     torch.cuda.synchronize()
     moved = compare(ref, start, "sanity", float("inf"))
-    worst = compare(model, ref, "2 ranks x B/2 captured two-stage vs 1 rank x B eager", 2e-2 * LR * steps)
-    print(f"rank {rank}: split parity: parameters moved {moved:.3e}, max difference {worst:.3e}", flush=True)
+    worst = compare(model, ref, f"{world} ranks x B/{world} captured ({'two-stage' if cap.two_stage else 'serial'}) vs 1 rank x B eager", 2e-2 * LR * steps)
+    print(f"rank {rank}: split parity ({world} ranks, form {forms[0]}): parameters moved {moved:.3e}, max difference {worst:.3e}", flush=True)
     assert moved > 0.5 * LR
+    cap.close()
 
 
 def check_tail(rank, world, dev):
@@ -147,7 +164,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     with mock.patch("torch.randn_like", torch.zeros_like):
-        {"split": check_split, "tail": check_tail}[mode](rank, world, dev)
+        {"split": check_split, "split-auto": lambda r, w, d: check_split(r, w, d, overlap="auto"), "tail": check_tail}[mode](rank, world, dev)
     dist.barrier()
     if rank == 0:
         print("DP PARITY OK", flush=True)
