@@ -56,7 +56,7 @@ H = 64
 # "device" = one launch of the library's generator inside the step, as the device-resident training loops of ``procedures`` run it
 # (None would be torch's generator inside the step: two generator-state fills in front of every replay)
 STEP_RANDOM = "device"
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
+TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")   # PMC-measured HBM bytes per launch (profiles/README.md)
 
 
 def layer_algorithmic(n_nodes, n_edges, din, fe):
@@ -970,6 +970,18 @@ def main():
                     gk["span_us"] = span["mean"]
                     gk["achieved_over_span"] = round(gb / (span["mean"] * 1e-6), 1)
                     gk["frac_over_span"] = round(gb / (span["mean"] * 1e-6) / PEAK_HBM_GBS, 4)
+            # the contract, said once (DESIGN.md 4.1 "Roofline accounting"): which bound each number is priced against, and what became
+            # of the north star's HBM target
+            roof["contract"] = (
+                "frac = algorithmic FLOP of the dominant kernel (the fused EGNN layer backward: gather + edge / coordinate / node MLP "
+                "backward + segment sums in ONE launch, ~65 FLOP per algorithmic byte against a ridge of 157.3 TFLOP/s / 8 TB/s = "
+                "19.7 FLOP/B) / its slot time / the dense fp32 MFMA peak: the kernel is MFMA- (instruction-issue-) bound, `bound` says "
+                "so, and this is the fraction it is judged by.  hbm_frac = the SAME launch's algorithmic bytes / slot time / 8 TB/s: "
+                "reported because BASELINE.json's metric names HBM GB/s, NOT a target of the fused kernel -- fusing the per-edge "
+                "arithmetic into the gather is what removes its bytes.  The north star's '>= 40 % of the HBM roofline on the gather / "
+                "scatter kernel' applies to what is left as a pure gather, gather_segment_sum (layer 0's scatter-add to source rows, "
+                "one launch per step): gather_frac, by slot time -- NOT met at this batch size (a 26 MB launch lasts three dependent "
+                "round trips + the dispatch gap whatever its kernel does; gather_kernel.frac_over_span is the launch alone).")
         line = dict(metric=getattr(wl, "metric", "peptide-MHC graphs/sec (train step)"), value=round(graphs / dt, 1), unit="graphs/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", config=config,

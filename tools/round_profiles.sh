@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/round_profiles.sh TAG   -- the evidence set of a round, written to gpurun_out/TAG/:
+# usage (on the GPU box): bash tools/round_profiles.sh TAG [COMMIT]   -- the evidence set of a round, written to gpurun_out/TAG/
+# (COMMIT: the label stored in the traffic file -- the box has no .git: pass $(git rev-parse --short HEAD) from the build container):
 #   bench_{iedb,paired,stress}.json  the JSON lines of python bench.py [--workload W]
 #   kernel_stats.txt / timeline.txt  rocprofv3 --kernel-trace of a short default bench (per-kernel table, last step's timeline)
 #   pmc_{iedb,paired,stress}.json    HBM traffic per launch (two PMC passes per workload, tools/pmc_traffic.sh)
@@ -14,7 +15,7 @@ export TMPDIR=/tmp
 for wl in iedb paired stress; do
   bash tools/pmc_traffic.sh $wl $out/pmc_$wl.json
 done
-python tools/assemble_traffic.py $out $out/pmc_traffic.json
+python tools/assemble_traffic.py $out $out/pmc_traffic.json ${2:-unlabelled}
 cp $out/pmc_traffic.json $(python -c "import bench; print(bench.TRAFFIC_FILE)")
 for wl in iedb paired stress; do
   python bench.py --workload $wl --steps 30 --warmup 5 > $out/bench_$wl.json 2> $out/bench_$wl.err
