@@ -26,8 +26,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o rr -- python3 bench.py --s
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_stats.py $db > $out/kernel_stats.txt 2>> $out/prof.err
 python tools/rocpd_timeline.py $db > $out/timeline.txt 2>> $out/prof.err
-# the data-parallel step under a one-rank RCCL group (the nccl backend for real on the one GPU: VERDICT r03 item 1)
-IMMUNOSTRUCT_FORCE_COLLECTIVE=1 MASTER_PORT=29591 python bench.py --force-pack --steps 30 --warmup 5 --no-cpu-baseline --no-e2e > $out/bench_iedb_rccl1.json 2> $out/bench_iedb_rccl1.err
+# the data-parallel step under a one-rank RCCL group (the nccl backend for real on the one GPU: VERDICT r03 item 1), every form
+# captured and timed (IMMUNOSTRUCT_DP_ONE_GRAPH=auto; the default since round 6 is 0: the multi-graph forms only)
+IMMUNOSTRUCT_DP_ONE_GRAPH=auto IMMUNOSTRUCT_FORCE_COLLECTIVE=1 MASTER_PORT=29591 python bench.py --force-pack --steps 30 --warmup 5 --no-cpu-baseline --no-e2e > $out/bench_iedb_rccl1.json 2> $out/bench_iedb_rccl1.err
 cut -c1-200 $out/bench_iedb_rccl1.json
 # SQ counters of the two layer kernels and the node weight-gradient launch (instruction mix, LDS conflicts, waits)
 bash tools/pmc_passes.sh $out/sq_counters_layer_bwd.txt egnn_layer_bwd
