@@ -43,11 +43,19 @@ BWD_PAIRED = os.environ.get("IMMUNOSTRUCT_BWD_PAIRED", "1") == "1"
 
 
 def use_bwd_tiles(num_nodes, num_edges, slots, fe):
-    """The backward edge kernel runs ceil(tiles / slots) rounds of persistent workgroups.  Greedy tiles (~62 edges)
-    fill the 64-edge windows but only pay when they save a whole round; on the B = 128 benchmark batch both cuts need
-    3 rounds and the fuller windows are slower per round (measured 82 vs 78 us), at B = 512 they save 2 of 12."""
+    """Whether the backward layer launches cut the nodes into the greedy tile list (<= 64 in-edges, <= 24 nodes: full 64-edge
+    windows, the 256-thread kernel) instead of plain 16-node tiles.  Wherever the paired 512-thread kernel applies (Fe <= 1, z3 read
+    back: every reference model) the answer is NO: it runs plain tiles, and round 6's sweep has it ahead at every batch size and
+    edge density measured -- B = 128 ... 512 at E / N = 3: 72.6 / 86.7 / 106 / 134 / 199 / 264 us per launch against 83.1 / 96.6 / 110 /
+    142 / 214 / 272 for listed tiles on the 256-thread kernel; E / N = 6, 9: 118 / 164 against 145 / 201; E / N = 2: 65.0 against 62.5,
+    which half the records (reduce_partials_batched 24 against 37 us per step) give back (tools/exp_tiles_sweep.sh,
+    profiles/r06_experiments.txt) -- the paired step (config 4) gained 3.3 % when it stopped taking the list.  Under
+    IMMUNOSTRUCT_BWD_PAIRED=0 / IMMUNOSTRUCT_SAVE_Z3=0 the 256-thread kernel runs ceil(tiles / slots) rounds of persistent workgroups and
+    the list pays when it saves a whole round (round 3's rule)."""
     if fe > 1:
         return False          # the listed-tile instantiation exists for Fe <= 1 only (LDS)
+    if BWD_PAIRED and SAVE_Z3:
+        return False          # the paired kernel's domain (is_egnn_layer_bwd_paired_supported: Fe <= 1, plain tiles)
     rounds = lambda tiles: (tiles + slots - 1) // slots
     return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
 
