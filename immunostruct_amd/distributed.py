@@ -30,6 +30,10 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     forced = world == 1 and os.environ.get("IMMUNOSTRUCT_FORCE_COLLECTIVE") == "1"
     if (world > 1 or forced) and not dist.is_initialized():
+        # the host driver of these boxes supports dmabuf IPC only: without this RCCL / cross-process tensor sharing fails with
+        # "hipIpcGetMemHandle: invalid argument" (exported on the build and GPU boxes already; a launcher that scrubs the environment
+        # must not lose it).  Set before the first HIP call of the process.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
