@@ -622,7 +622,7 @@ class CapturedTrainStep:
         if self.one_graph:
             self.graph_c = {self.one_graph: self.graph_c[self.one_graph]}
             self.graph_a = self.graph_a1 = self.graph_a2 = self.graph_b = None
-            self._a2 = {}
+            self._a2, self._forms = {}, {}
         else:
             self.graph_c = {}
             if self.two_stage:
@@ -631,6 +631,7 @@ class CapturedTrainStep:
             else:
                 self.graph_a1 = self.graph_a2 = None
                 self._a2 = {}
+            self._forms = {k: v for k, v in self._forms.items() if k == self.two_stage}      # (their gradient sources go with them)
 
     def close(self):
         """Release every captured graph (after a synchronize).  Call BEFORE ``torch.distributed.destroy_process_group()``: a graph
