@@ -159,8 +159,7 @@ def measured_traffic(traffic_key):
 def _paired_bwd_in_use(n_nodes, n_edges, fe):
     """whether the backward layer launches of this batch run as the paired 512-thread kernel (functional.EgnnStackFn's rule)"""
     from immunostruct_amd import _lib
-    return bool(HF.BWD_PAIRED and HF.SAVE_Z3 and not HF.use_bwd_tiles(int(n_nodes), int(n_edges), HF.layer_slots(), fe)
-                and _lib.load().is_egnn_layer_bwd_paired_supported(fe, 0))
+    return bool(HF.BWD_PAIRED and HF.SAVE_Z3 and _lib.load().is_egnn_layer_bwd_paired_supported(fe))
 
 
 def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None, paired_bwd=False):

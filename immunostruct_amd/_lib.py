@@ -32,9 +32,9 @@ SIGNATURES = {
     "is_mfma_outer_selftest": [_P, _P, _P, _P],
     "is_egnn_layer_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I,
                           _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "is_egnn_layer_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _P, _I, _I, _I] + [_P] * 18 + [_P],
-    "is_egnn_layer_bwd_paired": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _P, _I, _I, _I] + [_P] * 18 + [_P],
-    "is_egnn_layer_bwd_paired_supported": [_I, _I],
+    "is_egnn_layer_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _I, _I, _I] + [_P] * 18 + [_P],
+    "is_egnn_layer_bwd_paired": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10 + [_I, _P, _P, _I, _I, _I] + [_P] * 18 + [_P],
+    "is_egnn_layer_bwd_paired_supported": [_I],
     "is_layer_saves_m1": [],
     "is_layer_saves_geo": [],
     "is_node_proj_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P],

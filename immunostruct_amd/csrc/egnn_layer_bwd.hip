@@ -18,14 +18,14 @@
 //     tile: wave w owns rows [16w, 16w+16) of dW2 / dWc1 / [dw_r | dW_a] and contracts over all four edge
 //     tiles of the 64-edge window, so a wave carries 3 x 16 accumulator registers and no cross-wave reduction
 //     is needed at the end;
-//   * a workgroup owns one node tile per pass: either NV16 = 16 consecutive destination nodes (~48 edges on
-//     degree-3 graphs: the fourth wave of the 64-edge window idles in the row phases), or -- when the caller
-//     passes the greedy tile list of graph.py (`tiles`: <= 64 in-edges and <= 24 nodes per tile) -- a
-//     node range that fills the window (63 of 64 rows on the same graphs, 24 % fewer passes).
+//   * a workgroup owns one node tile per pass: NV16 = 16 consecutive destination nodes (~48 edges on degree-3 graphs: the fourth
+//     wave of the 64-edge window idles in the row phases).  (Rounds 2 - 5 also took a greedy tile list -- <= 64 in-edges, <= 24 nodes:
+//     full windows, 24 % fewer passes; round 6's sweep has plain tiles on the paired kernel, egnn_layer_bwd8.hip, ahead at every
+//     batch size and density, and the list went: HISTORY.md 9.6.)
 // This file is compiled TWICE: as itself (z3 read back from HBM: the default) and, through egnn_layer_bwd_z3r.hip, with
 // IS_BWD_Z3R = 1 (z3 recomputed per tile: IMMUNOSTRUCT_SAVE_Z3=0).  A preprocessor switch, not a template parameter: with both
 // forms in one kernel template the discarded `if constexpr` branch still changed the register allocation of the default
-// instantiations (listed-tile launch 170 -> 176 us, 4 -> 12 spilled registers) -- the default build must not see the other form.
+// instantiations (4 -> 12 spilled registers) -- the default build must not see the other form.
 #ifndef IS_BWD_Z3R
 #define IS_BWD_Z3R 0
 #endif
@@ -79,16 +79,14 @@ __device__ long long g_stamps_b[24];
 #endif
 
 constexpr int WB16 = 4;
-constexpr int NV16 = 16;   // nodes per tile without a tile list
-constexpr int NVB_LISTED = 24;    // most nodes a listed tile may hold
+constexpr int NV16 = 16;   // nodes per tile
 constexpr int RP_TILES = 8;       // tiles per workgroup whose rowptr slice is fetched ahead (B = 128: 3; the stress slice: 8)
 
 // Round 5: with plain 16-node tiles the node phase runs 48 rows per pass (three tiles: all of a workgroup's tiles at B = 128) and its
 // dzn1 tile overlays the g_psd tile (dead behind the dh product's barrier) -- 38.4 KB instead of 68.6 KB, which fits BESIDE the two
 // weight tiles (34.8 KB) in a workgroup's half of the CU's LDS.  The weight tiles and the rowptr slices are then staged at the very
 // START of the kernel, under the node phase's front, instead of behind its last barrier (stage stamps: 6.5 - 13 k of 158 k cycles
-// between the end of the node phase and the first window).  Listed tiles (24-node pitch: 64-row passes) and the z1-recompute build
-// (its Pd tile) keep the overlay of rounds 2 - 4.
+// between the end of the node phase and the first window).  The z1-recompute build (its Pd tile) keeps the overlay of rounds 2 - 4.
 #ifndef IS_BWD_EARLY_STAGE
 #define IS_BWD_EARLY_STAGE 1      // (0: A/B builds with the staging of rounds 2 - 4)
 #endif
@@ -158,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
     const float* __restrict__ g_xout,
     float* __restrict__ dZ1, float* __restrict__ dD,
     float* __restrict__ dPd, float* __restrict__ dx,
-    float* __restrict__ partials, const int* __restrict__ tiles, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock,
+    float* __restrict__ partials, int N, int Fe, NodeBwdArgs nb, long long* __restrict__ wg_clock,
     const float* __restrict__ m1s, const float* __restrict__ dy1s, const float* __restrict__ geos) {
   static_assert(!GATHER || GX, "a gathered layer always receives a coordinate gradient");
   using D = Node16Dims<DIN>;
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform => scalar registers, scalar address math
   const int r = lane & 15, q = lane >> 4;
   constexpr int RA_LD = FE_MAX + 1;
-  const int num_tiles = (tiles != nullptr) ? tiles[0] : (N + NV16 - 1) / NV16;
+  const int num_tiles = (N + NV16 - 1) / NV16;
   const float* __restrict__ gxsrc = GATHER ? nb.gxtot : g_xout;
 
   STAMPP(13);
@@ -199,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
       const int k = idx / (NVB + 1), i = idx - k * (NVB + 1);
       const int t = blockIdx.x + k * gridDim.x;
       if (t < num_tiles) {
-        const int a0 = (tiles != nullptr) ? tiles[1 + t] : t * NV16;
-        const int cnt = (tiles != nullptr) ? min(NVB, tiles[2 + t] - a0) : min(NV16, N - a0);
+        const int a0 = t * NV16;
+        const int cnt = min(NV16, N - a0);
         sm.rp_tab[k][i] = rowptr[a0 + min(i, cnt)];
       }
     }
@@ -234,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
         const int tl = t0 + k * (int)gridDim.x;
         int a0 = 0, cnt = 0;
         if (k < ntp) {
-          a0 = (tiles != nullptr) ? tiles[1 + tl] : tl * NV16;
-          cnt = (tiles != nullptr) ? min(NVB, tiles[2 + tl] - a0) : min(NV16, N - a0);
+          a0 = tl * NV16;
+          cnt = min(NV16, N - a0);
         }
         ta0[k] = __builtin_amdgcn_readfirstlane(a0);
         tcnt[k] = __builtin_amdgcn_readfirstlane(cnt);
@@ -515,8 +513,8 @@ __global__ __launch_bounds__(256, 2) void IS_BWD_KERNEL(
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     STAMPB(0);
-    const int v0 = (tiles != nullptr) ? tiles[1 + tile] : tile * NV16;
-    const int nv = (tiles != nullptr) ? min(NVB, tiles[2 + tile] - v0) : min(NV16, N - v0);
+    const int v0 = tile * NV16;
+    const int nv = min(NV16, N - v0);
     const int tk = (tile - (int)blockIdx.x) / (int)gridDim.x;      // (wave-uniform) index of this tile in the workgroup's sequence
     const int* rp = (tk < RP_TILES) ? sm.rp_tab[tk] : sm.rp;
     // first tile: the tables and weight tiles are staged; later tiles need no barrier here (every window ends with one, and a
@@ -1144,17 +1142,17 @@ namespace is {
 int launch_layer_bwd_z3r(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
                          const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                          const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
-                         const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
+                         int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
                          long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, hipStream_t st);
 int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const float* ea, const int32_t* rowptr, const int32_t* srcs,
                     const float* W1, int din, const float* W2, const float* Wc1, const float* wc2, const float* z2s,
                     const float* z3s_or_bc1, const float* g_xout, float* dZ1, float* dD, float* dPd, float* dx, float* partials,
-                    const int32_t* tiles, int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
+                    int grid, int N, int Fe, bool gather, bool gx, const NodeBwdArgs& nb,
                     long long* wg_clock, const float* m1s, const float* dy1s, const float* geos, hipStream_t st) {
   const dim3 block(256);
 #define IS_LAUNCH_LB(FE, NVB, GXF, GA, DI)                                                                                       \
   hipLaunchKernelGGL((is::IS_BWD_KERNEL<FE, NVB, GXF, GA, DI>), dim3(grid), block, 0, st, ps, pd, x, ea, rowptr, srcs, W1, W2, Wc1, \
-                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, tiles, N, Fe, nb, wg_clock, m1s, dy1s, geos)
+                     wc2, z2s, z3s_or_bc1, g_xout, dZ1, dD, dPd, dx, partials, N, Fe, nb, wg_clock, m1s, dy1s, geos)
 #define IS_LAUNCH_LB_D(FE, NVB, GXF, GA) do { if (din == 20) IS_LAUNCH_LB(FE, NVB, GXF, GA, 20); else IS_LAUNCH_LB(FE, NVB, GXF, GA, 64); } while (0)
 #if IS_BWD_Z3R
 #define IS_LAUNCH_LB_G(FE, NVB) do { if (gather) IS_LAUNCH_LB_D(FE, NVB, true, true); else IS_LAUNCH_LB_D(FE, NVB, true, false); } while (0)
@@ -1167,11 +1165,8 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
     else IS_LAUNCH_LB_D(FE, NVB, false, false);                        \
   } while (0)
 #endif
-  if (Fe <= 1) {
-    if (tiles != nullptr) IS_LAUNCH_LB_G(1, is::NVB_LISTED); else IS_LAUNCH_LB_G(1, is::NV16);
-  } else {
-    IS_LAUNCH_LB_G(8, is::NV16);
-  }
+  if (Fe <= 1) IS_LAUNCH_LB_G(1, is::NV16);
+  else IS_LAUNCH_LB_G(8, is::NV16);
 #undef IS_LAUNCH_LB_G
 #undef IS_LAUNCH_LB_D
 #undef IS_LAUNCH_LB
@@ -1185,7 +1180,6 @@ int IS_BWD_LAUNCHER(const float* ps, const float* pd, const float* x, const floa
 //     gradients in CSR slot order, gathered by source by the NEXT call or by is_gather_segment_sum), dPd [N, ld_dpd] and dx
 //     [N,3] (destination-side parts), one partial weight-gradient record per workgroup (`grid` persistent workgroups):
 //       dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
-//     tiles: NULL (16 consecutive nodes per tile) or the greedy tile list (Fe <= 1).
 //   node half: g_h [N,64] direct gradient of the layer's output h (may be NULL); g_psd [N,128] gradient of the next
 //     pre-projection of h (NULL: none; then dh = g_h); zn1 saved; bpack = the layer's backward operand pack; outputs dh_total
 //     (with g_psd), dzn1, d_h (first din columns; may be NULL), d_hn (scratch [N,64] read back by the edge half).
@@ -1204,7 +1198,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
                                  const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                                  const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                                  const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
-                                 float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                                 float* dx, float* partials, int grid, int N, int Fe,
                                  const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                                  const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                                  const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
@@ -1221,7 +1215,7 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
       d_hn == nullptr || (g_psd != nullptr && dh_total == nullptr) || (g_psd == nullptr && g_h == nullptr) ||
       (gather && (g_xout != nullptr || dDn == nullptr || dxn == nullptr || rowptr_src == nullptr || pos_by_src == nullptr ||
                   g_psd == nullptr || gxtot == nullptr)) ||
-      (gx && z3s == nullptr && bc1 == nullptr) || (tiles != nullptr && Fe > 1) ||
+      (gx && z3s == nullptr && bc1 == nullptr) ||
       ld_p != 2 * is::H || ld_dpd != 2 * is::H || ldw != 2 * din + 1 + Fe)      // the layouts the kernels are built for
     return is::fail(__func__, -22);
   const bool z3r = gx && z3s == nullptr;      // z3 was not saved by the forward: recomputed from z2 (the other translation unit)
@@ -1229,9 +1223,9 @@ extern "C" int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, con
   const is::NodeBwdArgs nb{dZ1n, dDn, dxn, rowptr_src, pos_by_src, g_h, g_psd, zn1, bpack, dh_total, dzn1, d_h, d_hn, gxtot};
   if (z3r)
     return is::launch_layer_bwd_z3r(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, bc1, g_xout, dZ1, dD, dPd, dx, partials,
-                                    tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
+                                    grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
   return is::launch_layer_bwd(ps, pd, x, ea, rowptr, srcs, W1, din, W2, Wc1, wc2, z2s, z3s, g_xout, dZ1, dD, dPd, dx, partials,
-                              tiles, grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
+                              grid, N, Fe, gather, gx, nb, wg_clock, m1s, dy1s, geos, st);
 }
 
 // 1: this library's is_egnn_layer_bwd reads the edge geometry from geos (filled by is_egnn_layer_fwd); 0: it recomputes it.

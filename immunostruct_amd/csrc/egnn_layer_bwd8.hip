@@ -12,7 +12,7 @@
 //     input of reduce_partials_batched.
 // Barriers are workgroup-wide, so both groups run the same number of passes, tiles and windows (a group without work in an
 // iteration only meets the barriers).  Built for the library's default forms (z1 and the edge geometry read back, z3 read back:
-// IS_LAYER_M1 = 2, IS_LAYER_GEO = 1) and plain 16-node tiles; everything else stays on egnn_layer_bwd.hip.
+// IS_LAYER_M1 = 2, IS_LAYER_GEO = 1) and Fe <= 1; everything else stays on egnn_layer_bwd.hip.
 // Reference: dgl.nn.EGNNConv backward (third party; constructed models/hybrid_models.py:261-263, called :323-324).
 #ifndef IS_LAYER_M1
 #define IS_LAYER_M1 2
@@ -819,20 +819,20 @@ extern "C" int is_debug_stamps_bwd8(long long* out) {
 }
 #endif
 
-// 1: is_egnn_layer_bwd_paired covers a launch with Fe edge features and (listed_tiles != 0: a greedy tile list) in this build
-extern "C" int is_egnn_layer_bwd_paired_supported(int Fe, int listed_tiles) {
-  return (IS_BWD8_BUILT && Fe >= 0 && Fe <= 1 && !listed_tiles) ? 1 : 0;
+// 1: is_egnn_layer_bwd_paired covers a launch with Fe edge features in this build
+extern "C" int is_egnn_layer_bwd_paired_supported(int Fe) {
+  return (IS_BWD8_BUILT && Fe >= 0 && Fe <= 1) ? 1 : 0;
 }
 
 // is_egnn_layer_bwd on `grid` workgroups of 512 threads, each two groups of four waves that share one staged copy of the weight
 // tiles and write ONE partial record (so `partials` holds `grid` records; the virtual grid of 256-thread workgroups is 2 * grid).
-// Same arguments and outputs as is_egnn_layer_bwd; tiles must be NULL, Fe <= 1, z3s != NULL whenever a coordinate gradient
+// Same arguments and outputs as is_egnn_layer_bwd; Fe <= 1, z3s != NULL whenever a coordinate gradient
 // arrives (-38 where is_egnn_layer_bwd_paired_supported says 0).
 extern "C" int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                                         const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                                         const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                                         const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
-                                        float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                                        float* dx, float* partials, int grid, int N, int Fe,
                                         const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                                         const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                                         const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
@@ -842,7 +842,7 @@ extern "C" int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld
   return is::fail(__func__, -38);
 #else
   if (N <= 0) return 0;
-  if (tiles != nullptr || Fe < 0 || Fe > 1) return is::fail(__func__, -38);
+  if (Fe < 0 || Fe > 1) return is::fail(__func__, -38);
   if ((long long)N * is::H * 4 >= 0x7ffff000LL) return is::fail(__func__, -22);
   if (m1s == nullptr || geos == nullptr) return is::fail(__func__, -22);
   const bool gather = dZ1n != nullptr;

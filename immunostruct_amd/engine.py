@@ -63,7 +63,6 @@ class StaticGraphBatch(PackedGraphBatch):
         csr.src_sorted = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr.dst_sorted = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr._chunks = {}     # filled on first use from the loaded rowptr, refreshed by every load()
-        csr._tiles = {}      # same; sized for the edge capacity
         csr.pos_by_src = torch.zeros(self.edge_capacity, dtype=torch.int32, device=dev)
         csr.eperm = torch.zeros(0, dtype=torch.int64, device=dev)
         csr.num_nodes, csr.num_edges = n, self.edge_capacity
@@ -94,8 +93,7 @@ class StaticGraphBatch(PackedGraphBatch):
                 (src.rowptr_src, self._csr.rowptr_src), (src.src_sorted, self._csr.src_sorted[:e]),
                 (src.dst_sorted, self._csr.dst_sorted[:e]), (src.pos_by_src, self._csr.pos_by_src[:e]),
                 (g.edge_feat_csr(g.edata["edge_attr"]), self._ea_csr[:e])] + \
-               [(src.chunks(k), dst) for k, dst in self._csr._chunks.items()] + \
-               [(t, dst[:t.numel()]) for t, dst in ((src.tiles(*k), d) for k, d in self._csr._tiles.items())]
+               [(src.chunks(k), dst) for k, dst in self._csr._chunks.items()]
 
     def load(self, g: PackedGraphBatch):
         multi_copy(self.copy_pairs(g))
@@ -104,14 +102,11 @@ class StaticGraphBatch(PackedGraphBatch):
         """Recompute the edge kernels' work partitions from the rowptr currently in the buffers (after the on-device
         batcher wrote a new batch): vectorised torch ops on the device, no host sync, capturable."""
         from . import _lib
-        from .graph import CHUNK_SHARES, FULL_GRID_CHUNKS, greedy_node_tiles
+        from .graph import CHUNK_SHARES, FULL_GRID_CHUNKS
         lib = _lib.load()
         for k, dst in self._csr._chunks.items():      # == graph.balanced_node_chunks, one launch each
             _lib.check(lib.is_chunk_partition(_lib.ptr(self._csr.rowptr_dst), self._num_nodes, int(k), int(CHUNK_SHARES == "auto" and int(k) == FULL_GRID_CHUNKS), _lib.ptr(dst),
                                               _lib.stream_ptr()), "is_chunk_partition")
-        for key, dst in self._csr._tiles.items():
-            t = greedy_node_tiles(self._csr.rowptr_dst, self.edge_capacity, *key)
-            dst[:t.numel()].copy_(t)
 
 
 def multi_copy(pairs):
@@ -258,16 +253,6 @@ class CapturedTrainStep:
         self._a2 = {}
         self.reserved = self._reserved_candidates[0]
         if self.two_stage:
-            # the partitions every candidate's grids need exist BEFORE any capture (one built while capturing would live in
-            # the capture's memory pool and be overwritten by the next capture)
-            for res in self._reserved_candidates:
-                saved = HF.RESERVED_CUS
-                HF.RESERVED_CUS = res
-                try:
-                    for sg in (self.sgraph if self.paired else (self.sgraph,)):
-                        HF.prepare_layer_partitions(sg._csr, fe, forward=False)   # (the forward's: built by the warm-up steps)
-                finally:
-                    HF.RESERVED_CUS = saved
             self.graph_a1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a1, **_CAPTURE):
                 loss = self._stage1()

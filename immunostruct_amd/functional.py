@@ -42,36 +42,15 @@ def layer_slots():
 BWD_PAIRED = os.environ.get("IMMUNOSTRUCT_BWD_PAIRED", "1") == "1"
 
 
-def use_bwd_tiles(num_nodes, num_edges, slots, fe):
-    """Whether the backward layer launches cut the nodes into the greedy tile list (<= 64 in-edges, <= 24 nodes: full 64-edge
-    windows, the 256-thread kernel) instead of plain 16-node tiles.  Wherever the paired 512-thread kernel applies (Fe <= 1, z3 read
-    back: every reference model) the answer is NO: it runs plain tiles, and round 6's sweep has it ahead at every batch size and
-    edge density measured -- B = 128 ... 512 at E / N = 3: 72.6 / 86.7 / 106 / 134 / 199 / 264 us per launch against 83.1 / 96.6 / 110 /
-    142 / 214 / 272 for listed tiles on the 256-thread kernel; E / N = 6, 9: 118 / 164 against 145 / 201; E / N = 2: 65.0 against 62.5,
-    which half the records (reduce_partials_batched 24 against 37 us per step) give back (tools/exp_tiles_sweep.sh,
-    profiles/r06_experiments.txt) -- the paired step (config 4) gained 3.3 % when it stopped taking the list.  Under
-    IMMUNOSTRUCT_BWD_PAIRED=0 / IMMUNOSTRUCT_SAVE_Z3=0 the 256-thread kernel runs ceil(tiles / slots) rounds of persistent workgroups and
-    the list pays when it saves a whole round (round 3's rule)."""
-    if fe > 1:
-        return False          # the listed-tile instantiation exists for Fe <= 1 only (LDS)
-    if BWD_PAIRED and SAVE_Z3:
-        return False          # the paired kernel's domain (is_egnn_layer_bwd_paired_supported: Fe <= 1, plain tiles)
-    rounds = lambda tiles: (tiles + slots - 1) // slots
-    return rounds((num_edges + 61) // 62) < rounds((num_nodes + 15) // 16)
-
-
 FWD_NODES_PER_WG = 56      # nodes a forward workgroup should own at most on average: one 64-row pass of its node half, with a margin
 
 
 def prepare_layer_partitions(csr, fe, forward=True):
-    """build (and cache in ``csr``) the work partitions the two layer kernels will ask for under the CURRENT ``RESERVED_CUS`` --
-    to be called outside a stream capture: a partition built while capturing lives in the capture's memory pool.
-    ``forward=False``: only the backward kernel's tiles (the reserved-CU candidates of the data-parallel step's stack backward:
-    the forward is always captured on the full grid, and every cached chunk partition is refreshed per batch)"""
+    """build (and cache in ``csr``) the work partition the forward layer kernel will ask for -- to be called outside a stream capture:
+    a partition built while capturing lives in the capture's memory pool.  (The backward cuts the nodes into plain 16-node tiles
+    inside the kernel: nothing to prepare; ``forward=False`` is a no-op kept for the data-parallel engine's call.)"""
     if forward:
         csr.chunks(fwd_chunk_count(csr.num_edges, csr.num_nodes))
-    if use_bwd_tiles(csr.num_nodes, csr.num_edges, layer_slots(), fe):
-        csr.tiles(64, 24)
 
 
 def fwd_chunk_count(num_edges, num_nodes=0):
@@ -652,15 +631,13 @@ class EGNNStackFn(torch.autograd.Function):
         # no gradient at the final coordinates (unused, or never produced): the last layer's backward skips its
         # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
         g_xc = _lib.f32c(g_x) if g_x is not None else None
-        # greedy node tiles that fill the 64-edge windows (when that saves a round of workgroups)
-        tiles = csr.tiles(64, 24) if use_bwd_tiles(n, e, layer_slots(), fe) else None
         # the PAIRED form (csrc/egnn_layer_bwd8.hip): one 512-thread workgroup per CU = two groups that share the staged weight tiles
-        # and write ONE partial record -- half the records per launch.  Plain 16-node tiles, Fe <= 1, z3 read back.
-        paired = BWD_PAIRED and tiles is None and SAVE_Z3 and bool(lib.is_egnn_layer_bwd_paired_supported(fe, 0))
+        # and write ONE partial record -- half the records per launch.  Fe <= 1, z3 read back: every reference model.  Both kernels cut
+        # the nodes into plain 16-node tiles (the greedy tile list of rounds 2 - 5 lost to this kernel at every size and density
+        # measured and was removed: HISTORY.md 9.6)
+        paired = BWD_PAIRED and SAVE_Z3 and bool(lib.is_egnn_layer_bwd_paired_supported(fe))
         bwd_entry = lib.is_egnn_layer_bwd_paired if paired else lib.is_egnn_layer_bwd
-        if tiles is not None:
-            grid_e = max(1, min(layer_slots(), tiles.numel() - 2))
-        elif paired:
+        if paired:
             grid_e = max(1, min(layer_slots() // 2, ((n + 15) // 16 + 1) // 2))
         else:
             grid_e = max(1, min(layer_slots(), (n + 15) // 16))
@@ -706,7 +683,7 @@ class EGNNStackFn(torch.autograd.Function):
                     _lib.ptr(csr.rowptr_dst), _lib.ptr(csr.src_sorted), _lib.ptr(W1), ldw, din,
                     _lib.ptr(W2), _lib.ptr(Wc1), _lib.ptr(bc1), _lib.ptr(wc2), _lib.ptr(lay["z2s"]), _lib.ptr(lay["z3s"]),
                     _lib.ptr(g_xc) if above is None else None, _lib.ptr(dZ1), _lib.ptr(dD),
-                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), _lib.ptr(tiles), grid_e, n, fe,
+                    _lib.ptr(dpsd[:, HIDDEN:]), 2 * HIDDEN, _lib.ptr(dx), _lib.ptr(part_e), grid_e, n, fe,
                     _lib.ptr(dZ1n), _lib.ptr(dDn), _lib.ptr(dxn), _lib.ptr(csr.rowptr_src), _lib.ptr(csr.pos_by_src),
                     _lib.ptr(g_hd), _lib.ptr(g_psd_next), _lib.ptr(lay["zn1"]), _lib.ptr(ctx.packs[i, 1]),
                     _lib.ptr(dh_total) if has_psd else None, _lib.ptr(dzn1), _lib.ptr(d_h), _lib.ptr(d_hn), _lib.ptr(gxtot),

@@ -25,7 +25,7 @@ import torch
 
 class CSRIndex:
     __slots__ = ("rowptr_dst", "src_sorted", "dst_sorted", "eperm", "rowptr_src", "pos_by_src", "num_nodes", "num_edges",
-                 "_chunks", "_tiles")
+                 "_chunks")
 
     def __init__(self, src, dst, num_nodes):
         src = src.long()
@@ -42,7 +42,6 @@ class CSRIndex:
         self.rowptr_src = _rowptr(src, n)
         self.num_nodes, self.num_edges = n, e
         self._chunks = {}
-        self._tiles = {}
 
     def to(self, device):
         out = object.__new__(CSRIndex)
@@ -50,16 +49,7 @@ class CSRIndex:
             setattr(out, k, getattr(self, k).to(device))
         out.num_nodes, out.num_edges = self.num_nodes, self.num_edges
         out._chunks = {k: v.to(device) for k, v in self._chunks.items()}
-        out._tiles = {k: v.to(device) for k, v in self._tiles.items()}
         return out
-
-    def tiles(self, cap_edges, max_nodes):
-        """``[count, b_0, ..., b_cap]`` int32: greedy cut of the destination nodes into consecutive tiles of at most
-        ``cap_edges`` in-edges and ``max_nodes`` nodes -- the unit of work of one workgroup of the backward edge kernel."""
-        key = (int(cap_edges), int(max_nodes))
-        if key not in self._tiles:
-            self._tiles[key] = greedy_node_tiles(self.rowptr_dst, self.num_edges, *key)
-        return self._tiles[key]
 
     def chunks(self, k):
         """``chunk_ptr`` (k+1, 2) int32 = (node boundary b_j, rowptr[b_j]): the destination nodes cut into k contiguous
@@ -68,36 +58,6 @@ class CSRIndex:
         if k not in self._chunks:
             self._chunks[k] = balanced_node_chunks(self.rowptr_dst, k)
         return self._chunks[k]
-
-
-def tile_capacity(num_nodes, num_edges, cap_edges, max_nodes):
-    """upper bound on the number of greedy tiles: a tile ends because it is full of nodes (<= N / max_nodes of
-    those) or because the next node does not fit, and two consecutive tiles of the second kind hold > cap edges"""
-    return num_nodes // max_nodes + 2 * num_edges // cap_edges + 2
-
-
-def greedy_node_tiles(rowptr, num_edges, cap_edges, max_nodes):
-    """Greedy packing of consecutive nodes into tiles with <= cap_edges in-edges and <= max_nodes nodes (a single node
-    with more edges than cap_edges is a tile of its own).  The tile starts are the orbit of node 0 under
-    ``next(v) = end of the tile starting at v``; the orbit is enumerated by binary lifting, so the construction is
-    ~2 log2(T) vectorised torch ops on whichever device the index lives on (no host loop, no sync)."""
-    n = rowptr.numel() - 1
-    dev = rowptr.device
-    rp = rowptr.long()
-    v = torch.arange(n + 1, device=dev)
-    full = torch.full_like(v, n)
-    u = torch.searchsorted(rp, rp + cap_edges, right=True) - 1          # largest u with rp[u] <= rp[v] + cap
-    nxt = torch.minimum(torch.minimum(u, v + max_nodes), full)
-    nxt = torch.maximum(nxt, torch.minimum(v + 1, full))
-    t_cap = tile_capacity(n, int(num_edges), cap_edges, max_nodes)
-    idx = torch.arange(t_cap + 1, device=dev)
-    pos = torch.zeros(t_cap + 1, dtype=torch.long, device=dev)
-    jump = nxt
-    for k in range(max(1, t_cap.bit_length())):
-        pos = torch.where(((idx >> k) & 1) == 1, jump[pos], pos)
-        jump = jump[jump]
-    count = (pos[:-1] < n).sum().view(1)
-    return torch.cat([count, pos]).to(torch.int32)
 
 
 # Shares of the edges in the forward layer kernel's chunk partition (chunk c = wave c % 4 of workgroup c // 4).
@@ -306,5 +266,5 @@ def _concat_csr(parts):
         setattr(out, k, torch.cat(v))
     out.rowptr_dst, out.rowptr_src = torch.cat(rp_d).to(torch.int32), torch.cat(rp_s).to(torch.int32)
     out.num_nodes, out.num_edges = n_off, e_off
-    out._chunks, out._tiles = {}, {}
+    out._chunks = {}
     return out

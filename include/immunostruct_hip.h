@@ -90,8 +90,7 @@ int is_mfma_outer_selftest(const float* G, const float* M, float* out, void* str
  *       is_gather_segment_sum), dPd [N, ld_dpd] and dx [N,3] (destination-side parts, identity path included), ONE
  *       partial weight-gradient record per workgroup (`grid` persistent workgroups, 8960 floats):
  *         dW2 [64,64] | dWc1 [64,64] | db2 | dbc1 | dwc2 | dw_r [64] | dW_a [64,8]
- *       tiles: NULL (16 consecutive nodes per tile) or the greedy tile list [count, b_0 ... b_count] (<= 64 in-edges and
- *       <= 24 nodes per tile, graph.py greedy_node_tiles; Fe <= 1).
+ *       A tile = 16 consecutive destination nodes (the greedy tile list of rounds 2 - 5 was removed in round 6).
  *     node half: g_h [N,64] direct gradient of the layer's output h (may be NULL); g_psd [N,128] gradient of the next
  *       pre-projection of h (NULL: none, then dh = g_h); zn1; bpack; out: dh_total (with g_psd), dzn1, d_h (first din
  *       columns, may be NULL), d_hn [N,64] (scratch: dL/dh_neigh, read back by the edge half).
@@ -116,7 +115,7 @@ int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x
                       const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                       const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                       const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
-                      float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                      float* dx, float* partials, int grid, int N, int Fe,
                       const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                       const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                       const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,
@@ -125,14 +124,14 @@ int is_egnn_layer_bwd(const float* ps, const float* pd, int ld_p, const float* x
  * are what two co-resident 256-thread workgroups of is_egnn_layer_bwd were (group g of workgroup b owns the tiles of its workgroup
  * b + g * grid), sharing one staged copy of the weight tiles (requested at the kernel's start, under the node phase) and writing ONE
  * partial record per workgroup (`partials` holds `grid` records: half the bytes into is_reduce_partials_batched).  Same arguments,
- * outputs and per-tile arithmetic as is_egnn_layer_bwd.  Covers the default build (z1 / geometry / z3 read back), plain 16-node
- * tiles (tiles == NULL) and Fe <= 1: is_egnn_layer_bwd_paired_supported(Fe, listed_tiles) tells, -38 otherwise; grid <= ceil(N/16). */
-int is_egnn_layer_bwd_paired_supported(int Fe, int listed_tiles);
+ * outputs and per-tile arithmetic as is_egnn_layer_bwd.  Covers the default build (z1 / geometry / z3 read back) and Fe <= 1:
+ * is_egnn_layer_bwd_paired_supported(Fe) tells, -38 otherwise; grid <= ceil(N/16).                                                   */
+int is_egnn_layer_bwd_paired_supported(int Fe);
 int is_egnn_layer_bwd_paired(const float* ps, const float* pd, int ld_p, const float* x, const float* ea,
                              const int32_t* rowptr, const int32_t* srcs, const float* W1, int ldw, int din,
                              const float* W2, const float* Wc1, const float* bc1, const float* wc2, const float* z2s,
                              const float* z3s, const float* g_xout, float* dZ1, float* dD, float* dPd, int ld_dpd,
-                             float* dx, float* partials, const int32_t* tiles, int grid, int N, int Fe,
+                             float* dx, float* partials, int grid, int N, int Fe,
                              const float* dZ1n, const float* dDn, const float* dxn, const int32_t* rowptr_src,
                              const int32_t* pos_by_src, const float* g_h, float* g_psd, const float* zn1,
                              const float* bpack, float* dh_total, float* dzn1, float* d_h, float* d_hn, float* gxtot,

@@ -71,7 +71,7 @@ def test_failures_carry_their_text():
     text = lib.is_last_error_string().decode()
     assert text.startswith("is_reduce_partials: invalid argument") and text.endswith("(-22)")
     assert lib.is_version() >= 100 and lib.is_last_error_string().decode() == text      # a successful call leaves it alone
-    assert lib.is_egnn_layer_bwd_paired(*([None] * 2 + [128] + [None] * 5 + [131, 64] + [None] * 10 + [128, None, None, None, 1, 16, 8] + [None] * 19)) == -38
+    assert lib.is_egnn_layer_bwd_paired(*([None] * 2 + [128] + [None] * 5 + [131, 64] + [None] * 10 + [128, None, None, 1, 16, 8] + [None] * 19)) == -38
     assert "is_egnn_layer_bwd_paired: not covered by this build" in lib.is_last_error_string().decode()      # Fe = 8: the 256-thread kernel's
     with pytest.raises(_lib.HipExtensionError, match=r"code -22: is_multi_copy: invalid argument"):
         _lib.check(lib.is_multi_copy(None, 0, None), "is_multi_copy")

@@ -528,7 +528,8 @@ def test_captured_hip_graph_step_matches_eager(cuda_device, always_pack, optimiz
             # construction performs one eager step on batches[0] (optimizer state must exist before capture)
             eng = CapturedTrainStep(model, opt, red, forward_loss, batches[0], edge_capacity=max(r.num_edges for r in raws), warmup=1)
             if always_pack == "auto":
-                assert eng.dp_times is not None and set(eng._forms) == {True, False}
+                # both forms were captured and timed; the one that lost was released with its graphs (round 6)
+                assert eng.dp_times["serial_ms"] > 0 and eng.dp_times["two_stage_ms"] > 0 and set(eng._forms) == {eng.two_stage}
             else:
                 assert eng.two_stage == (always_pack is True)
             if eng._late is not None:
@@ -1186,10 +1187,6 @@ def test_device_batcher_matches_collate(cuda_device):
             assert torch.equal(c.chunks(k).cpu(), c_ref.chunks(k))
         sg.refresh_partitions()
         assert torch.equal(c.chunks(8).cpu(), c_ref.chunks(8))
-        tc = c.tiles(64, 24).cpu()
-        tr = c_ref.tiles(64, 24)
-        cnt = int(tr[0])
-        assert int(tc[0]) == cnt and torch.equal(tc[1:cnt + 2], tr[1:cnt + 2])
 
 
 def test_train_model_device_runs_and_preserves_the_start_state(cuda_device, tmp_path):

@@ -56,35 +56,6 @@ def test_synthetic_batch_invariants():
     assert np.array_equal(raw.x, again.x) and np.array_equal(raw.src, again.src)
 
 
-def test_greedy_node_tiles_match_a_sequential_greedy():
-    """graph.greedy_node_tiles (binary lifting, vectorised) == the obvious host loop, on ragged degrees incl. a hub."""
-    import numpy as np
-    from immunostruct_amd.graph import greedy_node_tiles, tile_capacity
-    rng = np.random.RandomState(0)
-    for trial in range(4):
-        n = int(rng.randint(1, 400))
-        deg = rng.randint(0, 7, size=n)
-        if trial == 1:
-            deg[rng.randint(0, n)] = 200            # one node alone exceeds the edge capacity
-        if trial == 2:
-            deg[:] = 0
-        rowptr = torch.tensor(np.concatenate([[0], np.cumsum(deg)]), dtype=torch.int32)
-        e = int(rowptr[-1])
-        t = greedy_node_tiles(rowptr, e, 64, 24)
-        count = int(t[0])
-        bounds = t[1:count + 2].tolist()
-        ref, v, rp = [0], 0, rowptr.tolist()
-        while v < n:
-            u = v + 1
-            while u < n and u - v < 24 and rp[u + 1] - rp[v] <= 64:
-                u += 1
-            ref.append(u)
-            v = u
-        assert bounds == ref
-        assert count <= tile_capacity(n, e, 64, 24) and t.numel() == tile_capacity(n, e, 64, 24) + 2
-        assert all(b == n for b in t[count + 1:].tolist())
-
-
 def test_balanced_node_chunks_cover_all_nodes():
     from immunostruct_amd.graph import balanced_node_chunks
     rowptr = torch.tensor([0, 3, 3, 10, 11, 11, 11, 40, 41], dtype=torch.int32)

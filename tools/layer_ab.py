@@ -15,9 +15,6 @@ from immunostruct_amd.graph import PackedGraphBatch  # noqa: E402
 from immunostruct_amd.nn import EGNNConv, egnn_stack_forward  # noqa: E402
 
 HF.LaunchClock.enabled = os.environ.get("CLOCKS", "0") == "1"      # the in-kernel workgroup stamps bench.py switches on
-if os.environ.get("TILES") in ("plain", "listed"):      # force the backward's tile cut (default: functional.use_bwd_tiles' rule)
-    _forced = os.environ["TILES"] == "listed"
-    HF.use_bwd_tiles = lambda n, e, slots, fe: _forced and fe <= 1
 dev = torch.device("cuda:0")
 B, DEG, FE = int(os.environ.get("B", 128)), int(os.environ.get("DEG", 2)), int(os.environ.get("FE", 1))
 raw = synthetic.make_batch(B, seed=1, deg_extra=DEG, edge_feats=FE)
