@@ -157,9 +157,8 @@ def measured_traffic(traffic_key):
 
 
 def _paired_bwd_in_use(n_nodes, n_edges, fe):
-    """whether the backward layer launches of this batch run as the paired 512-thread kernel (functional.EgnnStackFn's rule)"""
-    from immunostruct_amd import _lib
-    return bool(HF.BWD_PAIRED and HF.SAVE_Z3 and _lib.load().is_egnn_layer_bwd_paired_supported(fe))
+    """whether the backward layer launches of this batch run as the paired 512-thread kernel (functional.use_paired_bwd's rule)"""
+    return bool(HF.use_paired_bwd(int(n_nodes), fe))
 
 
 def roofline_from_timers(timers, n_nodes, n_edges, dins, fe, traffic_key, insitu=None, paired_bwd=False):

@@ -38,8 +38,22 @@ def layer_slots():
 
 
 # 1 (default): the backward layer launches run as ONE 512-thread workgroup per CU wherever csrc/egnn_layer_bwd8.hip covers the
-# shape; 0: always two 256-thread workgroups per CU (csrc/egnn_layer_bwd.hip) -- the A/B switch of round 5
+# shape and use_paired_bwd's measured rule picks it; 0: always two 256-thread workgroups per CU (csrc/egnn_layer_bwd.hip)
 BWD_PAIRED = os.environ.get("IMMUNOSTRUCT_BWD_PAIRED", "1") == "1"
+# The paired kernel halves the partial records (reduce_partials_batched - 13 us per step) and lets no co-running kernel take a slot
+# beside it (the step's first backward launches are not stretched by the sequence branch's backward); its lockstep costs 4 - 8 % per
+# launch.  The fixed gains win while the launches are short; measured on the replayed step (bench.py --batch B, E / N = 3, ms per step,
+# paired / 256-thread, two interleaved runs each, round 6): B = 128: 1.020 / 1.028, 160: 1.218 / 1.242, 200: 1.514 / 1.541,
+# 224: 1.614 / 1.635 -- and B = 256: 1.812 / 1.788, 320: 2.221 / 2.166, 384: 2.599 / 2.554, 512: 3.400 / 3.315; config 4 (128 pairs = 256
+# graphs): 1.915 / 1.892.  The cut sits between 2660 and 3040 node tiles of 16 (5.2 and 5.9 tiles per workgroup slot).
+PAIRED_BWD_MAX_TILES = 2816      # 5.5 tiles per slot of the full grid
+
+
+def use_paired_bwd(num_nodes, fe):
+    """whether the backward layer launches of a batch of ``num_nodes`` nodes run as the paired 512-thread kernel"""
+    if not (BWD_PAIRED and SAVE_Z3 and bool(_lib.load().is_egnn_layer_bwd_paired_supported(fe))):
+        return False
+    return (num_nodes + 15) // 16 <= PAIRED_BWD_MAX_TILES * layer_slots() // (2 * _MAX_BWD_GRID)
 
 
 FWD_NODES_PER_WG = 56      # nodes a forward workgroup should own at most on average: one 64-row pass of its node half, with a margin
@@ -632,10 +646,10 @@ class EGNNStackFn(torch.autograd.Function):
         # coordinate-MLP half (null g_xout; csrc/egnn_edge_bwd16.hip) instead of pushing zeros through it
         g_xc = _lib.f32c(g_x) if g_x is not None else None
         # the PAIRED form (csrc/egnn_layer_bwd8.hip): one 512-thread workgroup per CU = two groups that share the staged weight tiles
-        # and write ONE partial record -- half the records per launch.  Fe <= 1, z3 read back: every reference model.  Both kernels cut
-        # the nodes into plain 16-node tiles (the greedy tile list of rounds 2 - 5 lost to this kernel at every size and density
-        # measured and was removed: HISTORY.md 9.6)
-        paired = BWD_PAIRED and SAVE_Z3 and bool(lib.is_egnn_layer_bwd_paired_supported(fe))
+        # and write ONE partial record -- half the records per launch; Fe <= 1, z3 read back, and batches of up to ~ 5.5 tiles per
+        # workgroup slot (use_paired_bwd: the measured rule).  Both kernels cut the nodes into plain 16-node tiles (the greedy tile
+        # list of rounds 2 - 5 lost at every size and density measured and was removed: HISTORY.md 9.6)
+        paired = use_paired_bwd(n, fe)
         bwd_entry = lib.is_egnn_layer_bwd_paired if paired else lib.is_egnn_layer_bwd
         if paired:
             grid_e = max(1, min(layer_slots() // 2, ((n + 15) // 16 + 1) // 2))

@@ -155,6 +155,9 @@ def test_paired_backward_kernel_equals_the_256_thread_kernel(cuda_device, case, 
     gh = torch.randn(raw.num_nodes, 64, device=dev)
     gx = torch.randn(raw.num_nodes, 3, device=dev)
 
+    monkeypatch.setattr(HF, "PAIRED_BWD_MAX_TILES", 10 ** 9)      # the kernel itself at every size (the product's rule hands batches of
+                                                                  # more than ~ 5.5 tiles per workgroup slot to the 256-thread kernel)
+
     def run(paired):
         monkeypatch.setattr(HF, "BWD_PAIRED", paired)
         hh, xx = h0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
