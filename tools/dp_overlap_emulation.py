@@ -102,7 +102,7 @@ def main():
         for us in args.us:
             state["us"], state["channels"] = us, ch
             row = {"allreduce_us_per_25MB": us, "floor_us": args.floor_us, "channels": ch,
-                   "split_update": os.environ.get("IMMUNOSTRUCT_DP_SPLIT_UPDATE", "1") != "0", "serial_ms": round(run("0", "0")[0], 3)}
+                   "split_update": True, "serial_ms": round(run("0", "0")[0], 3)}
             for r in args.reserved.split(","):
                 row[f"two_stage_reserved{r}_ms"] = round(run("1", r)[0], 3)
             ms, eng = run("auto", args.reserved)
