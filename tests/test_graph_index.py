@@ -121,3 +121,23 @@ def test_sequence_branch_fork_point_follows_the_batch_size(monkeypatch):
     assert _core.fork_after_layer(144_700) == 2
     monkeypatch.setattr(_core, "FORK_AFTER_LAYER", 1)
     assert _core.fork_after_layer(72_313) == 1 and _core.fork_after_layer(500_000) == 1
+
+
+def test_backward_kernel_choice_follows_the_measured_rule(monkeypatch):
+    """``functional.use_paired_bwd``: the paired 512-thread backward kernel for Fe <= 1 batches of up to 5.5 node tiles of 16 per
+    workgroup slot (round 6's step-level sweep: B <= 224 at 190 nodes per graph), the 256-thread kernel beyond, for 8 edge features,
+    with z3 recomputed, and under IMMUNOSTRUCT_BWD_PAIRED=0; fewer slots (reserved CUs of the data-parallel step) move the cut with them"""
+    from immunostruct_amd import functional as HF
+    assert HF.use_paired_bwd(128 * 190, 1) and HF.use_paired_bwd(224 * 190, 1) and HF.use_paired_bwd(150 * 190, 0)
+    assert not HF.use_paired_bwd(256 * 190, 1) and not HF.use_paired_bwd(512 * 190, 1)
+    assert not HF.use_paired_bwd(128 * 190, 8)
+    assert HF.use_paired_bwd(16 * HF.PAIRED_BWD_MAX_TILES, 1) and not HF.use_paired_bwd(16 * HF.PAIRED_BWD_MAX_TILES + 1, 1)
+    monkeypatch.setattr(HF, "RESERVED_CUS", 128)      # half the grid: half the tiles
+    assert HF.use_paired_bwd(112 * 190, 1) and not HF.use_paired_bwd(128 * 190, 1)
+    monkeypatch.setattr(HF, "RESERVED_CUS", 0)
+    monkeypatch.setattr(HF, "SAVE_Z3", False)
+    assert not HF.use_paired_bwd(128 * 190, 1)
+    monkeypatch.setattr(HF, "SAVE_Z3", True)
+    monkeypatch.setattr(HF, "BWD_PAIRED", False)
+    assert not HF.use_paired_bwd(128 * 190, 1)
+
